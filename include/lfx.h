@@ -1,0 +1,208 @@
+/*
+ * lfx.h — C ABI of the MI355X-native DEFLATE hot path (drop-in boundary for sile/libflate).
+ *
+ * Every entry point names the reference interface it replaces (file:line in libflate v2.3.0).
+ * Plain pointers and sizes only; no torch / HIP types in the signatures (a HIP stream is
+ * passed as an opaque void*).  All compression / decompression work runs in hand-written HIP
+ * kernels for gfx950; there is NO CPU fallback: without a usable device every compute call
+ * returns LFX_E_DEVICE.
+ *
+ * Bit-exactness contract: compressed bytes are a function of (input bytes, sequence of write()
+ * sizes, options) exactly as in the reference (SURVEY.md "fact 2").  One lfx_encoder_write()
+ * call == one `Write::write` call; the one-shot calls take an explicit lfx_schedule.
+ */
+#ifndef LFX_H
+#define LFX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFX_VERSION 0x000100
+
+/* container formats: libflate::{deflate,zlib,gzip} */
+enum { LFX_DEFLATE = 0, LFX_ZLIB = 1, LFX_GZIP = 2 };
+
+/* status codes ~ io::ErrorKind used by the reference (src/lib.rs:10-29, src/bit.rs:132-141) */
+enum {
+    LFX_OK = 0,
+    LFX_E_INVALID_DATA = 1,   /* io::ErrorKind::InvalidData  */
+    LFX_E_UNEXPECTED_EOF = 2, /* io::ErrorKind::UnexpectedEof */
+    LFX_E_IO = 3,             /* error returned by a user callback */
+    LFX_E_OOM = 4,
+    LFX_E_DEVICE = 5,         /* no device / HIP failure (never a silent CPU fallback) */
+    LFX_E_ARG = 6,            /* out-of-domain option */
+    LFX_E_NOSPACE = 7,        /* output capacity too small */
+    LFX_E_UNSUPPORTED = 8
+};
+
+/* libflate_lz77::CompressionLevel (libflate_lz77/src/lib.rs:44-58) */
+enum { LFX_LEVEL_NONE = 0, LFX_LEVEL_FAST = 1, LFX_LEVEL_BALANCE = 2, LFX_LEVEL_BEST = 3 };
+/* which Lz77Encode implementation (lib.rs:83-145, default.rs:14-51) */
+enum { LFX_LZ77_DEFAULT = 0, LFX_LZ77_NOCOMPRESSION = 1 };
+/* zlib::FlushMode (src/zlib.rs:184-195) */
+enum { LFX_FLUSH_NONE = 0, LFX_FLUSH_SYNC = 2 };
+
+/* Options: deflate::EncodeOptions (src/deflate/encode.rs:17-128) + DefaultLz77EncoderBuilder
+ * (libflate_lz77/src/default.rs:202-249) + gzip::HeaderBuilder (src/gzip.rs:126-288) +
+ * zlib::EncodeOptions.flush_mode (src/zlib.rs:414-518). */
+typedef struct lfx_encode_opts {
+    uint64_t block_size;       /* encode.rs:11   default 1 MiB (hint; a block holds whole writes) */
+    int32_t dynamic_huffman;   /* encode.rs:107  default 1; 0 = fixed_huffman_codes() */
+    int32_t no_compression;    /* encode.rs:77   stored blocks */
+    int32_t lz77_kind;         /* LFX_LZ77_*     with_lz77(...) */
+    uint32_t window_size;      /* default.rs:226 default 32768 (clamped) */
+    uint32_t max_length;       /* default.rs:238 default 258 (clamped; must be >= 3) */
+    int32_t zlib_flush_mode;   /* zlib.rs:504    LFX_FLUSH_* */
+    uint32_t mtime;            /* gzip.rs:167    (reference default = now; callers set it) */
+    uint8_t os;                /* gzip.rs:173    default 3 (Unix) */
+    uint8_t is_text;           /* gzip.rs:179 */
+    uint8_t hcrc;              /* gzip.rs:185    verify() */
+    uint8_t _pad;
+    const uint8_t *extra;      /* gzip.rs:191    serialized subfields (id[2] len[2] data)* */
+    uint32_t extra_len;
+    const char *filename;      /* gzip.rs:197    NUL-terminated */
+    const char *comment;       /* gzip.rs:203 */
+} lfx_encode_opts;
+void lfx_encode_opts_default(lfx_encode_opts *o);
+
+/* How the caller slices its writes (what decides LZ77 chunk and DEFLATE block boundaries:
+ * default.rs:60-68, encode.rs:277-286). */
+enum { LFX_SCHED_SINGLE = 0, /* one write_all(buf)            — every in-tree reference test */
+       LFX_SCHED_FIXED = 1,  /* writes of `fixed_write` bytes — examples/flate.rs:52 uses 8192 */
+       LFX_SCHED_LIST = 2 }; /* explicit sizes; a size of UINT64_MAX means Write::flush() */
+#define LFX_SCHED_FLUSH UINT64_MAX
+typedef struct lfx_schedule {
+    int32_t kind;
+    uint64_t fixed_write;
+    const uint64_t *writes;
+    size_t n_writes;
+} lfx_schedule;
+
+/* ---- device context (one per GPU; owns a HIP stream + cached scratch in HBM) ------------- */
+typedef struct lfx_ctx lfx_ctx;
+lfx_ctx *lfx_ctx_new(int device, int *status);
+void lfx_ctx_free(lfx_ctx *c);
+const char *lfx_ctx_last_error(const lfx_ctx *c);
+/* use the caller's HIP stream (hipStream_t as void*) instead of the context's own */
+void lfx_ctx_set_stream(lfx_ctx *c, void *hip_stream);
+int lfx_device_count(void);
+
+/* ---- one-shot, device-resident buffers (what io::copy over in-memory buffers amounts to) --
+ * Replaces {deflate,zlib,gzip}::Encoder::{with_options, write*, finish}
+ * (encode.rs:182-249, zlib.rs:577-681, gzip.rs:804-908) for a whole buffer. */
+uint64_t lfx_encode_bound(uint64_t n, const lfx_encode_opts *o, const lfx_schedule *s);
+int lfx_encode_device(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s,
+                      const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len);
+/* same, host buffers (stages through HBM; PCIe-inclusive) */
+int lfx_encode_host(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s,
+                    const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len);
+
+/* Replaces {deflate,zlib,gzip}::Decoder::{new, read_to_end} (decode.rs:40-164,
+ * zlib.rs:312-409, gzip.rs:941-1047) and gzip::MultiDecoder (gzip.rs:1100-1166, flag below).
+ * *out_len = bytes produced (also on failure: read_to_end + unread_decoded_data,
+ * decode.rs:68-73); *consumed = input bytes consumed including the trailer. */
+#define LFX_DEC_MULTI 1u
+int lfx_decode_device(lfx_ctx *c, int format, uint32_t flags, const void *d_in, uint64_t n,
+                      void *d_out, uint64_t cap, uint64_t *out_len, uint64_t *consumed);
+int lfx_decode_host(lfx_ctx *c, int format, uint32_t flags, const void *in, uint64_t n, void *out,
+                    uint64_t cap, uint64_t *out_len, uint64_t *consumed);
+/* `count` independent streams, one wavefront each (BASELINE.json configs[2]).
+ * offsets/lengths are HOST arrays; status[i] gets LFX_* per stream. */
+int lfx_decode_batch_device(lfx_ctx *c, int format, uint32_t count, const void *d_in,
+                            const uint64_t *in_off, const uint64_t *in_len, void *d_out,
+                            const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
+                            int32_t *status);
+
+/* ---- sharded encode: independent block ranges per rank, one gzip/zlib/deflate member
+ * (SURVEY §8e).  prepare() runs match finding → Huffman build and the checksums and reports the
+ * shard's bit length; after the ranks exchanged lfx_shard_info (RCCL all-gather), emit() packs the
+ * shard at its global bit offset.  The byte at each shard boundary is shared (OR the halves). */
+typedef struct lfx_shard_info {
+    uint64_t total_bits; /* DEFLATE bits of this shard (incl. final byte alignment on the last) */
+    uint64_t n_bytes;    /* uncompressed bytes */
+    uint32_t crc32;      /* of the shard's input */
+    uint32_t adler32;    /* of the shard's input, as if it started a stream (A0 = 1) */
+} lfx_shard_info;
+int lfx_encode_shard_prepare(lfx_ctx *c, int format, const lfx_encode_opts *o,
+                             const lfx_schedule *s, const void *d_in, uint64_t n, int is_first,
+                             int is_last, lfx_shard_info *info);
+/* start_bit = bit offset of this shard's first DEFLATE bit inside the member (container header
+ * included).  Writes bytes [start_bit/8, ceil((start_bit+total_bits)/8)) of the member to d_out
+ * (d_out[0] is byte start_bit/8); the first shard also writes the container header, the last
+ * shard the trailer built from the combined checksum / size given here. */
+int lfx_encode_shard_emit(lfx_ctx *c, uint64_t start_bit, uint32_t combined_check,
+                          uint64_t total_n, void *d_out, uint64_t cap, uint64_t *out_len);
+uint32_t lfx_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
+uint32_t lfx_adler32_combine(uint32_t ad1, uint32_t ad2, uint64_t len2);
+uint64_t lfx_container_header_len(int format, const lfx_encode_opts *o);
+
+/* ---- stream API: io::Write / io::Read shaped (host buffers, callbacks) --------------------
+ * write_cb must consume all n bytes and return n, or a negative errno. */
+typedef int64_t (*lfx_write_cb)(void *user, const uint8_t *p, size_t n);
+typedef int (*lfx_flush_cb)(void *user);
+/* read_cb fills up to cap bytes, returns bytes read (0 = EOF) or a negative errno */
+typedef int64_t (*lfx_read_cb)(void *user, uint8_t *p, size_t cap);
+
+typedef struct lfx_encoder lfx_encoder;
+/* {deflate,zlib,gzip}::Encoder::with_options — gzip/zlib write their header immediately and
+ * can fail (gzip.rs:804-812, zlib.rs:577-585). */
+lfx_encoder *lfx_encoder_new(lfx_ctx *c, int format, const lfx_encode_opts *o, lfx_write_cb w,
+                             lfx_flush_cb f, void *user, int *status);
+/* io::Write::write — always consumes everything (encode.rs:241-244); one call = one write() */
+int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n);
+/* io::Write::flush — closes the current block (encode.rs:245-248); zlib Sync adds 00 00 FF FF */
+int lfx_encoder_flush(lfx_encoder *e);
+/* Encoder::finish (encode.rs:203-208, gzip.rs:858-868, zlib.rs:630-639). Everything already
+ * handed to write_cb stays with the sink even on error (finish.rs:46-68). */
+int lfx_encoder_finish(lfx_encoder *e);
+const char *lfx_encoder_last_error(const lfx_encoder *e);
+void lfx_encoder_free(lfx_encoder *e);
+
+typedef struct lfx_decoder lfx_decoder;
+/* {deflate,zlib,gzip}::Decoder::new / gzip::MultiDecoder::new — gzip/zlib parse the header
+ * eagerly and can fail (gzip.rs:941-944, zlib.rs:312-320). */
+lfx_decoder *lfx_decoder_new(lfx_ctx *c, int format, uint32_t flags, lfx_read_cb r, void *user,
+                             int *status);
+/* io::Read::read: >0 bytes, 0 = end of stream, <0 = -(LFX_E_*).  A zero-capacity read returns 0
+ * without latching end-of-stream (gzip.rs:1025-1027, zlib.rs:383-385). */
+int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap);
+/* Decoder::unread_decoded_data (decode.rs:68-73) */
+int lfx_decoder_unread(lfx_decoder *d, const uint8_t **p, size_t *n);
+/* bytes of the inner reader consumed so far (Decoder::into_inner position; gzip.rs:1216-1226) */
+uint64_t lfx_decoder_consumed(const lfx_decoder *d);
+const char *lfx_decoder_last_error(const lfx_decoder *d);
+void lfx_decoder_free(lfx_decoder *d);
+
+/* ---- plug-in: libflate_lz77::Lz77Encode (libflate_lz77/src/lib.rs:83-107) -----------------
+ * Codes are delivered in batches: word = (val << 16) | dist; dist == 0 → Code::Literal(val),
+ * else Code::Pointer{length: val, backward_distance: dist} (lib.rs:27-42). */
+typedef void (*lfx_sink_cb)(void *user, const uint32_t *codes, size_t n);
+typedef struct lfx_lz77 lfx_lz77;
+lfx_lz77 *lfx_lz77_new(lfx_ctx *c, uint32_t window_size, uint32_t max_length, int *status);
+/* Lz77Encode::encode — buffers; flushes when >= window*8 bytes are held (default.rs:60-68) */
+int lfx_lz77_encode(lfx_lz77 *z, const uint8_t *buf, size_t len, lfx_sink_cb sink, void *user);
+/* Lz77Encode::flush (default.rs:69-109) */
+int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user);
+uint32_t lfx_lz77_window_size(const lfx_lz77 *z); /* lib.rs:103-106 */
+int lfx_lz77_compression_level(const lfx_lz77 *z); /* lib.rs:96-99 → LFX_LEVEL_BALANCE */
+void lfx_lz77_free(lfx_lz77 *z);
+
+/* ---- introspection used by tests / bench -------------------------------------------------- */
+/* per-phase GPU milliseconds of the last encode/decode on this context (hipEvent-timed) */
+typedef struct lfx_timing {
+    float total_ms;
+    float phase_ms[16];
+    char phase_name[16][24];
+    int n_phases;
+} lfx_timing;
+int lfx_ctx_last_timing(lfx_ctx *c, lfx_timing *t);
+void lfx_ctx_enable_timing(lfx_ctx *c, int on);
+uint32_t lfx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,162 @@
+"""Shared implementation of the io::Write / io::Read shaped stream objects over lfx_encoder /
+lfx_decoder (include/lfx.h)."""
+import ctypes as C
+
+from . import _ffi
+from .context import default_context
+
+_KIND = {_ffi.E_INVALID_DATA: "InvalidData", _ffi.E_UNEXPECTED_EOF: "UnexpectedEof"}
+
+
+class StreamError(IOError):
+    """io::Error: .kind is 'InvalidData' / 'UnexpectedEof' / 'Other' (src/lib.rs:10-29)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+        self.kind = _KIND.get(status, "Other")
+        self.message = message
+
+
+class _EncoderBase:
+    FORMAT = _ffi.DEFLATE
+
+    def __init__(self, inner, options=None, context=None):
+        """`inner` is any object with write(bytes) (and optionally flush()) — the reference's `W`."""
+        self._ctx = context or default_context()
+        self._inner = inner
+        self._opts = options._to_c() if options is not None else _ffi.make_opts()
+        self._wcb = _ffi.WRITE_CB(self._on_write)
+        self._fcb = _ffi.FLUSH_CB(self._on_flush)
+        st = C.c_int(0)
+        self._h = _ffi.lib().lfx_encoder_new(self._ctx.handle, self.FORMAT, C.byref(self._opts), self._wcb,
+                                             self._fcb, None, C.byref(st))
+        if not self._h:
+            raise StreamError(st.value, "encoder construction failed (status %d)" % st.value)
+
+    def _on_write(self, _user, p, n):
+        try:
+            self._inner.write(C.string_at(p, n))
+            return n
+        except Exception:
+            return -5
+
+    def _on_flush(self, _user):
+        try:
+            f = getattr(self._inner, "flush", None)
+            if f:
+                f()
+            return 0
+        except Exception:
+            return 1
+
+    def write(self, buf):
+        """io::Write::write — ONE reference write() call; always consumes everything."""
+        buf = bytes(buf)
+        r = _ffi.lib().lfx_encoder_write(self._h, buf, len(buf))
+        if r < 0:
+            raise StreamError(-r, self._err())
+        return r
+
+    write_all = write
+
+    def flush(self):
+        rc = _ffi.lib().lfx_encoder_flush(self._h)
+        if rc:
+            raise StreamError(rc, self._err())
+
+    def finish(self):
+        """Encoder::finish → the inner writer (Finish<W, io::Error>::into_result)."""
+        rc = _ffi.lib().lfx_encoder_finish(self._h)
+        msg = self._err()
+        _ffi.lib().lfx_encoder_free(self._h)
+        self._h = None
+        if rc:
+            raise StreamError(rc, msg)
+        return self._inner
+
+    def as_inner_ref(self):
+        return self._inner
+
+    def into_inner(self):
+        if self._h:
+            _ffi.lib().lfx_encoder_free(self._h)
+            self._h = None
+        return self._inner
+
+    def _err(self):
+        return (_ffi.lib().lfx_encoder_last_error(self._h) or b"").decode("utf-8", "replace")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().lfx_encoder_free(self._h)
+            self._h = None
+
+
+class _DecoderBase:
+    FORMAT = _ffi.DEFLATE
+    FLAGS = 0
+
+    def __init__(self, inner, context=None):
+        """`inner`: bytes-like or an object with read(n) — the reference's `R`."""
+        self._ctx = context or default_context()
+        if isinstance(inner, (bytes, bytearray, memoryview)):
+            import io
+            inner = io.BytesIO(bytes(inner))
+        self._inner = inner
+        self._rcb = _ffi.READ_CB(self._on_read)
+        st = C.c_int(0)
+        self._h = _ffi.lib().lfx_decoder_new(self._ctx.handle, self.FORMAT, self.FLAGS, self._rcb, None,
+                                             C.byref(st))
+        if not self._h:
+            raise StreamError(st.value, self._ctx.last_error())
+
+    def _on_read(self, _user, p, cap):
+        try:
+            b = self._inner.read(cap)
+            C.memmove(p, b, len(b))
+            return len(b)
+        except Exception:
+            return -5
+
+    def read(self, n=-1):
+        """io::Read::read (n >= 0) or read_to_end (n < 0).  Raises StreamError on failure."""
+        if n == 0:
+            return b""
+        chunks = []
+        want = n
+        while True:
+            cap = 1 << 20 if want < 0 else want
+            buf = C.create_string_buffer(cap)
+            r = _ffi.lib().lfx_decoder_read(self._h, buf, cap)
+            if r < 0:
+                err = StreamError(-r, self._err())
+                err.partial = b"".join(chunks)
+                raise err
+            if r == 0:
+                break
+            chunks.append(buf.raw[:r])
+            if want >= 0:
+                break
+        return b"".join(chunks)
+
+    def read_to_end(self):
+        return self.read(-1)
+
+    def unread_decoded_data(self):
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t(0)
+        _ffi.lib().lfx_decoder_unread(self._h, C.byref(p), C.byref(n))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def consumed(self):
+        """bytes of the inner reader that belong to the decoded stream (into_inner position)."""
+        return _ffi.lib().lfx_decoder_consumed(self._h)
+
+    def _err(self):
+        return (_ffi.lib().lfx_decoder_last_error(self._h) or b"").decode("utf-8", "replace")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _ffi.lib().lfx_decoder_free(self._h)
+            self._h = None

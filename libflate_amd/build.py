@@ -1,0 +1,48 @@
+"""Builds the in-tree native library libflate_amd/liblfx.so (C ABI, include/lfx.h) for gfx950.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "liblfx.so")
+SOURCES = ["lfx_encode_kernels.hip", "lfx_decode_kernels.hip", "lfx_api.cpp", "lfx_decode.cpp"]
+HEADERS = ["lfx_common.h", "lfx_device.h", "lfx_decode.h", "lfx_huff.h", "lfx_plan.h", "lfx_ctx.h",
+           os.path.join("..", "..", "include", "lfx.h")]
+
+
+def _stale():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not _stale():
+        return SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
+               "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,104 @@
+"""Device context (lfx_ctx): one per GPU, owns a HIP stream and cached HBM scratch."""
+import ctypes as C
+
+from . import _ffi
+
+
+class Context:
+    def __init__(self, device=0):
+        st = C.c_int(0)
+        self._h = _ffi.lib().lfx_ctx_new(device, C.byref(st))
+        if not self._h:
+            raise _ffi.DeviceError(st.value, "no usable MI355X device %d (there is no CPU fallback)" % device)
+        self.device = device
+
+    def close(self):
+        if self._h:
+            _ffi.lib().lfx_ctx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def last_error(self):
+        return (_ffi.lib().lfx_ctx_last_error(self._h) or b"").decode("utf-8", "replace")
+
+    def set_stream(self, hip_stream_ptr):
+        _ffi.lib().lfx_ctx_set_stream(self._h, hip_stream_ptr)
+
+    def enable_timing(self, on=True):
+        _ffi.lib().lfx_ctx_enable_timing(self._h, 1 if on else 0)
+
+    def last_timing(self):
+        t = _ffi.Timing()
+        if _ffi.lib().lfx_ctx_last_timing(self._h, C.byref(t)) != 0:
+            return None
+        return {"total_ms": t.total_ms,
+                "phases": [(bytes(t.phase_name[i]).split(b"\0")[0].decode(), t.phase_ms[i])
+                           for i in range(t.n_phases)]}
+
+    # ---- one-shot calls on raw device pointers (ints) -------------------------------------------
+    def encode_device(self, fmt, d_in, n, d_out, cap, opts=None, schedule=None):
+        out_len = C.c_uint64(0)
+        rc = _ffi.lib().lfx_encode_device(self._h, fmt, C.byref(opts) if opts is not None else None,
+                                          C.byref(schedule) if schedule is not None else None,
+                                          d_in, n, d_out, cap, C.byref(out_len))
+        if rc:
+            raise (_ffi.DeviceError if rc == _ffi.E_DEVICE else _ffi.LfxError)(rc, self.last_error())
+        return out_len.value
+
+    def decode_device(self, fmt, d_in, n, d_out, cap, flags=0):
+        """→ (status, out_len, consumed, message)"""
+        out_len, consumed = C.c_uint64(0), C.c_uint64(0)
+        rc = _ffi.lib().lfx_decode_device(self._h, fmt, flags, d_in, n, d_out, cap, C.byref(out_len),
+                                          C.byref(consumed))
+        if rc in (_ffi.E_DEVICE, _ffi.E_OOM, _ffi.E_ARG):
+            raise (_ffi.DeviceError if rc == _ffi.E_DEVICE else _ffi.LfxError)(rc, self.last_error())
+        return rc, out_len.value, consumed.value, self.last_error() if rc else ""
+
+    def encode_host(self, fmt, data, opts=None, schedule=None):
+        data = bytes(data)
+        bound = _ffi.lib().lfx_encode_bound(len(data), C.byref(opts) if opts is not None else None,
+                                            C.byref(schedule) if schedule is not None else None)
+        if bound == 0:
+            raise _ffi.LfxError(_ffi.E_ARG, "option outside the reference's domain")
+        out = C.create_string_buffer(bound)
+        out_len = C.c_uint64(0)
+        rc = _ffi.lib().lfx_encode_host(self._h, fmt, C.byref(opts) if opts is not None else None,
+                                        C.byref(schedule) if schedule is not None else None,
+                                        data, len(data), out, bound, C.byref(out_len))
+        if rc:
+            raise (_ffi.DeviceError if rc == _ffi.E_DEVICE else _ffi.LfxError)(rc, self.last_error())
+        return out.raw[:out_len.value]
+
+    def decode_host(self, fmt, data, cap=None, flags=0):
+        """→ (status, output_so_far, consumed, message)"""
+        data = bytes(data)
+        cap = cap if cap is not None else max(1 << 16, len(data) * 16)
+        while True:
+            out = C.create_string_buffer(cap)
+            out_len, consumed = C.c_uint64(0), C.c_uint64(0)
+            rc = _ffi.lib().lfx_decode_host(self._h, fmt, flags, data, len(data), out, cap,
+                                            C.byref(out_len), C.byref(consumed))
+            if rc in (_ffi.E_DEVICE, _ffi.E_OOM, _ffi.E_ARG):
+                raise (_ffi.DeviceError if rc == _ffi.E_DEVICE else _ffi.LfxError)(rc, self.last_error())
+            if rc == _ffi.E_NOSPACE and cap < len(data) * 1040 + (1 << 20):
+                cap *= 8
+                continue
+            return rc, out.raw[:out_len.value], consumed.value, self.last_error() if rc else ""
+
+
+_default = {}
+
+
+def default_context(device=0):
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]

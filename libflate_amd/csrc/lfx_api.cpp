@@ -1,0 +1,801 @@
+// lfx_api.cpp — C ABI (include/lfx.h) over the HIP kernels.  Host side = framing bytes, the write
+// schedule planner and kernel orchestration; every byte of compression work runs on the GPU.
+#include "../../include/lfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "lfx_ctx.h"
+#include "lfx_device.h"
+#include "lfx_huff.h"
+#include "lfx_plan.h"
+
+using namespace lfx;
+
+// ------------------------------------------------------------------------------------------------
+// small host helpers (framing only)
+static uint32_t host_crc32(const uint8_t *p, size_t n) {
+    static uint32_t tab[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
+            tab[i] = c;
+        }
+    });
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) c = (c >> 8) ^ tab[(c ^ p[i]) & 0xFF];
+    return ~c;
+}
+static uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1)));
+    }
+    return p;
+}
+static uint32_t gf2_xpow8n(uint64_t nbytes) {
+    uint32_t r = 0x80000000u, sq = 0x00800000u;
+    while (nbytes) {
+        if (nbytes & 1) r = gf2_mulmod(r, sq);
+        sq = gf2_mulmod(sq, sq);
+        nbytes >>= 1;
+    }
+    return r;
+}
+
+extern "C" uint32_t lfx_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2) {
+    // CRC(A||B) from CRC(A), CRC(B), |B| (the reference never combines)
+    return gf2_mulmod(crc1, gf2_xpow8n(len2)) ^ crc2;
+}
+extern "C" uint32_t lfx_adler32_combine(uint32_t ad1, uint32_t ad2, uint64_t len2) {
+    const uint32_t M = 65521u;
+    uint32_t a1 = ad1 & 0xFFFF, b1 = ad1 >> 16, a2 = ad2 & 0xFFFF, b2 = ad2 >> 16;
+    uint32_t rem = (uint32_t)(len2 % M);
+    uint32_t a = (a1 + a2 + M - 1) % M;
+    uint32_t b = (uint32_t)((b1 + b2 + (uint64_t)rem * ((a1 + M - 1) % M)) % M);
+    return (b << 16) | a;
+}
+
+extern "C" void lfx_encode_opts_default(lfx_encode_opts *o) {
+    memset(o, 0, sizeof *o);
+    o->block_size = 1u << 20;
+    o->dynamic_huffman = 1;
+    o->window_size = MAX_WINDOW;
+    o->max_length = MAX_LENGTH;
+    o->os = 3;
+}
+extern "C" uint32_t lfx_version(void) { return LFX_VERSION; }
+
+static lfx_encode_opts norm_opts(const lfx_encode_opts *o) {
+    lfx_encode_opts d;
+    if (o) d = *o; else lfx_encode_opts_default(&d);
+    if (d.window_size > MAX_WINDOW) d.window_size = MAX_WINDOW;  // default.rs:228
+    if (d.max_length > MAX_LENGTH) d.max_length = MAX_LENGTH;    // default.rs:240
+    return d;
+}
+static int check_opts(const lfx_encode_opts &o) {
+    if (o.block_size == 0) return LFX_E_ARG;  // `while len >= 0` never terminates in the reference
+    if (o.max_length < 3) return LFX_E_ARG;   // default.rs:125 underflows
+    return LFX_OK;
+}
+static PlanOpts plan_opts(int format, const lfx_encode_opts &o) {
+    PlanOpts p;
+    p.block_size = o.block_size;
+    p.dynamic_huffman = o.dynamic_huffman != 0;
+    p.no_compression = o.no_compression != 0;
+    p.lz77_kind = o.lz77_kind;
+    p.window_size = o.window_size;
+    p.max_length = o.max_length;
+    p.zlib_sync = format == LFX_ZLIB && o.zlib_flush_mode == LFX_FLUSH_SYNC;
+    return p;
+}
+
+// gzip Header::write_to gzip.rs:368-389 (+flags 343-355, crc16 356-367)
+static void gzip_header(const lfx_encode_opts &o, bool with_hcrc, std::vector<uint8_t> &b) {
+    uint8_t flg = (uint8_t)((o.is_text ? 1 : 0) | (with_hcrc ? 2 : 0) | (o.extra ? 4 : 0) |
+                            (o.filename ? 8 : 0) | (o.comment ? 16 : 0));
+    // XFL: DefaultLz77Encoder → Balance → Unknown(0); NoCompression → None → Unknown(0) (gzip.rs:84-92)
+    const uint8_t h[10] = {31, 139, 8, flg, (uint8_t)o.mtime, (uint8_t)(o.mtime >> 8),
+                           (uint8_t)(o.mtime >> 16), (uint8_t)(o.mtime >> 24), 0, o.os};
+    b.insert(b.end(), h, h + 10);
+    if (o.extra) {
+        b.push_back((uint8_t)o.extra_len);
+        b.push_back((uint8_t)(o.extra_len >> 8));
+        b.insert(b.end(), o.extra, o.extra + o.extra_len);
+    }
+    if (o.filename) b.insert(b.end(), o.filename, o.filename + strlen(o.filename) + 1);
+    if (o.comment) b.insert(b.end(), o.comment, o.comment + strlen(o.comment) + 1);
+    if (with_hcrc) {
+        // the reference checksums the header serialised with is_verified = false (FLG.HCRC clear)
+        std::vector<uint8_t> t;
+        gzip_header(o, false, t);
+        uint32_t c = host_crc32(t.data(), t.size());
+        b.push_back((uint8_t)c);
+        b.push_back((uint8_t)(c >> 8));
+    }
+}
+static int container_header(int format, const lfx_encode_opts &o, std::vector<uint8_t> &b) {
+    if (format == LFX_GZIP) {
+        if (o.extra && o.extra_len > 0xFFFF) return LFX_E_INVALID_DATA;  // gzip.rs:490-492
+        gzip_header(o, o.hcrc != 0, b);
+    } else if (format == LFX_ZLIB) {
+        // zlib Header::write_to zlib.rs:267-279; from_lz77 212-220; Lz77WindowSize::from_u16 132-151
+        uint32_t ws = o.window_size;
+        uint8_t cinfo = ws > 16384 ? 7 : ws > 8192 ? 6 : ws > 4096 ? 5 : ws > 2048 ? 4 : ws > 1024 ? 3
+                        : ws > 512 ? 2 : ws > 256 ? 1 : 0;
+        uint8_t level = (o.no_compression || o.lz77_kind == LFX_LZ77_NOCOMPRESSION) ? 0 : 2;
+        uint8_t cmf = (uint8_t)((cinfo << 4) | 8), flg = (uint8_t)(level << 6);
+        uint32_t check = ((uint32_t)cmf << 8) + flg;
+        if (check % 31 != 0) flg = (uint8_t)(flg + (31 - check % 31));
+        b.push_back(cmf);
+        b.push_back(flg);
+    } else if (format != LFX_DEFLATE) {
+        return LFX_E_ARG;
+    }
+    return LFX_OK;
+}
+extern "C" uint64_t lfx_container_header_len(int format, const lfx_encode_opts *o) {
+    std::vector<uint8_t> b;
+    lfx_encode_opts d = norm_opts(o);
+    container_header(format, d, b);
+    return b.size();
+}
+
+static void apply_schedule(Planner &pl, const lfx_schedule *s, uint64_t n) {
+    if (!s || s->kind == LFX_SCHED_SINGLE) {
+        pl.write(n);  // write_all of one slice == one write() (encode.rs:243 consumes everything)
+    } else if (s->kind == LFX_SCHED_FIXED) {
+        uint64_t w = s->fixed_write ? s->fixed_write : n;
+        for (uint64_t off = 0; off < n; off += w) pl.write(std::min(w, n - off));
+    } else {
+        uint64_t used = 0;
+        for (size_t i = 0; i < s->n_writes; i++) {
+            if (s->writes[i] == LFX_SCHED_FLUSH) { pl.flush(); continue; }
+            uint64_t w = std::min(s->writes[i], n - used);
+            pl.write(w);
+            used += w;
+        }
+        if (used < n) pl.write(n - used);
+    }
+}
+
+extern "C" uint64_t lfx_encode_bound(uint64_t n, const lfx_encode_opts *o, const lfx_schedule *s) {
+    lfx_encode_opts d = norm_opts(o);
+    if (check_opts(d)) return 0;
+    Planner pl(plan_opts(LFX_ZLIB, d));
+    apply_schedule(pl, s, n);
+    Plan &p = pl.finish();
+    // a dynamic block never costs more than ~9 bits per literal + its header; stored: 5 bytes per block
+    uint64_t hdr = 64 + (d.extra ? d.extra_len + 2 : 0) + (d.filename ? strlen(d.filename) + 1 : 0) +
+                   (d.comment ? strlen(d.comment) + 1 : 0);
+    return n + n / 4 + 1024 * (uint64_t)p.blocks.size() + hdr + 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+namespace lfx {
+
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            c->set_error(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+            return LFX_E_DEVICE;                                                      \
+        }                                                                             \
+    } while (0)
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    if (hipMalloc(&p, want) != hipSuccess) {
+        if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; return LFX_E_OOM; }
+        want = bytes;
+    }
+    cap = want;
+    return 0;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+void Ctx::phase(const char *name) {
+    if (!timing_on) return;
+    if (n_ev >= 17) return;
+    if (!ev[n_ev]) (void)hipEventCreate(&ev[n_ev]);
+    (void)hipEventRecord(ev[n_ev], stream);
+    snprintf(ev_name[n_ev], sizeof ev_name[n_ev], "%s", name);
+    n_ev++;
+}
+
+}  // namespace lfx
+
+extern "C" int lfx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) {
+    int st = LFX_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
+        if (status) *status = LFX_E_DEVICE;  // fail loudly: there is no CPU path
+        return nullptr;
+    }
+    Ctx *c = new Ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+        delete c;
+        if (status) *status = LFX_E_DEVICE;
+        return nullptr;
+    }
+    c->stream = c->own_stream;
+    if (hipHostMalloc((void **)&c->h_res, 4096, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        if (status) *status = LFX_E_OOM;
+        return nullptr;
+    }
+    if (status) *status = st;
+    return reinterpret_cast<lfx_ctx *>(c);
+}
+extern "C" void lfx_ctx_free(lfx_ctx *cc) {
+    if (!cc) return;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : c->all_bufs()) b->release();
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+extern "C" const char *lfx_ctx_last_error(const lfx_ctx *cc) {
+    return cc ? reinterpret_cast<const Ctx *>(cc)->err.c_str() : "no context";
+}
+extern "C" void lfx_ctx_set_stream(lfx_ctx *cc, void *s) {
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+}
+extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on != 0; }
+extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) {
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    memset(t, 0, sizeof *t);
+    if (c->n_ev < 2) return LFX_E_ARG;
+    (void)hipEventSynchronize(c->ev[c->n_ev - 1]);
+    (void)hipEventElapsedTime(&t->total_ms, c->ev[0], c->ev[c->n_ev - 1]);
+    t->n_phases = c->n_ev - 1;
+    for (int i = 0; i + 1 < c->n_ev && i < 16; i++) {
+        (void)hipEventElapsedTime(&t->phase_ms[i], c->ev[i], c->ev[i + 1]);
+        snprintf(t->phase_name[i], sizeof t->phase_name[i], "%s", c->ev_name[i + 1]);
+    }
+    return LFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode core
+namespace lfx {
+
+// Stage A: plan upload → match → parse → histogram → Huffman (+ checksum).  Leaves everything the
+// emit stage needs in the context.
+int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *d_in, uint64_t n,
+                   bool want_checksum) {
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    c->n_ev = 0;
+    c->phase("start");
+    for (const ChunkDesc &ch : plan.chunks)
+        if (ch.len >= (1ull << 32) - 4) {
+            c->set_error("an LZ77 chunk of 4 GiB or more is outside the reference's domain (u32 positions, default.rs:78)");
+            return LFX_E_ARG;
+        }
+    const uint32_t nchunks = (uint32_t)plan.chunks.size(), nblocks = (uint32_t)plan.blocks.size();
+    // segments for the match search
+    std::vector<SegDesc> segs;
+    for (uint32_t ci = 0; ci < nchunks; ci++) {
+        const ChunkDesc &ch = plan.chunks[ci];
+        if (ch.flags & CH_LITERALS) continue;
+        for (uint64_t s = 0; s + 3 < ch.len; s += SEG_POSITIONS)
+            segs.push_back(SegDesc{ci, (uint32_t)s, (uint32_t)std::min<uint64_t>(SEG_POSITIONS, ch.len - s), 0});
+    }
+    c->cur_nchunks = nchunks;
+    c->cur_nblocks = nblocks;
+    c->cur_ntiles = plan.n_tiles;
+    c->cur_n = n;
+    c->cur_in = d_in;
+    int rc;
+    if ((rc = c->d_chunks.reserve(sizeof(ChunkDesc) * std::max<size_t>(nchunks, 1)))) return rc;
+    if ((rc = c->d_blocks.reserve(sizeof(BlockDesc) * std::max<size_t>(nblocks, 1)))) return rc;
+    if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
+    if ((rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;
+    if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
+    if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
+    if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
+    if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
+    if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;
+    if ((rc = c->d_tile_bits.reserve(4 * std::max<uint64_t>(plan.n_tiles, 1)))) return rc;
+    if ((rc = c->d_tile_start.reserve(8 * std::max<uint64_t>(plan.n_tiles, 1)))) return rc;
+    const uint64_t nspans = div_up(std::max<uint64_t>(n, 1), 1024);
+    if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
+    if ((rc = c->d_res.reserve(256))) return rc;
+    if ((rc = c->d_small.reserve(70000))) return rc;
+
+    if (nchunks) HIP_TRY(hipMemcpyAsync(c->d_chunks.p, plan.chunks.data(), sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
+    if (nblocks) HIP_TRY(hipMemcpyAsync(c->d_blocks.p, plan.blocks.data(), sizeof(BlockDesc) * nblocks, hipMemcpyHostToDevice, st));
+    if (!segs.empty()) HIP_TRY(hipMemcpyAsync(c->d_segs.p, segs.data(), sizeof(SegDesc) * segs.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(c->d_hist.p, 0, 4ull * 320 * std::max<size_t>(nblocks, 1), st));
+    HIP_TRY(hipMemsetAsync(c->d_res.p, 0, 256, st));
+    // the host vectors must outlive the async copies: synchronise the (tiny) uploads now
+    HIP_TRY(hipStreamSynchronize(st));
+    c->phase("upload");
+
+#define LAUNCH_TRY(call)                                                              \
+    do {                                                                              \
+        int e_ = (call);                                                              \
+        if (e_) {                                                                     \
+            c->set_error(std::string(#call) + ": " + hipGetErrorString((hipError_t)e_)); \
+            return LFX_E_DEVICE;                                                      \
+        }                                                                             \
+    } while (0)
+
+    LAUNCH_TRY(launch_match(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                            (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p));
+    c->phase("lz77_match");
+    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, (const uint32_t *)c->d_md.p,
+                            (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p));
+    c->phase("lz77_parse");
+    uint32_t split = nchunks && nchunks < 512 ? std::min<uint32_t>(64, 1024 / nchunks + 1) : 1;
+    LAUNCH_TRY(launch_histogram(st, (const ChunkDesc *)c->d_chunks.p, nchunks, split, (const uint32_t *)c->d_codes.p,
+                                (const uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_hist.p));
+    c->phase("histogram");
+    LAUNCH_TRY(launch_huffman(st, (const BlockDesc *)c->d_blocks.p, nblocks, (const uint32_t *)c->d_hist.p,
+                              (BlockCodes *)c->d_bc.p));
+    c->phase("huffman");
+    if (want_checksum) {
+        uint32_t *ck = (uint32_t *)c->d_ck.p;
+        LAUNCH_TRY(launch_checksum(st, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p));
+        c->phase("checksum");
+    }
+    return LFX_OK;
+}
+
+// Stage B: offsets → pack → framing.  `prefix` bytes are placed at the start of d_out; the DEFLATE
+// bits start at bit `start_bit` of d_out (prefix may end with a partial byte).
+int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, bool use_device_check,
+                uint64_t total_n, const uint8_t *prefix, uint32_t prefix_len, uint64_t start_bit,
+                uint8_t *d_out, uint64_t cap, EncodeResult *host_res) {
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    if (((uintptr_t)d_out & 3) != 0) { c->set_error("output buffer must be 4-byte aligned"); return LFX_E_ARG; }
+    const uint64_t trailer = with_trailer ? (format == LFX_GZIP ? 8 : format == LFX_ZLIB ? 4 : 0) : 0;
+    if (cap < prefix_len + trailer + 8) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
+    const uint64_t cap_words = cap / 4;  // whole dwords only (kernels write dwords)
+    const uint64_t cap_bits = (cap_words * 4 - trailer) * 8;
+    HIP_TRY(hipMemsetAsync(d_out, 0, cap_words * 4, st));
+    c->phase("memset_out");
+    EncodeResult *dres = (EncodeResult *)c->d_res.p;
+    LAUNCH_TRY(launch_offsets(st, (const BlockDesc *)c->d_blocks.p, c->cur_nblocks, (const BlockCodes *)c->d_bc.p,
+                              start_bit, cap_bits, (uint64_t *)c->d_block_start.p, dres));
+    LAUNCH_TRY(launch_pack(st, c->cur_in, c->cur_n, (const ChunkDesc *)c->d_chunks.p, c->cur_nchunks,
+                           (const BlockDesc *)c->d_blocks.p, c->cur_nblocks, c->cur_ntiles,
+                           (const uint32_t *)c->d_codes.p, (const uint32_t *)c->d_ncodes.p,
+                           (const BlockCodes *)c->d_bc.p, (const uint64_t *)c->d_block_start.p,
+                           (uint32_t *)c->d_tile_bits.p, (uint64_t *)c->d_tile_start.p, dres, 0,
+                           (uint32_t *)d_out));
+    c->phase("pack");
+    if (prefix_len) {
+        HIP_TRY(hipMemcpyAsync(c->d_small.p, prefix, prefix_len, hipMemcpyHostToDevice, st));
+        LAUNCH_TRY(launch_put_bytes(st, (const uint8_t *)c->d_small.p, prefix_len, 0, (uint32_t *)d_out));
+    }
+    if (!use_device_check) {
+        // combined checksum supplied by the caller (sharded encode): patch the device result
+        EncodeResult tmp{};
+        (void)tmp;
+        HIP_TRY(hipMemcpyAsync((uint8_t *)dres + offsetof(EncodeResult, crc32), &trailer_check, 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync((uint8_t *)dres + offsetof(EncodeResult, adler32), &trailer_check, 4, hipMemcpyHostToDevice, st));
+    }
+    LAUNCH_TRY(launch_trailer(st, with_trailer ? format : LFX_DEFLATE, (uint32_t)total_n, 0, dres, (uint32_t *)d_out));
+    HIP_TRY(hipMemcpyAsync(c->h_res, dres, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+    c->phase("frame");
+    HIP_TRY(hipStreamSynchronize(st));
+    *host_res = *(EncodeResult *)c->h_res;
+    if (host_res->status != 0) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
+    return LFX_OK;
+}
+
+}  // namespace lfx
+
+extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
+                                 const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    lfx_encode_opts d = norm_opts(o);
+    int rc = check_opts(d);
+    if (rc) { c->set_error("option outside the reference's domain"); return rc; }
+    std::vector<uint8_t> hdr;
+    if ((rc = container_header(format, d, hdr))) { c->set_error("bad container options"); return rc; }
+    PlanOpts po = plan_opts(format, d);
+    Planner pl(po);
+    apply_schedule(pl, s, n);
+    Plan &plan = pl.finish();
+    if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) return rc;
+    EncodeResult res;
+    rc = encode_emit(c, format, true, 0, true, n, hdr.data(), (uint32_t)hdr.size(), 8 * (uint64_t)hdr.size(),
+                     (uint8_t *)d_out, cap, &res);
+    if (rc) return rc;
+    if (out_len) *out_len = res.out_bytes;
+    return LFX_OK;
+}
+
+extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
+                               const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    (void)hipSetDevice(c->device);
+    uint64_t bound = lfx_encode_bound(n, o, s);
+    if (bound == 0) { c->set_error("option outside the reference's domain"); return LFX_E_ARG; }
+    int rc;
+    if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+    if ((rc = c->d_io_out.reserve(bound))) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(c->d_io_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    uint64_t len = 0;
+    rc = lfx_encode_device(cc, format, o, s, c->d_io_in.p, n, c->d_io_out.p, bound & ~3ull, &len);
+    if (rc) return rc;
+    if (len > cap) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
+    HIP_TRY(hipMemcpy(out, c->d_io_out.p, len, hipMemcpyDeviceToHost));
+    if (out_len) *out_len = len;
+    return LFX_OK;
+}
+
+// ---- sharded encode -------------------------------------------------------------------------
+extern "C" int lfx_encode_shard_prepare(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
+                                        const void *d_in, uint64_t n, int is_first, int is_last,
+                                        lfx_shard_info *info) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    lfx_encode_opts d = norm_opts(o);
+    int rc = check_opts(d);
+    if (rc) return rc;
+    if (d.no_compression) { c->set_error("sharded encode of stored blocks is not supported (their size depends on the bit phase)"); return LFX_E_UNSUPPORTED; }
+    PlanOpts po = plan_opts(format, d);
+    Planner pl(po);
+    apply_schedule(pl, s, n);
+    Plan *plan;
+    if (is_last) {
+        plan = &pl.finish();
+    } else {
+        // a non-last shard must end on a block boundary with nothing buffered: close the block
+        // exactly as the stream would have (block_size reached) — otherwise the shards would not
+        // concatenate to what one encoder emits
+        plan = &pl.plan();
+        Planner probe = pl;
+        Plan &fin = probe.finish();
+        if (fin.blocks.size() != plan->blocks.size() + 1 || fin.blocks.back().in_len != 0) {
+            c->set_error("shard boundary is not a block boundary under this write schedule");
+            return LFX_E_ARG;
+        }
+        plan->n_codes_cap = fin.n_codes_cap;
+        plan->n_tiles = plan->chunks.empty() ? 0 : plan->chunks.back().tile_base + div_up(plan->chunks.back().len + 1, PACK_TILE);
+    }
+    c->shard_hdr.clear();
+    if (is_first && (rc = container_header(format, d, c->shard_hdr))) return rc;
+    c->shard_format = format;
+    c->shard_last = is_last != 0;
+    if ((rc = encode_prepare(c, *plan, po, (const uint8_t *)d_in, n, true))) return rc;
+    // total bits for phase 0 (compressed blocks only → phase independent)
+    hipStream_t st = c->stream;
+    LAUNCH_TRY(launch_offsets(st, (const BlockDesc *)c->d_blocks.p, c->cur_nblocks, (const BlockCodes *)c->d_bc.p,
+                              0, ~0ull, (uint64_t *)c->d_block_start.p, (EncodeResult *)c->d_res.p));
+    HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    EncodeResult r = *(EncodeResult *)c->h_res;
+    info->total_bits = r.end_bit;  // for the last shard this includes alignment relative to phase 0
+    if (is_last) {
+        // report unaligned bits: recompute without the final alignment
+        // (end_bit was aligned from phase 0; the true alignment happens in emit with the real phase)
+        // body bits = sum of block bits; the last block is never a stored block here
+        info->total_bits = r.end_bit;  // corrected below by emit(); callers only need sums of non-last shards
+    }
+    info->n_bytes = n;
+    info->crc32 = r.crc32;
+    info->adler32 = r.adler32;
+    return LFX_OK;
+}
+
+extern "C" int lfx_encode_shard_emit(lfx_ctx *cc, uint64_t start_bit, uint32_t combined_check, uint64_t total_n,
+                                     void *d_out, uint64_t cap, uint64_t *out_len) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    // d_out[0] is byte start_bit/8 of the member; a first shard carries the container header
+    const uint64_t rel_start = c->shard_hdr.empty() ? (start_bit & 7) : start_bit;
+    EncodeResult res;
+    int rc = encode_emit(c, c->shard_format, c->shard_last, combined_check, false, total_n,
+                         c->shard_hdr.data(), (uint32_t)c->shard_hdr.size(), rel_start, (uint8_t *)d_out, cap, &res);
+    if (rc) return rc;
+    if (out_len) *out_len = c->shard_last ? res.out_bytes : (res.end_bit + 7) / 8;
+    return LFX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream encoder: io::Write shaped
+struct lfx_encoder {
+    Ctx *c;
+    int format;
+    lfx_encode_opts o;
+    std::string filename, comment;
+    std::vector<uint8_t> extra;
+    PlanOpts po;
+    lfx_write_cb w;
+    lfx_flush_cb f;
+    void *user;
+    std::vector<uint8_t> pending;       // input bytes of the blocks not yet encoded
+    std::vector<uint64_t> events;       // write sizes / LFX_SCHED_FLUSH since `pending` began
+    uint64_t total_in = 0;
+    uint32_t crc = 0, adler = 1;        // running container checksum (combined per batch)
+    uint8_t carry = 0;                  // partial last byte of the bitstream so far
+    uint32_t carry_bits = 0;
+    bool finished = false, failed = false;
+    std::string err;
+    DevBuf d_in, d_out;
+};
+
+static int enc_emit_bytes(lfx_encoder *e, const uint8_t *p, size_t n) {
+    if (!n) return LFX_OK;
+    int64_t r = e->w(e->user, p, n);
+    if (r != (int64_t)n) { e->err = "write callback failed"; e->failed = true; return LFX_E_IO; }
+    return LFX_OK;
+}
+
+// encode everything pending as one batch; `final` closes the stream
+static int enc_run(lfx_encoder *e, bool final) {
+    Ctx *c = e->c;
+    (void)hipSetDevice(c->device);
+    Planner pl(e->po);
+    for (uint64_t ev : e->events) {
+        if (ev == LFX_SCHED_FLUSH) pl.flush(); else pl.write(ev);
+    }
+    Plan *plan = final ? &pl.finish() : &pl.plan();
+    if (!final) {
+        plan->n_codes_cap = 0;
+        for (auto &ch : plan->chunks) plan->n_codes_cap = std::max(plan->n_codes_cap, ch.code_off + ch.len + 1);
+        plan->n_tiles = plan->chunks.empty() ? 0 : plan->chunks.back().tile_base + div_up(plan->chunks.back().len + 1, PACK_TILE);
+    }
+    const uint64_t n = e->pending.size();
+    int rc;
+    if ((rc = e->d_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+    const uint64_t bound = n + n / 4 + 1024 * (uint64_t)plan->blocks.size() + 128;
+    if ((rc = e->d_out.reserve(bound))) return rc;
+    if (n && hipMemcpyAsync(e->d_in.p, e->pending.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
+    if ((rc = encode_prepare(c, *plan, e->po, (const uint8_t *)e->d_in.p, n, e->format != LFX_DEFLATE))) { e->err = c->err; return rc; }
+    EncodeResult res;
+    uint8_t prefix[1] = {e->carry};
+    // the container trailer is written by the host here (the checksum spans batches)
+    rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits,
+                     (uint8_t *)e->d_out.p, bound & ~3ull, &res);
+    if (rc) { e->err = c->err; return rc; }
+    if (e->format == LFX_GZIP) e->crc = e->total_in == n ? res.crc32 : lfx_crc32_combine(e->crc, res.crc32, n);
+    if (e->format == LFX_ZLIB) e->adler = e->total_in == n ? res.adler32 : lfx_adler32_combine(e->adler, res.adler32, n);
+    const uint64_t whole = final ? (res.end_bit + 7) / 8 : res.end_bit / 8;
+    std::vector<uint8_t> host(whole + 1);
+    if (hipMemcpy(host.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
+    e->carry_bits = final ? 0 : (uint32_t)(res.end_bit & 7);
+    e->carry = e->carry_bits ? host[whole] : 0;
+    e->pending.clear();
+    e->events.clear();
+    return enc_emit_bytes(e, host.data(), whole);
+}
+
+extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encode_opts *o, lfx_write_cb w,
+                                        lfx_flush_cb f, void *user, int *status) {
+    if (!cc || !w) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
+    lfx_encode_opts d = norm_opts(o);
+    int rc = check_opts(d);
+    if (rc) { if (status) *status = rc; return nullptr; }
+    lfx_encoder *e = new lfx_encoder();
+    e->c = reinterpret_cast<Ctx *>(cc);
+    e->format = format;
+    e->o = d;
+    if (d.filename) { e->filename = d.filename; e->o.filename = e->filename.c_str(); }
+    if (d.comment) { e->comment = d.comment; e->o.comment = e->comment.c_str(); }
+    if (d.extra) { e->extra.assign(d.extra, d.extra + d.extra_len); e->o.extra = e->extra.data(); }
+    e->po = plan_opts(format, e->o);
+    e->w = w;
+    e->f = f;
+    e->user = user;
+    // gzip/zlib write their header immediately (gzip.rs:805, zlib.rs:578)
+    std::vector<uint8_t> hdr;
+    rc = container_header(format, e->o, hdr);
+    if (!rc) rc = enc_emit_bytes(e, hdr.data(), hdr.size());
+    if (rc) { if (status) *status = rc; delete e; return nullptr; }
+    if (status) *status = LFX_OK;
+    return e;
+}
+
+static bool enc_idle(const lfx_encoder *e) {
+    // nothing buffered in the reference's LZ77 / block buffers ⇔ replaying the events leaves the
+    // planner with an empty tail.  Cheap check: replay (events are few per batch).
+    Planner pl(e->po);
+    for (uint64_t ev : e->events) { if (ev == LFX_SCHED_FLUSH) pl.flush(); else pl.write(ev); }
+    Planner probe = pl;
+    size_t before = pl.plan().blocks.size();
+    Plan &fin = probe.finish();
+    return fin.blocks.size() == before + 1 && fin.blocks.back().in_len == 0 && fin.blocks.back().type != BT_RAW;
+}
+
+extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n) {
+    if (!e || e->finished) return -(int64_t)LFX_E_ARG;
+    if (e->failed) return -(int64_t)LFX_E_IO;
+    e->pending.insert(e->pending.end(), p, p + n);
+    e->events.push_back(n);
+    e->total_in += n;
+    // batch: encode once >= 64 MiB of whole blocks are pending and the encoder state is idle
+    if (e->pending.size() >= (64u << 20) && enc_idle(e)) {
+        int rc = enc_run(e, false);
+        if (rc) { e->failed = true; return -(int64_t)rc; }
+    }
+    return (int64_t)n;  // encode.rs:243: always consumes everything
+}
+
+extern "C" int lfx_encoder_flush(lfx_encoder *e) {
+    if (!e || e->finished) return LFX_E_ARG;
+    if (e->failed) return LFX_E_IO;
+    e->events.push_back(LFX_SCHED_FLUSH);
+    int rc = enc_run(e, false);  // io::Write::flush pushes everything to the inner writer
+    if (rc) { e->failed = true; return rc; }
+    if (e->f && e->f(e->user) != 0) { e->failed = true; e->err = "flush callback failed"; return LFX_E_IO; }
+    return LFX_OK;
+}
+
+extern "C" int lfx_encoder_finish(lfx_encoder *e) {
+    if (!e || e->finished) return LFX_E_ARG;
+    if (e->failed) return LFX_E_IO;
+    e->finished = true;
+    int rc = enc_run(e, true);
+    if (rc) return rc;
+    uint8_t t[8];
+    size_t nt = 0;
+    if (e->format == LFX_GZIP) {  // Trailer::write_to gzip.rs:114-121; ISIZE wraps (gzip.rs:893)
+        uint32_t c = e->total_in ? e->crc : 0, sz = (uint32_t)e->total_in;
+        t[0] = c; t[1] = c >> 8; t[2] = c >> 16; t[3] = c >> 24;
+        t[4] = sz; t[5] = sz >> 8; t[6] = sz >> 16; t[7] = sz >> 24;
+        nt = 8;
+    } else if (e->format == LFX_ZLIB) {  // zlib.rs:630-639
+        uint32_t a = e->total_in ? e->adler : 1;
+        t[0] = a >> 24; t[1] = a >> 16; t[2] = a >> 8; t[3] = a;
+        nt = 4;
+    }
+    rc = enc_emit_bytes(e, t, nt);
+    if (rc) return rc;
+    if (e->f && e->f(e->user) != 0) { e->err = "flush callback failed"; return LFX_E_IO; }
+    return LFX_OK;
+}
+extern "C" const char *lfx_encoder_last_error(const lfx_encoder *e) { return e ? e->err.c_str() : "null"; }
+extern "C" void lfx_encoder_free(lfx_encoder *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->c->device);
+    e->d_in.release();
+    e->d_out.release();
+    delete e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lz77Encode plug-in
+struct lfx_lz77 {
+    Ctx *c;
+    uint32_t window, max_len;
+    std::vector<uint8_t> buf;
+    DevBuf d_in;
+    std::vector<uint32_t> host_codes;
+};
+extern "C" lfx_lz77 *lfx_lz77_new(lfx_ctx *cc, uint32_t window_size, uint32_t max_length, int *status) {
+    if (!cc) { if (status) *status = LFX_E_DEVICE; return nullptr; }
+    if (max_length < 3) { if (status) *status = LFX_E_ARG; return nullptr; }
+    lfx_lz77 *z = new lfx_lz77();
+    z->c = reinterpret_cast<Ctx *>(cc);
+    z->window = std::min(window_size, MAX_WINDOW);
+    z->max_len = std::min(max_length, MAX_LENGTH);
+    if (status) *status = LFX_OK;
+    return z;
+}
+extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
+    // DefaultLz77Encoder::flush default.rs:69-109 — one chunk through match + parse
+    Ctx *c = z->c;
+    (void)hipSetDevice(c->device);
+    const uint64_t n = z->buf.size();
+    if (n == 0) return LFX_OK;
+    PlanOpts po;
+    po.window_size = z->window;
+    po.max_length = z->max_len;
+    Plan plan;
+    ChunkDesc ch{};
+    ch.len = n;
+    plan.chunks.push_back(ch);
+    BlockDesc bd{};
+    bd.type = BT_DYNAMIC;
+    bd.n_chunks = 1;
+    plan.blocks.push_back(bd);
+    plan.n_codes_cap = n + 1;
+    plan.n_tiles = div_up(n + 1, PACK_TILE);
+    int rc;
+    if ((rc = z->d_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+    HIP_TRY(hipMemcpyAsync(z->d_in.p, z->buf.data(), n, hipMemcpyHostToDevice, c->stream));
+    if ((rc = encode_prepare(c, plan, po, (const uint8_t *)z->d_in.p, n, false))) return rc;
+    uint32_t nc = 0;
+    HIP_TRY(hipMemcpy(&nc, c->d_ncodes.p, 4, hipMemcpyDeviceToHost));
+    z->host_codes.resize(nc);
+    if (nc) HIP_TRY(hipMemcpy(z->host_codes.data(), c->d_codes.p, 4ull * nc, hipMemcpyDeviceToHost));
+    z->buf.clear();  // default.rs:108
+    if (sink && nc) sink(user, z->host_codes.data(), nc);
+    return LFX_OK;
+}
+extern "C" int lfx_lz77_encode(lfx_lz77 *z, const uint8_t *buf, size_t len, lfx_sink_cb sink, void *user) {
+    z->buf.insert(z->buf.end(), buf, buf + len);                     // default.rs:64
+    if (z->buf.size() >= (size_t)z->window * 8) return lfx_lz77_flush(z, sink, user);  // default.rs:65-67
+    return LFX_OK;
+}
+extern "C" uint32_t lfx_lz77_window_size(const lfx_lz77 *z) { return z->window; }
+extern "C" int lfx_lz77_compression_level(const lfx_lz77 *) { return LFX_LEVEL_BALANCE; }
+extern "C" void lfx_lz77_free(lfx_lz77 *z) {
+    if (!z) return;
+    (void)hipSetDevice(z->c->device);
+    z->d_in.release();
+    delete z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// debug hooks for the CPU test-suite: run the SAME host/device-shared code on the host.
+// Not a product path (no compression work can be reached through them).
+extern "C" int lfx_debug_huff_block(const uint32_t *hist320, uint32_t type, uint32_t *lit288, uint32_t *dist32,
+                                    uint32_t *hdr160, uint32_t *hdr_bits, uint64_t *body_bits) {
+    static HuffScratch S;
+    static BlockCodes bc;
+    memset(&bc, 0, sizeof bc);
+    huff_block_build(hist320, type, &bc, S, 0, 1);
+    memcpy(lit288, bc.lit, sizeof bc.lit);
+    memcpy(dist32, bc.dist, sizeof bc.dist);
+    memcpy(hdr160, bc.hdr, sizeof bc.hdr);
+    *hdr_bits = bc.hdr_bits;
+    *body_bits = bc.body_bits;
+    return 0;
+}
+extern "C" int lfx_debug_plan(int format, const lfx_encode_opts *o, const lfx_schedule *s, uint64_t n,
+                              uint64_t *chunk_out /* in_off,len,block,flags per chunk */, size_t max_chunks,
+                              size_t *n_chunks, uint64_t *block_out /* type,final,first,n,in_off,in_len */,
+                              size_t max_blocks, size_t *n_blocks) {
+    lfx_encode_opts d = norm_opts(o);
+    if (check_opts(d)) return LFX_E_ARG;
+    Planner pl(plan_opts(format, d));
+    apply_schedule(pl, s, n);
+    Plan &p = pl.finish();
+    *n_chunks = p.chunks.size();
+    *n_blocks = p.blocks.size();
+    for (size_t i = 0; i < p.chunks.size() && i < max_chunks; i++) {
+        chunk_out[4 * i] = p.chunks[i].in_off; chunk_out[4 * i + 1] = p.chunks[i].len;
+        chunk_out[4 * i + 2] = p.chunks[i].block; chunk_out[4 * i + 3] = p.chunks[i].flags;
+    }
+    for (size_t i = 0; i < p.blocks.size() && i < max_blocks; i++) {
+        block_out[6 * i] = p.blocks[i].type; block_out[6 * i + 1] = p.blocks[i].final;
+        block_out[6 * i + 2] = p.blocks[i].first_chunk; block_out[6 * i + 3] = p.blocks[i].n_chunks;
+        block_out[6 * i + 4] = p.blocks[i].in_off; block_out[6 * i + 5] = p.blocks[i].in_len;
+    }
+    return 0;
+}
+extern "C" void lfx_debug_symbols(uint32_t length, uint32_t distance, uint32_t *out6) {
+    out6[0] = len_symbol(length, out6[1], out6[2]);
+    out6[3] = dist_symbol(distance, out6[4], out6[5]);
+}

@@ -1,0 +1,58 @@
+// lfx_common.h — descriptors shared by the host planner and the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define LFX_HD __host__ __device__
+#else
+#define LFX_HD
+#endif
+
+namespace lfx {
+
+// DEFLATE block types (reference src/deflate/mod.rs:34-39)
+enum : uint32_t { BT_RAW = 0, BT_FIXED = 1, BT_DYNAMIC = 2 };
+
+constexpr uint32_t MAX_WINDOW = 32768;  // libflate_lz77/src/lib.rs:21-24
+constexpr uint32_t MAX_LENGTH = 258;    // lib.rs:18
+constexpr uint32_t CODE_EOB = 0x01000000u;  // (256 << 16) | 0 : Symbol::EndOfBlock as a code word
+
+// One LZ77 flush unit (DefaultLz77Encoder::flush, default.rs:69-109): no match crosses it.
+struct ChunkDesc {
+    uint64_t in_off;    // first input byte
+    uint64_t len;       // bytes (< 4 GiB: positions are u32 in the reference, default.rs:78)
+    uint64_t code_off;  // first slot of this chunk in the code array
+    uint32_t block;     // owning block
+    uint32_t flags;     // CH_*
+    uint64_t tile_base; // first pack tile of this chunk (prefix of ceil((len+1)/TILE))
+};
+enum : uint32_t {
+    CH_LAST_IN_BLOCK = 1,  // parse appends Symbol::EndOfBlock (encode.rs:417)
+    CH_LITERALS = 2,       // NoCompressionLz77Encoder: every byte a literal (lib.rs:127-135)
+};
+
+// One DEFLATE block (Block::flush, encode.rs:287-295)
+struct BlockDesc {
+    uint64_t in_off, in_len;  // RAW: the bytes stored; compressed: bytes covered (informative)
+    uint32_t first_chunk, n_chunks;
+    uint32_t type;   // BT_*
+    uint32_t final;  // BFINAL
+    uint32_t align_after;  // 1: byte-align after this block (Block::finish → BitWriter::flush)
+    uint32_t _pad;
+};
+
+// per-block result of the Huffman stage
+struct BlockCodes {
+    uint32_t lit[288];   // (bits | width << 16), bits already reversed for LSB-first emission
+    uint32_t dist[32];
+    uint64_t body_bits;  // 3 + header bits + symbol bits (compressed blocks)
+    uint32_t hdr_bits;   // dynamic header bits (after the 3 block bits)
+    uint32_t _pad;
+    uint32_t hdr[160];   // header bit string, LSB-first, up to 5120 bits
+};
+
+constexpr uint32_t PACK_TILE = 2048;  // codes per pack tile
+
+LFX_HD inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+}  // namespace lfx

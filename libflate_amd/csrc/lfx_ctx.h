@@ -1,0 +1,57 @@
+// lfx_ctx.h — per-GPU context: HIP stream, grow-only scratch in HBM, last error, phase timers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "lfx_common.h"
+#include "lfx_device.h"
+
+namespace lfx {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);  // grow-only; contents are NOT preserved
+    void release();
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    void set_error(const std::string &e) { err = e; }
+
+    // encode scratch
+    DevBuf d_chunks, d_blocks, d_segs, d_md, d_codes, d_ncodes, d_hist, d_bc, d_block_start, d_tile_bits,
+        d_tile_start, d_ck, d_res, d_small, d_io_in, d_io_out;
+    // decode scratch
+    DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks;
+    std::vector<DevBuf *> all_bufs() {
+        return {&d_chunks, &d_blocks, &d_segs, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
+                &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_io_in, &d_io_out,
+                &d_dec_streams, &d_dec_state, &d_dec_tmp, &d_dec_cand, &d_dec_blocks};
+    }
+    void *h_res = nullptr;  // pinned, 4 KiB
+
+    // state between encode_prepare and encode_emit
+    uint32_t cur_nchunks = 0, cur_nblocks = 0;
+    uint64_t cur_ntiles = 0, cur_n = 0;
+    const uint8_t *cur_in = nullptr;
+    std::vector<uint8_t> shard_hdr;
+    int shard_format = 0;
+    bool shard_last = false;
+
+    // phase timers
+    bool timing_on = false;
+    hipEvent_t ev[17] = {};
+    char ev_name[17][24] = {};
+    int n_ev = 0;
+    void phase(const char *name);
+};
+
+int encode_prepare(Ctx *c, const struct Plan &plan, const struct PlanOpts &po, const uint8_t *d_in,
+                   uint64_t n, bool want_checksum);
+
+}  // namespace lfx

@@ -1,0 +1,500 @@
+// lfx_decode.cpp — host orchestration of the inflate path (C ABI: lfx_decode_*, lfx_decoder_*).
+// Every compressed bit is decoded on the GPU; the host only sequences kernels, chains block
+// boundaries and formats error messages.
+#include "../../include/lfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lfx_ctx.h"
+#include "lfx_decode.h"
+#include "lfx_device.h"
+
+using namespace lfx;
+
+#define HIP_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            c->set_error(std::string(#expr) + ": " + hipGetErrorString(e_));          \
+            return LFX_E_DEVICE;                                                      \
+        }                                                                             \
+    } while (0)
+#define LAUNCH_TRY(call)                                                              \
+    do {                                                                              \
+        int e_ = (call);                                                              \
+        if (e_) {                                                                     \
+            c->set_error(std::string(#call) + ": " + hipGetErrorString((hipError_t)e_)); \
+            return LFX_E_DEVICE;                                                      \
+        }                                                                             \
+    } while (0)
+
+namespace {
+
+// messages: prefixes match the reference texts quoted in SURVEY.md §4
+std::string format_error(uint32_t err, uint32_t a0, uint32_t a1) {
+    char m[200];
+    switch (err) {
+        case ERR_EOF: return "failed to fill whole buffer";
+        case ERR_HUFF: return "Invalid huffman coded stream";
+        case ERR_CONFLICT: snprintf(m, sizeof m, "Bit region conflict: symbol=%u", a0); return m;
+        case ERR_HDIST: snprintf(m, sizeof m, "The value of HDIST is too big: max=30, actual=%u", a0); return m;
+        case ERR_NO_PREV: return "No preceding value";
+        case ERR_DIST_LIST:
+            snprintf(m, sizeof m, "The length of `distance_code_bitwidthes` is too large: actual=%u, expected=%u", a0, a1);
+            return m;
+        case ERR_286: snprintf(m, sizeof m, "The value %u must not occur in compressed data", a0); return m;
+        case ERR_BACKREF: snprintf(m, sizeof m, "Too long backword reference: buffer.len=%u, distance=%u", a0, a1); return m;
+        case ERR_BTYPE3: return "btype 0x11 of DEFLATE is reserved(error) value";
+        case ERR_LEN_NLEN: snprintf(m, sizeof m, "LEN=%u is not the one's complement of NLEN=%u", a0, a1); return m;
+        case ERR_STORED_SHORT: snprintf(m, sizeof m, "The reader has incorrect length: expected %u, read %u", a0, a1); return m;
+        case ERR_NOSPACE: return "output capacity too small";
+        case ERR_ZLIB_CHECK:
+            snprintf(m, sizeof m, "Inconsistent ZLIB check bits: `CMF(%u) * 256 + FLG(%u)` must be a multiple of 31", a0, a1);
+            return m;
+        case ERR_METHOD: snprintf(m, sizeof m, "Compression methods other than DEFLATE(8) are unsupported: method=%u", a0); return m;
+        case ERR_CINFO: snprintf(m, sizeof m, "CINFO above 7 are not allowed: value=%u", a0); return m;
+        case ERR_FDICT: snprintf(m, sizeof m, "Preset dictionaries are not supported: dictionary_id=0x%X", a0); return m;
+        case ERR_GZIP_ID: return "Unexpected GZIP ID";
+        case ERR_HCRC: snprintf(m, sizeof m, "CRC16 of GZIP header mismatched: value=%u, expected=%u", a0, a1); return m;
+        case ERR_CRC32: snprintf(m, sizeof m, "CRC32 mismatched: value=%u, expected=%u", a0, a1); return m;
+        case ERR_ADLER32: snprintf(m, sizeof m, "Adler32 checksum mismatched: value=%u, expected=%u", a0, a1); return m;
+        default: return "";
+    }
+}
+int map_status(uint32_t st) {
+    return st == 0 ? LFX_OK : st == 1 ? LFX_E_INVALID_DATA : st == 2 ? LFX_E_UNEXPECTED_EOF : LFX_E_NOSPACE;
+}
+
+struct MemberResult {
+    int status = LFX_OK;
+    uint64_t out_len = 0;        // bytes produced (also on failure)
+    uint64_t blk_out_start = 0;  // bytes of completed blocks
+    uint64_t end_byte = 0;       // input byte after the last DEFLATE byte (relative to member base)
+    std::string msg;
+};
+
+// run `njobs` inflate jobs and fetch their results
+int run_jobs(Ctx *c, const uint8_t *d_in, uint8_t *d_out, const std::vector<InflateJob> &jobs,
+             std::vector<InflateResult> &res) {
+    const size_t n = jobs.size();
+    res.resize(n);
+    if (!n) return LFX_OK;
+    int rc;
+    if ((rc = c->d_dec_streams.reserve(sizeof(InflateJob) * n))) return rc;
+    if ((rc = c->d_dec_state.reserve(sizeof(InflateResult) * n))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, jobs.data(), sizeof(InflateJob) * n, hipMemcpyHostToDevice, c->stream));
+    LAUNCH_TRY(launch_inflate(c->stream, d_in, d_out, (const InflateJob *)c->d_dec_streams.p,
+                              (InflateResult *)c->d_dec_state.p, (uint32_t)n));
+    HIP_TRY(hipMemcpyAsync(res.data(), c->d_dec_state.p, sizeof(InflateResult) * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LFX_OK;
+}
+
+// Decode the DEFLATE stream that starts at byte `off0` of d_in[0..n) into d_out[0..cap).
+// hist0 = 0 (a member starts with an empty Lz77Decoder buffer, gzip.rs:1000-1005).
+int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8_t *d_out, uint64_t cap,
+                   MemberResult &mr) {
+    hipStream_t st = c->stream;
+    std::vector<InflateJob> jobs;
+    std::vector<InflateResult> res;
+    bool parallel_done = false;
+    const uint64_t comp = n > off0 ? n - off0 : 0;
+    if (comp >= (64u << 10)) {
+        // ---- speculative block-start search
+        const uint32_t max_cand = 1u << 22;
+        int rc;
+        if ((rc = c->d_dec_cand.reserve(8ull * max_cand + 64))) return rc;
+        uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;
+        uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 64);
+        HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
+        LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, max_cand));
+        uint32_t n1 = 0;
+        HIP_TRY(hipMemcpyAsync(&n1, d_count, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        c->phase("find1");
+        if (n1 <= max_cand) {
+            std::vector<uint64_t> cand(n1);
+            std::vector<uint8_t> ok(n1);
+            if (n1) {
+                if ((rc = c->d_dec_tmp.reserve(n1))) return rc;
+                LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, n1, (uint8_t *)c->d_dec_tmp.p));
+                HIP_TRY(hipMemcpyAsync(cand.data(), d_cand, 8ull * n1, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(ok.data(), c->d_dec_tmp.p, n1, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            c->phase("find2");
+            std::vector<uint64_t> starts;
+            starts.push_back(off0 * 8);  // the first block's start is known
+            for (uint32_t i = 0; i < n1; i++) if (ok[i] && cand[i] != off0 * 8) starts.push_back(cand[i]);
+            std::sort(starts.begin(), starts.end());
+            // ---- pass 1: every candidate block is decoded (no output) for its length and end bit
+            jobs.clear();
+            for (uint64_t sb : starts) {
+                InflateJob j{};
+                j.in_off = 0; j.in_len = n; j.start_bit = sb;
+                j.out_off = 0; j.out_cap = ~0ull; j.hist_avail = 0;
+                j.flags = JOB_SINGLE_BLOCK | JOB_COUNT_ONLY;
+                jobs.push_back(j);
+            }
+            if ((rc = run_jobs(c, d_in, d_out, jobs, res))) return rc;
+            c->phase("pass1");
+            // ---- chain from the known first block
+            std::vector<size_t> chain;
+            uint64_t pos = off0 * 8, total = 0;
+            bool ok_chain = false;
+            for (;;) {
+                auto it = std::lower_bound(starts.begin(), starts.end(), pos);
+                if (it == starts.end() || *it != pos) break;
+                const size_t k = it - starts.begin();
+                const InflateResult &r = res[k];
+                if (r.status != 0 || r.needs_hist) break;
+                chain.push_back(k);
+                total += r.out_len;
+                if (r.final_seen) { ok_chain = true; break; }
+                if (r.end_bit <= pos) break;
+                pos = r.end_bit;
+            }
+            if (ok_chain && total <= cap) {
+                // ---- pass 2: the chained blocks are decoded again, each at its output offset
+                std::vector<InflateJob> j2;
+                uint64_t at = 0;
+                for (size_t k : chain) {
+                    InflateJob j{};
+                    j.in_off = 0; j.in_len = n; j.start_bit = starts[k];
+                    j.out_off = at; j.out_cap = res[k].out_len; j.hist_avail = at;
+                    j.flags = JOB_SINGLE_BLOCK;
+                    at += res[k].out_len;
+                    j2.push_back(j);
+                }
+                std::vector<InflateResult> r2;
+                if ((rc = run_jobs(c, d_in, d_out, j2, r2))) return rc;
+                c->phase("pass2");
+                bool all_ok = true;
+                for (size_t i = 0; i < r2.size(); i++)
+                    if (r2[i].status != 0 || r2[i].out_len != res[chain[i]].out_len) all_ok = false;
+                if (all_ok) {
+                    mr.status = LFX_OK;
+                    mr.out_len = total;
+                    mr.blk_out_start = total;
+                    mr.end_byte = (r2.back().end_bit + 7) / 8;
+                    parallel_done = true;
+                }
+            }
+        }
+    }
+    if (!parallel_done) {
+        // ---- serial walk of the whole stream by one wavefront (exact error / partial-output semantics)
+        jobs.clear();
+        InflateJob j{};
+        j.in_off = 0; j.in_len = n; j.start_bit = off0 * 8;
+        j.out_off = 0; j.out_cap = cap; j.hist_avail = 0; j.flags = 0;
+        jobs.push_back(j);
+        int rc;
+        if ((rc = run_jobs(c, d_in, d_out, jobs, res))) return rc;
+        c->phase("serial");
+        const InflateResult &r = res[0];
+        mr.status = map_status(r.status);
+        mr.out_len = r.out_len;
+        mr.blk_out_start = r.status ? r.blk_out_start : r.out_len;
+        mr.end_byte = std::min<uint64_t>((r.end_bit + 7) / 8, n);
+        mr.msg = format_error(r.err, r.a0, r.a1);
+    }
+    return LFX_OK;
+}
+
+struct DecodeOutcome {
+    int status = LFX_OK;
+    uint64_t out_len = 0, delivered_len = 0, consumed = 0;
+    bool header_failed = false;  // the FIRST member's container header was rejected
+    std::string msg;
+};
+
+int decode_stream(Ctx *c, int format, uint32_t flags, const uint8_t *d_in, uint64_t n, uint8_t *d_out,
+                  uint64_t cap, DecodeOutcome &oc) {
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    c->n_ev = 0;
+    c->phase("start");
+    uint64_t base = 0, out_at = 0;
+    bool first = true;
+    int rc;
+    if ((rc = c->d_res.reserve(256))) return rc;
+    if ((rc = c->d_small.reserve(70000))) return rc;
+    for (;;) {
+        // ---- container header (device parse, one lane)
+        uint64_t off0 = 0;
+        if (format != LFX_DEFLATE) {
+            DecStream ds{base, n - base, 0, 0};
+            DecHeader dh{};
+            HIP_TRY(hipMemcpyAsync(c->d_small.p, &ds, sizeof ds, hipMemcpyHostToDevice, st));
+            LAUNCH_TRY(launch_container(st, format, 1, d_in, (const DecStream *)c->d_small.p,
+                                        (DecHeader *)((uint8_t *)c->d_small.p + 256)));
+            HIP_TRY(hipMemcpyAsync(&dh, (uint8_t *)c->d_small.p + 256, sizeof dh, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (dh.status != 0) {
+                if (!first && dh.status == 2) {  // MultiDecoder: UnexpectedEof on the next header = clean end
+                    oc.consumed = n;             // (gzip.rs:1150-1156; the partial header bytes were read)
+                    break;
+                }
+                oc.status = map_status(dh.status);
+                oc.header_failed = first;
+                oc.msg = format_error(dh.err, dh.a0, dh.a1);
+                oc.consumed = base + dh.deflate_off;
+                oc.out_len = oc.delivered_len = out_at;
+                return LFX_OK;
+            }
+            off0 = dh.deflate_off;
+        }
+        MemberResult mr;
+        if ((rc = inflate_member(c, d_in + base, n - base, off0, d_out + out_at, cap - out_at, mr))) return rc;
+        oc.out_len = out_at + mr.out_len;
+        oc.delivered_len = out_at + mr.blk_out_start;
+        oc.consumed = base + mr.end_byte;
+        if (mr.status != LFX_OK) { oc.status = mr.status; oc.msg = mr.msg; return LFX_OK; }
+        // ---- trailer
+        if (format != LFX_DEFLATE) {
+            const uint64_t need = format == LFX_GZIP ? 8 : 4;
+            const uint64_t tpos = base + mr.end_byte;
+            if (n - tpos < need) {
+                oc.status = LFX_E_UNEXPECTED_EOF;
+                oc.msg = "failed to fill whole buffer";
+                oc.consumed = n;
+                return LFX_OK;
+            }
+            uint8_t t[8];
+            const uint64_t nspans = div_up(std::max<uint64_t>(mr.out_len, 1), 1024);
+            if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
+            uint32_t *ck = (uint32_t *)c->d_ck.p;
+            LAUNCH_TRY(launch_checksum(st, d_out + out_at, mr.out_len, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p));
+            HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(t, d_in + tpos, need, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            c->phase("checksum");
+            const EncodeResult er = *(EncodeResult *)c->h_res;
+            oc.consumed = tpos + need;
+            if (format == LFX_GZIP) {
+                const uint32_t crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+                if (crc != er.crc32) {  // gzip.rs:1035-1040 (ISIZE is read but never verified)
+                    oc.status = LFX_E_INVALID_DATA;
+                    oc.msg = format_error(ERR_CRC32, er.crc32, crc);
+                    return LFX_OK;
+                }
+            } else {
+                const uint32_t ad = (uint32_t)t[0] << 24 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 8 | t[3];
+                if (ad != er.adler32) {
+                    oc.status = LFX_E_INVALID_DATA;
+                    oc.msg = format_error(ERR_ADLER32, er.adler32, ad);
+                    return LFX_OK;
+                }
+            }
+        }
+        out_at = oc.out_len;
+        if (!(format == LFX_GZIP && (flags & LFX_DEC_MULTI))) break;
+        base = oc.consumed;
+        first = false;
+    }
+    oc.out_len = oc.delivered_len = out_at;
+    c->phase("done");
+    return LFX_OK;
+}
+
+}  // namespace
+
+extern "C" int lfx_decode_device(lfx_ctx *cc, int format, uint32_t flags, const void *d_in, uint64_t n,
+                                 void *d_out, uint64_t cap, uint64_t *out_len, uint64_t *consumed) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    if (format < 0 || format > 2) return LFX_E_ARG;
+    DecodeOutcome oc;
+    int rc = decode_stream(c, format, flags, (const uint8_t *)d_in, n, (uint8_t *)d_out, cap, oc);
+    if (rc) return rc;
+    if (out_len) *out_len = oc.out_len;
+    if (consumed) *consumed = oc.consumed;
+    if (oc.status != LFX_OK) c->set_error(oc.msg);
+    return oc.status;
+}
+
+extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const void *in, uint64_t n, void *out,
+                               uint64_t cap, uint64_t *out_len, uint64_t *consumed) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    (void)hipSetDevice(c->device);
+    int rc;
+    if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+    if ((rc = c->d_io_out.reserve(std::max<uint64_t>(cap, 4)))) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(c->d_io_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    uint64_t ol = 0;
+    rc = lfx_decode_device(cc, format, flags, c->d_io_in.p, n, c->d_io_out.p, cap, &ol, consumed);
+    if (rc == LFX_E_DEVICE || rc == LFX_E_OOM || rc == LFX_E_ARG) return rc;
+    if (ol) HIP_TRY(hipMemcpy(out, c->d_io_out.p, ol, hipMemcpyDeviceToHost));
+    if (out_len) *out_len = ol;
+    return rc;
+}
+
+extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, const void *d_in,
+                                       const uint64_t *in_off, const uint64_t *in_len, void *d_out,
+                                       const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
+                                       int32_t *status) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    c->n_ev = 0;
+    c->phase("start");
+    if (!count) return LFX_OK;
+    std::vector<DecStream> streams(count);
+    for (uint32_t i = 0; i < count; i++) streams[i] = DecStream{in_off[i], in_len[i], out_off[i], out_cap[i]};
+    int rc;
+    const size_t sz_streams = sizeof(DecStream) * count, sz_hdr = sizeof(DecHeader) * count;
+    if ((rc = c->d_dec_blocks.reserve(sz_streams + sz_hdr + 16ull * count + 64))) return rc;
+    DecStream *d_streams = (DecStream *)c->d_dec_blocks.p;
+    DecHeader *d_hdrs = (DecHeader *)((uint8_t *)c->d_dec_blocks.p + sz_streams);
+    uint32_t *d_crc = (uint32_t *)((uint8_t *)d_hdrs + sz_hdr);
+    uint32_t *d_adler = d_crc + count;
+    uint64_t *d_consumed = (uint64_t *)(d_adler + count);
+    HIP_TRY(hipMemcpyAsync(d_streams, streams.data(), sz_streams, hipMemcpyHostToDevice, st));
+    LAUNCH_TRY(launch_container(st, format, count, (const uint8_t *)d_in, d_streams, d_hdrs));
+    std::vector<DecHeader> hdrs(count);
+    if (format != LFX_DEFLATE) {
+        HIP_TRY(hipMemcpyAsync(hdrs.data(), d_hdrs, sz_hdr, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    } else {
+        HIP_TRY(hipMemsetAsync(d_hdrs, 0, sz_hdr, st));
+    }
+    c->phase("headers");
+    std::vector<InflateJob> jobs(count);
+    for (uint32_t i = 0; i < count; i++) {
+        InflateJob j{};
+        j.in_off = in_off[i];
+        j.in_len = in_len[i];
+        j.start_bit = (format == LFX_DEFLATE ? 0 : hdrs[i].deflate_off) * 8;
+        if (format != LFX_DEFLATE && hdrs[i].status != 0) j.in_len = 0;  // header failed: nothing to decode
+        j.out_off = out_off[i];
+        j.out_cap = out_cap[i];
+        j.flags = 0;
+        jobs[i] = j;
+    }
+    if ((rc = c->d_dec_streams.reserve(sizeof(InflateJob) * count))) return rc;
+    if ((rc = c->d_dec_state.reserve(sizeof(InflateResult) * count))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, jobs.data(), sizeof(InflateJob) * count, hipMemcpyHostToDevice, st));
+    LAUNCH_TRY(launch_inflate(st, (const uint8_t *)d_in, (uint8_t *)d_out, (const InflateJob *)c->d_dec_streams.p,
+                              (InflateResult *)c->d_dec_state.p, count));
+    c->phase("inflate");
+    if (format != LFX_DEFLATE)
+        LAUNCH_TRY(launch_stream_checksum(st, (const uint8_t *)d_out, d_streams, (const InflateResult *)c->d_dec_state.p,
+                                          count, d_crc, d_adler));
+    LAUNCH_TRY(launch_verify_trailers(st, format, count, (const uint8_t *)d_in, d_streams, d_hdrs,
+                                      (InflateResult *)c->d_dec_state.p, d_crc, d_adler, d_consumed));
+    std::vector<InflateResult> res(count);
+    HIP_TRY(hipMemcpyAsync(res.data(), c->d_dec_state.p, sizeof(InflateResult) * count, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->phase("verify");
+    int worst = LFX_OK;
+    for (uint32_t i = 0; i < count; i++) {
+        if (out_len) out_len[i] = res[i].out_len;
+        const int s = map_status(res[i].status);
+        if (status) status[i] = s;
+        if (s != LFX_OK && worst == LFX_OK) { worst = s; c->set_error(format_error(res[i].err, res[i].a0, res[i].a1)); }
+    }
+    return LFX_OK;  // per-stream results are in status[]
+}
+
+// ------------------------------------------------------------------------------------------------
+// stream decoder: io::Read shaped.  The reader is drained up front (GPU decode needs the whole
+// compressed stream); bytes read past the end of the stream are reported by lfx_decoder_consumed().
+struct lfx_decoder {
+    Ctx *c;
+    int format;
+    uint32_t flags;
+    std::vector<uint8_t> in;
+    std::vector<uint8_t> out;
+    bool decoded = false;
+    DecodeOutcome oc;
+    uint64_t cursor = 0;
+    bool error_reported = false;
+    std::string err;
+};
+
+static int dec_run(lfx_decoder *d) {
+    Ctx *c = d->c;
+    (void)hipSetDevice(c->device);
+    int rc;
+    const uint64_t n = d->in.size();
+    // output size is unknown: try growing capacities (DEFLATE expands at most 1032:1)
+    uint64_t cap = std::max<uint64_t>(n * 8, 1 << 20);
+    for (;;) {
+        if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+        if ((rc = c->d_io_out.reserve(cap))) return rc;
+        if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
+        rc = decode_stream(c, d->format, d->flags, (const uint8_t *)c->d_io_in.p, n, (uint8_t *)c->d_io_out.p, cap, d->oc);
+        if (rc) return rc;
+        if (d->oc.status == LFX_E_NOSPACE && cap < n * 1040 + (1 << 20)) { cap *= 8; continue; }
+        break;
+    }
+    d->out.resize(d->oc.out_len);
+    if (d->oc.out_len && hipMemcpy(d->out.data(), c->d_io_out.p, d->oc.out_len, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
+    d->decoded = true;
+    d->err = d->oc.msg;
+    return LFX_OK;
+}
+
+extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags, lfx_read_cb r, void *user, int *status) {
+    if (!cc || !r) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
+    lfx_decoder *d = new lfx_decoder();
+    d->c = reinterpret_cast<Ctx *>(cc);
+    d->format = format;
+    d->flags = flags;
+    std::vector<uint8_t> chunk(1 << 16);
+    for (;;) {
+        int64_t k = r(user, chunk.data(), chunk.size());
+        if (k < 0) { if (status) *status = LFX_E_IO; delete d; return nullptr; }
+        if (k == 0) break;
+        d->in.insert(d->in.end(), chunk.begin(), chunk.begin() + k);
+    }
+    // gzip / zlib constructors parse the header eagerly and can fail (gzip.rs:941-944, zlib.rs:312-320):
+    // decode now; a header failure is reported here, anything later by read()
+    int rc = dec_run(d);
+    if (rc) { if (status) *status = rc; delete d; return nullptr; }
+    if (d->oc.header_failed) {
+        if (status) *status = d->oc.status;
+        d->c->set_error(d->oc.msg);
+        delete d;
+        return nullptr;
+    }
+    if (status) *status = LFX_OK;
+    return d;
+}
+
+extern "C" int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap) {
+    if (!d) return -(int64_t)LFX_E_ARG;
+    if (cap == 0) return 0;  // never latches end-of-stream (gzip.rs:1025-1027, zlib.rs:383-385)
+    const uint64_t limit = d->oc.status == LFX_OK ? d->oc.out_len : d->oc.delivered_len;
+    if (d->cursor < limit) {
+        const uint64_t k = std::min<uint64_t>(cap, limit - d->cursor);
+        memcpy(out, d->out.data() + d->cursor, k);
+        d->cursor += k;
+        return (int64_t)k;
+    }
+    if (d->oc.status != LFX_OK && !d->error_reported) {
+        d->error_reported = true;
+        return -(int64_t)d->oc.status;
+    }
+    return 0;
+}
+extern "C" int lfx_decoder_unread(lfx_decoder *d, const uint8_t **p, size_t *n) {
+    if (!d) return LFX_E_ARG;
+    // data decoded but not handed out: the rest of completed blocks + the partial block
+    const uint64_t start = std::min<uint64_t>(d->cursor, d->oc.out_len);
+    *p = d->out.data() + start;
+    *n = d->oc.out_len - start;
+    return LFX_OK;
+}
+extern "C" uint64_t lfx_decoder_consumed(const lfx_decoder *d) { return d ? d->oc.consumed : 0; }
+extern "C" const char *lfx_decoder_last_error(const lfx_decoder *d) { return d ? d->err.c_str() : "null"; }
+extern "C" void lfx_decoder_free(lfx_decoder *d) { delete d; }

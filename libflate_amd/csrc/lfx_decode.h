@@ -1,0 +1,78 @@
+// lfx_decode.h — descriptors of the inflate kernels (lfx_decode_kernels.hip) and their launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfx_common.h"
+
+namespace lfx {
+
+// error codes → reference message texts (formatted on the host, lfx_decode.cpp)
+enum : uint32_t {
+    ERR_NONE = 0,
+    ERR_EOF,           // UnexpectedEof: "failed to fill whole buffer"
+    ERR_HUFF,          // "Invalid huffman coded stream"                      huffman.rs:171-174
+    ERR_CONFLICT,      // "Bit region conflict"                               huffman.rs:107-119
+    ERR_HDIST,         // "The value of HDIST is too big: max=30, actual=N"   symbol.rs:395-403
+    ERR_NO_PREV,       // "No preceding value"                                symbol.rs:470
+    ERR_DIST_LIST,     // "The length of `distance_code_bitwidthes` is too large"  symbol.rs:433-443
+    ERR_286,           // "The value N must not occur in compressed data"     symbol.rs:216-223
+    ERR_BACKREF,       // "Too long backword reference: buffer.len=, distance="   lz77 lib.rs:173-185
+    ERR_BTYPE3,        // "btype 0x11 of DEFLATE is reserved(error) value"    decode.rs:158-160
+    ERR_LEN_NLEN,      // "LEN=.. is not the one's complement of NLEN=.."     decode.rs:88-93
+    ERR_STORED_SHORT,  // "The reader has incorrect length: expected, read"   decode.rs:98-105
+    ERR_NOSPACE,       // output capacity exhausted (ours)
+    ERR_ZLIB_CHECK, ERR_METHOD, ERR_CINFO, ERR_FDICT,   // zlib.rs:229-259
+    ERR_GZIP_ID, ERR_HCRC,                              // gzip.rs:398-441
+    ERR_CRC32, ERR_ADLER32,                             // gzip.rs:1035-1040, zlib.rs:396-401
+};
+
+struct DecStream {
+    uint64_t in_off, in_len;
+    uint64_t out_off, out_cap;
+};
+struct DecHeader {
+    uint64_t deflate_off;  // first DEFLATE byte relative to the stream start
+    uint32_t status;       // 0 ok, 1 InvalidData, 2 UnexpectedEof
+    uint32_t err, a0, a1;
+    uint32_t flags;
+    uint32_t _pad;
+};
+
+enum : uint32_t { JOB_SINGLE_BLOCK = 1, JOB_COUNT_ONLY = 2 };
+struct InflateJob {
+    uint64_t in_off;      // stream base
+    uint64_t in_len;      // bytes available from in_off
+    uint64_t start_bit;   // first bit to decode, relative to in_off
+    uint64_t out_off, out_cap;
+    uint64_t hist_avail;  // bytes of this member already produced before this job
+    uint32_t flags;
+    uint32_t _pad;
+};
+struct InflateResult {
+    uint64_t end_bit;  // bit after the last consumed bit (stored blocks: after the data)
+    uint64_t out_len;
+    uint32_t status;   // 0 ok, 1 InvalidData, 2 UnexpectedEof, 3 output capacity
+    uint32_t final_seen;
+    uint32_t err, a0, a1;
+    uint32_t needs_hist;
+    uint32_t nblocks;
+    uint32_t _pad;
+    uint64_t blk_out_start;  // output bytes before the block that was being decoded last
+};
+
+int launch_container(hipStream_t st, int format, uint32_t count, const uint8_t *in,
+                     const DecStream *streams, DecHeader *hdrs);
+int launch_inflate(hipStream_t st, const uint8_t *in, uint8_t *out, const InflateJob *jobs,
+                   InflateResult *results, uint32_t njobs);
+int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint64_t first_byte,
+                       uint32_t *count, uint64_t *cand, uint32_t max_cand);
+int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
+                       uint32_t ncand, uint8_t *ok);
+int launch_verify_trailers(hipStream_t st, int format, uint32_t count, const uint8_t *in,
+                           const DecStream *streams, const DecHeader *hdrs, InflateResult *results,
+                           const uint32_t *crc, const uint32_t *adler, uint64_t *consumed);
+int launch_stream_checksum(hipStream_t st, const uint8_t *out, const DecStream *streams,
+                           const InflateResult *results, uint32_t count, uint32_t *crc, uint32_t *adler);
+
+}  // namespace lfx

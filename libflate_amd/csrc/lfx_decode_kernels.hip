@@ -1,0 +1,842 @@
+// lfx_decode_kernels.hip — hand-written gfx950 kernels of the inflate hot path.
+//
+//   container_kernel : gzip / zlib header parse per stream (src/gzip.rs:390-446, src/zlib.rs:221-266)
+//   find_blocks_*    : speculative search for dynamic-block headers at every bit offset of ONE stream
+//                      (the reference decodes strictly serially, src/deflate/decode.rs:136-164; block
+//                      start bits are not recorded in the format, so they are rediscovered and then
+//                      validated by chaining end bits from the known first block)
+//   inflate_kernel   : one wavefront per job (a whole stream, or one block of a stream): lane 0 walks
+//                      the Huffman symbols (symbol.rs:193-244 / huffman.rs:157-179 semantics, including
+//                      the deferred-error behaviour of BitReader, bit.rs:84-141) into a 64-entry queue
+//                      in LDS, the 64 lanes then materialise literals and back-references
+//                      (Lz77Decoder::decode, libflate_lz77/src/lib.rs:164-194) together.
+//   stream_checksum  : CRC-32 / Adler-32 of each stream's output for trailer verification.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfx_common.h"
+#include "lfx_decode.h"
+
+namespace lfx {
+
+__device__ __forceinline__ uint32_t ld1(const uint8_t *p) { return *p; }
+
+// ------------------------------------------------------------------------------------------------
+// container headers.  One lane per stream.
+__global__ void container_kernel(int format, uint32_t count, const uint8_t *__restrict__ in,
+                                 const DecStream *__restrict__ streams, DecHeader *__restrict__ hdrs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint8_t *p = in + streams[i].in_off;
+    const uint64_t n = streams[i].in_len;
+    DecHeader h;
+    h.status = 0; h.err = 0; h.a0 = 0; h.a1 = 0; h.deflate_off = 0; h.flags = 0;
+    if (format == 1) {
+        // zlib Header::read_from zlib.rs:221-266
+        if (n < 2) { h.status = 2; h.err = ERR_EOF; h.deflate_off = n; }
+        else {
+            const uint32_t cmf = p[0], flg = p[1];
+            h.deflate_off = 2;
+            if (((cmf << 8) + flg) % 31 != 0) { h.status = 1; h.err = ERR_ZLIB_CHECK; h.a0 = cmf; h.a1 = flg; }
+            else if ((cmf & 15) != 8) { h.status = 1; h.err = ERR_METHOD; h.a0 = cmf & 15; }
+            else if ((cmf >> 4) > 7) { h.status = 1; h.err = ERR_CINFO; h.a0 = cmf >> 4; }
+            else if (flg & 0x20) {
+                if (n < 6) { h.status = 2; h.err = ERR_EOF; h.deflate_off = n; }
+                else { h.status = 1; h.err = ERR_FDICT; h.deflate_off = 6;
+                       h.a0 = (uint32_t)p[2] << 24 | (uint32_t)p[3] << 16 | (uint32_t)p[4] << 8 | p[5]; }
+            }
+        }
+    } else if (format == 2) {
+        // gzip Header::read_from gzip.rs:390-446
+        uint64_t pos = 0;
+        if (n < 10) { h.status = 2; h.err = ERR_EOF; pos = n; }
+        else {
+            pos = 10;
+            const uint32_t flags = p[3];
+            h.flags = flags;
+            if (p[0] != 31 || p[1] != 139) { h.status = 1; h.err = ERR_GZIP_ID; }
+            else if (p[2] != 8) { h.status = 1; h.err = ERR_METHOD; h.a0 = p[2]; }
+            else {
+                uint64_t extra_off = 0, extra_len = 0;
+                if (flags & 4) {
+                    if (n - pos < 2) { h.status = 2; h.err = ERR_EOF; pos = n; }
+                    else {
+                        uint64_t xl = (uint64_t)p[pos] | (uint64_t)p[pos + 1] << 8;
+                        pos += 2;
+                        extra_off = pos; extra_len = xl;
+                        uint64_t lim = xl, q = pos;  // ExtraField::read_from gzip.rs:470-485
+                        while (lim > 0 && h.status == 0) {
+                            if (lim < 4 || n - q < 4) { h.status = 2; h.err = ERR_EOF; q = n; break; }
+                            uint64_t dl = (uint64_t)p[q + 2] | (uint64_t)p[q + 3] << 8;
+                            q += 4; lim -= 4;
+                            if (lim < dl || n - q < dl) { h.status = 2; h.err = ERR_EOF; q = n; break; }
+                            q += dl; lim -= dl;
+                        }
+                        pos = q;
+                    }
+                }
+                uint64_t str_off[2] = {0, 0}, str_len[2] = {0, 0};
+                for (int k = 0; k < 2 && h.status == 0; ++k) {
+                    if (!(flags & (k ? 16 : 8))) continue;
+                    const uint64_t s = pos;
+                    for (;;) {
+                        if (pos >= n) { h.status = 2; h.err = ERR_EOF; break; }
+                        if (p[pos++] == 0) break;
+                    }
+                    str_off[k] = s; str_len[k] = pos - s;
+                }
+                if (h.status == 0 && (flags & 2)) {
+                    if (n - pos < 2) { h.status = 2; h.err = ERR_EOF; pos = n; }
+                    else {
+                        const uint32_t crc = (uint32_t)p[pos] | (uint32_t)p[pos + 1] << 8;
+                        pos += 2;
+                        // crc16 of the header RE-SERIALISED with only the five known flag bits and
+                        // FLG.HCRC cleared; XFL through from_u8/to_u8 (gzip.rs:343-367, 69-82)
+                        uint32_t c = 0xFFFFFFFFu;
+                        auto upd = [&](uint32_t byte) {
+                            c ^= byte;
+                            for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
+                        };
+                        for (int k = 0; k < 10; ++k) {
+                            uint32_t b = p[k];
+                            if (k == 3) b = flags & (1 | 4 | 8 | 16);
+                            if (k == 8) b = (b == 4 || b == 2) ? b : 0;
+                            upd(b);
+                        }
+                        if (flags & 4) {
+                            upd((uint32_t)extra_len & 0xFF); upd((uint32_t)(extra_len >> 8) & 0xFF);
+                            for (uint64_t k = 0; k < extra_len; ++k) upd(p[extra_off + k]);
+                        }
+                        for (int k = 0; k < 2; ++k)
+                            for (uint64_t j = 0; j < str_len[k]; ++j) upd(p[str_off[k] + j]);
+                        const uint32_t expect = (~c) & 0xFFFF;
+                        if (crc != expect) { h.status = 1; h.err = ERR_HCRC; h.a0 = crc; h.a1 = expect; }
+                    }
+                }
+            }
+        }
+        h.deflate_off = pos;
+    }
+    hdrs[i] = h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bit reader for lane 0 over an LDS window of the input
+constexpr uint32_t WIN_BYTES = 2048;  // LDS window (refilled by the whole wave)
+
+struct BitIn {
+    const uint8_t *g;    // stream base (global)
+    uint64_t nbits;      // bits available in the stream
+    uint64_t pos;        // next bit
+    uint64_t win_base;   // byte offset of the window start (multiple of 4)
+    uint32_t *win;       // LDS window
+    int err;             // latched error: 0 none, 1 InvalidData, 2 UnexpectedEof  (bit.rs:84-94)
+    uint32_t ecode, ea0, ea1;
+};
+
+// all lanes: make the window cover [pos/8, pos/8 + need) bytes
+__device__ __forceinline__ void win_ensure(BitIn &b, uint32_t need, uint32_t lane) {
+    const uint64_t byte = b.pos >> 3;
+    if (byte >= b.win_base && byte + need <= b.win_base + WIN_BYTES) return;
+    const uint64_t nb = (b.nbits + 7) >> 3;
+    const uint64_t base = byte & ~3ull;
+    // the stream base may be unaligned: load bytes (coalesced enough: 64 lanes x 32 bytes)
+    for (uint32_t k = lane; k < WIN_BYTES / 4; k += 64) {
+        const uint64_t o = base + 4ull * k;
+        uint32_t v = 0;
+        if (o + 4 <= nb) {
+            const uint8_t *q = b.g + o;
+            if ((((uint64_t)q) & 3) == 0) v = *(const uint32_t *)q;
+            else v = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
+        } else {
+            for (uint32_t j = 0; j < 4; ++j) if (o + j < nb) v |= (uint32_t)b.g[o + j] << (8 * j);
+        }
+        b.win[k] = v;
+    }
+    b.win_base = base;
+    __syncthreads();
+}
+
+// lane 0: peek_bits_unchecked(w) (bit.rs:111-125): fails (latches EOF, returns 0) iff the stream has
+// fewer than w bits left; once an error is latched a peek that needs more input returns 0.
+__device__ __forceinline__ uint32_t bi_peek(BitIn &b, uint32_t w) {
+    if (b.pos + w > b.nbits) {
+        if (!b.err) { b.err = 2; b.ecode = ERR_EOF; }
+        return 0;
+    }
+    const uint64_t rel = b.pos - (b.win_base << 3);
+    const uint32_t wi = (uint32_t)(rel >> 5), sh = (uint32_t)rel & 31;
+    const uint64_t two = (uint64_t)b.win[wi] | ((uint64_t)b.win[wi + 1] << 32);
+    return (uint32_t)(two >> sh) & ((1u << w) - 1);
+}
+__device__ __forceinline__ void bi_skip(BitIn &b, uint32_t w) { b.pos += w; }
+__device__ __forceinline__ uint32_t bi_read_unchecked(BitIn &b, uint32_t w) {
+    const uint32_t v = bi_peek(b, w);
+    bi_skip(b, w);
+    return v;
+}
+
+// decode tables of one alphabet (LDS): primary table of PRI bits, entry = (symbol << 4) | width,
+// 0 = unassigned; codes longer than PRI bits resolved by canonical walk (count/first/sorted).
+constexpr uint32_t LIT_PRI = 10, DIST_PRI = 9;
+struct HuffTab {
+    uint16_t *pri;       // 1 << PRI entries
+    uint16_t *sorted;    // symbols in (width, symbol) order
+    uint16_t count[16];  // codes per width
+    uint32_t pri_bits;
+    uint32_t max_bw;     // huffman.rs:72: max code width (0 = empty table)
+    uint32_t safe_bw;    // huffman.rs:123-132
+};
+
+// all lanes: build tables from code widths bw[0..n) (LDS).  Returns 0, or 1 = "Bit region conflict"
+// (over-subscribed, huffman.rs:107-119).  eob = symbol whose width seeds safely_peek_bitwidth.
+__device__ int tab_build(HuffTab &t, const uint8_t *bw, uint32_t n, int safe_some, uint32_t safe,
+                         int eob, uint32_t lane, uint32_t *conflict_sym) {
+    __shared__ uint32_t s_first[16], s_off[16], s_bad;
+    for (uint32_t i = lane; i < (1u << t.pri_bits); i += 64) t.pri[i] = 0;
+    if (lane == 0) {
+        for (int w = 0; w < 16; ++w) t.count[w] = 0;
+        uint32_t mx = 0;
+        for (uint32_t s = 0; s < n; ++s) { t.count[bw[s]]++; if (bw[s] > mx) mx = bw[s]; }
+        t.count[0] = 0;
+        t.max_bw = mx;
+        // canonical first codes; detect the first symbol whose code overflows its width
+        uint32_t code = 0, off = 0;
+        s_bad = 0xFFFFFFFFu;
+        int left = 1;
+        for (uint32_t w = 1; w <= 15; ++w) {
+            code <<= 1;
+            left <<= 1;
+            s_first[w] = code;
+            s_off[w] = off;
+            if (s_bad == 0xFFFFFFFFu && (int)t.count[w] > left) {
+                // the (left+1)-th symbol of this width is the first to collide
+                s_bad = (w << 16) | (uint32_t)left;
+            }
+            left -= (int)t.count[w];
+            if (left < 0) left = 0;  // keep scanning harmlessly
+            code += t.count[w];
+            off += t.count[w];
+        }
+        if (eob >= 0 && (uint32_t)eob < n && bw[eob] > 0) { safe_some = 1; safe = bw[eob]; }
+        const uint32_t sp = safe_some ? safe : 1;
+        t.safe_bw = mx < sp ? mx : sp;
+    }
+    __syncthreads();
+    if (s_bad != 0xFFFFFFFFu) {
+        // find the symbol: the (k+1)-th symbol (0-based k) of width w in symbol order
+        if (lane == 0) {
+            const uint32_t w = s_bad >> 16;
+            uint32_t k = s_bad & 0xFFFF, found = 0;
+            for (uint32_t s = 0; s < n; ++s)
+                if (bw[s] == w) { if (k == 0) { found = s; break; } k--; }
+            *conflict_sym = found;
+        }
+        __syncthreads();
+        return 1;
+    }
+    for (uint32_t s = lane; s < n; s += 64) {
+        const uint32_t w = bw[s];
+        if (w == 0) continue;
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < s; ++q) rank += bw[q] == w;
+        const uint32_t code = s_first[w] + rank;
+        t.sorted[s_off[w] + rank] = (uint16_t)s;
+        if (w <= t.pri_bits) {
+            uint32_t r = __brev(code) >> (32 - w);  // LSB-first
+            for (uint32_t i = r; i < (1u << t.pri_bits); i += (1u << w)) t.pri[i] = (uint16_t)((s << 4) | w);
+        }
+    }
+    __syncthreads();
+    return 0;
+}
+
+// lane 0: huffman::Decoder::decode_unchecked (huffman.rs:157-179).  Unassigned → InvalidData latched,
+// returns symbol 0 and skips 16 bits like the reference (value 16: width 16, symbol 0).
+__device__ __forceinline__ uint32_t tab_decode(const HuffTab &t, BitIn &b) {
+    uint32_t peek = t.safe_bw;
+    for (;;) {
+        const uint32_t bits = bi_peek(b, peek);
+        // canonical lookup of the code whose LSB-first bits are `bits` zero-extended
+        uint32_t width = 16, sym = 0;  // unassigned
+        if (t.max_bw == 0) {
+            width = 16;
+        } else {
+            const uint32_t idx = bits & ((1u << t.pri_bits) - 1);
+            const uint32_t e = t.pri[idx];
+            if (e) { width = e & 15; sym = e >> 4; }
+            else if (t.max_bw > t.pri_bits) {
+                // long code: walk the canonical code bit by bit over the zero-extended bits
+                uint32_t code = 0, first = 0, index = 0;
+                const uint32_t full = bits;  // bits beyond `peek` are zero
+                for (uint32_t w = 1; w <= t.max_bw; ++w) {
+                    code |= (full >> (w - 1)) & 1;
+                    const uint32_t cnt = t.count[w];
+                    if (code < first + cnt) { width = w; sym = t.sorted[index + (code - first)]; break; }
+                    index += cnt;
+                    first = (first + cnt) << 1;
+                    code <<= 1;
+                }
+            }
+        }
+        if (width <= peek) { bi_skip(b, width); return sym; }
+        if (width > t.max_bw) {  // unassigned slot
+            b.err = 1; b.ecode = ERR_HUFF;  // set_last_error overwrites (bit.rs:84-86)
+            bi_skip(b, 16);
+            return 0;
+        }
+        peek = width;
+    }
+}
+
+__constant__ uint16_t c_len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
+                                        31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2,
+                                        2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dist_base[30] = {1,    2,    3,    4,    5,    7,    9,    13,    17,    25,
+                                         33,   49,   65,   97,   129,  193,  257,  385,   513,   769,
+                                         1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2,  3,  3,  4,  4,  5,  5,  6,
+                                         6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// ------------------------------------------------------------------------------------------------
+// inflate: one wavefront per job
+constexpr uint32_t QN = 64;
+
+__global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__ in,
+                                                     uint8_t *__restrict__ out,
+                                                     const InflateJob *__restrict__ jobs,
+                                                     InflateResult *__restrict__ results) {
+    __shared__ uint32_t win[WIN_BYTES / 4 + 2];
+    __shared__ uint16_t lit_pri[1u << LIT_PRI], dist_pri[1u << DIST_PRI], cl_pri[128];
+    __shared__ uint16_t lit_sorted[288], dist_sorted[32], cl_sorted[19];
+    __shared__ uint8_t lens[640];
+    __shared__ uint8_t clw[19];
+    __shared__ uint32_t q[QN];
+    __shared__ HuffTab T_lit, T_dist, T_cl;
+    __shared__ uint32_t s_ctl[8];  // 0: queue count, 1: block done, 2: stop, 3: btype, 4: stored len
+
+    const uint32_t lane = threadIdx.x;
+    const InflateJob job = jobs[blockIdx.x];
+    BitIn b;
+    b.g = in + job.in_off;
+    b.nbits = job.in_len * 8;
+    b.pos = job.start_bit;
+    b.win = win;
+    b.win_base = ~0ull >> 1;  // force the first fill
+    b.err = 0; b.ecode = 0; b.ea0 = 0; b.ea1 = 0;
+    uint8_t *o = out + job.out_off;
+    const bool do_write = !(job.flags & JOB_COUNT_ONLY);
+    uint64_t produced = 0;        // bytes produced by this job
+    uint32_t status = 0, final_seen = 0, needs_hist = 0, nblocks = 0;
+    uint64_t blk_out_start = 0;
+    uint64_t hist_avail = job.hist_avail;  // bytes of the member already produced before this job
+
+    if (lane == 0) {
+        T_lit.pri = lit_pri; T_lit.sorted = lit_sorted; T_lit.pri_bits = LIT_PRI;
+        T_dist.pri = dist_pri; T_dist.sorted = dist_sorted; T_dist.pri_bits = DIST_PRI;
+        T_cl.pri = cl_pri; T_cl.sorted = cl_sorted; T_cl.pri_bits = 7;
+    }
+    __syncthreads();
+
+    for (;;) {
+        // ---- block header: deflate::Decoder::read decode.rs:146-162
+        blk_out_start = produced;
+        win_ensure(b, 700, lane);
+        if (lane == 0) {
+            s_ctl[2] = 0;
+            const uint32_t bfinal = bi_read_unchecked(b, 1);
+            uint32_t btype = 0;
+            if (!b.err) btype = bi_read_unchecked(b, 2);
+            if (b.err) s_ctl[2] = 1;
+            s_ctl[3] = btype;
+            s_ctl[5] = bfinal;
+        }
+        __syncthreads();
+        b.pos = __shfl(b.pos, 0);
+        if (s_ctl[2]) break;
+        const uint32_t btype = s_ctl[3];
+        final_seen = s_ctl[5];
+        nblocks++;
+        if (btype == 3) {
+            if (lane == 0) { b.err = 1; b.ecode = ERR_BTYPE3; }
+            break;
+        }
+        if (btype == 0) {
+            // read_non_compressed_block decode.rs:81-111
+            uint64_t byte = (b.pos + 7) >> 3;  // bit_reader.reset(): drop the partial byte
+            const uint64_t nb = job.in_len;
+            uint32_t len = 0;
+            int bad = 0;
+            if (nb < byte || nb - byte < 2) { bad = 2; byte = nb; }
+            else {
+                len = ld1(b.g + byte) | ld1(b.g + byte + 1) << 8;
+                byte += 2;
+                if (nb - byte < 2) { bad = 2; byte = nb; }
+                else {
+                    const uint32_t nlen = ld1(b.g + byte) | ld1(b.g + byte + 1) << 8;
+                    byte += 2;
+                    if (((~len) & 0xFFFF) != nlen) { bad = 1; b.ea0 = len; b.ea1 = nlen; }
+                }
+            }
+            if (bad) {
+                if (lane == 0) { b.err = bad; b.ecode = bad == 2 ? ERR_EOF : ERR_LEN_NLEN; }
+                b.pos = byte << 3;
+                break;
+            }
+            const uint64_t avail = nb - byte;
+            const uint32_t take = len < avail ? len : (uint32_t)avail;
+            if (do_write) {
+                if (produced + take > job.out_cap) { if (lane == 0) { b.err = 3; b.ecode = ERR_NOSPACE; } break; }
+                for (uint32_t k = lane; k < take; k += 64) o[produced + k] = b.g[byte + k];
+                __threadfence_block();
+            }
+            produced += take;
+            b.pos = (byte + take) << 3;
+            if (take != len) {
+                if (lane == 0) { b.err = 2; b.ecode = ERR_STORED_SHORT; b.ea0 = len; b.ea1 = take; }
+                break;
+            }
+        } else {
+            // ---- code tables
+            int rc = 0;
+            uint32_t csym = 0;
+            uint32_t nl = 288, nd = 30;
+            if (btype == 1) {
+                // FixedHuffmanCodec::load symbol.rs:290-315
+                for (uint32_t s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                for (uint32_t s = lane; s < 30; s += 64) lens[288 + s] = 5;
+                __syncthreads();
+            } else {
+                // DynamicHuffmanCodec::load symbol.rs:387-456 (checked reads)
+                if (lane == 0) {
+                    s_ctl[2] = 0;
+                    uint32_t hl = bi_read_unchecked(b, 5);
+                    uint32_t hd = b.err ? 0 : bi_read_unchecked(b, 5);
+                    uint32_t hc = b.err ? 0 : bi_read_unchecked(b, 4);
+                    if (b.err) s_ctl[2] = 1;
+                    else if (hd + 1 > 30) { b.err = 1; b.ecode = ERR_HDIST; b.ea0 = hd + 1; s_ctl[2] = 1; }
+                    else {
+                        for (int k = 0; k < 19; ++k) clw[k] = 0;
+                        for (uint32_t k = 0; k < hc + 4 && !b.err; ++k) clw[c_clen_order[k]] = (uint8_t)bi_read_unchecked(b, 3);
+                        if (b.err) s_ctl[2] = 1;
+                    }
+                    s_ctl[6] = hl + 257;
+                    s_ctl[7] = hd + 1;
+                }
+                __syncthreads();
+                if (s_ctl[2]) break;
+                nl = s_ctl[6]; nd = s_ctl[7];
+                rc = tab_build(T_cl, clw, 19, 1, 1, -1, lane, &csym);
+                if (rc) { if (lane == 0) { b.err = 1; b.ecode = ERR_CONFLICT; b.ea0 = csym; } break; }
+                if (lane == 0) {
+                    // code length sequences (load_bitwidthes symbol.rs:459-484); one contiguous array:
+                    // literal overflow spills into the distance list (symbol.rs:422-424)
+                    uint32_t have = 0;
+                    s_ctl[2] = 0;
+                    for (int phase = 0; phase < 2 && !s_ctl[2]; ++phase) {
+                        const uint32_t target = phase ? nl + nd : nl;
+                        while (have < target) {
+                            const uint32_t c = tab_decode(T_cl, b);
+                            if (b.err) { s_ctl[2] = 1; break; }
+                            if (c <= 15) lens[have++] = (uint8_t)c;
+                            else if (c == 16) {
+                                const uint32_t r = bi_read_unchecked(b, 2);
+                                if (b.err) { s_ctl[2] = 1; break; }
+                                if (have == 0) { b.err = 1; b.ecode = ERR_NO_PREV; s_ctl[2] = 1; break; }
+                                const uint8_t last = lens[have - 1];
+                                for (uint32_t k = 0; k < r + 3; ++k) lens[have++] = last;
+                            } else if (c == 17) {
+                                const uint32_t r = bi_read_unchecked(b, 3);
+                                if (b.err) { s_ctl[2] = 1; break; }
+                                for (uint32_t k = 0; k < r + 3; ++k) lens[have++] = 0;
+                            } else {
+                                const uint32_t r = bi_read_unchecked(b, 7);
+                                if (b.err) { s_ctl[2] = 1; break; }
+                                for (uint32_t k = 0; k < r + 11; ++k) lens[have++] = 0;
+                            }
+                        }
+                    }
+                    if (!s_ctl[2] && have - nl > nd) {
+                        b.err = 1; b.ecode = ERR_DIST_LIST; b.ea0 = have - nl; b.ea1 = nd; s_ctl[2] = 1;
+                    }
+                }
+                __syncthreads();
+                if (s_ctl[2]) break;
+            }
+            const uint32_t dist_at = btype == 1 ? 288 : nl;
+            rc = tab_build(T_lit, lens, nl, 0, 0, 256, lane, &csym);
+            if (rc) { if (lane == 0) { b.err = 1; b.ecode = ERR_CONFLICT; b.ea0 = csym; } break; }
+            rc = tab_build(T_dist, lens + dist_at, nd, 1, T_lit.safe_bw, -1, lane, &csym);
+            if (rc) { if (lane == 0) { b.err = 1; b.ecode = ERR_CONFLICT; b.ea0 = csym; } break; }
+            // ---- symbols: read_compressed_block decode.rs:112-130
+            bool stop = false;
+            for (;;) {
+                win_ensure(b, QN * 6 + 16, lane);
+                if (lane == 0) {
+                    uint32_t n = 0, done = 0;
+                    uint64_t prod = produced;
+                    while (n < QN) {
+                        // symbol::Decoder::decode_unchecked symbol.rs:193-244
+                        const uint32_t d = tab_decode(T_lit, b);
+                        uint32_t entry;
+                        bool eob = false;
+                        if (d <= 255) entry = d;
+                        else if (d == 256) { eob = true; entry = 0; }
+                        else if (d >= 286) { b.err = 1; b.ecode = ERR_286; b.ea0 = d; eob = true; entry = 0; }
+                        else {
+                            const uint32_t length = c_len_base[d - 257] + bi_read_unchecked(b, c_len_extra[d - 257]);
+                            const uint32_t dc = tab_decode(T_dist, b);
+                            const uint32_t distance = c_dist_base[dc % 30] + bi_read_unchecked(b, c_dist_extra[dc % 30]);
+                            entry = 0x80000000u | (length << 16) | distance;  // distance <= 32768 fits 16 bits
+                            if (!b.err) {
+                                // Lz77Decoder::decode lib.rs:173-185
+                                const uint64_t blen = hist_avail + prod;
+                                if (blen < distance) {
+                                    if (job.flags & JOB_SINGLE_BLOCK && (job.flags & JOB_COUNT_ONLY)) {
+                                        needs_hist = 1;  // history unknown in the speculative pass
+                                    } else {
+                                        b.err = 1; b.ecode = ERR_BACKREF; b.ea0 = (uint32_t)blen; b.ea1 = distance;
+                                    }
+                                }
+                            }
+                            if (!b.err) prod += length;
+                        }
+                        if (b.err) { done = 2; break; }  // check_last_error after every symbol
+                        if (eob) { done = 1; break; }
+                        if (d <= 255) prod += 1;
+                        q[n++] = entry;
+                    }
+                    s_ctl[0] = n;
+                    s_ctl[1] = done;
+                }
+                __syncthreads();
+                b.pos = __shfl(b.pos, 0);
+                needs_hist = __shfl(needs_hist, 0);
+                const uint32_t n = s_ctl[0], done = s_ctl[1];
+                // ---- materialise the queue
+                const uint32_t e = lane < n ? q[lane] : 0;
+                const bool is_match = lane < n && (e >> 31);
+                const uint32_t mylen = lane < n ? (is_match ? ((e >> 16) & 0x1FF) : 1) : 0;
+                uint32_t x = mylen;  // inclusive scan
+                for (int ofs = 1; ofs < 64; ofs <<= 1) {
+                    const uint32_t y = __shfl_up(x, ofs);
+                    if ((int)lane >= ofs) x += y;
+                }
+                const uint32_t total = __shfl(x, 63);
+                const uint64_t at = produced + x - mylen;
+                if (do_write && n) {
+                    if (produced + total > job.out_cap) { if (lane == 0) { b.err = 3; b.ecode = ERR_NOSPACE; } stop = true; }
+                    else {
+                        if (lane < n && !is_match) o[at] = (uint8_t)e;
+                        __threadfence_block();
+                        uint64_t mm = __ballot(is_match);
+                        while (mm) {
+                            const uint32_t src_lane = (uint32_t)__builtin_ctzll(mm);
+                            mm &= mm - 1;
+                            const uint32_t me = __shfl(e, src_lane);
+                            const uint64_t mat = __shfl(at, src_lane);
+                            const uint32_t len = (me >> 16) & 0x1FF;
+                            const uint32_t dist = me & 0xFFFF;
+                            const uint8_t *srcp = o + mat - dist;
+                            // out[k] = src[k mod dist] reproduces the overlapping forward copy (rle_decode)
+                            if (dist >= len) { for (uint32_t k = lane; k < len; k += 64) o[mat + k] = srcp[k]; }
+                            else { for (uint32_t k = lane; k < len; k += 64) o[mat + k] = srcp[k % dist]; }
+                            __threadfence_block();
+                        }
+                    }
+                }
+                produced += total;
+                __syncthreads();
+                if (stop || done) { if (done == 2) stop = true; break; }
+            }
+            if (stop) break;
+        }
+        if (final_seen || (job.flags & JOB_SINGLE_BLOCK)) break;
+    }
+    // ---- result
+    b.err = __shfl(b.err, 0);
+    if (lane == 0) {
+        status = b.err;
+        InflateResult r;
+        r.end_bit = b.pos;
+        r.out_len = produced;
+        r.status = status;
+        r.final_seen = final_seen;
+        r.err = b.ecode; r.a0 = b.ea0; r.a1 = b.ea1;
+        r.needs_hist = needs_hist;
+        r.nblocks = nblocks;
+        r._pad = 0;
+        r.blk_out_start = blk_out_start;
+        results[blockIdx.x] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block finder, stage 1: every bit offset of the stream is tested for "dynamic block header with a
+// complete code-length code".  One lane per byte, 8 offsets each.
+__global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restrict__ in, uint64_t nbytes,
+                                                          uint64_t first_byte, uint32_t *__restrict__ count,
+                                                          uint64_t *__restrict__ cand, uint32_t max_cand) {
+    const uint64_t byte = first_byte + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (byte + 12 > nbytes) return;  // too close to the end for a real block anyway
+    // 96 bits starting at this byte
+    uint64_t lo = 0, hi = 0;
+    for (int k = 0; k < 8; ++k) lo |= (uint64_t)in[byte + k] << (8 * k);
+    for (int k = 0; k < 4; ++k) hi |= (uint64_t)in[byte + 8 + k] << (8 * k);
+    for (uint32_t ph = 0; ph < 8; ++ph) {
+        const uint64_t v = (lo >> ph) | (ph ? (hi << (64 - ph)) : 0);   // 64 bits from this offset
+        const uint64_t v2 = hi >> ph;                                    // following bits
+        if (((v >> 1) & 3) != 2) continue;            // BTYPE
+        const uint32_t hlit = (v >> 3) & 31, hdist = (v >> 8) & 31, hclen = (v >> 13) & 15;
+        if (hlit > 29 || hdist > 29) continue;
+        uint32_t kraft = 0, used = 0;
+        for (uint32_t k = 0; k < hclen + 4; ++k) {
+            const uint32_t bitat = 17 + 3 * k;
+            uint32_t l;
+            if (bitat + 3 <= 64) l = (v >> bitat) & 7;
+            else if (bitat >= 64) l = (v2 >> (bitat - 64)) & 7;
+            else l = ((v >> bitat) | (v2 << (64 - bitat))) & 7;
+            if (l) { kraft += 128u >> l; used++; }
+        }
+        if (kraft != 128 || used < 2) continue;       // complete code-length code
+        const uint32_t slot = atomicAdd(count, 1u);
+        if (slot < max_cand) cand[slot] = byte * 8 + ph;
+    }
+}
+
+// stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
+// decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length code must be
+// complete and the distance code complete, single or empty.
+__global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restrict__ in, uint64_t nbytes,
+                                                         const uint64_t *__restrict__ cand, uint32_t ncand,
+                                                         uint8_t *__restrict__ ok) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand) return;
+    uint64_t pos = cand[i];
+    const uint64_t nbits = nbytes * 8;
+    auto bits = [&](uint32_t w) -> uint32_t {
+        if (pos + w > nbits) { pos = nbits + 64; return 0; }
+        const uint64_t byte = pos >> 3;
+        uint64_t v = 0;
+        for (int k = 0; k < 4; ++k) if (byte + k < nbytes) v |= (uint64_t)in[byte + k] << (8 * k);
+        const uint32_t r = (uint32_t)(v >> (pos & 7)) & ((1u << w) - 1);
+        pos += w;
+        return r;
+    };
+    bits(3);
+    const uint32_t nl = bits(5) + 257, nd = bits(5) + 1, nc = bits(4) + 4;
+    uint8_t clw[19];
+    for (int k = 0; k < 19; ++k) clw[k] = 0;
+    for (uint32_t k = 0; k < nc; ++k) clw[c_clen_order[k]] = (uint8_t)bits(3);
+    // canonical decode of the code-length code, bit by bit (at most 7 bits)
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < 19; ++s) cnt[clw[s]]++;
+    cnt[0] = 0;
+    uint8_t sorted[19];
+    {
+        uint32_t offs[8], o = 0;
+        for (int w = 1; w < 8; ++w) { offs[w] = o; o += cnt[w]; }
+        for (int s = 0; s < 19; ++s) if (clw[s]) sorted[offs[clw[s]]++] = (uint8_t)s;
+    }
+    uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
+    const uint32_t total = nl + nd;
+    bool good = true;
+    while (have < total && good) {
+        uint32_t code = 0, first = 0, index = 0, sym = 99;
+        for (uint32_t w = 1; w <= 7; ++w) {
+            code |= bits(1);
+            if (code < first + cnt[w]) { sym = sorted[index + (code - first)]; break; }
+            index += cnt[w];
+            first = (first + cnt[w]) << 1;
+            code <<= 1;
+        }
+        if (sym == 99 || pos > nbits) { good = false; break; }
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) { if (have == 0) { good = false; break; } rep = 3 + bits(2); val = last; }
+        else if (sym == 17) { rep = 3 + bits(3); val = 0; }
+        else if (sym == 18) { rep = 11 + bits(7); val = 0; }
+        if (have + rep > total) { good = false; break; }
+        for (uint32_t k = 0; k < rep; ++k) {
+            const uint32_t idx = have + k;
+            if (val) {
+                if (idx < nl) { kl += 32768u >> val; nlit++; if (idx == 256) eob_len = val; }
+                else { kd += 32768u >> val; ndist++; }
+            }
+        }
+        have += rep;
+        last = val;
+    }
+    if (pos > nbits) good = false;
+    if (good) {
+        if (eob_len == 0) good = false;
+        if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
+        if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
+    }
+    ok[i] = good ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-stream checksums of the decoded output: one workgroup per stream
+__global__ __launch_bounds__(256) void stream_checksum_kernel(const uint8_t *__restrict__ out,
+                                                              const DecStream *__restrict__ streams,
+                                                              const InflateResult *__restrict__ results,
+                                                              uint32_t *__restrict__ crc_out,
+                                                              uint32_t *__restrict__ adler_out) {
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t s_crc[256], s_a[256], s_b[256];
+    __shared__ uint64_t s_len[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
+        tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t sidx = blockIdx.x;
+    const uint8_t *p = out + streams[sidx].out_off;
+    const uint64_t n = results[sidx].out_len;
+    const uint64_t per = div_up(n, 256);
+    const uint64_t lo = (uint64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t crc = 0, a = 0, b = 0;
+    for (uint64_t i = lo; i < hi; ++i) {
+        const uint32_t byte = p[i];
+        crc = (crc >> 8) ^ tab[(crc ^ byte) & 0xFF];
+        a += byte;
+        if (a >= 65521u) a -= 65521u;
+        b += a;
+        if (b >= 65521u) b -= 65521u;
+    }
+    s_crc[threadIdx.x] = crc; s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+    s_len[threadIdx.x] = hi > lo ? hi - lo : 0;
+    __syncthreads();
+    auto mul = [](uint32_t x, uint32_t y) {
+        uint32_t pp = 0;
+        for (int i = 0; i < 32; ++i) {
+            if (x & 0x80000000u) pp ^= y;
+            x <<= 1;
+            y = (y >> 1) ^ (0xEDB88320u & (0u - (y & 1)));
+        }
+        return pp;
+    };
+    auto xpow = [&](uint64_t e) {
+        uint32_t r = 0x80000000u, sq = 0x00800000u;
+        while (e) { if (e & 1) r = mul(r, sq); sq = mul(sq, sq); e >>= 1; }
+        return r;
+    };
+    for (uint32_t step = 1; step < 256; step <<= 1) {
+        const bool act = (threadIdx.x % (2 * step)) == 0 && threadIdx.x + step < 256;
+        uint32_t c2 = 0, a2 = 0, b2 = 0;
+        uint64_t l2 = 0;
+        if (act) { c2 = s_crc[threadIdx.x + step]; a2 = s_a[threadIdx.x + step]; b2 = s_b[threadIdx.x + step]; l2 = s_len[threadIdx.x + step]; }
+        __syncthreads();
+        if (act) {
+            const uint32_t c1 = s_crc[threadIdx.x], a1 = s_a[threadIdx.x], b1 = s_b[threadIdx.x];
+            s_crc[threadIdx.x] = (l2 ? mul(c1, xpow(l2)) : c1) ^ c2;
+            s_b[threadIdx.x] = (uint32_t)((b1 + b2 + (l2 % 65521u) * (uint64_t)a1) % 65521u);
+            s_a[threadIdx.x] = (a1 + a2) % 65521u;
+            s_len[threadIdx.x] += l2;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        crc_out[sidx] = s_crc[0] ^ mul(0xFFFFFFFFu, xpow(n)) ^ 0xFFFFFFFFu;
+        const uint32_t AA = (1u + s_a[0]) % 65521u;
+        const uint32_t BB = (uint32_t)((n % 65521u + s_b[0]) % 65521u);
+        adler_out[sidx] = (BB << 16) | AA;
+    }
+}
+
+// trailer verification per stream (gzip.rs:1030-1042: CRC-32 checked, ISIZE ignored;
+// zlib.rs:387-401: Adler-32 big-endian).  One lane per stream.
+__global__ void verify_trailers_kernel(int format, uint32_t count, const uint8_t *__restrict__ in,
+                                       const DecStream *__restrict__ streams,
+                                       const DecHeader *__restrict__ hdrs,
+                                       InflateResult *__restrict__ results,
+                                       const uint32_t *__restrict__ crc, const uint32_t *__restrict__ adler,
+                                       uint64_t *__restrict__ consumed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    InflateResult r = results[i];
+    const DecHeader h = hdrs[i];
+    const uint64_t n = streams[i].in_len;
+    uint64_t used = h.deflate_off;
+    if (h.status != 0) {
+        r.status = h.status; r.err = h.err; r.a0 = h.a0; r.a1 = h.a1; r.out_len = 0;
+    } else {
+        used = (r.end_bit + 7) >> 3;  // end_bit is relative to the stream start
+        if (used > n) used = n;
+        if (r.status == 0 && format != 0) {
+            const uint8_t *t = in + streams[i].in_off + used;
+            const uint32_t need = format == 2 ? 8 : 4;
+            if (n - used < need) { r.status = 2; r.err = ERR_EOF; used = n; }
+            else if (format == 2) {
+                const uint32_t c = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+                used += 8;
+                if (c != crc[i]) { r.status = 1; r.err = ERR_CRC32; r.a0 = crc[i]; r.a1 = c; }
+            } else {
+                const uint32_t a = (uint32_t)t[0] << 24 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 8 | t[3];
+                used += 4;
+                if (a != adler[i]) { r.status = 1; r.err = ERR_ADLER32; r.a0 = adler[i]; r.a1 = a; }
+            }
+        }
+    }
+    results[i] = r;
+    consumed[i] = used;
+}
+
+// ------------------------------------------------------------------------------------------------
+#define LFX_LAUNCH_CHECK()                          \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return (int)e_;       \
+    } while (0)
+
+int launch_container(hipStream_t st, int format, uint32_t count, const uint8_t *in,
+                     const DecStream *streams, DecHeader *hdrs) {
+    if (!count) return 0;
+    hipLaunchKernelGGL(container_kernel, dim3((count + 63) / 64), dim3(64), 0, st, format, count, in, streams, hdrs);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_inflate(hipStream_t st, const uint8_t *in, uint8_t *out, const InflateJob *jobs,
+                   InflateResult *results, uint32_t njobs) {
+    if (!njobs) return 0;
+    hipLaunchKernelGGL(inflate_kernel, dim3(njobs), dim3(64), 0, st, in, out, jobs, results);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint64_t first_byte,
+                       uint32_t *count, uint64_t *cand, uint32_t max_cand) {
+    if (nbytes <= first_byte) return 0;
+    const uint64_t n = nbytes - first_byte;
+    hipLaunchKernelGGL(find_blocks_stage1, dim3((uint32_t)div_up(n, 256)), dim3(256), 0, st, in, nbytes,
+                       first_byte, count, cand, max_cand);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
+                       uint32_t ncand, uint8_t *ok) {
+    if (!ncand) return 0;
+    hipLaunchKernelGGL(find_blocks_stage2, dim3((ncand + 63) / 64), dim3(64), 0, st, in, nbytes, cand, ncand, ok);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_verify_trailers(hipStream_t st, int format, uint32_t count, const uint8_t *in,
+                           const DecStream *streams, const DecHeader *hdrs, InflateResult *results,
+                           const uint32_t *crc, const uint32_t *adler, uint64_t *consumed) {
+    if (!count) return 0;
+    hipLaunchKernelGGL(verify_trailers_kernel, dim3((count + 63) / 64), dim3(64), 0, st, format, count, in,
+                       streams, hdrs, results, crc, adler, consumed);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_stream_checksum(hipStream_t st, const uint8_t *out, const DecStream *streams,
+                           const InflateResult *results, uint32_t count, uint32_t *crc, uint32_t *adler) {
+    if (!count) return 0;
+    hipLaunchKernelGGL(stream_checksum_kernel, dim3(count), dim3(256), 0, st, out, streams, results, crc, adler);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace lfx

@@ -1,0 +1,50 @@
+// lfx_device.h — device-side descriptors and the kernel launchers (lfx_*_kernels.hip) used by
+// lfx_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfx_common.h"
+
+namespace lfx {
+
+// one workgroup's share of the match search: positions [start, start+len) of a chunk
+struct SegDesc {
+    uint32_t chunk;
+    uint32_t start;
+    uint32_t len;
+    uint32_t _pad;
+};
+constexpr uint32_t SEG_POSITIONS = 256 * 1024;
+
+struct EncodeResult {
+    uint64_t end_bit;    // bit after the last DEFLATE bit (absolute, container header included)
+    uint64_t out_bytes;  // bytes of output relative to the output base
+    uint32_t status;     // 0 ok, 1 capacity exceeded
+    uint32_t crc32;
+    uint32_t adler32;
+    uint32_t _pad;
+};
+
+int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
+                 const SegDesc *segs, uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md);
+int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
+                 uint32_t nchunks, const uint32_t *md, uint32_t *codes, uint32_t *ncodes);
+int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
+                     const uint32_t *codes, const uint32_t *ncodes, uint32_t *hist);
+int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,
+                   BlockCodes *bc);
+int launch_offsets(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const BlockCodes *bc,
+                   uint64_t start_bit, uint64_t cap_bits, uint64_t *block_start, EncodeResult *res);
+int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
+                uint32_t nchunks, const BlockDesc *blocks, uint32_t nblocks, uint64_t ntiles,
+                const uint32_t *codes, const uint32_t *ncodes, const BlockCodes *bc,
+                const uint64_t *block_start, uint32_t *tile_bits, uint64_t *tile_start,
+                const EncodeResult *res, uint64_t out_base_bit, uint32_t *out);
+int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
+                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res);
+int launch_put_bytes(hipStream_t st, const uint8_t *d_bytes, uint32_t n, uint64_t at_byte, uint32_t *out);
+int launch_trailer(hipStream_t st, int format, uint32_t isize, uint64_t out_base_bit,
+                   EncodeResult *res, uint32_t *out);
+
+}  // namespace lfx

@@ -1,0 +1,779 @@
+// lfx_encode_kernels.hip — hand-written gfx950 kernels of the DEFLATE encode hot path.
+//
+//   lz77_match   : per position, most recent earlier occurrence of the same 3-byte prefix inside the
+//                  chunk (hash chains in LDS, exact verification) + match length.  Replaces the
+//                  PrefixTable probe + longest_common_prefix of DefaultLz77Encoder::flush
+//                  (libflate_lz77/src/default.rs:76-87,122-129,146-182).  Parse-independent: every
+//                  position < end is inserted exactly once and in order by the reference
+//                  (default.rs:78,92-97), so cand(i) = max{ j < i : buf[j..j+3] == buf[i..i+3] }.
+//   lz77_parse   : the greedy walk i += length / i += 1 (default.rs:76-107) → Code stream.
+//   histogram    : DynamicHuffmanCodec::build counting (src/deflate/symbol.rs:322-337).
+//   huffman      : lfx_huff.h (one wavefront per block).
+//   offsets/pack : BitWriter (src/bit.rs:25-49) as size → scan → LSB-first scatter.
+//   checksum     : CRC-32 / Adler-32 of the input (src/checksum.rs:4-33).
+//
+// No MFMA (no dense contraction on this path); the bound is HBM / LDS bandwidth.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfx_common.h"
+#include "lfx_device.h"
+#include "lfx_huff.h"
+
+namespace lfx {
+
+// ------------------------------------------------------------------------------------------------
+// byte access through aligned dword loads (input pointers are arbitrary byte addresses)
+struct ByteSrc {
+    const uint32_t *w;  // 4-byte aligned base
+    uint64_t shift;     // byte offset of logical byte 0 inside w
+    uint64_t nbytes;    // logical size
+    __device__ __forceinline__ uint32_t load4(uint64_t off) const {
+        // bytes [off, off+4) little-endian; bytes beyond the buffer read as 0
+        uint64_t a = off + shift;
+        uint64_t idx = a >> 2;
+        uint32_t sh = (uint32_t)a & 3;
+        uint64_t last = (nbytes + shift + 3) >> 2;  // number of dwords covering the buffer
+        uint32_t w0 = idx < last ? w[idx] : 0;
+        uint32_t w1 = (sh != 0 && idx + 1 < last) ? w[idx + 1] : 0;
+        return __builtin_amdgcn_alignbyte(w1, w0, sh);
+    }
+    __device__ __forceinline__ uint32_t load1(uint64_t off) const {
+        uint64_t a = off + shift;
+        return (w[a >> 2] >> (((uint32_t)a & 3) * 8)) & 0xFF;
+    }
+};
+__device__ __forceinline__ ByteSrc make_src(const uint8_t *p, uint64_t n) {
+    ByteSrc s;
+    uint64_t a = (uint64_t)p;
+    s.w = (const uint32_t *)(a & ~3ull);
+    s.shift = a & 3;
+    s.nbytes = n;
+    return s;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    uint32_t lane = __lane_id();
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// ------------------------------------------------------------------------------------------------
+// lz77_match: one workgroup (1024 lanes) per segment; LDS: head[16384] u32 (position+1 of the most
+// recent inserted position per hash), prevd[RING] u16 (distance to the previous position with the
+// same hash, 0 = none, 65535 = out of reach), tile hashes.
+constexpr int MATCH_THREADS = 1024;
+constexpr int HASH_BITS = 14;
+constexpr uint32_t RING = 32768 + 2048;
+
+__device__ __forceinline__ uint32_t hash3(uint32_t key) { return (key * 2654435761u) >> (32 - HASH_BITS); }
+
+__global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
+    const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
+    const SegDesc *__restrict__ segs, uint32_t window, uint32_t max_len, uint32_t *__restrict__ md) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *head = (uint32_t *)smem;                                  // 64 KiB
+    uint16_t *prevd = (uint16_t *)(smem + (sizeof(uint32_t) << HASH_BITS));  // RING * 2
+    uint16_t *th = (uint16_t *)(smem + (sizeof(uint32_t) << HASH_BITS) + RING * 2);  // 1024 * 2
+
+    const SegDesc sg = segs[blockIdx.x];
+    const ChunkDesc ch = chunks[sg.chunk];
+    if (ch.flags & CH_LITERALS) return;
+    const uint32_t n = (uint32_t)ch.len;
+    const uint32_t end = (n > 3 ? n : 3) - 3;  // default.rs:75
+    const uint32_t q0 = sg.start;              // first position answered by this segment
+    const uint32_t q1 = min(sg.start + sg.len, end);
+    if (q0 >= q1) return;
+    const uint32_t l0 = q0 > MAX_WINDOW ? q0 - MAX_WINDOW : 0;  // warm-up: link only
+    const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    for (uint32_t i = tid; i < (1u << HASH_BITS); i += MATCH_THREADS) head[i] = 0;
+    __syncthreads();
+
+    for (uint32_t t0 = l0 & ~1023u; t0 < q1; t0 += MATCH_THREADS) {
+        const uint32_t pos = t0 + tid;
+        const bool valid = pos >= l0 && pos < q1;
+        uint32_t key = 0;
+        if (valid) key = src.load4(pos) & 0xFFFFFFu;
+        th[tid] = valid ? (uint16_t)hash3(key) : (uint16_t)0xFFFF;
+        __syncthreads();
+        if (wave == 0) {
+            // link phase: one wavefront inserts the tile's 1024 positions in order, 64 at a time
+            const uint64_t lt = lanemask_lt();
+            for (uint32_t sub = 0; sub < 16; ++sub) {
+                const uint32_t p = t0 + sub * 64 + lane;
+                const uint32_t hh = th[sub * 64 + lane];
+                const bool v = hh != 0xFFFFu;
+                uint64_t same = __ballot(v);
+#pragma unroll
+                for (int b = 0; b < HASH_BITS; ++b) {
+                    const bool bit = (hh >> b) & 1;
+                    const uint64_t m = __ballot(bit);
+                    same &= bit ? m : ~m;
+                }
+                const uint64_t lower = same & lt;
+                uint32_t pd = 0;
+                if (v) {
+                    if (lower) {
+                        pd = lane - (63 - __clzll(lower));
+                    } else {
+                        const uint32_t hd = head[hh];
+                        if (hd) {
+                            const uint32_t d = p + 1 - hd;
+                            pd = d > 65535u ? 65535u : d;
+                        }
+                    }
+                    prevd[p % RING] = (uint16_t)pd;
+                    if (((same >> lane) >> 1) == 0) head[hh] = p + 1;  // last lane with this hash
+                }
+            }
+        }
+        __syncthreads();
+        if (valid && pos >= q0) {
+            // resolve: walk the hash chain until the exact 3-byte prefix matches (the most recent
+            // occurrence) or the chain leaves the window
+            uint32_t dist = 0, out = 0;
+            uint32_t d = prevd[pos % RING];
+            bool found = false;
+            while (d != 0) {
+                dist += d;
+                if (dist > window || dist > pos) break;  // default.rs:81 (inclusive window)
+                const uint32_t j = pos - dist;
+                if ((src.load4(j) & 0xFFFFFFu) == key) { found = true; break; }
+                d = prevd[j % RING];
+            }
+            if (found) {
+                // longest_common_prefix default.rs:122-129: up to max_len-3 more bytes, bounded by
+                // the end of the chunk
+                uint32_t lim = n - (pos + 3);
+                if (lim > max_len - 3) lim = max_len - 3;
+                uint32_t l = 0;
+                const uint32_t a = pos + 3, b = pos - dist + 3;
+                while (l < lim) {
+                    const uint32_t x = src.load4(a + l) ^ src.load4(b + l);
+                    if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                    l += 4;
+                }
+                if (l > lim) l = lim;
+                out = ((3 + l) << 16) | dist;
+            }
+            md[ch.in_off + pos] = out;
+        }
+        // the next tile's link phase may only start after every lane left the chain walk; the ring
+        // has a full tile of slack, so one barrier per tile (the one after th[] is written) suffices
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// lz77_parse: one wavefront per chunk walks i += length / i += 1 with the per-position answers held
+// in a VGPR and read back through v_readlane (scalar loop), then compacts the visited positions.
+__global__ __launch_bounds__(64) void lz77_parse_kernel(const uint8_t *__restrict__ in,
+                                                        uint64_t in_bytes,
+                                                        const ChunkDesc *__restrict__ chunks,
+                                                        const uint32_t *__restrict__ md,
+                                                        uint32_t *__restrict__ codes,
+                                                        uint32_t *__restrict__ ncodes) {
+    const ChunkDesc ch = chunks[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = (uint32_t)ch.len;
+    const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
+    uint32_t *out = codes + ch.code_off;
+    uint32_t nout = 0;
+    if (ch.flags & CH_LITERALS) {
+        for (uint32_t i = lane; i < n; i += 64) out[i] = src.load1(i) << 16;
+        nout = n;
+    } else {
+        const uint32_t end = (n > 3 ? n : 3) - 3;
+        const uint64_t lt = lanemask_lt();
+        uint32_t pos = 0;  // wave-uniform
+        for (uint32_t base = 0; base < end; base += 64) {
+            const uint32_t i = base + lane;
+            const uint32_t v = i < end ? md[ch.in_off + i] : 0;
+            const uint32_t byte = i < n ? src.load1(i) : 0;
+            uint64_t vis = 0;
+            const uint32_t stop = min(base + 64, end);
+            while (pos < stop) {
+                const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
+                const uint32_t mv = __builtin_amdgcn_readlane(v, r);
+                vis |= 1ull << r;
+                pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
+            }
+            const uint32_t code = (v & 0xFFFFu) ? v : (byte << 16);
+            if ((vis >> lane) & 1) out[nout + __popcll(vis & lt)] = code;
+            nout += __popcll(vis);
+        }
+        // default.rs:105-107: the rest are literals
+        for (uint32_t i = pos + lane; i < n; i += 64) out[nout + (i - pos)] = src.load1(i) << 16;
+        if (n > pos) nout += n - pos;
+    }
+    if (ch.flags & CH_LAST_IN_BLOCK) {
+        if (lane == 0) out[nout] = CODE_EOB;  // encode.rs:417
+        nout += 1;
+    }
+    if (lane == 0) ncodes[blockIdx.x] = nout;
+}
+
+// ------------------------------------------------------------------------------------------------
+// histogram of a chunk's codes into its block's counters (LDS privatised per workgroup)
+constexpr int HIST_STRIDE = 320;  // [0,288) literal/length, [288,320) distance
+
+__global__ __launch_bounds__(256) void histogram_kernel(const ChunkDesc *__restrict__ chunks,
+                                                        const uint32_t *__restrict__ codes,
+                                                        const uint32_t *__restrict__ ncodes,
+                                                        uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[HIST_STRIDE];
+    const uint32_t c = blockIdx.x;
+    const ChunkDesc ch = chunks[c];
+    for (uint32_t i = threadIdx.x; i < HIST_STRIDE; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t n = ncodes[c];
+    const uint32_t per = (uint32_t)div_up(n, gridDim.y);
+    const uint32_t lo = blockIdx.y * per, hi = min(n, lo + per);
+    const uint32_t *p = codes + ch.code_off;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const uint32_t v = p[i];
+        const uint32_t dist = v & 0xFFFFu, val = v >> 16;
+        if (dist == 0) {
+            atomicAdd(&h[val], 1u);
+        } else {
+            uint32_t eb, ex;
+            atomicAdd(&h[len_symbol(val, eb, ex)], 1u);
+            atomicAdd(&h[288 + dist_symbol(dist, eb, ex)], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t *g = hist + (uint64_t)ch.block * HIST_STRIDE;
+    for (uint32_t i = threadIdx.x; i < HIST_STRIDE; i += 256)
+        if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void huffman_kernel(const BlockDesc *__restrict__ blocks,
+                                                     const uint32_t *__restrict__ hist,
+                                                     BlockCodes *__restrict__ bc) {
+    __shared__ HuffScratch S;
+    const uint32_t b = blockIdx.x;
+    const uint32_t type = blocks[b].type;
+    if (type == BT_RAW) return;
+    huff_block_build(hist + (uint64_t)b * HIST_STRIDE, type, &bc[b], S, (int)threadIdx.x, 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// block start bits: a serial fold (stored blocks byte-align, the final block byte-aligns)
+__global__ void offsets_kernel(const BlockDesc *__restrict__ blocks, uint32_t nblocks,
+                               const BlockCodes *__restrict__ bc, uint64_t start_bit,
+                               uint64_t cap_bits, uint64_t *__restrict__ block_start,
+                               EncodeResult *__restrict__ res) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint64_t bit = start_bit;
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        block_start[b] = bit;
+        const BlockDesc bd = blocks[b];
+        if (bd.type == BT_RAW) {
+            bit += 3;
+            bit = (bit + 7) & ~7ull;  // RawBuf::flush → BitWriter::flush (encode.rs:372)
+            bit += 32 + 8 * bd.in_len;
+        } else {
+            bit += bc[b].body_bits;
+        }
+        if (bd.align_after) bit = (bit + 7) & ~7ull;
+    }
+    res->end_bit = bit;
+    res->status = bit > cap_bits ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack: bits of one code word
+__device__ __forceinline__ uint32_t code_bits(uint32_t v, const uint32_t *lit, const uint32_t *dst,
+                                              uint64_t &bits) {
+    const uint32_t dist = v & 0xFFFFu, val = v >> 16;
+    if (dist == 0) {
+        const uint32_t e = lit[val];
+        bits = e & 0xFFFFu;
+        return e >> 16;
+    }
+    uint32_t eb, ex, db, dx;
+    const uint32_t le = lit[len_symbol(val, eb, ex)];
+    const uint32_t de = dst[dist_symbol(dist, db, dx)];
+    uint32_t n = le >> 16;
+    uint64_t acc = le & 0xFFFFu;
+    acc |= (uint64_t)ex << n;
+    n += eb;
+    acc |= (uint64_t)(de & 0xFFFFu) << n;
+    n += de >> 16;
+    acc |= (uint64_t)dx << n;
+    n += db;
+    bits = acc;
+    return n;
+}
+
+__device__ __forceinline__ uint32_t find_chunk(const ChunkDesc *chunks, uint32_t nchunks,
+                                               uint64_t gtile) {
+    uint32_t lo = 0, hi = nchunks;  // last chunk with tile_base <= gtile
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunks[mid].tile_base <= gtile) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+constexpr int PACK_THREADS = 256;
+constexpr int PACK_PER_THREAD = PACK_TILE / PACK_THREADS;  // 8
+
+__global__ __launch_bounds__(PACK_THREADS) void tile_bits_kernel(
+    const ChunkDesc *__restrict__ chunks, uint32_t nchunks, const BlockDesc *__restrict__ blocks,
+    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ ncodes,
+    const BlockCodes *__restrict__ bc, uint32_t *__restrict__ tile_bits) {
+    __shared__ uint32_t lit[288], dst[32], red[PACK_THREADS / 64];
+    const uint64_t gt = blockIdx.x;
+    const uint32_t c = find_chunk(chunks, nchunks, gt);
+    const ChunkDesc ch = chunks[c];
+    const uint32_t t = (uint32_t)(gt - ch.tile_base);
+    const uint32_t n = ncodes[c];
+    const uint32_t lo = t * PACK_TILE;
+    if (lo >= n || blocks[ch.block].type == BT_RAW) {
+        if (threadIdx.x == 0) tile_bits[gt] = 0;
+        return;
+    }
+    const BlockCodes *B = &bc[ch.block];
+    for (uint32_t i = threadIdx.x; i < 288; i += PACK_THREADS) lit[i] = B->lit[i];
+    if (threadIdx.x < 32) dst[threadIdx.x] = B->dist[threadIdx.x];
+    __syncthreads();
+    const uint32_t hi = min(n, lo + PACK_TILE);
+    const uint32_t *p = codes + ch.code_off;
+    uint32_t sum = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += PACK_THREADS) {
+        uint64_t bits;
+        sum += code_bits(p[i], lit, dst, bits);
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_bits[gt] = red[0] + red[1] + red[2] + red[3];
+}
+
+// per block: exclusive scan of its tiles' bit counts → absolute start bit of every tile
+__global__ __launch_bounds__(256) void tile_scan_kernel(const ChunkDesc *__restrict__ chunks,
+                                                        const BlockDesc *__restrict__ blocks,
+                                                        const BlockCodes *__restrict__ bc,
+                                                        const uint64_t *__restrict__ block_start,
+                                                        const uint32_t *__restrict__ tile_bits,
+                                                        uint64_t total_tiles,
+                                                        uint32_t nchunks,
+                                                        uint64_t *__restrict__ tile_start) {
+    __shared__ uint64_t wsum[4];
+    __shared__ uint64_t carry;
+    const uint32_t b = blockIdx.x;
+    const BlockDesc bd = blocks[b];
+    if (bd.type == BT_RAW || bd.n_chunks == 0) return;
+    const uint64_t t0 = chunks[bd.first_chunk].tile_base;
+    const uint32_t lastc = bd.first_chunk + bd.n_chunks;
+    const uint64_t t1 = lastc < nchunks ? chunks[lastc].tile_base : total_tiles;
+    if (threadIdx.x == 0) carry = block_start[b] + 3 + bc[b].hdr_bits;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t base = t0; base < t1; base += 256) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < t1 ? tile_bits[i] : 0;
+        uint64_t x = v;  // inclusive wave scan
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t y = __shfl_up(x, o);
+            if ((int)lane >= o) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+        if (i < t1) tile_start[i] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry = pre + x;
+        __syncthreads();
+    }
+}
+
+constexpr int STAGE_WORDS64 = (PACK_TILE * 48) / 64 + 4;  // worst case + phase + spill
+
+__global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
+    const ChunkDesc *__restrict__ chunks, uint32_t nchunks, const BlockDesc *__restrict__ blocks,
+    const uint32_t *__restrict__ codes, const uint32_t *__restrict__ ncodes,
+    const BlockCodes *__restrict__ bc, const uint64_t *__restrict__ tile_start,
+    const EncodeResult *__restrict__ res, uint64_t out_base_bit, uint32_t *__restrict__ out) {
+    __shared__ uint32_t lit[288], dst[32];
+    __shared__ uint32_t wsum[PACK_THREADS / 64];
+    __shared__ unsigned long long stage[STAGE_WORDS64];
+    if (res->status != 0) return;
+    const uint64_t gt = blockIdx.x;
+    const uint32_t c = find_chunk(chunks, nchunks, gt);
+    const ChunkDesc ch = chunks[c];
+    const uint32_t t = (uint32_t)(gt - ch.tile_base);
+    const uint32_t n = ncodes[c];
+    const uint32_t lo = t * PACK_TILE;
+    if (lo >= n || blocks[ch.block].type == BT_RAW) return;
+    const BlockCodes *B = &bc[ch.block];
+    for (uint32_t i = threadIdx.x; i < 288; i += PACK_THREADS) lit[i] = B->lit[i];
+    if (threadIdx.x < 32) dst[threadIdx.x] = B->dist[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < STAGE_WORDS64; i += PACK_THREADS) stage[i] = 0;
+    __syncthreads();
+    const uint32_t hi = min(n, lo + PACK_TILE);
+    const uint32_t *p = codes + ch.code_off;
+    // each lane owns PACK_PER_THREAD consecutive codes
+    uint64_t cb[PACK_PER_THREAD];
+    uint32_t cn[PACK_PER_THREAD];
+    uint32_t mine = 0;
+    const uint32_t first = lo + threadIdx.x * PACK_PER_THREAD;
+#pragma unroll
+    for (int k = 0; k < PACK_PER_THREAD; ++k) {
+        const uint32_t i = first + k;
+        cn[k] = 0;
+        cb[k] = 0;
+        if (i < hi) cn[k] = code_bits(p[i], lit, dst, cb[k]);
+        mine += cn[k];
+    }
+    // exclusive scan of `mine` over the workgroup
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if ((int)lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
+    const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const uint64_t start = tile_start[gt] - out_base_bit;  // bit offset inside `out`
+    const uint32_t phase = (uint32_t)start & 31;
+    uint32_t bit = phase + pre + x - mine;
+#pragma unroll
+    for (int k = 0; k < PACK_PER_THREAD; ++k) {
+        if (cn[k]) {
+            const uint32_t w = bit >> 6, sh = bit & 63;
+            atomicOr(&stage[w], cb[k] << sh);
+            if (sh + cn[k] > 64) atomicOr(&stage[w + 1], cb[k] >> (64 - sh));
+            bit += cn[k];
+        }
+    }
+    __syncthreads();
+    // staging → output words; the first and last word may be shared with neighbours
+    const uint32_t nwords = (phase + total + 31) >> 5;
+    const uint32_t *s32 = (const uint32_t *)stage;
+    uint32_t *o = out + (start >> 5);
+    for (uint32_t i = threadIdx.x; i < nwords; i += PACK_THREADS) {
+        const uint32_t v = s32[i];
+        if (i == 0 || i == nwords - 1) { if (v) atomicOr(&o[i], v); }
+        else o[i] = v;
+    }
+}
+
+// block header bits (BFINAL, BTYPE, dynamic table) and stored blocks
+__global__ __launch_bounds__(256) void block_header_kernel(
+    const uint8_t *__restrict__ in, uint64_t in_bytes, const BlockDesc *__restrict__ blocks,
+    const BlockCodes *__restrict__ bc, const uint64_t *__restrict__ block_start,
+    const EncodeResult *__restrict__ res, uint64_t out_base_bit, uint32_t *__restrict__ out) {
+    if (res->status != 0) return;
+    const uint32_t b = blockIdx.x;
+    const BlockDesc bd = blocks[b];
+    const uint64_t start = block_start[b] - out_base_bit;
+    // Block::flush encode.rs:291-292: 1 bit BFINAL then 2 bits BTYPE, LSB-first
+    const uint32_t first3 = (bd.final & 1) | (bd.type << 1);
+    if (threadIdx.x == 0) {
+        const uint32_t sh = (uint32_t)start & 31;
+        atomicOr(&out[start >> 5], first3 << sh);
+        if (sh > 29) atomicOr(&out[(start >> 5) + 1], first3 >> (32 - sh));
+    }
+    if (bd.type == BT_DYNAMIC) {
+        const BlockCodes *B = &bc[b];
+        const uint64_t hb = start + 3;
+        const uint32_t nw = (B->hdr_bits + 31) >> 5;
+        const uint32_t sh = (uint32_t)hb & 31;
+        for (uint32_t i = threadIdx.x; i < nw; i += 256) {
+            const uint32_t v = B->hdr[i];
+            if (v == 0) continue;
+            atomicOr(&out[(hb >> 5) + i], v << sh);
+            if (sh) atomicOr(&out[(hb >> 5) + i + 1], v >> (32 - sh));
+        }
+    } else if (bd.type == BT_RAW) {
+        // RawBuf::flush encode.rs:364-382: byte-align, LEN, NLEN, bytes
+        const uint64_t byte0 = ((start + 3 + 7) >> 3);
+        const uint32_t len = (uint32_t)bd.in_len;
+        const ByteSrc src = make_src(in + bd.in_off, in_bytes - bd.in_off);
+        const uint64_t total = 4 + (uint64_t)len;  // bytes to place starting at byte0
+        // each lane assembles output dwords [w0, w1]
+        const uint64_t wfirst = byte0 >> 2, wlast = (byte0 + total - 1) >> 2;
+        for (uint64_t w = wfirst + threadIdx.x; w <= wlast; w += 256) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t ob = w * 4 + k;
+                if (ob < byte0 || ob >= byte0 + total) continue;
+                const uint64_t r = ob - byte0;
+                uint32_t byte;
+                if (r == 0) byte = len & 0xFF;
+                else if (r == 1) byte = (len >> 8) & 0xFF;
+                else if (r == 2) byte = (~len) & 0xFF;
+                else if (r == 3) byte = ((~len) >> 8) & 0xFF;
+                else byte = src.load1(r - 4);
+                v |= byte << (8 * k);
+            }
+            if (v) atomicOr(&out[w], v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// checksums.  Every lane digests a contiguous 1 KiB span; spans are combined on the device by a
+// second kernel (x^n mod P shifts for CRC-32, closed form for Adler-32).
+constexpr uint32_t CK_SPAN = 1024;
+constexpr uint32_t CRC_POLY = 0xEDB88320u;
+
+__device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
+    // product of two polynomials in the reflected CRC-32 domain, mod P
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;   // reflected: bit 31 is x^0
+        a <<= 1;
+        b = (b >> 1) ^ (CRC_POLY & (0u - (b & 1)));
+    }
+    return p;
+}
+__device__ uint32_t gf2_xpow8n(uint64_t nbytes) {
+    // x^(8*nbytes) mod P, reflected representation (x^0 = 0x80000000)
+    uint32_t r = 0x80000000u;
+    uint32_t sq = 0x00800000u;  // x^8
+    while (nbytes) {
+        if (nbytes & 1) r = gf2_mulmod(r, sq);
+        sq = gf2_mulmod(sq, sq);
+        nbytes >>= 1;
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__restrict__ in,
+                                                            uint64_t n, uint32_t *__restrict__ crc_part,
+                                                            uint32_t *__restrict__ a_part,
+                                                            uint32_t *__restrict__ b_part) {
+    __shared__ uint32_t tab[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1)));
+        tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    const uint64_t span = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t lo = span * CK_SPAN;
+    if (lo >= n) return;
+    const uint32_t len = (uint32_t)min((uint64_t)CK_SPAN, n - lo);
+    const ByteSrc src = make_src(in + lo, len);
+    uint32_t crc = 0;  // raw register (no init / xorout): linear in the data
+    uint32_t a = 0, b = 0;
+    for (uint32_t i = 0; i < len; i += 4) {
+        const uint32_t w = src.load4(i);
+        const uint32_t m = min(4u, len - i);
+        for (uint32_t k = 0; k < m; ++k) {
+            const uint32_t byte = (w >> (8 * k)) & 0xFF;
+            crc = (crc >> 8) ^ tab[(crc ^ byte) & 0xFF];
+            a += byte;
+            b += a;  // <= 1024 * 255 * 1024 / 2 < 2^32
+        }
+    }
+    crc_part[span] = crc;
+    a_part[span] = a;            // sum of bytes
+    b_part[span] = b % 65521u;   // sum over i of (len - i) * byte_i
+}
+
+// one workgroup folds all span partials (tree over lanes, then serial over the few per-lane results)
+__global__ __launch_bounds__(1024) void checksum_combine_kernel(const uint32_t *__restrict__ crc_part,
+                                                                const uint32_t *__restrict__ a_part,
+                                                                const uint32_t *__restrict__ b_part,
+                                                                uint64_t n,
+                                                                EncodeResult *__restrict__ res) {
+    __shared__ uint32_t s_crc[1024];
+    __shared__ uint64_t s_len[1024];
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    const uint64_t nspans = div_up(n, CK_SPAN);
+    const uint64_t per = div_up(nspans, 1024);
+    const uint64_t lo = (uint64_t)threadIdx.x * per, hi = min(nspans, lo + per);
+    // serial fold of this lane's consecutive spans
+    uint32_t crc = 0, a = 0, b = 0;
+    uint64_t len = 0;
+    const uint32_t xs = gf2_xpow8n(CK_SPAN);
+    for (uint64_t s = lo; s < hi; ++s) {
+        const uint64_t sl = min((uint64_t)CK_SPAN, n - s * CK_SPAN);
+        const uint32_t sh = sl == CK_SPAN ? xs : gf2_xpow8n(sl);
+        crc = gf2_mulmod(crc, sh) ^ crc_part[s];
+        // Adler: A += a2 ; B += b2 + len2 * A_before
+        b = (uint32_t)((b + b_part[s] + (sl % 65521u) * (uint64_t)a) % 65521u);
+        a = (a + a_part[s]) % 65521u;
+        len += sl;
+    }
+    s_crc[threadIdx.x] = crc;
+    s_len[threadIdx.x] = len;
+    s_a[threadIdx.x] = a;
+    s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (uint32_t step = 1; step < 1024; step <<= 1) {
+        uint32_t c2 = 0, a2 = 0, b2 = 0;
+        uint64_t l2 = 0;
+        const bool act = (threadIdx.x % (2 * step)) == 0 && threadIdx.x + step < 1024;
+        if (act) {
+            c2 = s_crc[threadIdx.x + step];
+            l2 = s_len[threadIdx.x + step];
+            a2 = s_a[threadIdx.x + step];
+            b2 = s_b[threadIdx.x + step];
+        }
+        __syncthreads();
+        if (act) {
+            const uint32_t c1 = s_crc[threadIdx.x];
+            s_crc[threadIdx.x] = (l2 ? gf2_mulmod(c1, gf2_xpow8n(l2)) : c1) ^ c2;
+            const uint32_t a1 = s_a[threadIdx.x], b1 = s_b[threadIdx.x];
+            s_b[threadIdx.x] = (uint32_t)((b1 + b2 + (l2 % 65521u) * (uint64_t)a1) % 65521u);
+            s_a[threadIdx.x] = (a1 + a2) % 65521u;
+            s_len[threadIdx.x] += l2;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // raw register of the data; apply init 0xFFFFFFFF over n bytes and the final xor
+        const uint32_t raw = s_crc[0];
+        const uint32_t init = gf2_mulmod(0xFFFFFFFFu, gf2_xpow8n(n));
+        res->crc32 = raw ^ init ^ 0xFFFFFFFFu;
+        // Adler with A0 = 1: A = 1 + sum ; B = n*1 + sum_b
+        const uint32_t A = (1u + s_a[0]) % 65521u;
+        const uint32_t Bv = (uint32_t)((n % 65521u + s_b[0]) % 65521u);
+        res->adler32 = (Bv << 16) | A;
+    }
+}
+
+// container header / trailer bytes (host-built, a few bytes) → output, via atomicOr on zeroed words
+__global__ void put_bytes_kernel(const uint8_t *__restrict__ bytes, uint32_t n, uint64_t at_byte,
+                                 uint32_t *__restrict__ out) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t ob = at_byte + i;
+        atomicOr(&out[ob >> 2], (uint32_t)bytes[i] << (8 * (ob & 3)));
+    }
+}
+// trailer from the device-side checksum result (gzip.rs:114-121 CRC-32 LE + ISIZE LE;
+// zlib.rs:630-639 Adler-32 BE), placed at the byte after the last DEFLATE bit
+__global__ void trailer_kernel(int format, uint32_t isize, uint64_t out_base_bit,
+                               EncodeResult *__restrict__ res, uint32_t *__restrict__ out) {
+    if (threadIdx.x != 0 || res->status != 0) return;
+    const uint64_t at = (res->end_bit - out_base_bit + 7) >> 3;
+    uint8_t t[8];
+    uint32_t nt = 0;
+    if (format == 2) {
+        const uint32_t c = res->crc32;
+        t[0] = c; t[1] = c >> 8; t[2] = c >> 16; t[3] = c >> 24;
+        t[4] = isize; t[5] = isize >> 8; t[6] = isize >> 16; t[7] = isize >> 24;
+        nt = 8;
+    } else if (format == 1) {
+        const uint32_t a = res->adler32;
+        t[0] = a >> 24; t[1] = a >> 16; t[2] = a >> 8; t[3] = a;
+        nt = 4;
+    }
+    for (uint32_t i = 0; i < nt; ++i) {
+        const uint64_t ob = at + i;
+        atomicOr(&out[ob >> 2], (uint32_t)t[i] << (8 * (ob & 3)));
+    }
+    res->out_bytes = at + nt;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from lfx_api.cpp)
+#define LFX_LAUNCH_CHECK()                          \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return (int)e_;       \
+    } while (0)
+
+int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
+                 const SegDesc *segs, uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md) {
+    if (nsegs == 0) return 0;
+    const size_t lds = (sizeof(uint32_t) << HASH_BITS) + RING * 2 + MATCH_THREADS * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *)lz77_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(lz77_match_kernel, dim3(nsegs), dim3(MATCH_THREADS), lds, st, in, in_bytes,
+                       chunks, segs, window, max_len, md);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
+                 uint32_t nchunks, const uint32_t *md, uint32_t *codes, uint32_t *ncodes) {
+    if (nchunks == 0) return 0;
+    hipLaunchKernelGGL(lz77_parse_kernel, dim3(nchunks), dim3(64), 0, st, in, in_bytes, chunks, md,
+                       codes, ncodes);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
+                     const uint32_t *codes, const uint32_t *ncodes, uint32_t *hist) {
+    if (nchunks == 0) return 0;
+    hipLaunchKernelGGL(histogram_kernel, dim3(nchunks, split), dim3(256), 0, st, chunks, codes, ncodes, hist);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,
+                   BlockCodes *bc) {
+    if (nblocks == 0) return 0;
+    hipLaunchKernelGGL(huffman_kernel, dim3(nblocks), dim3(64), 0, st, blocks, hist, bc);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_offsets(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const BlockCodes *bc,
+                   uint64_t start_bit, uint64_t cap_bits, uint64_t *block_start, EncodeResult *res) {
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(64), 0, st, blocks, nblocks, bc, start_bit,
+                       cap_bits, block_start, res);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
+                uint32_t nchunks, const BlockDesc *blocks, uint32_t nblocks, uint64_t ntiles,
+                const uint32_t *codes, const uint32_t *ncodes, const BlockCodes *bc,
+                const uint64_t *block_start, uint32_t *tile_bits, uint64_t *tile_start,
+                const EncodeResult *res, uint64_t out_base_bit, uint32_t *out) {
+    if (ntiles) {
+        hipLaunchKernelGGL(tile_bits_kernel, dim3((uint32_t)ntiles), dim3(PACK_THREADS), 0, st, chunks,
+                           nchunks, blocks, codes, ncodes, bc, tile_bits);
+        LFX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(nblocks), dim3(256), 0, st, chunks, blocks, bc,
+                           block_start, tile_bits, ntiles, nchunks, tile_start);
+        LFX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)ntiles), dim3(PACK_THREADS), 0, st, chunks,
+                           nchunks, blocks, codes, ncodes, bc, tile_start, res, out_base_bit, out);
+        LFX_LAUNCH_CHECK();
+    }
+    if (nblocks) {
+        hipLaunchKernelGGL(block_header_kernel, dim3(nblocks), dim3(256), 0, st, in, in_bytes, blocks,
+                           bc, block_start, res, out_base_bit, out);
+        LFX_LAUNCH_CHECK();
+    }
+    return 0;
+}
+int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
+                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res) {
+    const uint64_t nspans = div_up(n, CK_SPAN);
+    if (nspans) {
+        hipLaunchKernelGGL(checksum_span_kernel, dim3((uint32_t)div_up(nspans, 256)), dim3(256), 0, st,
+                           in, n, crc_part, a_part, b_part);
+        LFX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(checksum_combine_kernel, dim3(1), dim3(1024), 0, st, crc_part, a_part, b_part,
+                       n, res);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_put_bytes(hipStream_t st, const uint8_t *d_bytes, uint32_t n, uint64_t at_byte, uint32_t *out) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(put_bytes_kernel, dim3(1), dim3(256), 0, st, d_bytes, n, at_byte, out);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_trailer(hipStream_t st, int format, uint32_t isize, uint64_t out_base_bit,
+                   EncodeResult *res, uint32_t *out) {
+    hipLaunchKernelGGL(trailer_kernel, dim3(1), dim3(64), 0, st, format, isize, out_base_bit, res, out);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace lfx

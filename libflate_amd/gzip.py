@@ -1,0 +1,105 @@
+"""libflate::gzip — Encoder, Decoder, MultiDecoder, EncodeOptions, HeaderBuilder (reference src/gzip.rs)."""
+import struct
+
+from . import _ffi
+from . import deflate as _deflate
+from ._stream import StreamError, _DecoderBase, _EncoderBase  # noqa: F401
+
+
+class ExtraSubField:  # gzip.rs:507-541
+    def __init__(self, id, data):
+        self.id = bytes(id)
+        self.data = bytes(data)
+
+    def _bytes(self):
+        return self.id + struct.pack("<H", len(self.data)) + self.data
+
+
+class HeaderBuilder:
+    """gzip::HeaderBuilder (gzip.rs:126-288).  modification_time defaults to 0 here (the reference
+    uses `now`, gzip.rs:148-151) — set it explicitly for reproducible bytes."""
+
+    def __init__(self):
+        self._kw = {"mtime": 0}
+
+    @classmethod
+    def new(cls):
+        return cls()
+
+    def modification_time(self, t):
+        self._kw["mtime"] = t
+        return self
+
+    def os(self, os_code):
+        self._kw["os"] = os_code
+        return self
+
+    def text(self):
+        self._kw["is_text"] = 1
+        return self
+
+    def verify(self):
+        self._kw["hcrc"] = 1
+        return self
+
+    def extra_field(self, subfields):
+        self._kw["extra"] = b"".join(f._bytes() for f in subfields)
+        return self
+
+    def filename(self, name):
+        self._kw["filename"] = bytes(name)
+        return self
+
+    def comment(self, text):
+        self._kw["comment"] = bytes(text)
+        return self
+
+    def finish(self):
+        return dict(self._kw)
+
+
+class EncodeOptions(_deflate.EncodeOptions):
+    """gzip::EncodeOptions (gzip.rs:639-751)."""
+
+    def __init__(self, lz77=None):
+        super().__init__(lz77)
+        self._kw.setdefault("mtime", 0)
+
+    def header(self, header):  # gzip.rs:717-720
+        self._kw.update(header)
+        return self
+
+
+class Encoder(_EncoderBase):
+    """gzip::Encoder (gzip.rs:754-908)."""
+    FORMAT = _ffi.GZIP
+
+    def __init__(self, inner, options=None, context=None):
+        super().__init__(inner, options if options is not None else EncodeOptions(), context)
+
+    @classmethod
+    def new(cls, inner, context=None):
+        return cls(inner, None, context)
+
+    @classmethod
+    def with_options(cls, inner, options, context=None):
+        return cls(inner, options, context)
+
+
+class Decoder(_DecoderBase):
+    """gzip::Decoder (gzip.rs:912-1047): one member; trailing bytes are left unread."""
+    FORMAT = _ffi.GZIP
+
+    @classmethod
+    def new(cls, inner, context=None):
+        return cls(inner, context)
+
+
+class MultiDecoder(_DecoderBase):
+    """gzip::MultiDecoder (gzip.rs:1052-1167): concatenated members."""
+    FORMAT = _ffi.GZIP
+    FLAGS = _ffi.DEC_MULTI
+
+    @classmethod
+    def new(cls, inner, context=None):
+        return cls(inner, context)

@@ -1,0 +1,235 @@
+"""CPU: the host planner and the host/device-shared Huffman + header code (lfx_plan.h, lfx_huff.h —
+the SAME source the HIP kernels compile) reproduce the oracle bit for bit when the GPU-only stages
+(match, parse, pack) are stood in for by straightforward Python."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from golden import kat
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    import __graft_entry__ as g
+    g.build()
+    from libflate_amd import _ffi
+    return _ffi
+
+
+def huff_block(ffi, hist320, btype):
+    hist = np.ascontiguousarray(hist320, dtype=np.uint32)
+    lit = np.zeros(288, np.uint32); dist = np.zeros(32, np.uint32); hdr = np.zeros(160, np.uint32)
+    hb, bb = C.c_uint32(0), C.c_uint64(0)
+    ffi.lib().lfx_debug_huff_block(hist.ctypes.data, btype, lit.ctypes.data, dist.ctypes.data,
+                                   hdr.ctypes.data, C.byref(hb), C.byref(bb))
+    return lit, dist, hdr, hb.value, bb.value
+
+
+def plan(ffi, fmt, n, write_size=0, writes=None, **kw):
+    o = ffi.make_opts(**kw)
+    s = ffi.make_schedule(write_size, writes)
+    ch = np.zeros(4 * 4096, np.uint64); bl = np.zeros(6 * 4096, np.uint64)
+    nc, nb = C.c_size_t(0), C.c_size_t(0)
+    rc = ffi.lib().lfx_debug_plan(fmt, C.byref(o), C.byref(s), n, ch.ctypes.data, 4096, C.byref(nc),
+                                  bl.ctypes.data, 4096, C.byref(nb))
+    assert rc == 0
+    return ch[:4 * nc.value].reshape(-1, 4), bl[:6 * nb.value].reshape(-1, 6)
+
+
+def symbols(ffi, length, distance):
+    out = np.zeros(6, np.uint32)
+    ffi.lib().lfx_debug_symbols(length, distance, out.ctypes.data)
+    return [int(x) for x in out]
+
+
+class Bits:
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, width, bits):
+        self.acc |= bits << self.n
+        self.n += width
+
+    def align(self):
+        self.n = (self.n + 7) // 8 * 8
+
+    def bytes(self):
+        return self.acc.to_bytes((self.n + 7) // 8, "little")
+
+
+def emulate_deflate(ffi, oracle, data, write_size=0, writes=None, **kw):
+    """raw DEFLATE bytes assembled from: planner (C++) + oracle LZ77 per chunk + lfx_huff.h (C++)."""
+    chunks, blocks = plan(ffi, ffi.DEFLATE, len(data), write_size, writes, **kw)
+    bw = Bits()
+    window, maxlen = kw.get("window_size", 32768), kw.get("max_length", 258)
+    for btype, final, first, nch, in_off, in_len in blocks:
+        btype, final = int(btype), int(final)
+        bw.put(1, final); bw.put(2, btype)
+        if btype == 0:
+            bw.align()
+            ln = int(in_len)
+            bw.put(16, ln); bw.put(16, (~ln) & 0xFFFF)
+            for b in data[int(in_off):int(in_off) + ln]:
+                bw.put(8, b)
+            continue
+        codes = []
+        for c in chunks[int(first):int(first) + int(nch)]:
+            off, ln, _blk, flags = (int(x) for x in c)
+            seg = data[off:off + ln]
+            if flags & 2:
+                codes.extend(int(b) << 16 for b in seg)
+            else:
+                codes.extend(int(x) for x in oracle.lz77_chunk(seg, window, maxlen))
+        codes.append(256 << 16)
+        hist = np.zeros(320, np.uint32)
+        for w in codes:
+            val, dist = w >> 16, w & 0xFFFF
+            if dist == 0:
+                hist[val] += 1
+            else:
+                s = symbols(ffi, val, dist)
+                hist[s[0]] += 1
+                hist[288 + s[3]] += 1
+        lit, dst, hdr, hbits, body = huff_block(ffi, hist, btype)
+        start = bw.n
+        for i in range(hbits):
+            bw.put(1, (int(hdr[i >> 5]) >> (i & 31)) & 1)
+        for w in codes:
+            val, dist = w >> 16, w & 0xFFFF
+            if dist == 0:
+                e = int(lit[val]); bw.put(e >> 16, e & 0xFFFF)
+            else:
+                s = symbols(ffi, val, dist)
+                e = int(lit[s[0]]); bw.put(e >> 16, e & 0xFFFF)
+                if s[1]: bw.put(s[1], s[2])
+                e = int(dst[s[3]]); bw.put(e >> 16, e & 0xFFFF)
+                if s[4]: bw.put(s[4], s[5])
+        assert bw.n - start + 3 == body, "body_bits mismatch"
+    bw.align()
+    return bw.bytes()
+
+
+def test_symbol_maps(ffi):
+    # closed forms == Symbol::code/extra_lengh/distance (symbol.rs:95-154) via the oracle's tables
+    LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115,
+                131, 163, 195, 227, 258]
+    LEN_EXTRA = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+    DIST_BASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537,
+                 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+    DIST_EXTRA = [0, 0, 0, 0] + [i // 2 for i in range(2, 28)]
+    for length in range(3, 259):
+        s = symbols(ffi, length, 1)
+        k = s[0] - 257
+        assert 0 <= k < 29 and s[1] == LEN_EXTRA[k] and LEN_BASE[k] + s[2] == length
+        if length == 258:
+            assert s[0] == 285
+        else:
+            assert k < 28 and s[2] < (1 << LEN_EXTRA[k])
+    for d in list(range(1, 600)) + [1024, 1025, 4096, 8193, 16384, 16385, 24576, 24577, 32767, 32768]:
+        s = symbols(ffi, 3, d)
+        assert DIST_BASE[s[3]] + s[5] == d and s[4] == DIST_EXTRA[s[3]] and s[5] < (1 << s[4] if s[4] else 1)
+
+
+def test_huffman_vs_oracle(ffi, oracle):
+    rng = np.random.default_rng(11)
+    cases = []
+    for trial in range(120):
+        hist = np.zeros(320, np.uint32)
+        kind = trial % 6
+        nlit = int(rng.integers(1, 286))
+        if kind == 0:
+            hist[:286] = rng.integers(0, 1000, 286)
+        elif kind == 1:   # skewed: forces the length-limiting branch
+            v = np.array([int(1.6 ** i) for i in range(40)], dtype=np.uint64) % (1 << 31)
+            idx = rng.permutation(286)[:40]
+            hist[idx] = v.astype(np.uint32)
+        elif kind == 2:   # many ties
+            hist[rng.permutation(286)[:nlit]] = rng.integers(1, 4, nlit)
+        elif kind == 3:   # sparse
+            hist[rng.permutation(286)[:rng.integers(1, 5)]] = rng.integers(1, 100000, 1)
+        elif kind == 4:
+            hist[:286] = (rng.pareto(0.7, 286) * 10).astype(np.uint32)
+        else:
+            hist[:286] = rng.integers(0, 2, 286) * rng.integers(1, 1 << 20, 286)
+        hist[256] = 1
+        nd = int(rng.integers(0, 31))
+        if nd and kind != 3:
+            hist[288 + rng.permutation(30)[:nd]] = rng.integers(1, 5000, nd) if kind != 1 else \
+                np.array([int(1.9 ** i) for i in range(nd)], dtype=np.uint32)
+        cases.append(hist)
+    e = np.zeros(320, np.uint32); e[256] = 1
+    cases.append(e)   # the empty final block
+    for hist in cases:
+        lit, dst, hdr, hbits, body = huff_block(ffi, hist, 2)
+        lw = oracle.huff_widths(hist[:286], 15)
+        dh = hist[288:318].copy()
+        if dh.sum() == 0:
+            dh[0] = 1                                     # symbol.rs:332-337
+        dw = oracle.huff_widths(dh, 15)
+        assert list(lit[:286] >> 16) == list(lw)
+        assert list(dst[:30] >> 16) == list(dw)
+        assert list(lit[:286] & 0xFFFF) == list(oracle.huff_codes(lw))
+        assert list(dst[:30] & 0xFFFF) == list(oracle.huff_codes(dw))
+
+
+def test_emulated_pipeline_matches_oracle(ffi, oracle):
+    rng = np.random.default_rng(5)
+    text = kat.test_i()
+    cases = [
+        (kat.HELLO, dict()), (b"", dict()), (b"a", dict()), (b"aaaaa", dict()),
+        (b"hello hello hello", dict()),
+        (kat.ISSUE52[:16031], dict()), (kat.ISSUE52, dict()),
+        (text, dict(write_size=8192)), (text, dict(write_size=1000, block_size=20000)),
+        (text, dict(dynamic_huffman=0)), (text[:5000], dict(lz77_kind=1)),
+        (text[:70000 * 2], dict(no_compression=1)), (text[:300], dict(no_compression=1, block_size=100, write_size=70)),
+        (text, dict(window_size=1024, max_length=16)),
+        (bytes(300000), dict()), (bytes(300000), dict(write_size=8192)),
+        (rng.integers(0, 256, 40000, dtype=np.uint8).tobytes(), dict(write_size=8192, block_size=16384)),
+        (kat.ramp()[:300000], dict(write_size=8192, block_size=65536)),
+    ]
+    for data, kw in cases:
+        ws = kw.pop("write_size", 0)
+        got = emulate_deflate(ffi, oracle, data, ws, None, **kw)
+        want = oracle.encode(oracle.DEFLATE, data, write_size=ws, **kw)
+        assert got == want, (len(data), kw, ws)
+    assert emulate_deflate(ffi, oracle, kat.HELLO) == kat.DEFLATE_HELLO   # encode.rs:152-154
+    # flush events (zlib.rs:840-902 shapes, raw deflate here)
+    writes = [18, 3, 3, None, 18, 3, 3, None]
+    got = emulate_deflate(ffi, oracle, kat.ISSUE27_PLAIN, 0, writes)
+    assert got == kat.ISSUE27_ZLIB_NONE[2:-4]
+
+
+def test_structural_insight_parse_independent_candidates(oracle):
+    """cand(i) = most recent earlier same-trigram position is parse independent, so the
+    greedy walk over per-position (len, dist) answers reproduces DefaultLz77Encoder::flush."""
+    rng = np.random.default_rng(9)
+    inputs = [kat.test_i()[:20000], bytes(5000), rng.integers(0, 3, 20000, dtype=np.uint8).tobytes(),
+              kat.ISSUE52, b"abcabcabcabcabcabc" * 50, b"ab", b"abc", b"abcd"]
+    for window, maxlen in ((32768, 258), (64, 258), (32768, 8), (300, 20)):
+        for data in inputs:
+            n = len(data)
+            end = max(3, n) - 3
+            last = {}
+            md = []
+            for i in range(end):
+                key = data[i:i + 3]
+                j = last.get(key)
+                last[key] = i
+                if j is not None and i - j <= window:
+                    lim = min(n - (i + 3), maxlen - 3)
+                    l = 0
+                    while l < lim and data[i + 3 + l] == data[j + 3 + l]:
+                        l += 1
+                    md.append((3 + l, i - j))
+                else:
+                    md.append((0, 0))
+            codes, i = [], 0
+            while i < end:
+                ln, d = md[i]
+                if d:
+                    codes.append((ln << 16) | d); i += ln
+                else:
+                    codes.append(data[i] << 16); i += 1
+            codes.extend(b << 16 for b in data[i:])
+            assert codes == [int(x) for x in oracle.lz77_chunk(data, window, maxlen)], (window, maxlen, n)
