@@ -135,6 +135,13 @@ int lfx_encode_shard_prepare(lfx_ctx *c, int format, const lfx_encode_opts *o,
  * shard the trailer built from the combined checksum / size given here. */
 int lfx_encode_shard_emit(lfx_ctx *c, uint64_t start_bit, uint32_t combined_check,
                           uint64_t total_n, void *d_out, uint64_t cap, uint64_t *out_len);
+/* inverse of the sharded encode: decodes the blocks of ONE shard of a member.  d_in[0] is the byte
+ * that holds bit `start_bit` (0..7) of the shard; a non-last shard ends when a block ends exactly
+ * `total_bits` later (it holds no BFINAL block).  Reference-made blocks never reference earlier
+ * blocks (fresh PrefixTable per flush, default.rs:73), which is what makes shards decodable alone. */
+int lfx_decode_shard_device(lfx_ctx *c, const void *d_in, uint64_t n, uint64_t start_bit,
+                            uint64_t total_bits, int is_last, void *d_out, uint64_t cap,
+                            uint64_t *out_len);
 uint32_t lfx_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 uint32_t lfx_adler32_combine(uint32_t ad1, uint32_t ad2, uint64_t len2);
 uint64_t lfx_container_header_len(int format, const lfx_encode_opts *o);

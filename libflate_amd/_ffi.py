@@ -21,7 +21,7 @@ DEC_MULTI = 1
 EXPORTS = [
     "lfx_encode_opts_default", "lfx_ctx_new", "lfx_ctx_free", "lfx_ctx_last_error", "lfx_ctx_set_stream",
     "lfx_device_count", "lfx_encode_bound", "lfx_encode_device", "lfx_encode_host", "lfx_decode_device",
-    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit",
+    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device",
     "lfx_crc32_combine", "lfx_adler32_combine", "lfx_container_header_len", "lfx_encoder_new",
     "lfx_encoder_write", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
     "lfx_encoder_free", "lfx_decoder_new", "lfx_decoder_read", "lfx_decoder_unread",
@@ -84,6 +84,13 @@ def lib():
         raise ImportError(
             "libflate_amd: native library %s is missing — run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc, gfx950). There is no CPU fallback." % SO_PATH)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64; if
+    # /opt/rocm's copy were initialised first, torch (device memory, RCCL) could no longer see the
+    # GPU.  Importing torch first makes our DT_NEEDED libamdhip64.so.7 resolve to the loaded one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     u64, u32, vp, i32 = C.c_uint64, C.c_uint32, C.c_void_p, C.c_int
     L.lfx_encode_opts_default.argtypes = [C.POINTER(EncodeOpts)]
@@ -105,6 +112,7 @@ def lib():
     L.lfx_encode_shard_prepare.argtypes = [vp, i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), vp, u64, i32,
                                            i32, C.POINTER(ShardInfo)]
     L.lfx_encode_shard_emit.argtypes = [vp, u64, u32, u64, vp, u64, C.POINTER(u64)]
+    L.lfx_decode_shard_device.argtypes = [vp, vp, u64, u64, u64, i32, vp, u64, C.POINTER(u64)]
     L.lfx_crc32_combine.restype = u32
     L.lfx_crc32_combine.argtypes = [u32, u32, u64]
     L.lfx_adler32_combine.restype = u32

@@ -98,8 +98,11 @@ int run_jobs(Ctx *c, const uint8_t *d_in, uint8_t *d_out, const std::vector<Infl
 
 // Decode the DEFLATE stream that starts at byte `off0` of d_in[0..n) into d_out[0..cap).
 // hist0 = 0 (a member starts with an empty Lz77Decoder buffer, gzip.rs:1000-1005).
+// stop_bit != ~0: the walk ends cleanly when a block ends exactly at stop_bit (a shard of a member that
+// does not hold the BFINAL block); start_bit0 may be any bit of the first byte.
 int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8_t *d_out, uint64_t cap,
-                   MemberResult &mr) {
+                   MemberResult &mr, uint64_t start_bit0 = ~0ull, uint64_t stop_bit = ~0ull) {
+    const uint64_t first_bit = start_bit0 == ~0ull ? off0 * 8 : start_bit0;
     hipStream_t st = c->stream;
     std::vector<InflateJob> jobs;
     std::vector<InflateResult> res;
@@ -130,8 +133,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
             c->phase("find2");
             std::vector<uint64_t> starts;
-            starts.push_back(off0 * 8);  // the first block's start is known
-            for (uint32_t i = 0; i < n1; i++) if (ok[i] && cand[i] != off0 * 8) starts.push_back(cand[i]);
+            starts.push_back(first_bit);  // the first block's start is known
+            for (uint32_t i = 0; i < n1; i++) if (ok[i] && cand[i] != first_bit) starts.push_back(cand[i]);
             std::sort(starts.begin(), starts.end());
             // ---- pass 1: every candidate block is decoded (no output) for its length and end bit
             jobs.clear();
@@ -146,9 +149,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             c->phase("pass1");
             // ---- chain from the known first block
             std::vector<size_t> chain;
-            uint64_t pos = off0 * 8, total = 0;
+            uint64_t pos = first_bit, total = 0;
             bool ok_chain = false;
             for (;;) {
+                if (pos == stop_bit && !chain.empty()) { ok_chain = true; break; }
                 auto it = std::lower_bound(starts.begin(), starts.end(), pos);
                 if (it == starts.end() || *it != pos) break;
                 const size_t k = it - starts.begin();
@@ -188,11 +192,15 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
         }
     }
+    if (!parallel_done && stop_bit != ~0ull) {
+        c->set_error("shard decode needs chainable (history-free) blocks");
+        return LFX_E_UNSUPPORTED;
+    }
     if (!parallel_done) {
         // ---- serial walk of the whole stream by one wavefront (exact error / partial-output semantics)
         jobs.clear();
         InflateJob j{};
-        j.in_off = 0; j.in_len = n; j.start_bit = off0 * 8;
+        j.in_off = 0; j.in_len = n; j.start_bit = first_bit;
         j.out_off = 0; j.out_cap = cap; j.hist_avail = 0; j.flags = 0;
         jobs.push_back(j);
         int rc;
@@ -314,10 +322,28 @@ extern "C" int lfx_decode_device(lfx_ctx *cc, int format, uint32_t flags, const 
     DecodeOutcome oc;
     int rc = decode_stream(c, format, flags, (const uint8_t *)d_in, n, (uint8_t *)d_out, cap, oc);
     if (rc) return rc;
+    if (oc.out_len > cap) oc.out_len = cap;  // defensive: never report more than the buffer holds
     if (out_len) *out_len = oc.out_len;
     if (consumed) *consumed = oc.consumed;
     if (oc.status != LFX_OK) c->set_error(oc.msg);
     return oc.status;
+}
+
+extern "C" int lfx_decode_shard_device(lfx_ctx *cc, const void *d_in, uint64_t n, uint64_t start_bit,
+                                       uint64_t total_bits, int is_last, void *d_out, uint64_t cap,
+                                       uint64_t *out_len) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    (void)hipSetDevice(c->device);
+    c->n_ev = 0;
+    c->phase("start");
+    MemberResult mr;
+    int rc = inflate_member(c, (const uint8_t *)d_in, n, start_bit >> 3, (uint8_t *)d_out, cap, mr, start_bit,
+                            is_last ? ~0ull : start_bit + total_bits);
+    if (rc) return rc;
+    if (out_len) *out_len = mr.out_len;
+    if (mr.status != LFX_OK) c->set_error(mr.msg);
+    return mr.status;
 }
 
 extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const void *in, uint64_t n, void *out,

@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
             rc = tab_build(T_dist, lens + dist_at, nd, 1, T_lit.safe_bw, -1, lane, &csym);
             if (rc) { if (lane == 0) { b.err = 1; b.ecode = ERR_CONFLICT; b.ea0 = csym; } break; }
             // ---- symbols: read_compressed_block decode.rs:112-130
-            bool stop = false;
+            bool stop = false, nospace = false;
             for (;;) {
                 win_ensure(b, QN * 6 + 16, lane);
                 if (lane == 0) {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                 const uint32_t total = __shfl(x, 63);
                 const uint64_t at = produced + x - mylen;
                 if (do_write && n) {
-                    if (produced + total > job.out_cap) { if (lane == 0) { b.err = 3; b.ecode = ERR_NOSPACE; } stop = true; }
+                    if (produced + total > job.out_cap) { if (lane == 0) { b.err = 3; b.ecode = ERR_NOSPACE; } stop = true; nospace = true; }
                     else {
                         if (lane < n && !is_match) o[at] = (uint8_t)e;
                         __threadfence_block();
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                         }
                     }
                 }
-                produced += total;
+                if (!nospace) produced += total;  // never report bytes that were not written
                 __syncthreads();
                 if (stop || done) { if (done == 2) stop = true; break; }
             }

@@ -1,0 +1,84 @@
+"""GPU: BASELINE.json-size checks through size-independent properties (round trip, checksum of the
+round trip, python-zlib as an independent inflater) plus a 64 MiB byte-for-byte oracle comparison."""
+import zlib as pyzlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import os, sys
+    import __graft_entry__ as g
+    g.build()
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth
+    import libflate_amd
+    from libflate_amd import _ffi
+    return libflate_amd.Context(0), _ffi, synth
+
+
+def test_cfg2_64mib_bit_exact_vs_oracle(env, oracle):
+    import torch
+    ctx, ffi, synth = env
+    n = 64 << 20
+    data = synth.text(n)
+    d_in = torch.from_numpy(data).cuda()
+    sched, opts = ffi.make_schedule(8192), ffi.make_opts()
+    bound = ffi.lib().lfx_encode_bound(n, None, None)
+    d_out = torch.empty(bound, dtype=torch.uint8, device="cuda")
+    m = ctx.encode_device(ffi.GZIP, d_in.data_ptr(), n, d_out.data_ptr(), bound, opts, sched)
+    got = d_out[:m].cpu().numpy().tobytes()
+    want = oracle.encode(oracle.GZIP, data.tobytes(), write_size=8192)
+    assert got == want
+    assert len(oracle.scan_blocks(got[10:-8])) == 65   # 64 one-MiB blocks + the empty final block
+
+
+def test_cfg2_256mib_roundtrip(env):
+    import torch
+    ctx, ffi, synth = env
+    n = 256 << 20
+    data = synth.text(n)
+    d_in = torch.from_numpy(data).cuda()
+    sched, opts = ffi.make_schedule(8192), ffi.make_opts()
+    bound = ffi.lib().lfx_encode_bound(n, None, None)
+    d_out = torch.empty(bound, dtype=torch.uint8, device="cuda")
+    m = ctx.encode_device(ffi.GZIP, d_in.data_ptr(), n, d_out.data_ptr(), bound, opts, sched)
+    comp = d_out[:m].cpu().numpy().tobytes()
+    # independent inflater + independent CRC
+    plain = pyzlib.decompress(comp, 31)
+    assert len(plain) == n and pyzlib.crc32(plain) == pyzlib.crc32(data.tobytes())
+    assert int.from_bytes(comp[-8:-4], "little") == pyzlib.crc32(plain) and int.from_bytes(comp[-4:], "little") == n
+    d_dec = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    rc, ol, used, msg = ctx.decode_device(ffi.GZIP, d_out.data_ptr(), m, d_dec.data_ptr(), n)
+    assert (rc, ol, used) == (0, n, m), msg
+    assert torch.equal(d_dec, d_in)
+
+
+def test_cfg5_lowent_zlib(env, oracle):
+    import torch
+    ctx, ffi, synth = env
+    n = 32 << 20                               # the oracle finishes this in seconds; cfg5 proper is 1 GiB
+    data = synth.lowent(n)
+    d_in = torch.from_numpy(data).cuda()
+    sched, opts = ffi.make_schedule(8192), ffi.make_opts()
+    bound = ffi.lib().lfx_encode_bound(n, None, None)
+    d_out = torch.empty(bound, dtype=torch.uint8, device="cuda")
+    m = ctx.encode_device(ffi.ZLIB, d_in.data_ptr(), n, d_out.data_ptr(), bound, opts, sched)
+    got = d_out[:m].cpu().numpy().tobytes()
+    assert got == oracle.encode(oracle.ZLIB, data.tobytes(), write_size=8192)
+    d_dec = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    rc, ol, used, msg = ctx.decode_device(ffi.ZLIB, d_out.data_ptr(), m, d_dec.data_ptr(), n)
+    assert (rc, ol, used) == (0, n, m), msg
+    assert torch.equal(d_dec, d_in)
+
+
+def test_s1_single_write_multi_segment(env, oracle):
+    # schedule S1 on 3 MiB: ONE LZ77 chunk split into 256 Ki-position segments with 32 KiB warm-up
+    ctx, ffi, synth = env
+    data = synth.text(3 << 20).tobytes()
+    got = ctx.encode_host(ffi.GZIP, data, ffi.make_opts(), ffi.make_schedule(0))
+    assert got == oracle.encode(oracle.GZIP, data, write_size=0)
+    assert ctx.decode_host(ffi.GZIP, got)[:2] == (0, data)
