@@ -53,6 +53,14 @@ struct BlockCodes {
 
 constexpr uint32_t PACK_TILE = 2048;  // codes per pack tile
 
+#ifdef __HIPCC__
+// pointers that are known to address global memory (HBM): keeps loads on the global_load path —
+// a pointer rebuilt from an integer becomes `flat`, and flat loads also tick lgkmcnt, which makes
+// every LDS wait drain outstanding memory prefetches
+typedef const __attribute__((address_space(1))) uint32_t *gptr_u32;
+typedef const __attribute__((address_space(1))) uint8_t *gptr_u8;
+#endif
+
 LFX_HD inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 }  // namespace lfx

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -136,57 +137,99 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             starts.push_back(first_bit);  // the first block's start is known
             for (uint32_t i = 0; i < n1; i++) if (ok[i] && cand[i] != first_bit) starts.push_back(cand[i]);
             std::sort(starts.begin(), starts.end());
-            // ---- pass 1: every candidate block is decoded (no output) for its length and end bit
-            jobs.clear();
-            for (uint64_t sb : starts) {
-                InflateJob j{};
-                j.in_off = 0; j.in_len = n; j.start_bit = sb;
-                j.out_off = 0; j.out_cap = ~0ull; j.hist_avail = 0;
-                j.flags = JOB_SINGLE_BLOCK | JOB_COUNT_ONLY;
-                jobs.push_back(j);
+            // ---- K1: every candidate block is scanned by a 256-lane workgroup (speculative slices,
+            //      chained exits) for its end bit, byte and code counts
+            const uint32_t nc = (uint32_t)starts.size();
+            std::vector<BlkJob> bj(nc);
+            for (uint32_t i = 0; i < nc; i++) bj[i] = BlkJob{starts[i], i + 1 < nc ? starts[i + 1] : n * 8};
+            if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * nc))) return rc;
+            if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * nc))) return rc;
+            if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)nc))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nc, hipMemcpyHostToDevice, st));
+            LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nc, (BlkInfo *)c->d_dec_state.p,
+                                       (BlkLanes *)c->d_dec_blocks.p));
+            std::vector<BlkInfo> bi(nc);
+            HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nc, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            c->phase("blk_scan");
+            if (getenv("LFX_DEBUG")) {
+                fprintf(stderr, "[lfx] finder: stage1=%u candidates=%u\n", n1, nc);
+                for (uint32_t i = 0; i < nc && i < 12; i++)
+                    fprintf(stderr, "[lfx]  cand %u start=%llu status=%u btype=%u final=%u end=%llu n_out=%llu n_codes=%u lanes=%u rounds=%u cyc_hdr=%u cyc_total=%u\n",
+                            i, (unsigned long long)starts[i], bi[i].status, bi[i].btype, bi[i].bfinal,
+                            (unsigned long long)bi[i].end_bit, (unsigned long long)bi[i].n_out, bi[i].n_codes,
+                            bi[i].nlanes, bi[i].rounds, bi[i].cyc_hdr, bi[i].cyc_total);
+                uint32_t nbad = 0, maxr = 0;
+                for (uint32_t i = 0; i < nc; i++) { nbad += bi[i].status != BLK_OK; maxr = std::max(maxr, bi[i].rounds); }
+                fprintf(stderr, "[lfx]  not-ok=%u max_rounds=%u\n", nbad, maxr);
             }
-            if ((rc = run_jobs(c, d_in, d_out, jobs, res))) return rc;
-            c->phase("pass1");
             // ---- chain from the known first block
-            std::vector<size_t> chain;
-            uint64_t pos = first_bit, total = 0;
+            std::vector<BlkEmit> emit;
+            uint64_t pos = first_bit, total = 0, total_codes = 0;
             bool ok_chain = false;
             for (;;) {
-                if (pos == stop_bit && !chain.empty()) { ok_chain = true; break; }
+                if (pos == stop_bit && !emit.empty()) { ok_chain = true; break; }
                 auto it = std::lower_bound(starts.begin(), starts.end(), pos);
                 if (it == starts.end() || *it != pos) break;
-                const size_t k = it - starts.begin();
-                const InflateResult &r = res[k];
-                if (r.status != 0 || r.needs_hist) break;
-                chain.push_back(k);
-                total += r.out_len;
-                if (r.final_seen) { ok_chain = true; break; }
-                if (r.end_bit <= pos) break;
+                const uint32_t k = (uint32_t)(it - starts.begin());
+                // a false candidate inside this block cut its range short: rescan with wider ranges
+                for (uint32_t widen = 2; bi[k].status == BLK_NO_EOB && k + widen <= nc && widen <= 6; widen++) {
+                    BlkJob one{pos, k + widen < nc ? starts[k + widen] : n * 8};
+                    HIP_TRY(hipMemcpyAsync((BlkJob *)c->d_dec_streams.p + k, &one, sizeof one, hipMemcpyHostToDevice, st));
+                    LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p + k, 1,
+                                               (BlkInfo *)c->d_dec_state.p + k, (BlkLanes *)c->d_dec_blocks.p + k));
+                    HIP_TRY(hipMemcpyAsync(&bi[k], (BlkInfo *)c->d_dec_state.p + k, sizeof(BlkInfo), hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                }
+                const BlkInfo &r = bi[k];
+                if (r.status != BLK_OK || r.end_bit <= pos) break;
+                BlkEmit e{};
+                e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
+                e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
+                emit.push_back(e);
+                total += r.n_out;
+                total_codes += r.n_codes;
+                if (r.bfinal) { ok_chain = true; break; }
                 pos = r.end_bit;
             }
+            if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  chain ok=%d blocks=%zu pos=%llu total=%llu\n", (int)ok_chain, emit.size(), (unsigned long long)pos, (unsigned long long)total);
             if (ok_chain && total <= cap) {
-                // ---- pass 2: the chained blocks are decoded again, each at its output offset
-                std::vector<InflateJob> j2;
-                uint64_t at = 0;
-                for (size_t k : chain) {
-                    InflateJob j{};
-                    j.in_off = 0; j.in_len = n; j.start_bit = starts[k];
-                    j.out_off = at; j.out_cap = res[k].out_len; j.hist_avail = at;
-                    j.flags = JOB_SINGLE_BLOCK;
-                    at += res[k].out_len;
-                    j2.push_back(j);
+                // ---- K2 + K3: validated lanes emit codes, one wavefront per block materialises them
+                const uint32_t ne = (uint32_t)emit.size();
+                if ((rc = c->d_dec_tmp.reserve(sizeof(BlkEmit) * ne + 64))) return rc;
+                if ((rc = c->d_dec_cand.reserve(sizeof(BlkUnits) * (size_t)ne + 64))) return rc;
+                if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(total_codes, 1)))) return rc;
+                uint32_t *d_flags = (uint32_t *)c->d_dec_tmp.p;
+                BlkEmit *d_emit = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64);
+                uint64_t *dbgbuf = nullptr;
+                if (getenv("LFX_DEBUG")) {
+                    if ((rc = c->d_ck.reserve(64ull * 8 * ne + 64))) return rc;
+                    dbgbuf = (uint64_t *)c->d_ck.p;
+                    HIP_TRY(hipMemsetAsync(dbgbuf, 0, 64ull * 8 * ne, st));
                 }
-                std::vector<InflateResult> r2;
-                if ((rc = run_jobs(c, d_in, d_out, j2, r2))) return rc;
-                c->phase("pass2");
-                bool all_ok = true;
-                for (size_t i = 0; i < r2.size(); i++)
-                    if (r2[i].status != 0 || r2[i].out_len != res[chain[i]].out_len) all_ok = false;
-                if (all_ok) {
+                HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
+                HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
+                LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
+                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_dec_cand.p, d_out, dbgbuf));
+                uint32_t fl = 0;
+                HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                c->phase("emit+lz77");
+                if (getenv("LFX_DEBUG")) {
+                    fprintf(stderr, "[lfx]  emit flags=%u\n", fl);
+                    std::vector<uint64_t> dv(64ull * ne);
+                    (void)hipMemcpy(dv.data(), dbgbuf, 64ull * 8 * ne, hipMemcpyDeviceToHost);
+                    for (uint32_t u = 0; u < 8 && u < 8 * ne; u++)
+                        fprintf(stderr, "[lfx]  K3 unit %u: scan=%llu par=%llu seq=%llu flush=%llu nseq=%llu ncodes=%llu\n", u,
+                                (unsigned long long)dv[u * 8], (unsigned long long)dv[u * 8 + 1], (unsigned long long)dv[u * 8 + 2],
+                                (unsigned long long)dv[u * 8 + 3], (unsigned long long)dv[u * 8 + 4], (unsigned long long)dv[u * 8 + 5]);
+                }
+                if (fl == 0) {   // no back-reference reached before its block's first byte
                     mr.status = LFX_OK;
                     mr.out_len = total;
                     mr.blk_out_start = total;
-                    mr.end_byte = (r2.back().end_bit + 7) / 8;
+                    mr.end_byte = (pos == stop_bit ? pos : bi[emit.back().cand].end_bit) / 8 +
+                                  (((pos == stop_bit ? pos : bi[emit.back().cand].end_bit) & 7) ? 1 : 0);
                     parallel_done = true;
                 }
             }
@@ -196,6 +239,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         c->set_error("shard decode needs chainable (history-free) blocks");
         return LFX_E_UNSUPPORTED;
     }
+    if (!parallel_done && getenv("LFX_NO_SERIAL")) { c->set_error("serial fallback disabled (LFX_NO_SERIAL)"); return LFX_E_UNSUPPORTED; }
     if (!parallel_done) {
         // ---- serial walk of the whole stream by one wavefront (exact error / partial-output semantics)
         jobs.clear();

@@ -61,6 +61,43 @@ struct InflateResult {
     uint64_t blk_out_start;  // output bytes before the block that was being decoded last
 };
 
+// ---- lane-parallel single-stream path (lfx_inflate_fast.hip)
+enum : uint32_t { BLK_OK = 0, BLK_BAD = 1, BLK_NO_EOB = 2 };
+struct BlkJob {
+    uint64_t start_bit;  // block header bit
+    uint64_t end_bit;    // range end guess: the next candidate's start (or the end of the input)
+};
+struct BlkInfo {
+    uint64_t end_bit;    // bit after EndOfBlock (stored: after the data)
+    uint64_t n_out;      // bytes the block produces
+    uint64_t data_bit;   // first symbol bit (stored: first data bit)
+    uint32_t n_codes;
+    uint32_t status, btype, bfinal, nlanes, rounds;
+    uint32_t _pad;
+    uint32_t cyc_hdr, cyc_total;   // shader-clock stamps (diagnostics)
+};
+struct BlkLanes {
+    uint64_t start[1024];     // validated first bit of every lane's slice
+    uint64_t out_off[1024];   // bytes of the block produced before the slice
+    uint32_t code_off[1024];  // codes of the block before the slice
+};
+struct BlkEmit {
+    uint64_t start_bit, data_bit;
+    uint64_t code_off;   // first code slot of the block
+    uint64_t out_off;    // first output byte of the block
+    uint64_t n_out;
+    uint32_t n_codes, nlanes, btype, cand;
+};
+struct BlkUnits {
+    uint32_t n;          // independent units of the block (no back-reference crosses a cut)
+    uint32_t code0[9];   // unit u covers codes [code0[u], code0[u+1]) of the block
+    uint64_t out0[9];    // ... and bytes [out0[u], out0[u+1]) of the block's output
+};
+int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
+                    BlkInfo *infos, BlkLanes *lanes);
+int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
+                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint8_t *out, uint64_t *dbg);
+
 int launch_container(hipStream_t st, int format, uint32_t count, const uint8_t *in,
                      const DecStream *streams, DecHeader *hdrs);
 int launch_inflate(hipStream_t st, const uint8_t *in, uint8_t *out, const InflateJob *jobs,

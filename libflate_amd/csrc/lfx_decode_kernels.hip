@@ -19,7 +19,7 @@
 
 namespace lfx {
 
-__device__ __forceinline__ uint32_t ld1(const uint8_t *p) { return *p; }
+__device__ __forceinline__ uint32_t ld1(gptr_u8 p) { return *p; }
 
 // ------------------------------------------------------------------------------------------------
 // container headers.  One lane per stream.
@@ -125,7 +125,7 @@ __global__ void container_kernel(int format, uint32_t count, const uint8_t *__re
 constexpr uint32_t WIN_BYTES = 2048;  // LDS window (refilled by the whole wave)
 
 struct BitIn {
-    const uint8_t *g;    // stream base (global)
+    gptr_u8 g;           // stream base (global address space)
     uint64_t nbits;      // bits available in the stream
     uint64_t pos;        // next bit
     uint64_t win_base;   // byte offset of the window start (multiple of 4)
@@ -145,8 +145,8 @@ __device__ __forceinline__ void win_ensure(BitIn &b, uint32_t need, uint32_t lan
         const uint64_t o = base + 4ull * k;
         uint32_t v = 0;
         if (o + 4 <= nb) {
-            const uint8_t *q = b.g + o;
-            if ((((uint64_t)q) & 3) == 0) v = *(const uint32_t *)q;
+            gptr_u8 q = b.g + o;
+            if ((((uint64_t)q) & 3) == 0) v = *(gptr_u32)q;
             else v = (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
         } else {
             for (uint32_t j = 0; j < 4; ++j) if (o + j < nb) v |= (uint32_t)b.g[o + j] << (8 * j);
@@ -316,11 +316,15 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
     __shared__ uint32_t q[QN];
     __shared__ HuffTab T_lit, T_dist, T_cl;
     __shared__ uint32_t s_ctl[8];  // 0: queue count, 1: block done, 2: stop, 3: btype, 4: stored len
+    __shared__ uint16_t l_len_base[29], l_dist_base[30];
+    __shared__ uint8_t l_len_extra[29], l_dist_extra[30];
+    if (threadIdx.x < 29) { l_len_base[threadIdx.x] = c_len_base[threadIdx.x]; l_len_extra[threadIdx.x] = c_len_extra[threadIdx.x]; }
+    if (threadIdx.x < 30) { l_dist_base[threadIdx.x] = c_dist_base[threadIdx.x]; l_dist_extra[threadIdx.x] = c_dist_extra[threadIdx.x]; }
 
     const uint32_t lane = threadIdx.x;
     const InflateJob job = jobs[blockIdx.x];
     BitIn b;
-    b.g = in + job.in_off;
+    b.g = (gptr_u8)(in + job.in_off);
     b.nbits = job.in_len * 8;
     b.pos = job.start_bit;
     b.win = win;
@@ -486,9 +490,9 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
                         else if (d == 256) { eob = true; entry = 0; }
                         else if (d >= 286) { b.err = 1; b.ecode = ERR_286; b.ea0 = d; eob = true; entry = 0; }
                         else {
-                            const uint32_t length = c_len_base[d - 257] + bi_read_unchecked(b, c_len_extra[d - 257]);
+                            const uint32_t length = l_len_base[d - 257] + bi_read_unchecked(b, l_len_extra[d - 257]);
                             const uint32_t dc = tab_decode(T_dist, b);
-                            const uint32_t distance = c_dist_base[dc % 30] + bi_read_unchecked(b, c_dist_extra[dc % 30]);
+                            const uint32_t distance = l_dist_base[dc % 30] + bi_read_unchecked(b, l_dist_extra[dc % 30]);
                             entry = 0x80000000u | (length << 16) | distance;  // distance <= 32768 fits 16 bits
                             if (!b.err) {
                                 // Lz77Decoder::decode lib.rs:173-185
@@ -604,77 +608,6 @@ __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restr
         const uint32_t slot = atomicAdd(count, 1u);
         if (slot < max_cand) cand[slot] = byte * 8 + ph;
     }
-}
-
-// stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
-// decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length code must be
-// complete and the distance code complete, single or empty.
-__global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restrict__ in, uint64_t nbytes,
-                                                         const uint64_t *__restrict__ cand, uint32_t ncand,
-                                                         uint8_t *__restrict__ ok) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ncand) return;
-    uint64_t pos = cand[i];
-    const uint64_t nbits = nbytes * 8;
-    auto bits = [&](uint32_t w) -> uint32_t {
-        if (pos + w > nbits) { pos = nbits + 64; return 0; }
-        const uint64_t byte = pos >> 3;
-        uint64_t v = 0;
-        for (int k = 0; k < 4; ++k) if (byte + k < nbytes) v |= (uint64_t)in[byte + k] << (8 * k);
-        const uint32_t r = (uint32_t)(v >> (pos & 7)) & ((1u << w) - 1);
-        pos += w;
-        return r;
-    };
-    bits(3);
-    const uint32_t nl = bits(5) + 257, nd = bits(5) + 1, nc = bits(4) + 4;
-    uint8_t clw[19];
-    for (int k = 0; k < 19; ++k) clw[k] = 0;
-    for (uint32_t k = 0; k < nc; ++k) clw[c_clen_order[k]] = (uint8_t)bits(3);
-    // canonical decode of the code-length code, bit by bit (at most 7 bits)
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < 19; ++s) cnt[clw[s]]++;
-    cnt[0] = 0;
-    uint8_t sorted[19];
-    {
-        uint32_t offs[8], o = 0;
-        for (int w = 1; w < 8; ++w) { offs[w] = o; o += cnt[w]; }
-        for (int s = 0; s < 19; ++s) if (clw[s]) sorted[offs[clw[s]]++] = (uint8_t)s;
-    }
-    uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
-    const uint32_t total = nl + nd;
-    bool good = true;
-    while (have < total && good) {
-        uint32_t code = 0, first = 0, index = 0, sym = 99;
-        for (uint32_t w = 1; w <= 7; ++w) {
-            code |= bits(1);
-            if (code < first + cnt[w]) { sym = sorted[index + (code - first)]; break; }
-            index += cnt[w];
-            first = (first + cnt[w]) << 1;
-            code <<= 1;
-        }
-        if (sym == 99 || pos > nbits) { good = false; break; }
-        uint32_t rep = 1, val = sym;
-        if (sym == 16) { if (have == 0) { good = false; break; } rep = 3 + bits(2); val = last; }
-        else if (sym == 17) { rep = 3 + bits(3); val = 0; }
-        else if (sym == 18) { rep = 11 + bits(7); val = 0; }
-        if (have + rep > total) { good = false; break; }
-        for (uint32_t k = 0; k < rep; ++k) {
-            const uint32_t idx = have + k;
-            if (val) {
-                if (idx < nl) { kl += 32768u >> val; nlit++; if (idx == 256) eob_len = val; }
-                else { kd += 32768u >> val; ndist++; }
-            }
-        }
-        have += rep;
-        last = val;
-    }
-    if (pos > nbits) good = false;
-    if (good) {
-        if (eob_len == 0) good = false;
-        if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
-        if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
-    }
-    ok[i] = good ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -812,13 +745,6 @@ int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint6
     const uint64_t n = nbytes - first_byte;
     hipLaunchKernelGGL(find_blocks_stage1, dim3((uint32_t)div_up(n, 256)), dim3(256), 0, st, in, nbytes,
                        first_byte, count, cand, max_cand);
-    LFX_LAUNCH_CHECK();
-    return 0;
-}
-int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
-                       uint32_t ncand, uint8_t *ok) {
-    if (!ncand) return 0;
-    hipLaunchKernelGGL(find_blocks_stage2, dim3((ncand + 63) / 64), dim3(64), 0, st, in, nbytes, cand, ncand, ok);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -25,7 +25,7 @@ namespace lfx {
 // ------------------------------------------------------------------------------------------------
 // byte access through aligned dword loads (input pointers are arbitrary byte addresses)
 struct ByteSrc {
-    const uint32_t *w;  // 4-byte aligned base
+    gptr_u32 w;         // 4-byte aligned base (global address space)
     uint64_t shift;     // byte offset of logical byte 0 inside w
     uint64_t nbytes;    // logical size
     __device__ __forceinline__ uint32_t load4(uint64_t off) const {
@@ -46,7 +46,7 @@ struct ByteSrc {
 __device__ __forceinline__ ByteSrc make_src(const uint8_t *p, uint64_t n) {
     ByteSrc s;
     uint64_t a = (uint64_t)p;
-    s.w = (const uint32_t *)(a & ~3ull);
+    s.w = (gptr_u32)(a & ~3ull);
     s.shift = a & 3;
     s.nbytes = n;
     return s;

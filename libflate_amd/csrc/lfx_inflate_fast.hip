@@ -1,0 +1,797 @@
+// lfx_inflate_fast.hip — lane-parallel inflate of ONE large DEFLATE stream (gfx950).
+//
+// The reference decodes a stream strictly serially (src/deflate/decode.rs:136-164, one symbol at a
+// time through symbol.rs:193-244).  Here every candidate block (found by find_blocks_*) is decoded by
+// a 256-lane workgroup: the block's bit range is cut into 256 slices, every lane starts decoding at
+// its slice start *speculatively* (Huffman streams self-synchronise within a few symbols), and the
+// exits are chained from lane 0 — whose start is exact — until nothing changes.  Validated lanes then
+// re-decode their slices into a code stream (same word format as the encoder's: (val << 16) | dist),
+// and one wavefront per block materialises literals and back-references through a 64 KiB LDS window
+// (Lz77Decoder::decode, libflate_lz77/src/lib.rs:164-194).  Any anomaly (error, cross-block
+// reference, unchained block) makes the host fall back to the exact serial kernel, which reproduces
+// the reference's error kinds and partial output.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfx_common.h"
+#include "lfx_decode.h"
+
+namespace lfx {
+
+__constant__ uint16_t f_len_base[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
+                                        31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t f_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2,
+                                        2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t f_dist_base[30] = {1,    2,    3,    4,    5,    7,    9,    13,    17,    25,
+                                         33,   49,   65,   97,   129,  193,  257,  385,   513,   769,
+                                         1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t f_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2,  3,  3,  4,  4,  5,  5,  6,
+                                         6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t f_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// table entry: bits 0-3 code width (0 = no direct code), bits 4-5 kind (0 literal, 1 length, 2 EOB,
+// 3 long-code prefix), bits 6-10 extra-bit count, bits 16-31 value (literal byte / length base /
+// distance base).  0 = unassigned.
+constexpr uint32_t K_LIT = 0, K_LEN = 1, K_EOB = 2, K_LONG = 3;
+constexpr uint32_t E_LONG = (K_LONG << 4);
+
+// per-lane bit source over global memory: 64-bit window + a prefetched 4-dword FIFO
+struct LaneBits {
+    gptr_u32 w;          // 4-byte aligned base (global address space)
+    uint64_t wlast;      // last readable dword index
+    uint64_t widx;       // next dword to fetch
+    uint64_t pos;        // stream bit position of buf bit 0 (relative to the stream's first byte)
+    uint64_t buf;
+    uint32_t nb;
+    uint32_t c0, c1, c2, c3, cn;
+    uint32_t n0, n1, n2, n3;
+    // clamped, branch-free: words past the end repeat the last word (callers stop by bit position)
+    __device__ __forceinline__ uint32_t ld(uint64_t i) const { return w[i < wlast ? i : wlast]; }
+    __device__ __forceinline__ void init(const uint8_t *base, uint64_t nbytes, uint64_t bitpos) {
+        const uint64_t a = (uint64_t)base;
+        w = (gptr_u32)(a & ~3ull);
+        const uint64_t sh = (a & 3) * 8;
+        wlast = ((a & 3) + nbytes + 3) / 4;
+        wlast = wlast ? wlast - 1 : 0;
+        const uint64_t abs = bitpos + sh;
+        widx = abs >> 5;
+        const uint32_t off = (uint32_t)abs & 31;
+        c0 = ld(widx); c1 = ld(widx + 1); c2 = ld(widx + 2); c3 = ld(widx + 3);
+        n0 = ld(widx + 4); n1 = ld(widx + 5); n2 = ld(widx + 6); n3 = ld(widx + 7);
+        widx += 8;
+        buf = (uint64_t)(c0 >> off);
+        nb = 32 - off;
+        c0 = c1; c1 = c2; c2 = c3; cn = 3;
+        pos = bitpos;
+    }
+    __device__ __forceinline__ void refill() {
+        if (nb <= 32) {
+            buf |= (uint64_t)c0 << nb;
+            nb += 32;
+            c0 = c1; c1 = c2; c2 = c3;
+            if (--cn == 0) {
+                c0 = n0; c1 = n1; c2 = n2; c3 = n3; cn = 4;
+                n0 = ld(widx); n1 = ld(widx + 1); n2 = ld(widx + 2); n3 = ld(widx + 3);
+                widx += 4;
+            }
+        }
+    }
+    __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; nb -= k; pos += k; }
+};
+
+constexpr uint32_t LIT_BITS = 12, DIST_BITS = 10;
+struct FastTabs {
+    uint32_t lit[1u << LIT_BITS];
+    uint32_t dist[1u << DIST_BITS];
+    uint32_t lit_info[288];   // entry of every literal/length symbol without its width
+    uint32_t dist_info[32];
+    uint16_t lit_sorted[288];
+    uint16_t dist_sorted[32];
+    uint16_t lit_count[16];
+    uint16_t dist_count[16];
+};
+
+// canonical walk for codes longer than the primary table (rare)
+__device__ __forceinline__ uint32_t long_decode(const uint16_t *count, const uint16_t *sorted, uint64_t bits,
+                                                uint32_t &width) {
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t w = 1; w <= 15; ++w) {
+        code |= (uint32_t)(bits >> (w - 1)) & 1;
+        const uint32_t cnt = count[w];
+        if (code < first + cnt) { width = w; return sorted[index + (code - first)]; }
+        index += cnt;
+        first = (first + cnt) << 1;
+        code <<= 1;
+    }
+    width = 0;
+    return 0xFFFF;
+}
+
+__device__ __forceinline__ uint32_t lit_entry_of(uint32_t s, uint32_t w) {
+    if (s < 256) return w | (K_LIT << 4) | (s << 16);
+    if (s == 256) return w | (K_EOB << 4);
+    if (s < 286) return w | (K_LEN << 4) | ((uint32_t)f_len_extra[s - 257] << 6) | ((uint32_t)f_len_base[s - 257] << 16);
+    return 0;  // 286 / 287 must not occur (symbol.rs:216-223): treated as undecodable here
+}
+__device__ __forceinline__ uint32_t dist_entry_of(uint32_t s, uint32_t w) {
+    if (s >= 30) return 0;
+    return w | ((uint32_t)f_dist_extra[s] << 6) | ((uint32_t)f_dist_base[s] << 16);
+}
+
+// workgroup-wide: canonical tables from code widths.  Returns false when over-subscribed.
+__device__ bool build_fast(FastTabs &T, const uint8_t *lw, uint32_t nl, const uint8_t *dw, uint32_t nd,
+                           uint32_t tid, uint32_t nthreads) {
+    __shared__ uint32_t s_first[2][16], s_off[2][16], s_bad;
+    for (uint32_t i = tid; i < (1u << LIT_BITS); i += nthreads) T.lit[i] = 0;
+    for (uint32_t i = tid; i < (1u << DIST_BITS); i += nthreads) T.dist[i] = 0;
+    for (uint32_t i = tid; i < 288; i += nthreads) T.lit_info[i] = lit_entry_of(i, 0);
+    for (uint32_t i = tid; i < 32; i += nthreads) T.dist_info[i] = dist_entry_of(i, 0);
+    if (tid == 0) {
+        s_bad = 0;
+        for (int t = 0; t < 2; ++t) {
+            uint16_t *cnt = t ? T.dist_count : T.lit_count;
+            const uint8_t *bw = t ? dw : lw;
+            const uint32_t n = t ? nd : nl;
+            for (int w = 0; w < 16; ++w) cnt[w] = 0;
+            for (uint32_t s = 0; s < n; ++s) cnt[bw[s]]++;
+            cnt[0] = 0;
+            uint32_t code = 0, off = 0;
+            int left = 1;
+            for (uint32_t w = 1; w <= 15; ++w) {
+                code <<= 1; left <<= 1;
+                s_first[t][w] = code; s_off[t][w] = off;
+                left -= (int)cnt[w];
+                if (left < 0) s_bad = 1;
+                code += cnt[w]; off += cnt[w];
+            }
+        }
+    }
+    __syncthreads();
+    if (s_bad) return false;
+    for (uint32_t s = tid; s < nl + nd; s += nthreads) {
+        const int t = s >= nl;
+        const uint32_t sym = t ? s - nl : s;
+        const uint8_t *bw = t ? dw : lw;
+        const uint32_t w = bw[sym];
+        if (w == 0) continue;
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < sym; ++q) rank += bw[q] == w;
+        const uint32_t code = s_first[t][w] + rank;
+        (t ? T.dist_sorted : T.lit_sorted)[s_off[t][w] + rank] = (uint16_t)sym;
+        const uint32_t pri = t ? DIST_BITS : LIT_BITS;
+        const uint32_t r = __brev(code) >> (32 - w);
+        uint32_t *tab = t ? T.dist : T.lit;
+        if (w <= pri) {
+            const uint32_t e = t ? dist_entry_of(sym, w) : lit_entry_of(sym, w);
+            for (uint32_t i = r; i < (1u << pri); i += (1u << w)) tab[i] = e;
+        } else {
+            tab[r & ((1u << pri) - 1)] = E_LONG;
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// rare path, kept out of line so the hot loop stays small: a code longer than the primary table
+__device__ __noinline__ uint32_t long_lookup(const uint16_t *count, const uint16_t *sorted, const uint32_t *info,
+                                            uint32_t nsym, uint64_t bits) {
+    uint32_t w = 0;
+    const uint32_t s = long_decode(count, sorted, bits, w);
+    if (w == 0 || s >= nsym) return 0;
+    return info[s] | w;
+}
+
+// Hot bit source of lane_decode: 64-bit window `buf` (nb valid bits), a FIFO of up to five dwords in
+// registers (q0 first) and four more dwords in flight (x0..x3).  The in-flight dwords are merged into
+// the FIFO only between symbols, *before* the next four loads are issued, so the loads write straight
+// into dead registers and the only wait for them sits one reload period (~8 symbols) later.
+struct FastBits {
+    gptr_u32 w;
+    uint64_t wlast, widx;
+    uint64_t buf;
+    uint32_t nb, used;              // used = bits consumed since init
+    uint32_t q0, q1, q2, q3, q4, qn;
+    uint32_t x0, x1, x2, x3;
+    __device__ __forceinline__ uint32_t ld(uint64_t i) const { return w[i < wlast ? i : wlast]; }
+    __device__ __forceinline__ void init(const uint8_t *base, uint64_t nbytes, uint64_t bitpos) {
+        const uint64_t a = (uint64_t)base;
+        w = (gptr_u32)(a & ~3ull);
+        wlast = ((a & 3) + nbytes + 3) / 4;
+        wlast = wlast ? wlast - 1 : 0;
+        const uint64_t abs = bitpos + (a & 3) * 8;
+        widx = abs >> 5;
+        const uint32_t off = (uint32_t)abs & 31;
+        const uint32_t f = ld(widx);
+        q0 = ld(widx + 1); q1 = ld(widx + 2); q2 = ld(widx + 3); q3 = ld(widx + 4); q4 = 0; qn = 4;
+        x0 = ld(widx + 5); x1 = ld(widx + 6); x2 = ld(widx + 7); x3 = ld(widx + 8);
+        widx += 9;
+        buf = (uint64_t)(f >> off);
+        nb = 32 - off;
+        used = 0;
+    }
+    __device__ __forceinline__ void append() {   // needs qn >= 1
+        if (nb <= 32) {
+            buf |= (uint64_t)q0 << nb;
+            nb += 32;
+            q0 = q1; q1 = q2; q2 = q3; q3 = q4;
+            qn--;
+        }
+    }
+    __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; nb -= k; used += k; }
+    __device__ __forceinline__ void reload() {   // qn is 0 or 1 here
+        if (qn == 0) { q0 = x0; q1 = x1; q2 = x2; q3 = x3; qn = 4; }
+        else { q1 = x0; q2 = x1; q3 = x2; q4 = x3; qn = 5; }
+        __builtin_amdgcn_sched_barrier(0);       // keep the loads below the moves above
+        x0 = ld(widx); x1 = ld(widx + 1); x2 = ld(widx + 2); x3 = ld(widx + 3);
+        widx += 4;
+    }
+};
+
+// One lane decodes symbols from bit `start` until a symbol would start at or after `limit`, or
+// EndOfBlock.  EMIT: write code words.  Returns 0 ok / 1 EOB / 2 undecodable; `endpos` = bit reached.
+template <bool EMIT>
+__device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
+                                           uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
+                                           int64_t &reach, uint64_t &endpos) {
+    FastBits b;
+    b.init(in, nbytes, start);
+    const uint64_t span = limit > start ? limit - start : 0;
+    const uint32_t lim = span > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)span;
+    int ret = 0;
+    uint32_t no = 0;   // bytes produced by this call (added to nout at the end)
+    while (b.used < lim && ret == 0) {
+        // each symbol takes at most two dwords from the FIFO
+        while (b.qn >= 2 && b.used < lim) {
+            b.append();
+            uint32_t e = T.lit[(uint32_t)b.buf & ((1u << LIT_BITS) - 1)];
+            if (__builtin_expect((e & 15) == 0, 0)) {
+                e = e == E_LONG ? long_lookup(T.lit_count, T.lit_sorted, T.lit_info, 286, b.buf) : 0;
+                if (e == 0) { ret = 2; break; }
+            }
+            const uint32_t kind = (e >> 4) & 3;
+            if (kind == K_LIT) {
+                b.skip(e & 15);
+                if (EMIT) codes[ncodes] = e & 0x00FF0000u;
+                ncodes++;
+                no++;
+                continue;
+            }
+            if (kind == K_EOB) { b.skip(e & 15); ret = 1; break; }
+            const uint32_t w = e & 15, eb = (e >> 6) & 31;
+            const uint32_t length = (e >> 16) + (((uint32_t)(b.buf >> w)) & ((1u << eb) - 1));
+            b.skip(w + eb);
+            b.append();
+            uint32_t d = T.dist[(uint32_t)b.buf & ((1u << DIST_BITS) - 1)];
+            if (__builtin_expect((d & 15) == 0, 0)) {
+                d = d == E_LONG ? long_lookup(T.dist_count, T.dist_sorted, T.dist_info, 30, b.buf) : 0;
+                if (d == 0) { ret = 2; break; }
+            }
+            const uint32_t dw = d & 15, db = (d >> 6) & 31;
+            const uint32_t distance = (d >> 16) + (((uint32_t)(b.buf >> dw)) & ((1u << db) - 1));
+            b.skip(dw + db);
+            if (EMIT) {
+                codes[ncodes] = (length << 16) | distance;
+                const int64_t srcpos = (int64_t)(nout + no) - (int64_t)distance;   // first byte this match reads
+                if (srcpos < reach) reach = srcpos;
+            }
+            ncodes++;
+            no += length;
+        }
+        if (ret == 0 && b.used < lim && b.qn < 2) b.reload();
+    }
+    nout += no;
+    endpos = start + b.used;
+    return ret;
+}
+
+// ------------------------------------------------------------------------------------------------
+// header parse (lane 0, plain byte loads — ~300 short steps per block) + tables
+struct HdrBits {
+    LaneBits b;       // register bit buffer + prefetched dwords (no per-call memory latency)
+    uint64_t nbits;
+    bool bad;
+    __device__ __forceinline__ void init(const uint8_t *g, uint64_t nbytes, uint64_t pos) {
+        b.init(g, nbytes, pos);
+        nbits = nbytes * 8;
+        bad = false;
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t w) {
+        if (b.pos + w > nbits) { bad = true; return 0; }
+        b.refill();
+        const uint32_t r = (uint32_t)b.buf & ((1u << w) - 1);
+        b.skip(w);
+        return r;
+    }
+};
+
+constexpr int SCAN_THREADS = 1024;   // lanes per block: 16 wavefronts, 4 per SIMD hide each other's latency
+
+// parse the block header at job.start_bit and build T.  → btype in hdr[0], bfinal hdr[1],
+// data start bit hdr64[0]; status in hdr[2] (0 ok, 1 undecodable header)
+__device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_bit, FastTabs &T,
+                             uint8_t *lens, uint32_t *hdr, uint64_t *hdr64, uint32_t tid) {
+    if (tid == 0) {
+        HdrBits hb;
+        hb.init(in, nbytes, start_bit);
+        hdr[2] = 0;
+        const uint32_t bfinal = hb.get(1), btype = hb.get(2);
+        hdr[0] = btype; hdr[1] = bfinal;
+        if (hb.bad || btype == 3) hdr[2] = 1;
+        else if (btype == 1) {
+            for (uint32_t s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            for (uint32_t s = 0; s < 30; ++s) lens[288 + s] = 5;
+            hdr[3] = 288; hdr[4] = 30;
+        } else if (btype == 2) {
+            const uint32_t nl = hb.get(5) + 257, nd = hb.get(5) + 1, nc = hb.get(4) + 4;
+            hdr[3] = nl; hdr[4] = nd;
+            uint8_t clw[19];
+            for (int k = 0; k < 19; ++k) clw[k] = 0;
+            for (uint32_t k = 0; k < nc; ++k) clw[f_clen_order[k]] = (uint8_t)hb.get(3);
+            uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int s = 0; s < 19; ++s) cnt[clw[s]]++;
+            cnt[0] = 0;
+            uint8_t sorted[19];
+            {
+                uint32_t offs[8], o = 0;
+                for (int w = 1; w < 8; ++w) { offs[w] = o; o += cnt[w]; }
+                for (int s = 0; s < 19; ++s) if (clw[s]) sorted[offs[clw[s]]++] = (uint8_t)s;
+            }
+            uint32_t have = 0, last = 0;
+            const uint32_t total = nl + nd;
+            if (nd > 30 || hb.bad) hdr[2] = 1;
+            while (have < total && !hdr[2]) {
+                uint32_t code = 0, first = 0, index = 0, sym = 99;
+                for (uint32_t w = 1; w <= 7; ++w) {
+                    code |= hb.get(1);
+                    if (code < first + cnt[w]) { sym = sorted[index + (code - first)]; break; }
+                    index += cnt[w];
+                    first = (first + cnt[w]) << 1;
+                    code <<= 1;
+                }
+                if (sym == 99 || hb.bad) { hdr[2] = 1; break; }
+                uint32_t rep = 1, val = sym;
+                if (sym == 16) { if (have == 0) { hdr[2] = 1; break; } rep = 3 + hb.get(2); val = last; }
+                else if (sym == 17) { rep = 3 + hb.get(3); val = 0; }
+                else if (sym == 18) { rep = 11 + hb.get(7); val = 0; }
+                if (have + rep > total || hb.bad) { hdr[2] = 1; break; }
+                for (uint32_t k = 0; k < rep; ++k) lens[have + k] = (uint8_t)val;
+                have += rep;
+                last = val;
+            }
+        }
+        hdr64[0] = hb.b.pos;
+    }
+    __syncthreads();
+    if (hdr[2] || hdr[0] == 0) return;
+    const uint32_t nl = hdr[3], nd = hdr[4];
+    if (!build_fast(T, lens, nl, lens + nl, nd, tid, SCAN_THREADS)) {
+        if (tid == 0) hdr[2] = 1;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: speculative scan of one candidate block: validated per-lane starts, code and byte counts
+__global__ __launch_bounds__(SCAN_THREADS) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+                                                                const BlkJob *__restrict__ jobs,
+                                                                BlkInfo *__restrict__ infos,
+                                                                BlkLanes *__restrict__ lanes) {
+    __shared__ FastTabs T;
+    __shared__ uint8_t lens[640];
+    __shared__ uint32_t hdr[8];
+    __shared__ uint64_t hdr64[2];
+    __shared__ uint64_t s_start[SCAN_THREADS + 1];
+    __shared__ uint32_t s_nc[SCAN_THREADS], s_flag[SCAN_THREADS];
+    __shared__ uint64_t s_no[SCAN_THREADS], s_exit[SCAN_THREADS];
+    __shared__ uint32_t s_scan[SCAN_THREADS / 64];
+    __shared__ uint64_t s_scan64[SCAN_THREADS / 64];
+    const uint32_t tid = threadIdx.x;
+    const BlkJob job = jobs[blockIdx.x];
+    BlkInfo bi;
+    bi.status = BLK_OK; bi.btype = 0; bi.bfinal = 0; bi.nlanes = 0; bi.end_bit = 0; bi.n_codes = 0; bi.n_out = 0;
+    bi.data_bit = 0; bi.rounds = 0; bi._pad = 0; bi.cyc_hdr = 0; bi.cyc_total = 0;
+    const uint64_t t_begin = clock64();
+    parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
+    const uint64_t t_hdr = clock64();
+    bi.btype = hdr[0]; bi.bfinal = hdr[1]; bi.data_bit = hdr64[0];
+    if (hdr[2]) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
+    if (hdr[0] == 0) {
+        // stored block (decode.rs:81-111): LEN / NLEN after byte alignment
+        uint64_t byte = (hdr64[0] + 7) >> 3;
+        if (byte + 4 > nbytes) bi.status = BLK_BAD;
+        else {
+            const uint32_t len = in[byte] | in[byte + 1] << 8, nlen = in[byte + 2] | in[byte + 3] << 8;
+            if (((~len) & 0xFFFF) != nlen || byte + 4 + len > nbytes) bi.status = BLK_BAD;
+            else { bi.n_out = len; bi.data_bit = (byte + 4) * 8; bi.end_bit = (byte + 4 + len) * 8; }
+        }
+        if (tid == 0) infos[blockIdx.x] = bi;
+        return;
+    }
+    const uint64_t d0 = hdr64[0];
+    uint64_t e = job.end_bit;
+    if (e > nbytes * 8) e = nbytes * 8;
+    if (e < d0 + 1) e = d0 + 1;
+    // slices of >= 128 bits so that one symbol (<= 48 bits) never skips a whole slice
+    uint64_t slice = (e - d0 + SCAN_THREADS - 1) / SCAN_THREADS;
+    if (slice < 128) slice = 128;
+    const uint32_t nl = (uint32_t)((e - d0 + slice - 1) / slice);  // lanes in use (<= 256)
+    const uint64_t my_bound = d0 + (uint64_t)(tid + 1) * slice;     // end of my slice
+    s_start[tid] = tid == 0 ? d0 : (tid < nl ? d0 + (uint64_t)tid * slice : ~0ull);
+    if (tid == 0) s_start[SCAN_THREADS] = ~0ull;
+    __syncthreads();
+    uint32_t rounds = 0;
+    for (;;) {
+        uint32_t nc = 0;
+        int64_t dummy = 0;
+        uint64_t no = 0, exitpos = ~0ull;
+        uint32_t flag = 0;  // 1 EOB hit, 2 undecodable, 4 not started
+        const uint64_t st = s_start[tid];
+        if (tid < nl && st != ~0ull) {
+            // the last lane keeps going to the end of the stream range (the block may end exactly at e)
+            const uint64_t lim = tid + 1 == nl ? e + 64 : my_bound;
+            const int r = lane_decode<false>(T, in, nbytes, st, lim, nc, no, nullptr, dummy, exitpos);
+            flag = r == 1 ? 1 : r == 2 ? 2 : 0;
+        } else flag = 4;
+        s_nc[tid] = nc; s_no[tid] = no; s_flag[tid] = flag; s_exit[tid] = exitpos;
+        __syncthreads();
+        // lane k+1 must start where lane k stopped (only while no EOB / failure)
+        bool changed = false;
+        // A lane that stopped on EndOfBlock / an undecodable code may simply have been mis-aligned:
+        // it must not disturb its successor's (speculative) start.  Validity is settled after
+        // convergence: lanes before the first flagged lane are chained from the exact lane 0.
+        if (tid + 1 < nl && flag == 0 && s_start[tid + 1] != exitpos) { s_start[tid + 1] = exitpos; changed = true; }
+        rounds++;
+        const int any = __syncthreads_or(changed ? 1 : 0);
+        if (!any || rounds >= 64) break;
+    }
+    // the EOB lane: first lane whose (validated) decode hit EndOfBlock; every lane before it must be clean
+    __shared__ uint32_t s_eob, s_err;
+    if (tid == 0) { s_eob = 0xFFFFFFFFu; s_err = 0; }
+    __syncthreads();
+    if (tid < nl && s_flag[tid] != 0) atomicMin(&s_eob, tid);   // first flagged lane of the chain
+    __syncthreads();
+    const uint32_t eobl = s_eob;
+    bi.rounds = rounds;
+    if (eobl == 0xFFFFFFFFu || rounds >= 64) {
+        bi.status = rounds >= 64 ? BLK_BAD : BLK_NO_EOB;
+        if (tid == 0) infos[blockIdx.x] = bi;
+        return;
+    }
+    if (s_flag[eobl] != 1) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
+    // exclusive scans of code / byte counts over lanes <= eobl
+    const uint32_t mync = tid <= eobl ? s_nc[tid] : 0;
+    const uint64_t myno = tid <= eobl ? s_no[tid] : 0;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    uint32_t x = mync;
+    uint64_t y = myno;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t a = __shfl_up(x, o);
+        const uint64_t c = __shfl_up(y, o);
+        if ((int)lane >= o) { x += a; y += c; }
+    }
+    if (lane == 63) { s_scan[wave] = x; s_scan64[wave] = y; }
+    __syncthreads();
+    uint32_t px = 0;
+    uint64_t py = 0;
+    for (uint32_t w = 0; w < wave; ++w) { px += s_scan[w]; py += s_scan64[w]; }
+    BlkLanes *L = &lanes[blockIdx.x];
+    L->start[tid] = tid <= eobl ? s_start[tid] : ~0ull;
+    L->code_off[tid] = px + x - mync;
+    L->out_off[tid] = py + y - myno;
+    if (tid == SCAN_THREADS - 1) {
+        bi.n_codes = px + x;
+        bi.n_out = py + y;
+    }
+    // broadcast totals through LDS
+    __shared__ uint32_t s_tot;
+    __shared__ uint64_t s_tot64;
+    if (tid == SCAN_THREADS - 1) { s_tot = px + x; s_tot64 = py + y; }
+    __syncthreads();
+    if (tid == 0) {
+        bi.n_codes = s_tot; bi.n_out = s_tot64; bi.end_bit = s_exit[eobl]; bi.nlanes = eobl + 1; bi.rounds = rounds;
+        bi.cyc_hdr = (uint32_t)(t_hdr - t_begin); bi.cyc_total = (uint32_t)(clock64() - t_begin);
+        infos[blockIdx.x] = bi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: validated lanes decode their slices into the code array; the block is then cut into units
+// that no back-reference crosses (reference-made blocks fall apart at every LZ77 chunk boundary,
+// default.rs:73) so that K3 can materialise them concurrently.
+constexpr uint32_t MAX_UNITS = 8;
+
+__global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+                                                                const BlkEmit *__restrict__ jobs,
+                                                                const BlkLanes *__restrict__ lanes,
+                                                                uint32_t *__restrict__ codes,
+                                                                uint32_t *__restrict__ flags,
+                                                                BlkUnits *__restrict__ units) {
+    __shared__ FastTabs T;
+    __shared__ uint8_t lens[640];
+    __shared__ uint32_t hdr[8];
+    __shared__ uint64_t hdr64[2];
+    __shared__ int64_t s_reach[SCAN_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const BlkEmit job = jobs[blockIdx.x];
+    BlkUnits *U = &units[blockIdx.x];
+    if (job.btype == 0) {
+        if (tid == 0) { U->n = 1; U->code0[0] = 0; U->code0[1] = 0; U->out0[0] = 0; U->out0[1] = job.n_out; }
+        return;
+    }
+    parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
+    const BlkLanes *L = &lanes[job.cand];
+    int64_t reach = INT64_MAX;
+    if (tid < job.nlanes) {
+        const uint64_t st = L->start[tid];
+        const uint64_t lim = tid + 1 < job.nlanes ? L->start[tid + 1] : ~0ull >> 1;
+        uint32_t nc = 0;
+        uint64_t no = L->out_off[tid], endpos;   // bytes of this block produced before my slice
+        lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos);
+        if (reach < 0) atomicOr(&flags[0], 1u);   // a back-reference reaches before the block start
+    }
+    s_reach[tid] = reach;
+    __syncthreads();
+    // suffix minimum over LATER lanes (serial, 1024 short steps once per block)
+    __shared__ int64_t s_later[SCAN_THREADS];
+    __shared__ uint32_t s_cut_code[SCAN_THREADS];
+    __shared__ uint64_t s_cut_pos[SCAN_THREADS];
+    if (tid == 0) {
+        int64_t m = INT64_MAX;
+        for (int k = (int)job.nlanes - 1; k >= 0; --k) { s_later[k] = m; if (s_reach[k] < m) m = s_reach[k]; }
+    }
+    __syncthreads();
+    // every lane walks its codes backwards: a cut before code i is legal iff no code at or after i
+    // (in this lane or any later one) reads a byte produced before code i's first byte
+    uint32_t cut_code = 0xFFFFFFFFu;
+    uint64_t cut_pos = 0;
+    if (tid < job.nlanes) {
+        const uint32_t cbeg = L->code_off[tid];
+        const uint32_t cend = tid + 1 < job.nlanes ? L->code_off[tid + 1] : job.n_codes;
+        uint64_t pos = tid + 1 < job.nlanes ? L->out_off[tid + 1] : job.n_out;
+        int64_t m = s_later[tid];
+        const uint32_t *cp = codes + job.code_off;
+        for (uint32_t i = cend; i > cbeg; --i) {
+            const uint32_t c = cp[i - 1];
+            const uint32_t dist = c & 0xFFFFu, val = c >> 16;
+            pos -= dist ? val : 1u;
+            if (dist) { const int64_t sp = (int64_t)pos - (int64_t)dist; if (sp < m) m = sp; }
+            if (m >= (int64_t)pos) { cut_code = i - 1; cut_pos = pos; }   // keeps the earliest cut of the lane
+        }
+    }
+    s_cut_code[tid] = cut_code;
+    s_cut_pos[tid] = cut_pos;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t nu = 0, last = 0;
+        const uint32_t want = job.n_codes / MAX_UNITS + 1;
+        U->code0[0] = 0; U->out0[0] = 0;
+        for (uint32_t k = 0; k < job.nlanes && nu + 1 < MAX_UNITS; ++k) {
+            const uint32_t cc = s_cut_code[k];
+            if (cc != 0xFFFFFFFFu && cc != 0 && cc - last >= want) { nu++; U->code0[nu] = cc; U->out0[nu] = s_cut_pos[k]; last = cc; }
+        }
+        nu++;
+        U->code0[nu] = job.n_codes; U->out0[nu] = job.n_out;
+        U->n = nu;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: one wavefront per unit turns codes into bytes through a 64 KiB LDS window
+constexpr uint32_t MWIN = 65536;
+constexpr uint32_t PAR_LEN = 8;   // matches up to this length that read only pre-batch bytes go in parallel
+
+__global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__restrict__ in,
+                                                             const BlkEmit *__restrict__ jobs,
+                                                             const BlkLanes *__restrict__ lanes,
+                                                             const BlkUnits *__restrict__ units,
+                                                             const uint32_t *__restrict__ codes,
+                                                             uint8_t *__restrict__ out, uint64_t *__restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    const uint32_t bidx = blockIdx.x / MAX_UNITS, u = blockIdx.x % MAX_UNITS;
+    const BlkEmit job = jobs[bidx];
+    const uint32_t lane = threadIdx.x;
+    if (job.btype == 0) {
+        if (u != 0) return;
+        uint8_t *o = out + job.out_off;
+        const uint8_t *src = in + (job.data_bit >> 3);
+        for (uint64_t k = lane; k < job.n_out; k += 64) o[k] = src[k];
+        return;
+    }
+    const BlkUnits *U = &units[bidx];
+    if (u >= U->n) return;
+    const uint32_t c0 = U->code0[u], c1 = U->code0[u + 1];
+    const uint64_t ob = U->out0[u];                      // unit's first byte inside the block
+    const uint64_t gbase = job.out_off + ob;             // ... inside the output buffer
+    uint8_t *o = out + gbase;
+    const uint32_t *cp = codes + job.code_off + c0;
+    const uint32_t n = c1 - c0;
+    uint64_t produced = 0, flushed = 0;
+    uint64_t cy_scan = 0, cy_par = 0, cy_seq = 0, cy_flush = 0, nseq = 0;
+    uint32_t c_next = lane < n ? cp[lane] : 0;           // code words are prefetched one batch ahead
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint64_t t0 = clock64();
+        const uint32_t i = base + lane;
+        const uint32_t c = c_next;
+        c_next = i + 64 < n ? cp[i + 64] : 0;
+        const uint32_t dist = c & 0xFFFFu, val = c >> 16;
+        const bool is_match = i < n && dist != 0;
+        const uint32_t mylen = i < n ? (dist ? val : 1u) : 0u;
+        uint32_t x = mylen;
+        for (int ofs = 1; ofs < 64; ofs <<= 1) {
+            const uint32_t y = __shfl_up(x, ofs);
+            if ((int)lane >= ofs) x += y;
+        }
+        const uint32_t total = __shfl(x, 63);
+        const uint32_t rel = x - mylen;                  // my first byte relative to the batch start
+        const uint32_t at = (uint32_t)produced + rel;
+        const uint64_t t1 = clock64();
+        if (i < n && !is_match) ring[at & (MWIN - 1)] = (unsigned char)val;
+        // a match is "far" when every byte it reads was produced before this batch
+        const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
+        const bool par = far && mylen <= PAR_LEN && dist >= mylen;
+        if (par) {
+            unsigned char t[PAR_LEN];
+            const uint32_t srcb = at - dist;
+#pragma unroll
+            for (uint32_t k = 0; k < PAR_LEN; ++k) t[k] = k < mylen ? ring[(srcb + k) & (MWIN - 1)] : 0;
+#pragma unroll
+            for (uint32_t k = 0; k < PAR_LEN; ++k)
+                if (k < mylen) ring[(at + k) & (MWIN - 1)] = t[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t t2 = clock64();
+        uint64_t mm = __ballot(is_match && !par);
+        nseq += __popcll(mm);
+        while (mm) {
+            const uint32_t sl = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint32_t mc = __builtin_amdgcn_readlane(c, sl);
+            const uint32_t mat_lo = __builtin_amdgcn_readlane(at, sl);
+            const uint32_t len = mc >> 16, d = mc & 0xFFFFu;
+            const uint32_t srcb = mat_lo - d;
+            // out[k] = src[k mod d] reproduces the overlapping forward copy (rle_decode, lib.rs:186-190);
+            // LDS operations of one wavefront execute in order, so later matches see these bytes
+            if (d >= len) {
+                for (uint32_t k = lane; k < len; k += 64) ring[(mat_lo + k) & (MWIN - 1)] = ring[(srcb + k) & (MWIN - 1)];
+            } else {
+                for (uint32_t k = lane; k < len; k += 64) ring[(mat_lo + k) & (MWIN - 1)] = ring[(srcb + k % d) & (MWIN - 1)];
+            }
+        }
+        produced += total;
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t t3 = clock64();
+        // flush in >= 16 KiB pieces; the ring always keeps the last 32 KiB for back-references
+        const bool last = base + 64 >= n;
+        if (produced - flushed >= 16384 || last) {
+            const uint64_t upto = produced;
+            while (flushed < upto && ((gbase + flushed) & 3)) {   // head: align the global address
+                if (lane == 0) o[flushed] = ring[flushed & (MWIN - 1)];
+                flushed++;
+            }
+            const uint64_t ndw = (upto - flushed) >> 2;
+            uint32_t *o32 = (uint32_t *)(o + flushed);
+            const bool aligned = (((uint64_t)o32) & 3) == 0;
+            for (uint64_t k = lane; k < ndw; k += 64) {
+                const uint64_t p = flushed + 4 * k;
+                const uint32_t v = (uint32_t)ring[p & (MWIN - 1)] | (uint32_t)ring[(p + 1) & (MWIN - 1)] << 8 |
+                                   (uint32_t)ring[(p + 2) & (MWIN - 1)] << 16 | (uint32_t)ring[(p + 3) & (MWIN - 1)] << 24;
+                if (aligned) o32[k] = v;
+                else { o[p] = (uint8_t)v; o[p + 1] = (uint8_t)(v >> 8); o[p + 2] = (uint8_t)(v >> 16); o[p + 3] = (uint8_t)(v >> 24); }
+            }
+            flushed += 4 * ndw;
+            if (last) {
+                for (uint64_t k = flushed + lane; k < upto; k += 64) o[k] = ring[k & (MWIN - 1)];
+                flushed = upto;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        const uint64_t t4 = clock64();
+        cy_scan += t1 - t0; cy_par += t2 - t1; cy_seq += t3 - t2; cy_flush += t4 - t3;
+    }
+    if (dbg && lane == 0) {
+        uint64_t *d = dbg + (uint64_t)blockIdx.x * 8;
+        d[0] = cy_scan; d[1] = cy_par; d[2] = cy_seq; d[3] = cy_flush; d[4] = nseq; d[5] = n;
+    }
+}
+
+// block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
+// decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length code must be
+// complete and the distance code complete, single or empty.
+__global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restrict__ in, uint64_t nbytes,
+                                                         const uint64_t *__restrict__ cand, uint32_t ncand,
+                                                         uint8_t *__restrict__ ok) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand) return;
+    HdrBits hb;
+    hb.init(in, nbytes, cand[i]);
+    auto bits = [&](uint32_t w) -> uint32_t { return hb.get(w); };
+    bits(3);
+    const uint32_t nl = bits(5) + 257, nd = bits(5) + 1, nc = bits(4) + 4;
+    uint8_t clw[19];
+    for (int k = 0; k < 19; ++k) clw[k] = 0;
+    for (uint32_t k = 0; k < nc; ++k) clw[f_clen_order[k]] = (uint8_t)bits(3);
+    // canonical decode of the code-length code, bit by bit (at most 7 bits)
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < 19; ++s) cnt[clw[s]]++;
+    cnt[0] = 0;
+    uint8_t sorted[19];
+    {
+        uint32_t offs[8], o = 0;
+        for (int w = 1; w < 8; ++w) { offs[w] = o; o += cnt[w]; }
+        for (int s = 0; s < 19; ++s) if (clw[s]) sorted[offs[clw[s]]++] = (uint8_t)s;
+    }
+    uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
+    const uint32_t total = nl + nd;
+    bool good = true;
+    while (have < total && good) {
+        uint32_t code = 0, first = 0, index = 0, sym = 99;
+        for (uint32_t w = 1; w <= 7; ++w) {
+            code |= bits(1);
+            if (code < first + cnt[w]) { sym = sorted[index + (code - first)]; break; }
+            index += cnt[w];
+            first = (first + cnt[w]) << 1;
+            code <<= 1;
+        }
+        if (sym == 99 || hb.bad) { good = false; break; }
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) { if (have == 0) { good = false; break; } rep = 3 + bits(2); val = last; }
+        else if (sym == 17) { rep = 3 + bits(3); val = 0; }
+        else if (sym == 18) { rep = 11 + bits(7); val = 0; }
+        if (have + rep > total) { good = false; break; }
+        for (uint32_t k = 0; k < rep; ++k) {
+            const uint32_t idx = have + k;
+            if (val) {
+                if (idx < nl) { kl += 32768u >> val; nlit++; if (idx == 256) eob_len = val; }
+                else { kd += 32768u >> val; ndist++; }
+            }
+        }
+        have += rep;
+        last = val;
+    }
+    if (hb.bad) good = false;
+    if (good) {
+        if (eob_len == 0) good = false;
+        if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
+        if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
+    }
+    ok[i] = good ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+#define LFX_LAUNCH_CHECK()                          \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return (int)e_;       \
+    } while (0)
+
+int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
+                    BlkInfo *infos, BlkLanes *lanes) {
+    if (!njobs) return 0;
+    hipLaunchKernelGGL(blk_scan_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
+                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint8_t *out, uint64_t *dbg) {
+    if (!njobs) return 0;
+    hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, lanes, codes, flags, units);
+    LFX_LAUNCH_CHECK();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)blk_materialize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MWIN);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), MWIN, st, in, jobs, lanes, units, codes, out, dbg);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
+                       uint32_t ncand, uint8_t *ok) {
+    if (!ncand) return 0;
+    hipLaunchKernelGGL(find_blocks_stage2, dim3((ncand + 63) / 64), dim3(64), 0, st, in, nbytes, cand, ncand, ok);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace lfx
