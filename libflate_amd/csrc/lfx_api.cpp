@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -353,8 +354,18 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         }                                                                             \
     } while (0)
 
+    uint64_t *mdbg = nullptr;
+    if (getenv("LFX_DEBUG")) { mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768); (void)hipMemsetAsync(mdbg - 512 / 8 * 0, 0, 0, st); }
     LAUNCH_TRY(launch_match(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                            (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p));
+                            (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
+    if (mdbg) {
+        uint64_t hv[128];
+        (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 16; w++)
+            fprintf(stderr, "[lfx] match wave%d: load=%llu work=%llu wait=%llu hops=%llu lcp_iters=%llu tiles=%llu\n", w,
+                    (unsigned long long)hv[w * 8], (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2],
+                    (unsigned long long)hv[w * 8 + 3], (unsigned long long)hv[w * 8 + 4], (unsigned long long)hv[w * 8 + 5]);
+    }
     c->phase("lz77_match");
     LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, (const uint32_t *)c->d_md.p,
                             (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p));

@@ -52,28 +52,62 @@ __device__ __forceinline__ ByteSrc make_src(const uint8_t *p, uint64_t n) {
     return s;
 }
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a release fence for
+// global memory (s_waitcnt vmcnt(0)): inside a streaming loop that makes every iteration wait for
+// its HBM store acknowledgements.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt() {
     uint32_t lane = __lane_id();
     return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz77_match: one workgroup (1024 lanes) per segment; LDS: head[16384] u32 (position+1 of the most
-// recent inserted position per hash), prevd[RING] u16 (distance to the previous position with the
-// same hash, 0 = none, 65535 = out of reach), tile hashes.
+// lz77_match: one workgroup (16 wavefronts) per segment, software pipelined over tiles of 960
+// positions: wavefront 0 LINKS tile i+1 (hash + insert, in position order) while wavefronts 1..15
+// RESOLVE tile i (chain walk with exact 3-byte verification + match length).  Everything the inner
+// loops touch lives in LDS:
+//   head[16384] u16 : low 16 bits of the most recent inserted position per hash (stale entries are
+//                     swept to a "far" marker every <= 16 Ki positions so they can never alias)
+//   prevd[PRING] u16: distance to the previous position with the same hash (0 = none in window)
+//   win[WRING+8] u8 : the input bytes [tile - 32 KiB, tile + lookahead) as a ring
 constexpr int MATCH_THREADS = 1024;
+constexpr uint32_t MTILE = 960;                 // 15 resolver wavefronts x 64 lanes
 constexpr int HASH_BITS = 14;
-constexpr uint32_t RING = 32768 + 2048;
+constexpr uint32_t PRING = 32768 + 2048;        // prevd ring (entries)
+constexpr uint32_t WRING = 36864;               // window ring (bytes), multiple of 4096
+constexpr uint32_t HEAD_FAR = 40000;            // distance marker of a swept head entry
+constexpr size_t MATCH_LDS = (2u << HASH_BITS) + PRING * 2 + WRING + 8 + MTILE * 4 + MTILE * 4;
 
 __device__ __forceinline__ uint32_t hash3(uint32_t key) { return (key * 2654435761u) >> (32 - HASH_BITS); }
+__device__ __forceinline__ uint32_t wring_off(uint32_t pos) {
+    // pos % 36864 = ((pos >> 12) % 9) << 12 | (pos & 4095)
+    const uint32_t x = pos >> 12;
+    const uint32_t q = (uint32_t)(((uint64_t)x * 954437177ull) >> 33);  // x / 9
+    return ((x - q * 9) << 12) | (pos & 4095);
+}
+__device__ __forceinline__ uint32_t win_at(const uint32_t *win32, uint32_t off) {
+    // 4 bytes at ring byte offset `off` (the 8 mirror bytes after the ring make the wrap seamless)
+    const uint32_t w0 = win32[off >> 2], w1 = win32[(off >> 2) + 1];
+    return __builtin_amdgcn_alignbyte(w1, w0, off & 3);
+}
 
 __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
-    const SegDesc *__restrict__ segs, uint32_t window, uint32_t max_len, uint32_t *__restrict__ md) {
+    const SegDesc *__restrict__ segs, uint32_t window, uint32_t max_len, uint32_t *__restrict__ md,
+    uint64_t *__restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *head = (uint32_t *)smem;                                  // 64 KiB
-    uint16_t *prevd = (uint16_t *)(smem + (sizeof(uint32_t) << HASH_BITS));  // RING * 2
-    uint16_t *th = (uint16_t *)(smem + (sizeof(uint32_t) << HASH_BITS) + RING * 2);  // 1024 * 2
+    uint16_t *head = (uint16_t *)smem;
+    uint16_t *prevd = (uint16_t *)(smem + (2u << HASH_BITS));
+    uint32_t *win32 = (uint32_t *)(smem + (2u << HASH_BITS) + PRING * 2);
+    // staging of the link tile: 24-bit prefix | (lane delta to the nearest lower same-hash lane, bit 6:
+    // that lane has the same prefix, bit 7: last lane with this hash) << 24 ; 0xFFFFFFFF = no position
+    uint32_t *st_k = (uint32_t *)(smem + (2u << HASH_BITS) + PRING * 2 + WRING + 8);
+    // cd[parity][idx]: distance to the most recent same-prefix position when the insertion already
+    // knows it (0 = the resolver has to walk the chain)
+    uint16_t *cd = (uint16_t *)(st_k + MTILE);
 
     const SegDesc sg = segs[blockIdx.x];
     const ChunkDesc ch = chunks[sg.chunk];
@@ -84,83 +118,178 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     const uint32_t q1 = min(sg.start + sg.len, end);
     if (q0 >= q1) return;
     const uint32_t l0 = q0 > MAX_WINDOW ? q0 - MAX_WINDOW : 0;  // warm-up: link only
+    const uint32_t base = l0 & ~3u;                              // tile origin (dword aligned)
     const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t ntiles = (q1 - base + MTILE - 1) / MTILE;
 
-    for (uint32_t i = tid; i < (1u << HASH_BITS); i += MATCH_THREADS) head[i] = 0;
-    __syncthreads();
+    for (uint32_t i = tid; i < (1u << HASH_BITS); i += MATCH_THREADS) head[i] = (uint16_t)(base - HEAD_FAR);
+    uint32_t loaded_to = base;      // window holds [.., loaded_to)
+    uint32_t swept_at = base;
+    uint64_t cy_load = 0, cy_work = 0, cy_wait = 0, hops = 0, lcps = 0;
 
-    for (uint32_t t0 = l0 & ~1023u; t0 < q1; t0 += MATCH_THREADS) {
-        const uint32_t pos = t0 + tid;
-        const bool valid = pos >= l0 && pos < q1;
-        uint32_t key = 0;
-        if (valid) key = src.load4(pos) & 0xFFFFFFu;
-        th[tid] = valid ? (uint16_t)hash3(key) : (uint16_t)0xFFFF;
-        __syncthreads();
-        if (wave == 0) {
-            // link phase: one wavefront inserts the tile's 1024 positions in order, 64 at a time
-            const uint64_t lt = lanemask_lt();
-            for (uint32_t sub = 0; sub < 16; ++sub) {
-                const uint32_t p = t0 + sub * 64 + lane;
-                const uint32_t hh = th[sub * 64 + lane];
-                const bool v = hh != 0xFFFFu;
-                uint64_t same = __ballot(v);
+    // iteration it links tile it+1 and resolves tile it (it = -1: prologue)
+    for (int it = -1; it < (int)ntiles; ++it) {
+        const uint64_t c0 = clock64();
+        const uint32_t t_res = base + (uint32_t)it * MTILE;        // tile being resolved (it >= 0)
+        const uint32_t t_link = base + (uint32_t)(it + 1) * MTILE; // tile being linked
+        const bool do_link = (uint32_t)(it + 1) < ntiles;
+        // ---- A: everyone extends the window to cover the link tile (+3) and the resolve lookahead
+        const uint32_t need = min(t_link + MTILE + 4, (n + 3) & ~3u);
+        for (uint32_t p = loaded_to + 4 * tid; p < need; p += 4 * MATCH_THREADS) {
+            const uint32_t v = src.load4(p);
+            const uint32_t o = wring_off(p);
+            win32[o >> 2] = v;
+            if (o < 8) win32[(WRING + o) >> 2] = v;   // mirror
+        }
+        if (need > loaded_to) loaded_to = need;
+        if (do_link && t_link + MTILE - swept_at > 16384) {
+            // stale heads (older than the window) → "far", so that 16-bit distances never alias
+            for (uint32_t i = tid; i < (1u << HASH_BITS); i += MATCH_THREADS) {
+                const uint32_t d = (t_link - head[i]) & 0xFFFFu;
+                if (d == 0 || d > MAX_WINDOW) head[i] = (uint16_t)(t_link - HEAD_FAR);
+            }
+            swept_at = t_link;
+        }
+        lds_barrier();
+        // ---- X: wavefronts 1..15 each pre-digest one 64-position sub-tile of the link tile: hash,
+        //      nearest lower lane with the same hash (match-any by ballots), "last lane with this hash"
+        if (wave > 0 && do_link) {
+            const uint32_t idx = (wave - 1) * 64 + lane;
+            const uint32_t p = t_link + idx;
+            const bool v = p >= l0 && p < q1;
+            uint32_t key = 0, hh = 0;
+            if (v) { key = win_at(win32, wring_off(p)) & 0xFFFFFFu; hh = hash3(key); }
+            uint64_t same = __ballot(v);
 #pragma unroll
-                for (int b = 0; b < HASH_BITS; ++b) {
-                    const bool bit = (hh >> b) & 1;
-                    const uint64_t m = __ballot(bit);
-                    same &= bit ? m : ~m;
-                }
-                const uint64_t lower = same & lt;
-                uint32_t pd = 0;
-                if (v) {
-                    if (lower) {
-                        pd = lane - (63 - __clzll(lower));
-                    } else {
-                        const uint32_t hd = head[hh];
-                        if (hd) {
-                            const uint32_t d = p + 1 - hd;
-                            pd = d > 65535u ? 65535u : d;
+            for (int b = 0; b < HASH_BITS; ++b) {
+                const bool bit = (hh >> b) & 1;
+                const uint64_t m = __ballot(bit);
+                same &= bit ? m : ~m;
+            }
+            const uint64_t lower = same & lanemask_lt();
+            const uint32_t hb = lower ? 63 - __clzll(lower) : lane;
+            const uint32_t kprev = __shfl(key, hb);
+            uint32_t f = lower ? lane - hb : 0;                 // 1..63, 0 = none in this sub-tile
+            if (lower && kprev == key) f |= 0x40;               // ... and it has the same 3-byte prefix
+            if (((same >> lane) >> 1) == 0) f |= 0x80;          // last lane with this hash
+            st_k[idx] = v ? (key | (f << 24)) : 0xFFFFFFFFu;
+        }
+        lds_barrier();
+        const uint64_t c1 = clock64();
+        if (wave == 0) {
+            if (do_link) {
+                // ---- Y: the ordered part of the insertion (head read → prev link → head write).
+                // Duplicate collapsing: when the bucket head carries the SAME prefix as this position
+                // it is this position's answer (cd), and the new link bypasses it — an older
+                // occurrence of the same prefix can never be an answer again.  Chains therefore hold
+                // about one entry per distinct prefix and a rare prefix that shares a bucket with a
+                // frequent one no longer walks through hundreds of useless entries.
+                uint16_t *cdw = cd + (((uint32_t)(it + 1) & 1) * MTILE);
+                for (uint32_t sub = 0; sub < MTILE / 64; ++sub) {
+                    const uint32_t idx = sub * 64 + lane;
+                    const uint32_t p = t_link + idx;
+                    const uint32_t sk = st_k[idx];
+                    if (sk != 0xFFFFFFFFu) {
+                        const uint32_t key = sk & 0xFFFFFFu, f = sk >> 24, hh = hash3(key);
+                        uint32_t pd = f & 0x3F, cdv = (f & 0x40) ? pd : 0;
+                        if (pd == 0) {
+                            const uint32_t d = (p - head[hh]) & 0xFFFFu;
+                            if (d != 0 && d <= MAX_WINDOW) {
+                                const uint32_t q = p - d;
+                                pd = d;
+                                if ((win_at(win32, wring_off(q)) & 0xFFFFFFu) == key) {
+                                    cdv = d;
+                                    const uint32_t pq = prevd[q % PRING];
+                                    pd = pq ? d + pq : 0;
+                                    if (pd > MAX_WINDOW) pd = 0;
+                                }
+                            }
                         }
+                        prevd[p % PRING] = (uint16_t)pd;
+                        cdw[idx] = (uint16_t)cdv;
+                        if (f & 0x80) head[hh] = (uint16_t)p;   // last lane with this hash
                     }
-                    prevd[p % RING] = (uint16_t)pd;
-                    if (((same >> lane) >> 1) == 0) head[hh] = p + 1;  // last lane with this hash
                 }
             }
-        }
-        __syncthreads();
-        if (valid && pos >= q0) {
-            // resolve: walk the hash chain until the exact 3-byte prefix matches (the most recent
-            // occurrence) or the chain leaves the window
-            uint32_t dist = 0, out = 0;
-            uint32_t d = prevd[pos % RING];
+        } else if (it >= 0) {
+            const uint32_t pos = t_res + (wave - 1) * 64 + lane;
+            const bool act = pos >= q0 && pos < q1;
+            uint32_t dist = 0, l = 0, lim = 0, oa = 0, ob = 0;
             bool found = false;
-            while (d != 0) {
-                dist += d;
-                if (dist > window || dist > pos) break;  // default.rs:81 (inclusive window)
-                const uint32_t j = pos - dist;
-                if ((src.load4(j) & 0xFFFFFFu) == key) { found = true; break; }
-                d = prevd[j % RING];
-            }
-            if (found) {
-                // longest_common_prefix default.rs:122-129: up to max_len-3 more bytes, bounded by
-                // the end of the chunk
-                uint32_t lim = n - (pos + 3);
-                if (lim > max_len - 3) lim = max_len - 3;
-                uint32_t l = 0;
-                const uint32_t a = pos + 3, b = pos - dist + 3;
-                while (l < lim) {
-                    const uint32_t x = src.load4(a + l) ^ src.load4(b + l);
-                    if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
-                    l += 4;
+            if (act) {
+                // resolve: walk the hash chain until the exact 3-byte prefix matches (the most recent
+                // occurrence) or the chain leaves the window
+                const uint32_t key = win_at(win32, wring_off(pos)) & 0xFFFFFFu;
+                const uint32_t known = cd[((uint32_t)it & 1) * MTILE + (wave - 1) * 64 + lane];
+                uint32_t d = prevd[pos % PRING];
+                if (known) { dist = known; found = dist <= window; d = 0; }
+                while (d != 0) {
+                    dist += d;
+                    hops++;
+                    if (dist > window || dist > pos) break;  // default.rs:81 (inclusive window)
+                    const uint32_t j = pos - dist;
+                    if ((win_at(win32, wring_off(j)) & 0xFFFFFFu) == key) { found = true; break; }
+                    d = prevd[j % PRING];
                 }
-                if (l > lim) l = lim;
-                out = ((3 + l) << 16) | dist;
+                if (found) {
+                    // longest_common_prefix default.rs:122-129: up to max_len-3 more bytes, bounded by
+                    // the end of the chunk.  Phase 1: the first 16 bytes, every lane on its own.
+                    lim = n - (pos + 3);
+                    if (lim > max_len - 3) lim = max_len - 3;
+                    oa = wring_off(pos + 3); ob = wring_off(pos - dist + 3);
+                    while (l < lim && l < 16) {
+                        const uint32_t x = win_at(win32, oa) ^ win_at(win32, ob);
+                        if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+                        l += 4;
+                        lcps++;
+                        oa += 4; if (oa >= WRING) oa -= WRING;
+                        ob += 4; if (ob >= WRING) ob -= WRING;
+                    }
+                }
             }
-            md[ch.in_off + pos] = out;
+            // Phase 2: a lane still matching after 16 bytes gets the whole wavefront: lane k compares
+            // bytes [16+4k, 16+4k+4) — one step settles up to 256 more bytes
+            uint64_t lm = __ballot(found && l == 16 && l < lim);
+            while (lm) {
+                const uint32_t sl = (uint32_t)__builtin_ctzll(lm);
+                lm &= lm - 1;
+                const uint32_t boa = __builtin_amdgcn_readlane(oa, sl), bob = __builtin_amdgcn_readlane(ob, sl);
+                const uint32_t blim = __builtin_amdgcn_readlane(lim, sl);
+                const uint32_t off = 4 * lane;
+                uint32_t x = 0;
+                if (16 + off < blim) {
+                    uint32_t a = boa + off, b = bob + off;
+                    if (a >= WRING) a -= WRING;
+                    if (b >= WRING) b -= WRING;
+                    x = win_at(win32, a) ^ win_at(win32, b);
+                }
+                const uint64_t mis = __ballot(x != 0);
+                uint32_t res = blim;
+                if (mis) {
+                    const uint32_t fl = (uint32_t)__builtin_ctzll(mis);
+                    const uint32_t cand = 16 + off + ((uint32_t)__builtin_ctz(x | 0x80000000u) >> 3);
+                    res = __builtin_amdgcn_readlane(cand, fl);
+                }
+                if (lane == sl) l = res;
+            }
+            if (act) {
+                uint32_t out = 0;
+                if (found) {
+                    if (l > lim) l = lim;
+                    out = ((3 + l) << 16) | dist;
+                }
+                md[ch.in_off + pos] = out;
+            }
         }
-        // the next tile's link phase may only start after every lane left the chain walk; the ring
-        // has a full tile of slack, so one barrier per tile (the one after th[] is written) suffices
+        const uint64_t c2 = clock64();
+        lds_barrier();
+        const uint64_t c3 = clock64();
+        cy_load += c1 - c0; cy_work += c2 - c1; cy_wait += c3 - c2;
+    }
+    if (dbg && blockIdx.x == 0 && lane == 0) {
+        uint64_t *d = dbg + wave * 8;
+        d[0] = cy_load; d[1] = cy_work; d[2] = cy_wait; d[3] = hops; d[4] = lcps; d[5] = ntiles;
     }
 }
 
@@ -685,16 +814,16 @@ __global__ void trailer_kernel(int format, uint32_t isize, uint64_t out_base_bit
     } while (0)
 
 int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
-                 const SegDesc *segs, uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md) {
+                 const SegDesc *segs, uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint64_t *dbg) {
     if (nsegs == 0) return 0;
-    const size_t lds = (sizeof(uint32_t) << HASH_BITS) + RING * 2 + MATCH_THREADS * 2;
+    const size_t lds = MATCH_LDS;
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void *)lz77_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipLaunchKernelGGL(lz77_match_kernel, dim3(nsegs), dim3(MATCH_THREADS), lds, st, in, in_bytes,
-                       chunks, segs, window, max_len, md);
+                       chunks, segs, window, max_len, md, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
