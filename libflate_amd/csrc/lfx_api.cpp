@@ -326,6 +326,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
+    if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
+    if ((rc = c->d_segtmp.reserve(12ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
     if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;
@@ -367,8 +369,9 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                     (unsigned long long)hv[w * 8 + 3], (unsigned long long)hv[w * 8 + 4], (unsigned long long)hv[w * 8 + 5]);
     }
     c->phase("lz77_match");
-    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, (const uint32_t *)c->d_md.p,
-                            (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p));
+    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
+                            (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
+                            (uint32_t *)c->d_ncodes.p));
     c->phase("lz77_parse");
     uint32_t split = nchunks && nchunks < 512 ? std::min<uint32_t>(64, 1024 / nchunks + 1) : 1;
     LAUNCH_TRY(launch_histogram(st, (const ChunkDesc *)c->d_chunks.p, nchunks, split, (const uint32_t *)c->d_codes.p,
@@ -735,6 +738,9 @@ extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
     Plan plan;
     ChunkDesc ch{};
     ch.len = n;
+    ch.n_seg = (uint32_t)div_up(n, PARSE_SEG);
+    plan.n_segs = ch.n_seg;
+    plan.n_vis = (uint64_t)ch.n_seg * (PARSE_SEG / 64);
     plan.chunks.push_back(ch);
     BlockDesc bd{};
     bd.type = BT_DYNAMIC;

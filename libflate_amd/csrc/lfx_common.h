@@ -25,6 +25,9 @@ struct ChunkDesc {
     uint32_t block;     // owning block
     uint32_t flags;     // CH_*
     uint64_t tile_base; // first pack tile of this chunk (prefix of ceil((len+1)/TILE))
+    uint64_t vis_base;  // first 64-position visited-mask word of this chunk
+    uint32_t seg_base;  // first parse segment of this chunk
+    uint32_t n_seg;     // parse segments (PARSE_SEG positions each)
 };
 enum : uint32_t {
     CH_LAST_IN_BLOCK = 1,  // parse appends Symbol::EndOfBlock (encode.rs:417)
@@ -52,6 +55,7 @@ struct BlockCodes {
 };
 
 constexpr uint32_t PACK_TILE = 2048;  // codes per pack tile
+constexpr uint32_t PARSE_SEG = 4096;  // positions per speculative parse segment (64 groups of 64)
 
 #ifdef __HIPCC__
 // pointers that are known to address global memory (HBM): keeps loads on the global_load path —

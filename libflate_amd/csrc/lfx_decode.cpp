@@ -111,31 +111,36 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
     const uint64_t comp = n > off0 ? n - off0 : 0;
     if (comp >= (64u << 10)) {
         // ---- speculative block-start search
-        const uint32_t max_cand = 1u << 22;
+        const uint32_t shard_cap = 1u << 17, final_cap = 1u << 16;
         int rc;
-        if ((rc = c->d_dec_cand.reserve(8ull * max_cand + 64))) return rc;
-        uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;
-        uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 64);
-        HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
-        LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, max_cand));
-        uint32_t n1 = 0;
-        HIP_TRY(hipMemcpyAsync(&n1, d_count, 4, hipMemcpyDeviceToHost, st));
+        if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 512))) return rc;
+        uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // FIND_SHARDS + 1 words, then final count
+        uint32_t *d_final_count = d_count + 64;
+        uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 512);
+        uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
+        HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
+        LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap));
+        uint32_t counts[FIND_SHARDS + 1];
+        HIP_TRY(hipMemcpyAsync(counts, d_count, sizeof counts, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         c->phase("find1");
-        if (n1 <= max_cand) {
-            std::vector<uint64_t> cand(n1);
-            std::vector<uint8_t> ok(n1);
-            if (n1) {
-                if ((rc = c->d_dec_tmp.reserve(n1))) return rc;
-                LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, n1, (uint8_t *)c->d_dec_tmp.p));
-                HIP_TRY(hipMemcpyAsync(cand.data(), d_cand, 8ull * n1, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipMemcpyAsync(ok.data(), c->d_dec_tmp.p, n1, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-            }
+        FindPrefix pre;
+        bool overflow = counts[FIND_SHARDS] != 0;
+        pre.off[0] = 0;
+        for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (counts[k] > shard_cap) overflow = true; pre.off[k + 1] = pre.off[k] + counts[k]; }
+        const uint32_t n1 = pre.off[FIND_SHARDS];
+        if (!overflow) {
+            LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, pre, d_final_count, d_final, final_cap));
+            uint32_t nf = 0;
+            HIP_TRY(hipMemcpyAsync(&nf, d_final_count, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (nf > final_cap) nf = final_cap;
+            std::vector<uint64_t> cand(nf);
+            if (nf) HIP_TRY(hipMemcpy(cand.data(), d_final, 8ull * nf, hipMemcpyDeviceToHost));
             c->phase("find2");
             std::vector<uint64_t> starts;
             starts.push_back(first_bit);  // the first block's start is known
-            for (uint32_t i = 0; i < n1; i++) if (ok[i] && cand[i] != first_bit) starts.push_back(cand[i]);
+            for (uint32_t i = 0; i < nf; i++) if (cand[i] != first_bit) starts.push_back(cand[i]);
             std::sort(starts.begin(), starts.end());
             // ---- K1: every candidate block is scanned by a 256-lane workgroup (speculative slices,
             //      chained exits) for its end bit, byte and code counts
@@ -197,7 +202,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 // ---- K2 + K3: validated lanes emit codes, one wavefront per block materialises them
                 const uint32_t ne = (uint32_t)emit.size();
                 if ((rc = c->d_dec_tmp.reserve(sizeof(BlkEmit) * ne + 64))) return rc;
-                if ((rc = c->d_dec_cand.reserve(sizeof(BlkUnits) * (size_t)ne + 64))) return rc;
+                if ((rc = c->d_hist.reserve(sizeof(BlkUnits) * (size_t)ne + 64))) return rc;
                 if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(total_codes, 1)))) return rc;
                 uint32_t *d_flags = (uint32_t *)c->d_dec_tmp.p;
                 BlkEmit *d_emit = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64);
@@ -210,7 +215,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
                 HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
-                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_dec_cand.p, d_out, dbgbuf));
+                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, d_out, dbgbuf));
                 uint32_t fl = 0;
                 HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));

@@ -102,10 +102,15 @@ int launch_container(hipStream_t st, int format, uint32_t count, const uint8_t *
                      const DecStream *streams, DecHeader *hdrs);
 int launch_inflate(hipStream_t st, const uint8_t *in, uint8_t *out, const InflateJob *jobs,
                    InflateResult *results, uint32_t njobs);
+constexpr uint32_t FIND_SHARDS = 32;
+struct FindPrefix { uint32_t off[FIND_SHARDS + 1]; };   // prefix sums of the per-shard survivor counts
+// count: FIND_SHARDS + 1 words (the last one marks a workgroup overflow)
 int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint64_t first_byte,
-                       uint32_t *count, uint64_t *cand, uint32_t max_cand);
+                       uint32_t *count, uint64_t *cand, uint32_t shard_cap);
+// survivors of the full header check are appended to final[] (final_count = number appended)
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
-                       uint32_t ncand, uint8_t *ok);
+                       uint32_t shard_cap, FindPrefix pre, uint32_t *final_count, uint64_t *final_list,
+                       uint32_t final_cap);
 int launch_verify_trailers(hipStream_t st, int format, uint32_t count, const uint8_t *in,
                            const DecStream *streams, const DecHeader *hdrs, InflateResult *results,
                            const uint32_t *crc, const uint32_t *adler, uint64_t *consumed);

@@ -294,52 +294,169 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz77_parse: one wavefront per chunk walks i += length / i += 1 with the per-position answers held
-// in a VGPR and read back through v_readlane (scalar loop), then compacts the visited positions.
-__global__ __launch_bounds__(64) void lz77_parse_kernel(const uint8_t *__restrict__ in,
-                                                        uint64_t in_bytes,
-                                                        const ChunkDesc *__restrict__ chunks,
+// lz77_parse: the greedy walk i += length / i += 1 (default.rs:76-107) is a serial chain per chunk.
+// It is run speculatively in parallel: every PARSE_SEG-position segment is walked from its FIRST
+// position (P1); greedy parses that start at different positions merge after a few steps, so almost all
+// of each speculative walk is the true walk.  One wavefront per chunk (P2) then chains the true entry
+// points through the segments, re-walking only from a segment's true entry to the merge point, and
+// turns the per-segment counts into offsets; every segment finally emits its codes (P3).
+// The walk itself keeps 64 per-position answers in a VGPR and steps through them with v_readlane.
+__device__ __forceinline__ uint32_t find_seg_chunk(const ChunkDesc *chunks, uint32_t nchunks, uint32_t seg) {
+    uint32_t lo = 0, hi = nchunks;  // last chunk with seg_base <= seg and n_seg > 0 reachable
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (chunks[mid].seg_base <= seg) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
                                                         const uint32_t *__restrict__ md,
-                                                        uint32_t *__restrict__ codes,
-                                                        uint32_t *__restrict__ ncodes) {
+                                                        uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit,
+                                                        uint32_t *__restrict__ seg_count) {
+    const uint32_t seg = blockIdx.x;
+    const uint32_t c = find_seg_chunk(chunks, nchunks, seg);
+    const ChunkDesc ch = chunks[c];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s = seg - ch.seg_base;
+    const uint32_t n = (uint32_t)ch.len;
+    const uint32_t end = (n > 3 ? n : 3) - 3;
+    const uint32_t s0 = s * PARSE_SEG;
+    uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
+    if (ch.flags & CH_LITERALS) return;   // no walk: every byte is a literal
+    uint32_t pos = s0, cnt = 0;
+    for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
+        const uint32_t base = s0 + g * 64;
+        uint64_t m = 0;
+        if (base < end) {
+            const uint32_t i = base + lane;
+            const uint32_t v = i < end ? md[ch.in_off + i] : 0;
+            const uint32_t stop = min(base + 64, end);
+            while (pos < stop) {
+                const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
+                const uint32_t mv = __builtin_amdgcn_readlane(v, r);
+                m |= 1ull << r;
+                pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
+            }
+        }
+        if (lane == 0) vw[g] = m;
+        cnt += __popcll(m);
+    }
+    if (lane == 0) { seg_exit[seg] = pos; seg_count[seg] = cnt; }
+}
+
+// P2: one wavefront per chunk
+__global__ __launch_bounds__(64) void parse_fix_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                       const ChunkDesc *__restrict__ chunks,
+                                                       const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
+                                                       const uint32_t *__restrict__ seg_exit,
+                                                       const uint32_t *__restrict__ seg_count,
+                                                       uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
+                                                       uint32_t *__restrict__ ncodes) {
     const ChunkDesc ch = chunks[blockIdx.x];
     const uint32_t lane = threadIdx.x;
     const uint32_t n = (uint32_t)ch.len;
     const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
     uint32_t *out = codes + ch.code_off;
-    uint32_t nout = 0;
+    uint32_t total = 0;
     if (ch.flags & CH_LITERALS) {
-        for (uint32_t i = lane; i < n; i += 64) out[i] = src.load1(i) << 16;
-        nout = n;
+        for (uint32_t s = lane; s < ch.n_seg; s += 64) seg_off[ch.seg_base + s] = s * PARSE_SEG;
+        total = n;
     } else {
         const uint32_t end = (n > 3 ? n : 3) - 3;
-        const uint64_t lt = lanemask_lt();
-        uint32_t pos = 0;  // wave-uniform
-        for (uint32_t base = 0; base < end; base += 64) {
-            const uint32_t i = base + lane;
-            const uint32_t v = i < end ? md[ch.in_off + i] : 0;
-            const uint32_t byte = i < n ? src.load1(i) : 0;
-            uint64_t vis = 0;
-            const uint32_t stop = min(base + 64, end);
-            while (pos < stop) {
-                const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
-                const uint32_t mv = __builtin_amdgcn_readlane(v, r);
-                vis |= 1ull << r;
-                pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
+        uint32_t e = 0;   // true entry position of the next segment (wave-uniform)
+        for (uint32_t s = 0; s < ch.n_seg; ++s) {
+            const uint32_t s0 = s * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
+            uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
+            uint32_t cnt = seg_count[ch.seg_base + s], ex = seg_exit[ch.seg_base + s];
+            if (s0 >= end) { cnt = 0; ex = e; }
+            else if (e != s0) {
+                // the true parse enters at e > s0: re-walk from e until it lands on a position the
+                // speculative walk visited (from there on both walks coincide)
+                uint32_t pos = e, walked = 0, spec_below = 0;
+                bool merged = false;
+                for (uint32_t g = 0; g < PARSE_SEG / 64 && !merged; ++g) {
+                    const uint32_t base = s0 + g * 64;
+                    if (base >= s1) break;
+                    const uint64_t V = vw[g];
+                    if (pos >= base + 64) {          // wholly before the true entry: nothing visited here
+                        spec_below += __popcll(V);
+                        if (lane == 0 && V) vw[g] = 0;
+                        continue;
+                    }
+                    const uint32_t i = base + lane;
+                    const uint32_t v = i < end ? md[ch.in_off + i] : 0;
+                    const uint32_t stop = min(base + 64, s1);
+                    uint64_t T = 0;
+                    uint32_t mr = 64;
+                    while (pos < stop) {
+                        const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
+                        if ((V >> r) & 1) { merged = true; mr = r; break; }
+                        const uint32_t mv = __builtin_amdgcn_readlane(v, r);
+                        T |= 1ull << r;
+                        walked++;
+                        pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
+                    }
+                    const uint64_t keep = mr < 64 ? (V & ~((1ull << mr) - 1)) : 0;   // speculative bits from the merge on
+                    spec_below += __popcll(V & ~keep);
+                    if (lane == 0) vw[g] = T | keep;
+                }
+                if (merged) cnt = cnt - spec_below + walked;        // exit stays the speculative one
+                else { cnt = walked; ex = pos; }                     // never merged inside this segment
             }
-            const uint32_t code = (v & 0xFFFFu) ? v : (byte << 16);
-            if ((vis >> lane) & 1) out[nout + __popcll(vis & lt)] = code;
-            nout += __popcll(vis);
+            if (lane == 0) seg_off[ch.seg_base + s] = total;
+            total += cnt;
+            e = ex;
         }
-        // default.rs:105-107: the rest are literals
-        for (uint32_t i = pos + lane; i < n; i += 64) out[nout + (i - pos)] = src.load1(i) << 16;
-        if (n > pos) nout += n - pos;
+        // default.rs:105-107: the rest are literals (at most 3 bytes)
+        const uint32_t pos = ch.n_seg ? e : 0;
+        for (uint32_t i = pos + lane; i < n; i += 64) out[total + (i - pos)] = src.load1(i) << 16;
+        if (n > pos) total += n - pos;
     }
     if (ch.flags & CH_LAST_IN_BLOCK) {
-        if (lane == 0) out[nout] = CODE_EOB;  // encode.rs:417
-        nout += 1;
+        if (lane == 0) out[total] = CODE_EOB;  // encode.rs:417
+        total += 1;
     }
-    if (lane == 0) ncodes[blockIdx.x] = nout;
+    if (lane == 0) ncodes[blockIdx.x] = total;
+}
+
+// P3: every segment emits the codes of its visited positions
+__global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                        const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
+                                                        const uint32_t *__restrict__ md,
+                                                        const uint64_t *__restrict__ vis,
+                                                        const uint32_t *__restrict__ seg_off,
+                                                        uint32_t *__restrict__ codes) {
+    const uint32_t seg = blockIdx.x;
+    const uint32_t c = find_seg_chunk(chunks, nchunks, seg);
+    const ChunkDesc ch = chunks[c];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s = seg - ch.seg_base;
+    const uint32_t n = (uint32_t)ch.len;
+    const uint32_t s0 = s * PARSE_SEG;
+    const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
+    uint32_t *out = codes + ch.code_off + seg_off[seg];
+    if (ch.flags & CH_LITERALS) {
+        const uint32_t s1 = min(s0 + PARSE_SEG, n);
+        for (uint32_t i = s0 + lane; i < s1; i += 64) out[i - s0] = src.load1(i) << 16;
+        return;
+    }
+    const uint32_t end = (n > 3 ? n : 3) - 3;
+    const uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
+    const uint64_t lt = lanemask_lt();
+    uint32_t nout = 0;
+    for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
+        const uint32_t base = s0 + g * 64;
+        if (base >= end) break;
+        const uint64_t m = vw[g];
+        if (m == 0) continue;
+        const uint32_t i = base + lane;
+        if ((m >> lane) & 1) {
+            const uint32_t v = md[ch.in_off + i];
+            out[nout + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (src.load1(i) << 16);
+        }
+        nout += __popcll(m);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -828,11 +945,22 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     return 0;
 }
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
-                 uint32_t nchunks, const uint32_t *md, uint32_t *codes, uint32_t *ncodes) {
+                 uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
+                 uint32_t *codes, uint32_t *ncodes) {
     if (nchunks == 0) return 0;
-    hipLaunchKernelGGL(lz77_parse_kernel, dim3(nchunks), dim3(64), 0, st, in, in_bytes, chunks, md,
-                       codes, ncodes);
+    uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
+    if (nsegs) {
+        hipLaunchKernelGGL(parse_spec_kernel, dim3(nsegs), dim3(64), 0, st, chunks, nchunks, md, vis, seg_exit, seg_count);
+        LFX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(64), 0, st, in, in_bytes, chunks, md, vis, seg_exit,
+                       seg_count, seg_off, codes, ncodes);
     LFX_LAUNCH_CHECK();
+    if (nsegs) {
+        hipLaunchKernelGGL(parse_emit_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis,
+                           seg_off, codes);
+        LFX_LAUNCH_CHECK();
+    }
     return 0;
 }
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,

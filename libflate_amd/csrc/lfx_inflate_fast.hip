@@ -28,6 +28,14 @@ __constant__ uint16_t f_dist_base[30] = {1,    2,    3,    4,    5,    7,    9, 
 __constant__ uint8_t f_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2,  3,  3,  4,  4,  5,  5,  6,
                                          6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t f_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+// BITWIDTH_CODE_ORDER (symbol.rs:16-18) without a memory lookup: 5 bits per entry
+__device__ __forceinline__ uint32_t clen_order(uint32_t k) {
+    // entries 0..11 in lo, 12..18 in hi
+    const uint64_t lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                        10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+    const uint64_t hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    return k < 12 ? (uint32_t)(lo >> (5 * k)) & 31 : (uint32_t)(hi >> (5 * (k - 12))) & 31;
+}
 
 // table entry: bits 0-3 code width (0 = no direct code), bits 4-5 kind (0 literal, 1 length, 2 EOB,
 // 3 long-code prefix), bits 6-10 extra-bit count, bits 16-31 value (literal byte / length base /
@@ -304,6 +312,44 @@ struct HdrBits {
     }
 };
 
+// The code-length code (at most 19 symbols, widths <= 7) kept entirely in registers: per-lane arrays
+// with dynamic indexing would live in scratch memory (~1 us per access).
+struct ClenCode {
+    uint64_t cnt;      // 5 bits per width 1..7 at bit 5*w
+    uint64_t sym_lo;   // sorted symbols 0..11, 5 bits each
+    uint64_t sym_hi;   // sorted symbols 12..18
+    __device__ __forceinline__ uint32_t count(uint32_t w) const { return (uint32_t)(cnt >> (5 * w)) & 31; }
+    __device__ __forceinline__ uint32_t sorted(uint32_t i) const {
+        return i < 12 ? (uint32_t)(sym_lo >> (5 * i)) & 31 : (uint32_t)(sym_hi >> (5 * (i - 12))) & 31;
+    }
+    // clw: 3-bit widths of symbols 0..18 packed at bit 3*s
+    __device__ __forceinline__ void build(uint64_t clw) {
+        cnt = 0; sym_lo = 0; sym_hi = 0;
+        for (uint32_t s = 0; s < 19; ++s) { const uint32_t w = (uint32_t)(clw >> (3 * s)) & 7; if (w) cnt += 1ull << (5 * w); }
+        uint32_t k = 0;
+        for (uint32_t w = 1; w <= 7; ++w)
+            for (uint32_t s = 0; s < 19; ++s)
+                if (((uint32_t)(clw >> (3 * s)) & 7) == w) {
+                    if (k < 12) sym_lo |= (uint64_t)s << (5 * k); else sym_hi |= (uint64_t)s << (5 * (k - 12));
+                    k++;
+                }
+    }
+    // canonical walk over the next (at most 7) bits; returns the symbol or 99, *used = bits consumed
+    __device__ __forceinline__ uint32_t decode(uint32_t bits, uint32_t &used) const {
+        uint32_t code = 0, first = 0, index = 0;
+        for (uint32_t w = 1; w <= 7; ++w) {
+            code |= (bits >> (w - 1)) & 1;
+            const uint32_t c = count(w);
+            if (code < first + c) { used = w; return sorted(index + (code - first)); }
+            index += c;
+            first = (first + c) << 1;
+            code <<= 1;
+        }
+        used = 0;
+        return 99;
+    }
+};
+
 constexpr int SCAN_THREADS = 1024;   // lanes per block: 16 wavefronts, 4 per SIMD hide each other's latency
 
 // parse the block header at job.start_bit and build T.  → btype in hdr[0], bfinal hdr[1],
@@ -324,31 +370,20 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
         } else if (btype == 2) {
             const uint32_t nl = hb.get(5) + 257, nd = hb.get(5) + 1, nc = hb.get(4) + 4;
             hdr[3] = nl; hdr[4] = nd;
-            uint8_t clw[19];
-            for (int k = 0; k < 19; ++k) clw[k] = 0;
-            for (uint32_t k = 0; k < nc; ++k) clw[f_clen_order[k]] = (uint8_t)hb.get(3);
-            uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int s = 0; s < 19; ++s) cnt[clw[s]]++;
-            cnt[0] = 0;
-            uint8_t sorted[19];
-            {
-                uint32_t offs[8], o = 0;
-                for (int w = 1; w < 8; ++w) { offs[w] = o; o += cnt[w]; }
-                for (int s = 0; s < 19; ++s) if (clw[s]) sorted[offs[clw[s]]++] = (uint8_t)s;
-            }
+            uint64_t clw = 0;
+            for (uint32_t k = 0; k < nc; ++k) clw |= (uint64_t)hb.get(3) << (3 * clen_order(k));
+            ClenCode cc;
+            cc.build(clw);
             uint32_t have = 0, last = 0;
             const uint32_t total = nl + nd;
             if (nd > 30 || hb.bad) hdr[2] = 1;
             while (have < total && !hdr[2]) {
-                uint32_t code = 0, first = 0, index = 0, sym = 99;
-                for (uint32_t w = 1; w <= 7; ++w) {
-                    code |= hb.get(1);
-                    if (code < first + cnt[w]) { sym = sorted[index + (code - first)]; break; }
-                    index += cnt[w];
-                    first = (first + cnt[w]) << 1;
-                    code <<= 1;
-                }
-                if (sym == 99 || hb.bad) { hdr[2] = 1; break; }
+                if (hb.b.pos + 7 > hb.nbits && hb.b.pos >= hb.nbits) { hdr[2] = 1; break; }
+                hb.b.refill();
+                uint32_t used = 0;
+                const uint32_t sym = cc.decode((uint32_t)hb.b.buf & 127, used);
+                if (sym == 99 || hb.b.pos + used > hb.nbits) { hdr[2] = 1; break; }
+                hb.b.skip(used);
                 uint32_t rep = 1, val = sym;
                 if (sym == 16) { if (have == 0) { hdr[2] = 1; break; } rep = 3 + hb.get(2); val = last; }
                 else if (sym == 17) { rep = 3 + hb.get(3); val = 0; }
@@ -698,52 +733,45 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
 // decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length code must be
 // complete and the distance code complete, single or empty.
 __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restrict__ in, uint64_t nbytes,
-                                                         const uint64_t *__restrict__ cand, uint32_t ncand,
-                                                         uint8_t *__restrict__ ok) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ncand) return;
+                                                         const uint64_t *__restrict__ cand, uint32_t shard_cap,
+                                                         FindPrefix pre, uint32_t *__restrict__ final_count,
+                                                         uint64_t *__restrict__ final_list, uint32_t final_cap) {
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= pre.off[FIND_SHARDS]) return;
+    uint32_t shard = 0;
+    for (uint32_t k = 1; k < FIND_SHARDS; ++k) shard += gi >= pre.off[k];
+    const uint64_t i = (uint64_t)shard * shard_cap + (gi - pre.off[shard]);
     HdrBits hb;
     hb.init(in, nbytes, cand[i]);
     auto bits = [&](uint32_t w) -> uint32_t { return hb.get(w); };
     bits(3);
     const uint32_t nl = bits(5) + 257, nd = bits(5) + 1, nc = bits(4) + 4;
-    uint8_t clw[19];
-    for (int k = 0; k < 19; ++k) clw[k] = 0;
-    for (uint32_t k = 0; k < nc; ++k) clw[f_clen_order[k]] = (uint8_t)bits(3);
-    // canonical decode of the code-length code, bit by bit (at most 7 bits)
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < 19; ++s) cnt[clw[s]]++;
-    cnt[0] = 0;
-    uint8_t sorted[19];
-    {
-        uint32_t offs[8], o = 0;
-        for (int w = 1; w < 8; ++w) { offs[w] = o; o += cnt[w]; }
-        for (int s = 0; s < 19; ++s) if (clw[s]) sorted[offs[clw[s]]++] = (uint8_t)s;
-    }
+    uint64_t clw = 0;
+    for (uint32_t k = 0; k < nc; ++k) clw |= (uint64_t)bits(3) << (3 * clen_order(k));
+    ClenCode cc;
+    cc.build(clw);
     uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
     const uint32_t total = nl + nd;
-    bool good = true;
+    bool good = !hb.bad;
     while (have < total && good) {
-        uint32_t code = 0, first = 0, index = 0, sym = 99;
-        for (uint32_t w = 1; w <= 7; ++w) {
-            code |= bits(1);
-            if (code < first + cnt[w]) { sym = sorted[index + (code - first)]; break; }
-            index += cnt[w];
-            first = (first + cnt[w]) << 1;
-            code <<= 1;
-        }
-        if (sym == 99 || hb.bad) { good = false; break; }
+        if (hb.b.pos >= hb.nbits) { good = false; break; }
+        hb.b.refill();
+        uint32_t used = 0;
+        const uint32_t sym = cc.decode((uint32_t)hb.b.buf & 127, used);
+        if (sym == 99 || hb.b.pos + used > hb.nbits) { good = false; break; }
+        hb.b.skip(used);
         uint32_t rep = 1, val = sym;
         if (sym == 16) { if (have == 0) { good = false; break; } rep = 3 + bits(2); val = last; }
         else if (sym == 17) { rep = 3 + bits(3); val = 0; }
         else if (sym == 18) { rep = 11 + bits(7); val = 0; }
-        if (have + rep > total) { good = false; break; }
-        for (uint32_t k = 0; k < rep; ++k) {
-            const uint32_t idx = have + k;
-            if (val) {
-                if (idx < nl) { kl += 32768u >> val; nlit++; if (idx == 256) eob_len = val; }
-                else { kd += 32768u >> val; ndist++; }
-            }
+        if (have + rep > total || hb.bad) { good = false; break; }
+        if (val) {
+            // [have, have+rep) split at the literal / distance boundary
+            const uint32_t nlit_part = have < nl ? (have + rep <= nl ? rep : nl - have) : 0;
+            const uint32_t ndist_part = rep - nlit_part;
+            kl += nlit_part * (32768u >> val); nlit += nlit_part;
+            kd += ndist_part * (32768u >> val); ndist += ndist_part;
+            if (have <= 256 && 256 < have + rep) eob_len = val;
         }
         have += rep;
         last = val;
@@ -754,7 +782,10 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
         if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
         if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
     }
-    ok[i] = good ? 1 : 0;
+    if (good) {
+        const uint32_t slot = atomicAdd(final_count, 1u);   // a few hundred per stream
+        if (slot < final_cap) final_list[slot] = cand[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -787,9 +818,12 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
 }
 
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
-                       uint32_t ncand, uint8_t *ok) {
+                       uint32_t shard_cap, FindPrefix pre, uint32_t *final_count, uint64_t *final_list,
+                       uint32_t final_cap) {
+    const uint32_t ncand = pre.off[FIND_SHARDS];
     if (!ncand) return 0;
-    hipLaunchKernelGGL(find_blocks_stage2, dim3((ncand + 63) / 64), dim3(64), 0, st, in, nbytes, cand, ncand, ok);
+    hipLaunchKernelGGL(find_blocks_stage2, dim3((ncand + 63) / 64), dim3(64), 0, st, in, nbytes, cand, shard_cap, pre,
+                       final_count, final_list, final_cap);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -29,6 +29,8 @@ struct Plan {
     std::vector<BlockDesc> blocks;
     uint64_t n_codes_cap = 0;  // slots needed in the code array
     uint64_t n_tiles = 0;      // pack tiles (upper bound)
+    uint64_t n_vis = 0;        // visited-mask words
+    uint32_t n_segs = 0;       // parse segments
 };
 
 class Planner {
@@ -83,6 +85,11 @@ class Planner {
         c.block = (uint32_t)plan_.blocks.size();
         c.flags = flags;
         c.tile_base = tile_cursor_;
+        c.vis_base = plan_.n_vis;
+        c.seg_base = plan_.n_segs;
+        c.n_seg = (uint32_t)div_up(len, PARSE_SEG);
+        plan_.n_vis += (uint64_t)c.n_seg * (PARSE_SEG / 64);
+        plan_.n_segs += c.n_seg;
         code_cursor_ += len + 1;  // worst case all literals + a possible EndOfBlock
         tile_cursor_ += div_up(len + 1, PACK_TILE);
         plan_.chunks.push_back(c);
