@@ -766,9 +766,12 @@ __global__ __launch_bounds__(256) void block_header_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// checksums.  Every lane digests a contiguous 1 KiB span; spans are combined on the device by a
-// second kernel (x^n mod P shifts for CRC-32, closed form for Adler-32).
-constexpr uint32_t CK_SPAN = 1024;
+// checksums.  A wavefront owns a 64 KiB region and sweeps it 4 KiB at a time: lane l digests bytes
+// [64 l, 64 l + 64) of every 4 KiB slice (four 16-byte loads, well coalesced), then advances its CRC
+// register over the 4032 bytes it skips with one multiplication by x^(8*4032) mod P.  At the end every
+// lane advances to the region end and — CRC being linear — the 64 registers simply XOR together.
+// Regions are combined by a second kernel (x^n mod P shifts for CRC-32, closed form for Adler-32).
+constexpr uint32_t CK_SPAN = 65536;
 constexpr uint32_t CRC_POLY = 0xEDB88320u;
 
 __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
@@ -797,33 +800,77 @@ __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__res
                                                             uint64_t n, uint32_t *__restrict__ crc_part,
                                                             uint32_t *__restrict__ a_part,
                                                             uint32_t *__restrict__ b_part) {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[4][256];   // slice-by-4: four independent lookups per input dword
+    __shared__ uint32_t s_adv;
     {
         uint32_t c = threadIdx.x;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1)));
-        tab[threadIdx.x] = c;
+        tab[0][threadIdx.x] = c;
     }
     __syncthreads();
-    const uint64_t span = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t lo = span * CK_SPAN;
-    if (lo >= n) return;
-    const uint32_t len = (uint32_t)min((uint64_t)CK_SPAN, n - lo);
-    const ByteSrc src = make_src(in + lo, len);
-    uint32_t crc = 0;  // raw register (no init / xorout): linear in the data
-    uint32_t a = 0, b = 0;
-    for (uint32_t i = 0; i < len; i += 4) {
-        const uint32_t w = src.load4(i);
-        const uint32_t m = min(4u, len - i);
-        for (uint32_t k = 0; k < m; ++k) {
-            const uint32_t byte = (w >> (8 * k)) & 0xFF;
-            crc = (crc >> 8) ^ tab[(crc ^ byte) & 0xFF];
-            a += byte;
-            b += a;  // <= 1024 * 255 * 1024 / 2 < 2^32
-        }
+    for (int t = 1; t < 4; ++t) {
+        const uint32_t pv = tab[t - 1][threadIdx.x];
+        tab[t][threadIdx.x] = (pv >> 8) ^ tab[0][pv & 0xFF];
+        __syncthreads();
     }
-    crc_part[span] = crc;
-    a_part[span] = a;            // sum of bytes
-    b_part[span] = b % 65521u;   // sum over i of (len - i) * byte_i
+    if (threadIdx.x == 0) s_adv = gf2_xpow8n(4096 - 64);
+    __syncthreads();
+    const uint32_t adv = s_adv;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t region = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t r0 = region * CK_SPAN;
+    if (r0 >= n) return;
+    const uint32_t rlen = (uint32_t)min((uint64_t)CK_SPAN, n - r0);
+    const ByteSrc src = make_src(in + r0, rlen);
+    // Invariant: `crc` is the raw register (init 0, no xorout — linear in the data) of this lane's
+    // bytes with zeros everywhere else, standing at region offset `stand`.
+    uint32_t crc = 0, stand = 0;
+    uint32_t s1 = 0, s1_before = 0;   // sum of bytes
+    uint64_t s2 = 0;                  // sum of (offset in region) * byte
+    const uint32_t first = 64 * lane;
+    for (uint32_t o = first; o < rlen; o += 4096) {
+        if (o != first) crc = gf2_mulmod(crc, adv);      // over the other lanes' 4032 bytes
+        const uint32_t len = min(64u, rlen - o);         // only the last piece can be short
+        // all sixteen loads are issued before the (serially dependent) table walk starts
+        uint32_t w[16];
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) w[q] = 4 * q < len ? src.load4(o + 4 * q) : 0u;
+        uint32_t wsum = 0;       // sum of (offset in piece) * byte, fits 32 bits
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) {
+            const uint32_t m = len > 4 * q ? min(4u, len - 4 * q) : 0u;
+            if (m == 4) {
+                const uint32_t x = crc ^ w[q];
+                crc = tab[3][x & 0xFF] ^ tab[2][(x >> 8) & 0xFF] ^ tab[1][(x >> 16) & 0xFF] ^ tab[0][x >> 24];
+                const uint32_t b0 = w[q] & 0xFF, b1 = (w[q] >> 8) & 0xFF, b2 = (w[q] >> 16) & 0xFF, b3 = w[q] >> 24;
+                s1 += b0 + b1 + b2 + b3;
+                wsum += 4 * q * (b0 + b1 + b2 + b3) + b1 + 2 * b2 + 3 * b3;
+            } else {
+                for (uint32_t k = 0; k < m; ++k) {
+                    const uint32_t byte = (w[q] >> (8 * k)) & 0xFF;
+                    crc = (crc >> 8) ^ tab[0][(crc ^ byte) & 0xFF];
+                    s1 += byte;
+                    wsum += (4 * q + k) * byte;
+                }
+            }
+        }
+        s2 += (uint64_t)o * (s1 - s1_before) + wsum;
+        s1_before = s1;
+        stand = o + len;
+    }
+    // every lane's register is brought to the region end; then they simply XOR together
+    uint32_t reg = first < rlen ? gf2_mulmod(crc, gf2_xpow8n(rlen - stand)) : 0u;
+    for (int o = 32; o > 0; o >>= 1) reg ^= __shfl_xor(reg, o);
+    uint64_t t1 = s1, t2 = s2 % 65521u;
+    for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+    if (lane == 0) {
+        crc_part[region] = reg;
+        const uint32_t a = (uint32_t)(t1 % 65521u);
+        // sum over i of (rlen - i) * byte_i = rlen * S1 - S2
+        const uint64_t bb = ((uint64_t)(rlen % 65521u) * a + 65521ull * 65521ull - (t2 % 65521u)) % 65521u;
+        a_part[region] = a;
+        b_part[region] = (uint32_t)bb;
+    }
 }
 
 // one workgroup folds all span partials (tree over lanes, then serial over the few per-lane results)
@@ -856,6 +903,10 @@ __global__ __launch_bounds__(1024) void checksum_combine_kernel(const uint32_t *
     s_a[threadIdx.x] = a;
     s_b[threadIdx.x] = b;
     __syncthreads();
+    // tree: at level k a full right-hand operand is `per * CK_SPAN << k` bytes long; its shift is the
+    // square of the previous level's, only the (single) short tail needs a fresh x^n
+    uint32_t lvl_shift = gf2_xpow8n(per * (uint64_t)CK_SPAN);
+    uint64_t lvl_len = per * (uint64_t)CK_SPAN;
     for (uint32_t step = 1; step < 1024; step <<= 1) {
         uint32_t c2 = 0, a2 = 0, b2 = 0;
         uint64_t l2 = 0;
@@ -869,12 +920,15 @@ __global__ __launch_bounds__(1024) void checksum_combine_kernel(const uint32_t *
         __syncthreads();
         if (act) {
             const uint32_t c1 = s_crc[threadIdx.x];
-            s_crc[threadIdx.x] = (l2 ? gf2_mulmod(c1, gf2_xpow8n(l2)) : c1) ^ c2;
+            const uint32_t sh = l2 == lvl_len ? lvl_shift : (l2 ? gf2_xpow8n(l2) : 0x80000000u);
+            s_crc[threadIdx.x] = gf2_mulmod(c1, sh) ^ c2;
             const uint32_t a1 = s_a[threadIdx.x], b1 = s_b[threadIdx.x];
             s_b[threadIdx.x] = (uint32_t)((b1 + b2 + (l2 % 65521u) * (uint64_t)a1) % 65521u);
             s_a[threadIdx.x] = (a1 + a2) % 65521u;
             s_len[threadIdx.x] += l2;
         }
+        lvl_shift = gf2_mulmod(lvl_shift, lvl_shift);
+        lvl_len *= 2;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -1011,7 +1065,7 @@ int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc
                     uint32_t *a_part, uint32_t *b_part, EncodeResult *res) {
     const uint64_t nspans = div_up(n, CK_SPAN);
     if (nspans) {
-        hipLaunchKernelGGL(checksum_span_kernel, dim3((uint32_t)div_up(nspans, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(checksum_span_kernel, dim3((uint32_t)div_up(nspans, 4)), dim3(256), 0, st,
                            in, n, crc_part, a_part, b_part);
         LFX_LAUNCH_CHECK();
     }
