@@ -215,11 +215,14 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
                 HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
-                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, d_out, dbgbuf));
+                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p));
+                c->phase("blk_emit");
+                LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
+                                                  (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
                 uint32_t fl = 0;
                 HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                c->phase("emit+lz77");
+                c->phase("lz77_copy");
                 if (getenv("LFX_DEBUG")) {
                     fprintf(stderr, "[lfx]  emit flags=%u\n", fl);
                     std::vector<uint64_t> dv(64ull * ne);

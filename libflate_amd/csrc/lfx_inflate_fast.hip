@@ -611,9 +611,22 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: one wavefront per unit turns codes into bytes through a 64 KiB LDS window
-constexpr uint32_t MWIN = 65536;
-constexpr uint32_t PAR_LEN = 8;   // matches up to this length that read only pre-batch bytes go in parallel
+// K3: one wavefront per unit turns codes into bytes through a 40 KiB LDS ring: the last 32 KiB of
+// output (the DEFLATE window) plus at most 7 KiB in flight, so that four units are resident per CU.
+// The ring size is 5 * 8192, its index is pos mod 40960.
+constexpr uint32_t MWIN = 40960;
+constexpr uint32_t MBATCH_MAX = 7168;   // bytes one batch may produce (a code produces <= 258)
+constexpr uint32_t PAR_LEN = 8;         // matches up to this length that read only pre-batch bytes go in parallel
+
+__device__ __forceinline__ uint32_t ring_idx(uint32_t pos) {
+    const uint32_t x = pos >> 13;
+    const uint32_t q = (uint32_t)(((uint64_t)x * 0xCCCCCCCDull) >> 34);   // x / 5
+    return ((x - 5 * q) << 13) | (pos & 8191);
+}
+__device__ __forceinline__ uint32_t ring_add(uint32_t idx, uint32_t k) {   // k < MWIN
+    const uint32_t r = idx + k;
+    return r >= MWIN ? r - MWIN : r;
+}
 
 __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__restrict__ in,
                                                              const BlkEmit *__restrict__ jobs,
@@ -621,7 +634,7 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
                                                              const BlkUnits *__restrict__ units,
                                                              const uint32_t *__restrict__ codes,
                                                              uint8_t *__restrict__ out, uint64_t *__restrict__ dbg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
+    __shared__ __attribute__((aligned(16))) unsigned char ring[MWIN];
     const uint32_t bidx = blockIdx.x / MAX_UNITS, u = blockIdx.x % MAX_UNITS;
     const BlkEmit job = jobs[bidx];
     const uint32_t lane = threadIdx.x;
@@ -641,92 +654,93 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     const uint32_t *cp = codes + job.code_off + c0;
     const uint32_t n = c1 - c0;
     uint64_t produced = 0, flushed = 0;
-    uint64_t cy_scan = 0, cy_par = 0, cy_seq = 0, cy_flush = 0, nseq = 0;
-    uint32_t c_next = lane < n ? cp[lane] : 0;           // code words are prefetched one batch ahead
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint64_t t0 = clock64();
+    uint32_t base = 0;
+    uint32_t c_cur = lane < n ? cp[lane] : 0;
+    while (base < n) {
         const uint32_t i = base + lane;
-        const uint32_t c = c_next;
-        c_next = i + 64 < n ? cp[i + 64] : 0;
+        const uint32_t c_pref = i + 64 < n ? cp[i + 64] : 0;   // next batch's code words, assuming 64 are taken
+        const uint32_t c = c_cur;
         const uint32_t dist = c & 0xFFFFu, val = c >> 16;
-        const bool is_match = i < n && dist != 0;
-        const uint32_t mylen = i < n ? (dist ? val : 1u) : 0u;
+        bool valid = i < n;
+        uint32_t mylen = valid ? (dist ? val : 1u) : 0u;
         uint32_t x = mylen;
         for (int ofs = 1; ofs < 64; ofs <<= 1) {
             const uint32_t y = __shfl_up(x, ofs);
             if ((int)lane >= ofs) x += y;
         }
-        const uint32_t total = __shfl(x, 63);
+        uint32_t take = 64;
+        if (__shfl(x, 63) > MBATCH_MAX) {
+            // rare (long runs): only the codes whose output fits are taken in this round
+            take = (uint32_t)__popcll(__ballot(x <= MBATCH_MAX));
+            if (lane >= take) { valid = false; mylen = 0; x = 0; }
+        }
+        const uint32_t total = __shfl(x, take - 1);
+        const bool is_match = valid && dist != 0;
         const uint32_t rel = x - mylen;                  // my first byte relative to the batch start
         const uint32_t at = (uint32_t)produced + rel;
-        const uint64_t t1 = clock64();
-        if (i < n && !is_match) ring[at & (MWIN - 1)] = (unsigned char)val;
+        const uint32_t at_i = ring_idx(at);
+        if (valid && !is_match) ring[at_i] = (unsigned char)val;
         // a match is "far" when every byte it reads was produced before this batch
         const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
         const bool par = far && mylen <= PAR_LEN && dist >= mylen;
         if (par) {
             unsigned char t[PAR_LEN];
-            const uint32_t srcb = at - dist;
+            const uint32_t src_i = ring_idx(at - dist);
 #pragma unroll
-            for (uint32_t k = 0; k < PAR_LEN; ++k) t[k] = k < mylen ? ring[(srcb + k) & (MWIN - 1)] : 0;
+            for (uint32_t k = 0; k < PAR_LEN; ++k) t[k] = k < mylen ? ring[ring_add(src_i, k)] : 0;
 #pragma unroll
             for (uint32_t k = 0; k < PAR_LEN; ++k)
-                if (k < mylen) ring[(at + k) & (MWIN - 1)] = t[k];
+                if (k < mylen) ring[ring_add(at_i, k)] = t[k];
         }
         __builtin_amdgcn_wave_barrier();
-        const uint64_t t2 = clock64();
         uint64_t mm = __ballot(is_match && !par);
-        nseq += __popcll(mm);
         while (mm) {
             const uint32_t sl = (uint32_t)__builtin_ctzll(mm);
             mm &= mm - 1;
             const uint32_t mc = __builtin_amdgcn_readlane(c, sl);
-            const uint32_t mat_lo = __builtin_amdgcn_readlane(at, sl);
+            const uint32_t mat_i = __builtin_amdgcn_readlane(at_i, sl);
             const uint32_t len = mc >> 16, d = mc & 0xFFFFu;
-            const uint32_t srcb = mat_lo - d;
+            const uint32_t src_i = mat_i >= d ? mat_i - d : mat_i + MWIN - d;   // d <= 32768 < MWIN
             // out[k] = src[k mod d] reproduces the overlapping forward copy (rle_decode, lib.rs:186-190);
             // LDS operations of one wavefront execute in order, so later matches see these bytes
             if (d >= len) {
-                for (uint32_t k = lane; k < len; k += 64) ring[(mat_lo + k) & (MWIN - 1)] = ring[(srcb + k) & (MWIN - 1)];
+                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k)];
             } else {
-                for (uint32_t k = lane; k < len; k += 64) ring[(mat_lo + k) & (MWIN - 1)] = ring[(srcb + k % d) & (MWIN - 1)];
+                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k % d)];
             }
         }
         produced += total;
+        base += take;
         __builtin_amdgcn_wave_barrier();
-        const uint64_t t3 = clock64();
-        // flush in >= 16 KiB pieces; the ring always keeps the last 32 KiB for back-references
-        const bool last = base + 64 >= n;
-        if (produced - flushed >= 16384 || last) {
+        // flush early and often: history (32 KiB) + in flight (7 KiB) + unflushed must fit the ring
+        const bool last = base >= n;
+        if (produced - flushed >= 512 || last) {
             const uint64_t upto = produced;
             while (flushed < upto && ((gbase + flushed) & 3)) {   // head: align the global address
-                if (lane == 0) o[flushed] = ring[flushed & (MWIN - 1)];
+                if (lane == 0) o[flushed] = ring[ring_idx((uint32_t)flushed)];
                 flushed++;
             }
             const uint64_t ndw = (upto - flushed) >> 2;
             uint32_t *o32 = (uint32_t *)(o + flushed);
             const bool aligned = (((uint64_t)o32) & 3) == 0;
             for (uint64_t k = lane; k < ndw; k += 64) {
-                const uint64_t p = flushed + 4 * k;
-                const uint32_t v = (uint32_t)ring[p & (MWIN - 1)] | (uint32_t)ring[(p + 1) & (MWIN - 1)] << 8 |
-                                   (uint32_t)ring[(p + 2) & (MWIN - 1)] << 16 | (uint32_t)ring[(p + 3) & (MWIN - 1)] << 24;
+                const uint32_t p = (uint32_t)flushed + 4 * (uint32_t)k;
+                const uint32_t pi = ring_idx(p);
+                const uint32_t v = (uint32_t)ring[pi] | (uint32_t)ring[ring_add(pi, 1)] << 8 |
+                                   (uint32_t)ring[ring_add(pi, 2)] << 16 | (uint32_t)ring[ring_add(pi, 3)] << 24;
                 if (aligned) o32[k] = v;
-                else { o[p] = (uint8_t)v; o[p + 1] = (uint8_t)(v >> 8); o[p + 2] = (uint8_t)(v >> 16); o[p + 3] = (uint8_t)(v >> 24); }
+                else { uint8_t *ob8 = o + flushed + 4 * k; ob8[0] = (uint8_t)v; ob8[1] = (uint8_t)(v >> 8); ob8[2] = (uint8_t)(v >> 16); ob8[3] = (uint8_t)(v >> 24); }
             }
             flushed += 4 * ndw;
             if (last) {
-                for (uint64_t k = flushed + lane; k < upto; k += 64) o[k] = ring[k & (MWIN - 1)];
+                for (uint64_t k = flushed + lane; k < upto; k += 64) o[k] = ring[ring_idx((uint32_t)k)];
                 flushed = upto;
             }
             __builtin_amdgcn_wave_barrier();
         }
-        const uint64_t t4 = clock64();
-        cy_scan += t1 - t0; cy_par += t2 - t1; cy_seq += t3 - t2; cy_flush += t4 - t3;
+        c_cur = take == 64 ? c_pref : (base + lane < n ? cp[base + lane] : 0);   // rare path: reload
     }
-    if (dbg && lane == 0) {
-        uint64_t *d = dbg + (uint64_t)blockIdx.x * 8;
-        d[0] = cy_scan; d[1] = cy_par; d[2] = cy_seq; d[3] = cy_flush; d[4] = nseq; d[5] = n;
-    }
+    (void)dbg;
 }
 
 // block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
@@ -803,20 +817,20 @@ int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
     return 0;
 }
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
-                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint8_t *out, uint64_t *dbg) {
+                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units) {
     if (!njobs) return 0;
     hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, lanes, codes, flags, units);
     LFX_LAUNCH_CHECK();
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)blk_materialize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MWIN);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), MWIN, st, in, jobs, lanes, units, codes, out, dbg);
+    return 0;
+}
+int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
+                           const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
+                           uint64_t *dbg) {
+    if (!njobs) return 0;
+    hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), 0, st, in, jobs, lanes, units, codes, out, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
-
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
                        uint32_t shard_cap, FindPrefix pre, uint32_t *final_count, uint64_t *final_list,
                        uint32_t final_cap) {
