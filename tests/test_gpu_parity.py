@@ -298,3 +298,47 @@ def test_device_api_and_capacity(ctx, ffi, oracle, synth):
     assert (rc, ol, used) == (0, data.size, n) and torch.equal(d_dec, d_in)
     rc, ol, _, _ = ctx.decode_device(ffi.GZIP, d_out.data_ptr(), n, d_dec.data_ptr(), 1000)
     assert rc == ffi.E_NOSPACE
+
+
+def test_sharded_encode_virtual_ranks(lfx, ffi, oracle, synth):
+    """SURVEY §8e with N virtual ranks on one device: per-rank prepare → (all-gather of shard infos) →
+    emit at the global bit offset → OR-assembled member == what ONE encoder emits for the whole input;
+    every rank can also decode its own shard alone."""
+    import ctypes as C
+    import torch
+    from libflate_amd import sharded
+    world, n = 3, 3 << 20
+    datas = [synth.text(n, seed=synth.SEED_BASE + 2 + r) for r in range(world)]
+    ctxs = [lfx.Context(0) for _ in range(world)]
+    opts, sched = ffi.make_opts(mtime=0), ffi.make_schedule(8192)
+    L = ffi.lib()
+    d_ins = [torch.from_numpy(d).cuda() for d in datas]
+    infos = []
+    for r in range(world):
+        info = ffi.ShardInfo()
+        rc = L.lfx_encode_shard_prepare(ctxs[r].handle, ffi.GZIP, C.byref(opts), C.byref(sched), d_ins[r].data_ptr(),
+                                        n, int(r == 0), int(r == world - 1), C.byref(info))
+        assert rc == 0, ctxs[r].last_error()
+        infos.append((info.total_bits, info.n_bytes, info.crc32, info.adler32))
+    hdr_len = L.lfx_container_header_len(ffi.GZIP, C.byref(opts))
+    start_bits, check, total_n = sharded.layout(infos, hdr_len, ffi.GZIP)
+    parts, d_outs = [], []
+    for r in range(world):
+        cap = n + n // 4 + 65536
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        m = C.c_uint64(0)
+        rc = L.lfx_encode_shard_emit(ctxs[r].handle, start_bits[r], check, total_n, d_out.data_ptr(), cap, C.byref(m))
+        assert rc == 0, ctxs[r].last_error()
+        parts.append(d_out[:m.value].cpu().numpy().tobytes())
+        d_outs.append((d_out, m.value))
+    member = sharded.assemble(parts, start_bits)
+    whole = b"".join(d.tobytes() for d in datas)
+    assert member == oracle.encode(oracle.GZIP, whole, write_size=8192)
+    for r in range(world):
+        d_dec = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        ol = C.c_uint64(0)
+        sb = start_bits[r] if r == 0 else start_bits[r] & 7
+        rc = L.lfx_decode_shard_device(ctxs[r].handle, d_outs[r][0].data_ptr(), d_outs[r][1], sb, infos[r][0],
+                                       int(r == world - 1), d_dec.data_ptr(), n, C.byref(ol))
+        assert rc == 0 and ol.value == n, ctxs[r].last_error()
+        assert torch.equal(d_dec, d_ins[r])

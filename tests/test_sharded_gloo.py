@@ -1,0 +1,103 @@
+"""CPU, world_size 2 over gloo: the sharded-encode exchange.  Each rank contributes the
+(total_bits, n_bytes, crc32, adler32) of its shard — produced here by the oracle standing in for the HIP
+shard encoder, which cannot run without a GPU — all-gathers them, derives its start bit and the combined
+trailer with the PRODUCT logic (libflate_amd.sharded + lfx_crc32_combine), and the assembled member must
+equal what ONE encoder emits for the concatenated input."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import lfo_oracle as oracle
+        import synth
+        from libflate_amd import _ffi, sharded
+        n = 2 << 20                                    # per rank; a multiple of the 1 MiB block size
+        data = synth.text(n, seed=synth.SEED_BASE + 2 + rank).tobytes()
+        # stand-in for lfx_encode_shard_prepare: raw DEFLATE of the shard; a non-last shard is the
+        # stream without the final (empty, BFINAL) block and without byte alignment
+        full = oracle.encode(oracle.DEFLATE, data, write_size=8192)
+        blocks = oracle.scan_blocks(full)
+        last = rank == world - 1
+        bits = blocks[-1][1] if last else blocks[-2][1]            # end bit of the last kept block
+        mine = torch.tensor([bits, n, oracle.crc32(data), oracle.adler32(data)], dtype=torch.int64)
+        allv = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allv, mine)                                 # the only collective on this path
+        infos = [tuple(int(x) for x in t) for t in allv]
+        opts = _ffi.make_opts(mtime=0)
+        import ctypes as C
+        hdr_len = _ffi.lib().lfx_container_header_len(_ffi.GZIP, C.byref(opts))
+        start_bits, check, total_n = sharded.layout(infos, hdr_len, _ffi.GZIP)
+        # stand-in for lfx_encode_shard_emit: place my bits at start_bits[rank] (bit-granular shift)
+        val = int.from_bytes(full, "little") & ((1 << bits) - 1)
+        sb = start_bits[rank]
+        first_byte = sb // 8 if rank else 0
+        shifted = val << (sb - 8 * first_byte)
+        nbytes = (sb - 8 * first_byte + bits + 7) // 8
+        part = bytearray(shifted.to_bytes(nbytes, "little"))
+        if rank == 0:
+            part[:hdr_len] = bytes([31, 139, 8, 0, 0, 0, 0, 0, 0, 3])
+        if last:
+            part += check.to_bytes(4, "little") + (total_n & 0xFFFFFFFF).to_bytes(4, "little")
+        parts = [None] * world
+        dist.all_gather_object(parts, bytes(part))                  # test-only: gather for the comparison
+        if rank == 0:
+            member = sharded.assemble(parts, start_bits)
+            whole = b"".join(synth.text(n, seed=synth.SEED_BASE + 2 + r).tobytes() for r in range(world))
+            want = oracle.encode(oracle.GZIP, whole, write_size=8192)
+            q.put(("ok", member == want, len(member), len(want)))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+def test_sharded_layout_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == "ok", res
+    assert res[1], ("assembled member differs from the single-encoder output", res)
+
+
+def test_layout_and_combine_single_process(oracle):
+    import numpy as np
+    from libflate_amd import _ffi, sharded
+    rng = np.random.default_rng(2)
+    shards = [rng.integers(0, 256, int(k), dtype=np.uint8).tobytes() for k in (70000, 1, 123457, 99)]
+    infos = [(1000 + 7 * i, len(s), oracle.crc32(s), oracle.adler32(s)) for i, s in enumerate(shards)]
+    sb, crc, tot = sharded.layout(infos, 10, _ffi.GZIP)
+    assert sb == [80, 1080, 2087, 3101] and tot == sum(len(s) for s in shards)
+    assert crc == oracle.crc32(b"".join(shards))
+    _, ad, _ = sharded.layout(infos, 2, _ffi.ZLIB)
+    assert ad == oracle.adler32(b"".join(shards))
+    # shared boundary bytes are OR-ed
+    assert sharded.assemble([b"\x01\x02\x03", b"\x30\x04"], [0, 20]) == b"\x01\x02\x33\x04"
