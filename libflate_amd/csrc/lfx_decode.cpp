@@ -168,6 +168,32 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 for (uint32_t i = 0; i < nc; i++) { nbad += bi[i].status != BLK_OK; maxr = std::max(maxr, bi[i].rounds); }
                 fprintf(stderr, "[lfx]  not-ok=%u max_rounds=%u\n", nbad, maxr);
             }
+            // a false candidate inside a block cuts that block's range short (NO_EOB): rescan all such
+            // blocks together with wider and wider ranges (one launch per widening step)
+            for (uint32_t widen = 2; widen <= 6; widen++) {
+                std::vector<uint32_t> redo;
+                for (uint32_t i = 0; i < nc; i++) if (bi[i].status == BLK_NO_EOB && i + widen <= nc) redo.push_back(i);
+                if (redo.empty()) break;
+                std::vector<BlkJob> rj(redo.size());
+                for (size_t q = 0; q < redo.size(); q++) rj[q] = BlkJob{starts[redo[q]], redo[q] + widen < nc ? starts[redo[q] + widen] : n * 8};
+                const size_t tail = sizeof(BlkJob) * nc, itail = sizeof(BlkInfo) * nc, ltail = sizeof(BlkLanes) * (size_t)nc;
+                if ((rc = c->d_dec_tmp.reserve(tail + itail + sizeof(BlkJob) * redo.size() + sizeof(BlkInfo) * redo.size() + 64))) return rc;
+                if ((rc = c->d_io_out.reserve(std::max<uint64_t>(cap, 4)))) return rc;
+                BlkJob *d_rj = (BlkJob *)c->d_dec_tmp.p;
+                BlkInfo *d_ri = (BlkInfo *)((uint8_t *)c->d_dec_tmp.p + sizeof(BlkJob) * redo.size() + 64);
+                (void)ltail;
+                // lanes of a rescanned block must land in its own slot: launch one job at a time into slot k
+                // but without host round trips in between
+                HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), sizeof(BlkJob) * redo.size(), hipMemcpyHostToDevice, st));
+                for (size_t q = 0; q < redo.size(); q++)
+                    LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_rj + q, 1, (BlkInfo *)c->d_dec_state.p + redo[q],
+                                               (BlkLanes *)c->d_dec_blocks.p + redo[q]));
+                (void)d_ri;
+                for (size_t q = 0; q < redo.size(); q++)
+                    HIP_TRY(hipMemcpyAsync(&bi[redo[q]], (BlkInfo *)c->d_dec_state.p + redo[q], sizeof(BlkInfo), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+            }
+            c->phase("repair");
             // ---- chain from the known first block
             std::vector<BlkEmit> emit;
             uint64_t pos = first_bit, total = 0, total_codes = 0;
@@ -177,15 +203,6 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 auto it = std::lower_bound(starts.begin(), starts.end(), pos);
                 if (it == starts.end() || *it != pos) break;
                 const uint32_t k = (uint32_t)(it - starts.begin());
-                // a false candidate inside this block cut its range short: rescan with wider ranges
-                for (uint32_t widen = 2; bi[k].status == BLK_NO_EOB && k + widen <= nc && widen <= 6; widen++) {
-                    BlkJob one{pos, k + widen < nc ? starts[k + widen] : n * 8};
-                    HIP_TRY(hipMemcpyAsync((BlkJob *)c->d_dec_streams.p + k, &one, sizeof one, hipMemcpyHostToDevice, st));
-                    LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p + k, 1,
-                                               (BlkInfo *)c->d_dec_state.p + k, (BlkLanes *)c->d_dec_blocks.p + k));
-                    HIP_TRY(hipMemcpyAsync(&bi[k], (BlkInfo *)c->d_dec_state.p + k, sizeof(BlkInfo), hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                }
                 const BlkInfo &r = bi[k];
                 if (r.status != BLK_OK || r.end_bit <= pos) break;
                 BlkEmit e{};

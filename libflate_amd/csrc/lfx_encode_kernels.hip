@@ -325,19 +325,26 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restr
     uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
     if (ch.flags & CH_LITERALS) return;   // no walk: every byte is a literal
     uint32_t pos = s0, cnt = 0;
+    uint32_t v_next = s0 + lane < end ? md[ch.in_off + s0 + lane] : 0;   // answers are prefetched one group ahead
     for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
         const uint32_t base = s0 + g * 64;
         uint64_t m = 0;
+        const uint32_t v = v_next;
+        {
+            const uint32_t in2 = base + 64 + lane;
+            v_next = (g + 1 < PARSE_SEG / 64 && in2 < end) ? md[ch.in_off + in2] : 0;
+        }
         if (base < end) {
-            const uint32_t i = base + lane;
-            const uint32_t v = i < end ? md[ch.in_off + i] : 0;
-            const uint32_t stop = min(base + 64, end);
-            while (pos < stop) {
-                const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
-                const uint32_t mv = __builtin_amdgcn_readlane(v, r);
+            // the scalar unit is shared by the whole CU: keep the serial loop at readlane / bitset /
+            // add / compare by precomputing every position's step on the vector side
+            const uint32_t stepv = (v & 0xFFFFu) ? (v >> 16) : 1u;
+            const uint32_t stop_r = min(base + 64, end) - base;
+            uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
+            while (r < stop_r) {
                 m |= 1ull << r;
-                pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
+                r += __builtin_amdgcn_readlane(stepv, r);
             }
+            pos = base + r;
         }
         if (lane == 0) vw[g] = m;
         cnt += __popcll(m);
@@ -445,16 +452,24 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
     const uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
     const uint64_t lt = lanemask_lt();
     uint32_t nout = 0;
+    // the segment's 64 mask words are read once (lane g holds word g); answers and bytes of the next
+    // group are in flight while the current one is compacted
+    const uint64_t my_word = s0 + lane * 64 < end ? vw[lane] : 0;
+    uint32_t v_next = s0 + lane < end ? md[ch.in_off + s0 + lane] : 0;
+    uint32_t b_next = s0 + lane < n ? src.load1(s0 + lane) : 0;
     for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
         const uint32_t base = s0 + g * 64;
         if (base >= end) break;
-        const uint64_t m = vw[g];
-        if (m == 0) continue;
-        const uint32_t i = base + lane;
-        if ((m >> lane) & 1) {
-            const uint32_t v = md[ch.in_off + i];
-            out[nout + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (src.load1(i) << 16);
+        const uint64_t m = __shfl(my_word, g);
+        const uint32_t v = v_next, byte = b_next;
+        {
+            const uint32_t in2 = base + 64 + lane;
+            const bool more = g + 1 < PARSE_SEG / 64;
+            v_next = (more && in2 < end) ? md[ch.in_off + in2] : 0;
+            b_next = (more && in2 < n) ? src.load1(in2) : 0;
         }
+        if (m == 0) continue;
+        if ((m >> lane) & 1) out[nout + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (byte << 16);
         nout += __popcll(m);
     }
 }
@@ -506,26 +521,41 @@ __global__ __launch_bounds__(64) void huffman_kernel(const BlockDesc *__restrict
 
 // ------------------------------------------------------------------------------------------------
 // block start bits: a serial fold (stored blocks byte-align, the final block byte-aligns)
-__global__ void offsets_kernel(const BlockDesc *__restrict__ blocks, uint32_t nblocks,
-                               const BlockCodes *__restrict__ bc, uint64_t start_bit,
-                               uint64_t cap_bits, uint64_t *__restrict__ block_start,
-                               EncodeResult *__restrict__ res) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint64_t bit = start_bit;
-    for (uint32_t b = 0; b < nblocks; ++b) {
-        block_start[b] = bit;
-        const BlockDesc bd = blocks[b];
-        if (bd.type == BT_RAW) {
-            bit += 3;
-            bit = (bit + 7) & ~7ull;  // RawBuf::flush → BitWriter::flush (encode.rs:372)
-            bit += 32 + 8 * bd.in_len;
-        } else {
-            bit += bc[b].body_bits;
+__global__ __launch_bounds__(256) void offsets_kernel(const BlockDesc *__restrict__ blocks, uint32_t nblocks,
+                                                      const BlockCodes *__restrict__ bc, uint64_t start_bit,
+                                                      uint64_t cap_bits, uint64_t *__restrict__ block_start,
+                                                      EncodeResult *__restrict__ res) {
+    // the fold is serial (stored blocks and the final block byte-align), its inputs are gathered in
+    // parallel: 256 blocks per round into LDS
+    __shared__ uint64_t s_bits[256];
+    __shared__ uint32_t s_kind[256];   // bit 0: stored block, bit 1: align after
+    __shared__ uint64_t s_bit;
+    if (threadIdx.x == 0) s_bit = start_bit;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
+        const uint32_t b = b0 + threadIdx.x;
+        if (b < nblocks) {
+            const BlockDesc bd = blocks[b];
+            s_kind[threadIdx.x] = (bd.type == BT_RAW ? 1u : 0u) | (bd.align_after ? 2u : 0u);
+            s_bits[threadIdx.x] = bd.type == BT_RAW ? 32 + 8 * bd.in_len : bc[b].body_bits;
         }
-        if (bd.align_after) bit = (bit + 7) & ~7ull;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t bit = s_bit;
+            const uint32_t cnt = min(256u, nblocks - b0);
+            for (uint32_t k = 0; k < cnt; ++k) {
+                block_start[b0 + k] = bit;
+                if (s_kind[k] & 1) { bit += 3; bit = (bit + 7) & ~7ull; }   // RawBuf::flush → BitWriter::flush (encode.rs:372)
+                bit += s_bits[k];
+                if (s_kind[k] & 2) bit = (bit + 7) & ~7ull;
+            }
+            s_bit = bit;
+        }
+        __syncthreads();
     }
-    res->end_bit = bit;
-    res->status = bit > cap_bits ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        res->end_bit = s_bit;
+        res->status = s_bit > cap_bits ? 1u : 0u;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1033,7 +1063,7 @@ int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, co
 }
 int launch_offsets(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const BlockCodes *bc,
                    uint64_t start_bit, uint64_t cap_bits, uint64_t *block_start, EncodeResult *res) {
-    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(64), 0, st, blocks, nblocks, bc, start_bit,
+    hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(256), 0, st, blocks, nblocks, bc, start_bit,
                        cap_bits, block_start, res);
     LFX_LAUNCH_CHECK();
     return 0;
