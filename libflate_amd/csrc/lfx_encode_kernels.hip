@@ -79,7 +79,7 @@ constexpr int HASH_BITS = 14;
 constexpr uint32_t PRING = 32768 + 2048;        // prevd ring (entries)
 constexpr uint32_t WRING = 36864;               // window ring (bytes), multiple of 4096
 constexpr uint32_t HEAD_FAR = 40000;            // distance marker of a swept head entry
-constexpr size_t MATCH_LDS = (2u << HASH_BITS) + PRING * 2 + WRING + 8 + MTILE * 4 + MTILE * 4;
+constexpr size_t MATCH_LDS = (2u << HASH_BITS) + PRING * 2 + WRING + 8 + 2 * MTILE * 4 + MTILE * 4;
 
 __device__ __forceinline__ uint32_t hash3(uint32_t key) { return (key * 2654435761u) >> (32 - HASH_BITS); }
 __device__ __forceinline__ uint32_t wring_off(uint32_t pos) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     uint32_t *st_k = (uint32_t *)(smem + (2u << HASH_BITS) + PRING * 2 + WRING + 8);
     // cd[parity][idx]: distance to the most recent same-prefix position when the insertion already
     // knows it (0 = the resolver has to walk the chain)
-    uint16_t *cd = (uint16_t *)(st_k + MTILE);
+    uint16_t *cd = (uint16_t *)(st_k + 2 * MTILE);
 
     const SegDesc sg = segs[blockIdx.x];
     const ChunkDesc ch = chunks[sg.chunk];
@@ -128,14 +128,46 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     uint32_t swept_at = base;
     uint64_t cy_load = 0, cy_work = 0, cy_wait = 0, hops = 0, lcps = 0;
 
-    // iteration it links tile it+1 and resolves tile it (it = -1: prologue)
-    for (int it = -1; it < (int)ntiles; ++it) {
+    // Pipeline, three stages one tile apart.  Iteration `it`:
+    //   resolvers (waves 1..15): resolve(tile it) ; pre-digest(tile it+2)
+    //   wave 0                 : ordered insert of tile it+1
+    // pre-digest : 3-byte prefix, nearest lower same-hash lane by ballots, flags       (parallel)
+    // insert     : head read → prev link → head write, sub-tile by sub-tile             (ordered)
+    // resolve    : chain walk + match length                                            (parallel)
+    // One barrier per tile; the ordered insert is the critical path, so wave 0 runs at raised priority.
+    constexpr uint32_t NSUB = MTILE / 64;
+    auto predigest = [&](uint32_t tile_idx) {
+        const uint32_t idx = (wave - 1) * 64 + lane;
+        const uint32_t p = base + tile_idx * MTILE + idx;
+        const bool v = tile_idx < ntiles && p >= l0 && p < q1;
+        uint32_t key = 0, hh = 0;
+        if (v) { key = win_at(win32, wring_off(p)) & 0xFFFFFFu; hh = hash3(key); }
+        uint64_t same = __ballot(v);
+#pragma unroll
+        for (int b = 0; b < HASH_BITS; ++b) {
+            const bool bit = (hh >> b) & 1;
+            const uint64_t m = __ballot(bit);
+            same &= bit ? m : ~m;
+        }
+        const uint64_t lower = same & lanemask_lt();
+        const uint32_t hb = lower ? 63 - __clzll(lower) : lane;
+        const uint32_t kprev = __shfl(key, hb);
+        uint32_t f = lower ? lane - hb : 0;                 // 1..63, 0 = none in this sub-tile
+        if (lower && kprev == key) f |= 0x40;               // ... and it has the same 3-byte prefix
+        if (((same >> lane) >> 1) == 0) f |= 0x80;          // last lane with this hash
+        st_k[(tile_idx & 1) * MTILE + idx] = v ? (key | (f << 24)) : 0xFFFFFFFFu;
+    };
+    if (wave == 0) __builtin_amdgcn_s_setprio(3);
+
+    for (int it = -2; it < (int)ntiles; ++it) {
         const uint64_t c0 = clock64();
-        const uint32_t t_res = base + (uint32_t)it * MTILE;        // tile being resolved (it >= 0)
-        const uint32_t t_link = base + (uint32_t)(it + 1) * MTILE; // tile being linked
-        const bool do_link = (uint32_t)(it + 1) < ntiles;
-        // ---- A: everyone extends the window to cover the link tile (+3) and the resolve lookahead
-        const uint32_t need = min(t_link + MTILE + 4, (n + 3) & ~3u);
+        const uint32_t t_res = base + (uint32_t)it * MTILE;              // tile being resolved (it >= 0)
+        const uint32_t link_idx = (uint32_t)(it + 1);                    // tile being inserted (it >= -1)
+        const uint32_t t_link = base + link_idx * MTILE;
+        const bool do_link = it >= -1 && link_idx < ntiles;
+        const uint32_t pre_idx = (uint32_t)(it + 2);                     // tile being pre-digested
+        // ---- A: everyone extends the window to cover the pre-digest tile (+3 bytes)
+        const uint32_t need = min(base + pre_idx * MTILE + MTILE + 4, (n + 3) & ~3u);
         for (uint32_t p = loaded_to + 4 * tid; p < need; p += 4 * MATCH_THREADS) {
             const uint32_t v = src.load4(p);
             const uint32_t o = wring_off(p);
@@ -152,44 +184,20 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
             swept_at = t_link;
         }
         lds_barrier();
-        // ---- X: wavefronts 1..15 each pre-digest one 64-position sub-tile of the link tile: hash,
-        //      nearest lower lane with the same hash (match-any by ballots), "last lane with this hash"
-        if (wave > 0 && do_link) {
-            const uint32_t idx = (wave - 1) * 64 + lane;
-            const uint32_t p = t_link + idx;
-            const bool v = p >= l0 && p < q1;
-            uint32_t key = 0, hh = 0;
-            if (v) { key = win_at(win32, wring_off(p)) & 0xFFFFFFu; hh = hash3(key); }
-            uint64_t same = __ballot(v);
-#pragma unroll
-            for (int b = 0; b < HASH_BITS; ++b) {
-                const bool bit = (hh >> b) & 1;
-                const uint64_t m = __ballot(bit);
-                same &= bit ? m : ~m;
-            }
-            const uint64_t lower = same & lanemask_lt();
-            const uint32_t hb = lower ? 63 - __clzll(lower) : lane;
-            const uint32_t kprev = __shfl(key, hb);
-            uint32_t f = lower ? lane - hb : 0;                 // 1..63, 0 = none in this sub-tile
-            if (lower && kprev == key) f |= 0x40;               // ... and it has the same 3-byte prefix
-            if (((same >> lane) >> 1) == 0) f |= 0x80;          // last lane with this hash
-            st_k[idx] = v ? (key | (f << 24)) : 0xFFFFFFFFu;
-        }
-        lds_barrier();
         const uint64_t c1 = clock64();
         if (wave == 0) {
             if (do_link) {
-                // ---- Y: the ordered part of the insertion (head read → prev link → head write).
                 // Duplicate collapsing: when the bucket head carries the SAME prefix as this position
                 // it is this position's answer (cd), and the new link bypasses it — an older
                 // occurrence of the same prefix can never be an answer again.  Chains therefore hold
                 // about one entry per distinct prefix and a rare prefix that shares a bucket with a
                 // frequent one no longer walks through hundreds of useless entries.
-                uint16_t *cdw = cd + (((uint32_t)(it + 1) & 1) * MTILE);
-                for (uint32_t sub = 0; sub < MTILE / 64; ++sub) {
+                const uint32_t *stl = st_k + (link_idx & 1) * MTILE;
+                uint16_t *cdw = cd + (link_idx & 1) * MTILE;
+                for (uint32_t sub = 0; sub < NSUB; ++sub) {
                     const uint32_t idx = sub * 64 + lane;
                     const uint32_t p = t_link + idx;
-                    const uint32_t sk = st_k[idx];
+                    const uint32_t sk = stl[idx];
                     if (sk != 0xFFFFFFFFu) {
                         const uint32_t key = sk & 0xFFFFFFu, f = sk >> 24, hh = hash3(key);
                         uint32_t pd = f & 0x3F, cdv = (f & 0x40) ? pd : 0;
@@ -212,7 +220,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                     }
                 }
             }
-        } else if (it >= 0) {
+        } else {
+            if (it >= 0) {
             const uint32_t pos = t_res + (wave - 1) * 64 + lane;
             const bool act = pos >= q0 && pos < q1;
             uint32_t dist = 0, l = 0, lim = 0, oa = 0, ob = 0;
@@ -281,6 +290,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                 }
                 md[ch.in_off + pos] = out;
             }
+            }
+            predigest(pre_idx);
         }
         const uint64_t c2 = clock64();
         lds_barrier();
@@ -1020,7 +1031,7 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     const size_t lds = MATCH_LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void *)lz77_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)lz77_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     hipLaunchKernelGGL(lz77_match_kernel, dim3(nsegs), dim3(MATCH_THREADS), lds, st, in, in_bytes,
