@@ -616,7 +616,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
 // The ring size is 5 * 8192, its index is pos mod 40960.
 constexpr uint32_t MWIN = 40960;
 constexpr uint32_t MBATCH_MAX = 7168;   // bytes one batch may produce (a code produces <= 258)
-constexpr uint32_t PAR_LEN = 8;         // matches up to this length that read only pre-batch bytes go in parallel
+constexpr uint32_t PAR_LEN = 8;         // matches up to 2x this length that read only pre-batch bytes go in parallel
 
 __device__ __forceinline__ uint32_t ring_idx(uint32_t pos) {
     const uint32_t x = pos >> 13;
@@ -626,6 +626,24 @@ __device__ __forceinline__ uint32_t ring_idx(uint32_t pos) {
 __device__ __forceinline__ uint32_t ring_add(uint32_t idx, uint32_t k) {   // k < MWIN
     const uint32_t r = idx + k;
     return r >= MWIN ? r - MWIN : r;
+}
+
+// eight ring bytes starting at any index: three aligned dwords and two byte-alignments
+__device__ __forceinline__ void ring_read8(const unsigned char *ring, uint32_t idx, uint32_t &lo, uint32_t &hi) {
+    const uint32_t a = idx & ~3u, sh = idx & 3u;
+    const uint32_t d0 = *(const uint32_t *)&ring[a];
+    const uint32_t d1 = *(const uint32_t *)&ring[ring_add(a, 4)];
+    const uint32_t d2 = *(const uint32_t *)&ring[ring_add(a, 8)];
+    lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+}
+__device__ __forceinline__ void ring_write_upto8(unsigned char *ring, uint32_t idx, uint32_t lo, uint32_t hi, uint32_t cnt) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k < cnt) ring[ring_add(idx, k)] = (unsigned char)(lo >> (8 * k));
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k)
+        if (k + 4 < cnt) ring[ring_add(idx, k + 4)] = (unsigned char)(hi >> (8 * k));
 }
 
 __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__restrict__ in,
@@ -653,6 +671,9 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     uint8_t *o = out + gbase;
     const uint32_t *cp = codes + job.code_off + c0;
     const uint32_t n = c1 - c0;
+    // byte `pos` of the unit lives at ring_idx(pos + shift): ring and output share their 4-byte alignment,
+    // so the flush moves aligned dwords
+    const uint32_t shift = (uint32_t)(gbase & 3);
     uint64_t produced = 0, flushed = 0;
     uint32_t base = 0;
     uint32_t c_cur = lane < n ? cp[lane] : 0;
@@ -677,20 +698,23 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
         const uint32_t total = __shfl(x, take - 1);
         const bool is_match = valid && dist != 0;
         const uint32_t rel = x - mylen;                  // my first byte relative to the batch start
-        const uint32_t at = (uint32_t)produced + rel;
+        const uint32_t at = (uint32_t)produced + shift + rel;
         const uint32_t at_i = ring_idx(at);
         if (valid && !is_match) ring[at_i] = (unsigned char)val;
         // a match is "far" when every byte it reads was produced before this batch
         const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
-        const bool par = far && mylen <= PAR_LEN && dist >= mylen;
+        const bool par = far && mylen <= 2 * PAR_LEN && dist >= mylen;
         if (par) {
-            unsigned char t[PAR_LEN];
-            const uint32_t src_i = ring_idx(at - dist);
-#pragma unroll
-            for (uint32_t k = 0; k < PAR_LEN; ++k) t[k] = k < mylen ? ring[ring_add(src_i, k)] : 0;
-#pragma unroll
-            for (uint32_t k = 0; k < PAR_LEN; ++k)
-                if (k < mylen) ring[ring_add(at_i, k)] = t[k];
+            uint32_t lo, hi;
+            ring_read8(ring, ring_idx(at - dist), lo, hi);
+            ring_write_upto8(ring, at_i, lo, hi, mylen);
+        }
+        if (__ballot(par && mylen > PAR_LEN)) {          // second half only when some lane needs it
+            if (par && mylen > PAR_LEN) {
+                uint32_t lo, hi;
+                ring_read8(ring, ring_add(ring_idx(at - dist), PAR_LEN), lo, hi);
+                ring_write_upto8(ring, ring_add(at_i, PAR_LEN), lo, hi, mylen - PAR_LEN);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         uint64_t mm = __ballot(is_match && !par);
@@ -717,23 +741,16 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
         if (produced - flushed >= 512 || last) {
             const uint64_t upto = produced;
             while (flushed < upto && ((gbase + flushed) & 3)) {   // head: align the global address
-                if (lane == 0) o[flushed] = ring[ring_idx((uint32_t)flushed)];
+                if (lane == 0) o[flushed] = ring[ring_idx((uint32_t)flushed + shift)];
                 flushed++;
             }
             const uint64_t ndw = (upto - flushed) >> 2;
             uint32_t *o32 = (uint32_t *)(o + flushed);
-            const bool aligned = (((uint64_t)o32) & 3) == 0;
-            for (uint64_t k = lane; k < ndw; k += 64) {
-                const uint32_t p = (uint32_t)flushed + 4 * (uint32_t)k;
-                const uint32_t pi = ring_idx(p);
-                const uint32_t v = (uint32_t)ring[pi] | (uint32_t)ring[ring_add(pi, 1)] << 8 |
-                                   (uint32_t)ring[ring_add(pi, 2)] << 16 | (uint32_t)ring[ring_add(pi, 3)] << 24;
-                if (aligned) o32[k] = v;
-                else { uint8_t *ob8 = o + flushed + 4 * k; ob8[0] = (uint8_t)v; ob8[1] = (uint8_t)(v >> 8); ob8[2] = (uint8_t)(v >> 16); ob8[3] = (uint8_t)(v >> 24); }
-            }
+            for (uint64_t k = lane; k < ndw; k += 64)
+                o32[k] = *(const uint32_t *)&ring[ring_idx((uint32_t)flushed + shift + 4 * (uint32_t)k)];
             flushed += 4 * ndw;
             if (last) {
-                for (uint64_t k = flushed + lane; k < upto; k += 64) o[k] = ring[ring_idx((uint32_t)k)];
+                for (uint64_t k = flushed + lane; k < upto; k += 64) o[k] = ring[ring_idx((uint32_t)k + shift)];
                 flushed = upto;
             }
             __builtin_amdgcn_wave_barrier();
