@@ -616,7 +616,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
 // The ring size is 5 * 8192, its index is pos mod 40960.
 constexpr uint32_t MWIN = 40960;
 constexpr uint32_t MBATCH_MAX = 7168;   // bytes one batch may produce (a code produces <= 258)
-constexpr uint32_t PAR_LEN = 8;         // matches up to 2x this length that read only pre-batch bytes go in parallel
+constexpr uint32_t PAR_LEN = 16;        // matches up to this length that read only pre-batch bytes go in parallel
 
 __device__ __forceinline__ uint32_t ring_idx(uint32_t pos) {
     const uint32_t x = pos >> 13;
@@ -628,22 +628,19 @@ __device__ __forceinline__ uint32_t ring_add(uint32_t idx, uint32_t k) {   // k 
     return r >= MWIN ? r - MWIN : r;
 }
 
-// eight ring bytes starting at any index: three aligned dwords and two byte-alignments
-__device__ __forceinline__ void ring_read8(const unsigned char *ring, uint32_t idx, uint32_t &lo, uint32_t &hi) {
-    const uint32_t a = idx & ~3u, sh = idx & 3u;
-    const uint32_t d0 = *(const uint32_t *)&ring[a];
-    const uint32_t d1 = *(const uint32_t *)&ring[ring_add(a, 4)];
-    const uint32_t d2 = *(const uint32_t *)&ring[ring_add(a, 8)];
-    lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
-}
-__device__ __forceinline__ void ring_write_upto8(unsigned char *ring, uint32_t idx, uint32_t lo, uint32_t hi, uint32_t cnt) {
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
-        if (k < cnt) ring[ring_add(idx, k)] = (unsigned char)(lo >> (8 * k));
-#pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
-        if (k + 4 < cnt) ring[ring_add(idx, k + 4)] = (unsigned char)(hi >> (8 * k));
+// gfx950's LDS takes dword accesses at any byte address
+__device__ __forceinline__ uint32_t lds_ld32(const unsigned char *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ void lds_st32(unsigned char *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// inclusive prefix sum over the wavefront: four row shifts and two row broadcasts, no LDS traffic
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 → rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 → rows 2, 3
+    return x;
 }
 
 __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__restrict__ in,
@@ -684,18 +681,14 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
         const uint32_t dist = c & 0xFFFFu, val = c >> 16;
         bool valid = i < n;
         uint32_t mylen = valid ? (dist ? val : 1u) : 0u;
-        uint32_t x = mylen;
-        for (int ofs = 1; ofs < 64; ofs <<= 1) {
-            const uint32_t y = __shfl_up(x, ofs);
-            if ((int)lane >= ofs) x += y;
-        }
+        uint32_t x = wave_inclusive_sum(mylen);
         uint32_t take = 64;
-        if (__shfl(x, 63) > MBATCH_MAX) {
+        if (__builtin_amdgcn_readlane(x, 63) > MBATCH_MAX) {
             // rare (long runs): only the codes whose output fits are taken in this round
             take = (uint32_t)__popcll(__ballot(x <= MBATCH_MAX));
             if (lane >= take) { valid = false; mylen = 0; x = 0; }
         }
-        const uint32_t total = __shfl(x, take - 1);
+        const uint32_t total = __builtin_amdgcn_readlane(x, take - 1);
         const bool is_match = valid && dist != 0;
         const uint32_t rel = x - mylen;                  // my first byte relative to the batch start
         const uint32_t at = (uint32_t)produced + shift + rel;
@@ -703,17 +696,25 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
         if (valid && !is_match) ring[at_i] = (unsigned char)val;
         // a match is "far" when every byte it reads was produced before this batch
         const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
-        const bool par = far && mylen <= 2 * PAR_LEN && dist >= mylen;
+        const uint32_t src_i = is_match ? ring_idx(at - dist) : 0;
+        const bool par = far && mylen <= PAR_LEN && dist >= mylen && src_i + PAR_LEN <= MWIN && at_i + PAR_LEN <= MWIN;
         if (par) {
-            uint32_t lo, hi;
-            ring_read8(ring, ring_idx(at - dist), lo, hi);
-            ring_write_upto8(ring, at_i, lo, hi, mylen);
-        }
-        if (__ballot(par && mylen > PAR_LEN)) {          // second half only when some lane needs it
-            if (par && mylen > PAR_LEN) {
-                uint32_t lo, hi;
-                ring_read8(ring, ring_add(ring_idx(at - dist), PAR_LEN), lo, hi);
-                ring_write_upto8(ring, ring_add(at_i, PAR_LEN), lo, hi, mylen - PAR_LEN);
+            // dwords at [0,4) [4,8) [8,12) as far as they fit, then the last four bytes (overlapping the
+            // previous store); all loads come before the stores, the source is older than this batch
+            const unsigned char *sp = ring + src_i;
+            unsigned char *dp = ring + at_i;
+            if (mylen >= 4) {
+                const uint32_t a0 = lds_ld32(sp), at4 = lds_ld32(sp + mylen - 4);
+                uint32_t a1 = 0, a2 = 0;
+                if (mylen >= 8) a1 = lds_ld32(sp + 4);
+                if (mylen >= 12) a2 = lds_ld32(sp + 8);
+                lds_st32(dp, a0);
+                if (mylen >= 8) lds_st32(dp + 4, a1);
+                if (mylen >= 12) lds_st32(dp + 8, a2);
+                lds_st32(dp + mylen - 4, at4);
+            } else {
+                const unsigned char b0 = sp[0], b1 = sp[1], b2 = sp[2];
+                dp[0] = b0; dp[1] = b1; dp[2] = b2;
             }
         }
         __builtin_amdgcn_wave_barrier();
