@@ -145,18 +145,42 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // ---- K1: every candidate block is scanned by a 256-lane workgroup (speculative slices,
             //      chained exits) for its end bit, byte and code counts
             const uint32_t nc = (uint32_t)starts.size();
+            auto start_at = [&](uint32_t i) { return i < nc ? starts[i] : n * 8; };
             std::vector<BlkJob> bj(nc);
-            for (uint32_t i = 0; i < nc; i++) bj[i] = BlkJob{starts[i], i + 1 < nc ? starts[i + 1] : n * 8};
-            if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * nc))) return rc;
-            if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * nc))) return rc;
-            if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)nc))) return rc;
-            HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nc, hipMemcpyHostToDevice, st));
-            LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nc, (BlkInfo *)c->d_dec_state.p,
+            for (uint32_t i = 0; i < nc; i++) bj[i] = BlkJob{starts[i], start_at(i + 1)};
+            // A false candidate inside a block cuts that block's range in two, and the first part then has
+            // no end-of-block.  Ranges much shorter than the median are the suspects: the candidate in
+            // front of each (and the suspect itself) also gets a job that ignores one candidate, in the
+            // same launch; what is still unresolved afterwards goes through the repair rescans below.
+            std::vector<int32_t> alt(nc, -1);
+            {
+                std::vector<uint64_t> len(nc);
+                for (uint32_t i = 0; i < nc; i++) len[i] = bj[i].end_bit - bj[i].start_bit;
+                std::vector<uint64_t> sorted = len;
+                std::nth_element(sorted.begin(), sorted.begin() + nc / 2, sorted.end());
+                const uint64_t thresh = sorted[nc / 2] / 5 * 3;
+                const uint32_t max_extra = nc / 4 + 4;
+                for (uint32_t i = 0; i + 1 < nc && bj.size() - nc < max_extra; i++) {
+                    if (len[i] >= thresh && len[i + 1] >= thresh) continue;
+                    alt[i] = (int32_t)bj.size();
+                    bj.push_back(BlkJob{starts[i], start_at(i + 2)});
+                }
+            }
+            const uint32_t nj = (uint32_t)bj.size();
+            if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * nj))) return rc;
+            if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * nj))) return rc;
+            if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)nj))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
+            LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
                                        (BlkLanes *)c->d_dec_blocks.p));
-            std::vector<BlkInfo> bi(nc);
-            HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nc, hipMemcpyDeviceToHost, st));
+            std::vector<BlkInfo> bi(nj);
+            HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             c->phase("blk_scan");
+            // slot[i]: where candidate i's scan result and lanes live (its own slot or the wider job's)
+            std::vector<uint32_t> slot(nc);
+            for (uint32_t i = 0; i < nc; i++)
+                slot[i] = (bi[i].status == BLK_NO_EOB && alt[i] >= 0 && bi[alt[i]].status == BLK_OK) ? (uint32_t)alt[i] : i;
             if (getenv("LFX_DEBUG")) {
                 fprintf(stderr, "[lfx] finder: stage1=%u candidates=%u\n", n1, nc);
                 for (uint32_t i = 0; i < nc && i < 12; i++)
@@ -168,27 +192,22 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 for (uint32_t i = 0; i < nc; i++) { nbad += bi[i].status != BLK_OK; maxr = std::max(maxr, bi[i].rounds); }
                 fprintf(stderr, "[lfx]  not-ok=%u max_rounds=%u\n", nbad, maxr);
             }
-            // a false candidate inside a block cuts that block's range short (NO_EOB): rescan all such
-            // blocks together with wider and wider ranges (one launch per widening step)
+            // still without an end-of-block: rescan those together with wider and wider ranges (one round
+            // trip per widening step; a rescanned block's lanes land in its own slot)
             for (uint32_t widen = 2; widen <= 6; widen++) {
                 std::vector<uint32_t> redo;
-                for (uint32_t i = 0; i < nc; i++) if (bi[i].status == BLK_NO_EOB && i + widen <= nc) redo.push_back(i);
+                for (uint32_t i = 0; i < nc; i++) if (bi[slot[i]].status == BLK_NO_EOB && i + widen <= nc) redo.push_back(i);
                 if (redo.empty()) break;
                 std::vector<BlkJob> rj(redo.size());
-                for (size_t q = 0; q < redo.size(); q++) rj[q] = BlkJob{starts[redo[q]], redo[q] + widen < nc ? starts[redo[q] + widen] : n * 8};
-                const size_t tail = sizeof(BlkJob) * nc, itail = sizeof(BlkInfo) * nc, ltail = sizeof(BlkLanes) * (size_t)nc;
-                if ((rc = c->d_dec_tmp.reserve(tail + itail + sizeof(BlkJob) * redo.size() + sizeof(BlkInfo) * redo.size() + 64))) return rc;
-                if ((rc = c->d_io_out.reserve(std::max<uint64_t>(cap, 4)))) return rc;
+                for (size_t q = 0; q < redo.size(); q++) rj[q] = BlkJob{starts[redo[q]], start_at(redo[q] + widen)};
+                if ((rc = c->d_dec_tmp.reserve(sizeof(BlkJob) * redo.size()))) return rc;
                 BlkJob *d_rj = (BlkJob *)c->d_dec_tmp.p;
-                BlkInfo *d_ri = (BlkInfo *)((uint8_t *)c->d_dec_tmp.p + sizeof(BlkJob) * redo.size() + 64);
-                (void)ltail;
-                // lanes of a rescanned block must land in its own slot: launch one job at a time into slot k
-                // but without host round trips in between
                 HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), sizeof(BlkJob) * redo.size(), hipMemcpyHostToDevice, st));
-                for (size_t q = 0; q < redo.size(); q++)
+                for (size_t q = 0; q < redo.size(); q++) {
+                    slot[redo[q]] = redo[q];
                     LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_rj + q, 1, (BlkInfo *)c->d_dec_state.p + redo[q],
                                                (BlkLanes *)c->d_dec_blocks.p + redo[q]));
-                (void)d_ri;
+                }
                 for (size_t q = 0; q < redo.size(); q++)
                     HIP_TRY(hipMemcpyAsync(&bi[redo[q]], (BlkInfo *)c->d_dec_state.p + redo[q], sizeof(BlkInfo), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -202,7 +221,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 if (pos == stop_bit && !emit.empty()) { ok_chain = true; break; }
                 auto it = std::lower_bound(starts.begin(), starts.end(), pos);
                 if (it == starts.end() || *it != pos) break;
-                const uint32_t k = (uint32_t)(it - starts.begin());
+                const uint32_t k = slot[(uint32_t)(it - starts.begin())];
                 const BlkInfo &r = bi[k];
                 if (r.status != BLK_OK || r.end_bit <= pos) break;
                 BlkEmit e{};

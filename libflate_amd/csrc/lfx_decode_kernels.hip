@@ -579,16 +579,18 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
 
 // ------------------------------------------------------------------------------------------------
 // block finder, stage 1: every bit offset of the stream is tested for "dynamic block header with a
-// complete code-length code".  A workgroup stages 1 KiB (+12 bytes) of the stream in LDS with coalesced
-// dword loads; every lane then tests the 32 bit offsets of one dword.  The Kraft sum of the (at most 19)
+// complete code-length code".  A workgroup stages 4 KiB (+16 bytes) of the stream in LDS with coalesced
+// dword loads; every lane then tests the bit offsets of four dwords.  The Kraft sum of the (at most 19)
 // 3-bit code-length-code widths comes from a 512-entry table of 3-field sums.
 // Survivors are collected per workgroup in LDS and appended with ONE atomic per workgroup to one of
 // FIND_SHARDS counters (a single device-scope counter serialises at ~11 ns per atomic).
+constexpr uint32_t FIND_DWORDS = 1024;   // dwords (4 KiB of stream) per workgroup
+constexpr uint32_t FIND_WL = 512;        // survivors a workgroup can hold (expected: ~30)
 __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                           uint64_t first_byte, uint32_t *__restrict__ count,
                                                           uint64_t *__restrict__ cand, uint32_t shard_cap) {
-    __shared__ uint32_t sd[256 + 4];
-    __shared__ uint64_t wl[256];
+    __shared__ uint32_t sd[FIND_DWORDS + 4];
+    __shared__ uint64_t wl[FIND_WL];
     __shared__ uint32_t wn, wbase;
     if (threadIdx.x == 0) wn = 0;
     __shared__ uint16_t lut[512];   // kraft contribution (128 >> l, 0 for l = 0) of three fields | used << 12
@@ -601,44 +603,50 @@ __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restr
     gptr_u32 w = (gptr_u32)(a & ~3ull);
     const uint64_t shift = a & 3;                      // stream byte b lives at aligned byte b + shift
     const uint64_t wlast = (shift + nbytes + 3) / 4 - 1;
-    const uint64_t wg_byte = first_byte + (uint64_t)blockIdx.x * 1024;   // first stream byte of this workgroup
+    const uint64_t wg_byte = first_byte + (uint64_t)blockIdx.x * (4 * FIND_DWORDS);   // first stream byte of this workgroup
     const uint64_t w0 = (wg_byte + shift) >> 2;
-    for (uint32_t i = threadIdx.x; i < 260; i += 256) { const uint64_t idx = w0 + i; sd[i] = w[idx < wlast ? idx : wlast]; }
+    for (uint32_t i = threadIdx.x; i < FIND_DWORDS + 4; i += 256) { const uint64_t idx = w0 + i; sd[i] = w[idx < wlast ? idx : wlast]; }
     __syncthreads();
-    // my dword = aligned dword w0 + tid ; its bit 0 is stream bit (4*(w0+tid) - shift) * 8
-    const uint64_t dword_bit0 = (4 * (w0 + threadIdx.x) - shift) * 8;    // may be "negative" only for tid 0 when shift > 0
-    const uint32_t d0 = sd[threadIdx.x], d1 = sd[threadIdx.x + 1], d2 = sd[threadIdx.x + 2], d3 = sd[threadIdx.x + 3];
-    const uint64_t lo = (uint64_t)d0 | (uint64_t)d1 << 32, hi = (uint64_t)d2 | (uint64_t)d3 << 32;
     const uint64_t stream_bits = nbytes * 8, lo_bit = first_byte * 8;
-    for (uint32_t ph = 0; ph < 32; ++ph) {
-        const uint64_t v = ph ? (lo >> ph) | (hi << (64 - ph)) : lo;   // 64 bits from this offset
-        if (((v >> 1) & 3) != 2) continue;            // BTYPE
-        const uint32_t hlit = (v >> 3) & 31, hdist = (v >> 8) & 31, hclen = (v >> 13) & 15;
-        if (hlit > 29 || hdist > 29) continue;
-        // the (hclen + 4) 3-bit fields start at bit 17
-        const uint64_t v2 = hi >> ph;                                    // bits 64.. of the window
-        const uint64_t f = (v >> 17) | (v2 << 47);                       // fields 0..20 (63 bits)
-        const uint32_t nf = hclen + 4;
-        const uint64_t fm = f & ((1ull << (3 * nf)) - 1);
-        uint32_t acc = 0;
+    for (uint32_t t = threadIdx.x; t < FIND_DWORDS; t += 256) {
+        // my dword = aligned dword w0 + t ; its bit 0 is stream bit (4*(w0+t) - shift) * 8
+        const uint64_t dword_bit0 = (4 * (w0 + t) - shift) * 8;    // "negative" only for the first dword when shift > 0
+        const uint32_t d0 = sd[t], d1 = sd[t + 1], d2 = sd[t + 2], d3 = sd[t + 3];
+        const uint64_t lo = (uint64_t)d0 | (uint64_t)d1 << 32, hi = (uint64_t)d2 | (uint64_t)d3 << 32;
+        // offsets whose BTYPE field (bits 1..2) reads 2: bit 1 clear, bit 2 set — a quarter of them
+        uint32_t pm = (uint32_t)(~(lo >> 1) & (lo >> 2));
+        while (pm) {
+            const uint32_t ph = (uint32_t)__builtin_ctz(pm);
+            pm &= pm - 1;
+            const uint64_t v = ph ? (lo >> ph) | (hi << (64 - ph)) : lo;   // 64 bits from this offset
+            const uint32_t hlit = (v >> 3) & 31, hdist = (v >> 8) & 31, hclen = (v >> 13) & 15;
+            if (hlit > 29 || hdist > 29) continue;
+            // the (hclen + 4) 3-bit fields start at bit 17
+            const uint64_t v2 = hi >> ph;                                    // bits 64.. of the window
+            const uint64_t f = (v >> 17) | (v2 << 47);                       // fields 0..20 (63 bits)
+            const uint32_t nf = hclen + 4;
+            const uint64_t fm = f & ((1ull << (3 * nf)) - 1);
+            uint32_t acc = 0;
 #pragma unroll
-        for (int g = 0; g < 7; ++g) acc += lut[(uint32_t)(fm >> (9 * g)) & 511];
-        if ((acc & 0xFFF) != 128 || (acc >> 12) < 2) continue;           // complete code-length code
-        const uint64_t bit = dword_bit0 + ph;
-        if ((int64_t)bit < (int64_t)lo_bit || bit + 96 > stream_bits) continue;
-        const uint32_t slot = atomicAdd(&wn, 1u);
-        if (slot < 256) wl[slot] = bit;
+            for (int g = 0; g < 7; ++g) acc += lut[(uint32_t)(fm >> (9 * g)) & 511];
+            if ((acc & 0xFFF) != 128 || (acc >> 12) < 2) continue;           // complete code-length code
+            const uint64_t bit = dword_bit0 + ph;
+            if ((int64_t)bit < (int64_t)lo_bit || bit + 96 > stream_bits) continue;
+            const uint32_t slot = atomicAdd(&wn, 1u);
+            if (slot < FIND_WL) wl[slot] = bit;
+        }
     }
     __syncthreads();
     const uint32_t shard = blockIdx.x % FIND_SHARDS;
-    const uint32_t mine = wn;   // > 256 would be a pathological input: counted, reported as overflow
+    const uint32_t mine = wn;   // > FIND_WL would be a pathological input: counted, reported as overflow
     if (threadIdx.x == 0 && mine) wbase = atomicAdd(&count[shard], mine);
     __syncthreads();
     if (mine) {
         const uint32_t b = wbase;
-        if (threadIdx.x < mine && threadIdx.x < 256 && b + threadIdx.x < shard_cap && mine <= 256)
-            cand[(uint64_t)shard * shard_cap + b + threadIdx.x] = wl[threadIdx.x];
-        if (mine > 256 && threadIdx.x == 0) atomicAdd(&count[FIND_SHARDS], 1u);   // overflow marker
+        if (mine <= FIND_WL)
+            for (uint32_t k = threadIdx.x; k < mine; k += 256)
+                if (b + k < shard_cap) cand[(uint64_t)shard * shard_cap + b + k] = wl[k];
+        if (mine > FIND_WL && threadIdx.x == 0) atomicAdd(&count[FIND_SHARDS], 1u);   // overflow marker
     }
 }
 
@@ -775,7 +783,7 @@ int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint6
                        uint32_t *count, uint64_t *cand, uint32_t shard_cap) {
     if (nbytes <= first_byte) return 0;
     const uint64_t n = nbytes - first_byte;
-    hipLaunchKernelGGL(find_blocks_stage1, dim3((uint32_t)div_up(n + 4, 1024)), dim3(256), 0, st, in, nbytes,
+    hipLaunchKernelGGL(find_blocks_stage1, dim3((uint32_t)div_up(n + 4, 4 * FIND_DWORDS)), dim3(256), 0, st, in, nbytes,
                        first_byte, count, cand, shard_cap);
     LFX_LAUNCH_CHECK();
     return 0;

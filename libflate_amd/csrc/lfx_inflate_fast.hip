@@ -804,6 +804,7 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
             kl += nlit_part * (32768u >> val); nlit += nlit_part;
             kd += ndist_part * (32768u >> val); ndist += ndist_part;
             if (have <= 256 && 256 < have + rep) eob_len = val;
+            if (kl > 32768u || kd > 32768u) { good = false; break; }   // over-subscribed: most false candidates end here
         }
         have += rep;
         last = val;
