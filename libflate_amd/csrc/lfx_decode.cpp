@@ -261,6 +261,11 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 c->phase("lz77_copy");
                 if (getenv("LFX_DEBUG")) {
                     fprintf(stderr, "[lfx]  emit flags=%u\n", fl);
+                    std::vector<BlkUnits> uv(ne);
+                    (void)hipMemcpy(uv.data(), c->d_hist.p, sizeof(BlkUnits) * ne, hipMemcpyDeviceToHost);
+                    for (uint32_t u = 0; u < 3 && u < ne; u++)
+                        fprintf(stderr, "[lfx]  K2 block %u: units=%u hdr=%u decode=%u cut=%u select=%u\n", u, uv[u].n, uv[u].cyc[0],
+                                uv[u].cyc[1], uv[u].cyc[2], uv[u].cyc[3]);
                     std::vector<uint64_t> dv(64ull * ne);
                     (void)hipMemcpy(dv.data(), dbgbuf, 64ull * 8 * ne, hipMemcpyDeviceToHost);
                     for (uint32_t u = 0; u < 8 && u < 8 * ne; u++)

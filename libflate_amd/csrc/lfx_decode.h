@@ -92,6 +92,7 @@ struct BlkUnits {
     uint32_t n;          // independent units of the block (no back-reference crosses a cut)
     uint32_t code0[9];   // unit u covers codes [code0[u], code0[u+1]) of the block
     uint64_t out0[9];    // ... and bytes [out0[u], out0[u+1]) of the block's output
+    uint32_t cyc[4];     // diagnostics: header, decode, cut search, unit selection (clock64 ticks)
 };
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
                     BlkInfo *infos, BlkLanes *lanes);

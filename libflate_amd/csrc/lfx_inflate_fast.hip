@@ -126,55 +126,83 @@ __device__ __forceinline__ uint32_t dist_entry_of(uint32_t s, uint32_t w) {
     return w | ((uint32_t)f_dist_extra[s] << 6) | ((uint32_t)f_dist_base[s] << 16);
 }
 
+// canonical walk limited to `maxw` bits (stream bit k of the code at bit k of `bits`)
+__device__ __forceinline__ uint32_t short_decode(const uint16_t *count, const uint16_t *sorted, uint32_t bits,
+                                                 uint32_t maxw, uint32_t &width) {
+    uint32_t code = 0, first = 0, index = 0;
+    for (uint32_t w = 1; w <= maxw; ++w) {
+        code |= (bits >> (w - 1)) & 1;
+        const uint32_t cnt = count[w];
+        if (code < first + cnt) { width = w; return sorted[index + (code - first)]; }
+        index += cnt;
+        first = (first + cnt) << 1;
+        code <<= 1;
+    }
+    width = 0;
+    return 0xFFFF;
+}
+
 // workgroup-wide: canonical tables from code widths.  Returns false when over-subscribed.
+// Every step is spread over the workgroup: width histogram by LDS atomics, symbol order by rank,
+// and the primary tables entry by entry (each entry walks the canonical code of its own index).
 __device__ bool build_fast(FastTabs &T, const uint8_t *lw, uint32_t nl, const uint8_t *dw, uint32_t nd,
                            uint32_t tid, uint32_t nthreads) {
-    __shared__ uint32_t s_first[2][16], s_off[2][16], s_bad;
-    for (uint32_t i = tid; i < (1u << LIT_BITS); i += nthreads) T.lit[i] = 0;
-    for (uint32_t i = tid; i < (1u << DIST_BITS); i += nthreads) T.dist[i] = 0;
+    __shared__ uint32_t s_cnt[2][16], s_off[2][16], s_bad, s_long[2];
+    if (tid < 32) s_cnt[tid >> 4][tid & 15] = 0;
     for (uint32_t i = tid; i < 288; i += nthreads) T.lit_info[i] = lit_entry_of(i, 0);
     for (uint32_t i = tid; i < 32; i += nthreads) T.dist_info[i] = dist_entry_of(i, 0);
-    if (tid == 0) {
-        s_bad = 0;
-        for (int t = 0; t < 2; ++t) {
-            uint16_t *cnt = t ? T.dist_count : T.lit_count;
-            const uint8_t *bw = t ? dw : lw;
-            const uint32_t n = t ? nd : nl;
-            for (int w = 0; w < 16; ++w) cnt[w] = 0;
-            for (uint32_t s = 0; s < n; ++s) cnt[bw[s]]++;
-            cnt[0] = 0;
-            uint32_t code = 0, off = 0;
-            int left = 1;
-            for (uint32_t w = 1; w <= 15; ++w) {
-                code <<= 1; left <<= 1;
-                s_first[t][w] = code; s_off[t][w] = off;
-                left -= (int)cnt[w];
-                if (left < 0) s_bad = 1;
-                code += cnt[w]; off += cnt[w];
-            }
+    __syncthreads();
+    for (uint32_t s = tid; s < nl + nd; s += nthreads) {
+        const uint32_t t = s >= nl;
+        const uint32_t w = t ? dw[s - nl] : lw[s];
+        if (w) atomicAdd(&s_cnt[t][w], 1u);
+    }
+    __syncthreads();
+    if (tid < 2) {
+        const uint32_t t = tid;
+        uint16_t *cnt = t ? T.dist_count : T.lit_count;
+        const uint32_t pri = t ? DIST_BITS : LIT_BITS;
+        uint32_t off = 0, nlong = 0;
+        int left = 1;
+        bool bad = false;
+        cnt[0] = 0;
+        for (uint32_t w = 1; w <= 15; ++w) {
+            const uint32_t c = s_cnt[t][w];
+            cnt[w] = (uint16_t)c;
+            s_off[t][w] = off;
+            left = (left << 1) - (int)c;
+            if (left < 0) bad = true;
+            off += c;
+            if (w > pri) nlong += c;
         }
+        s_long[t] = nlong;
+        if (t == 0) s_bad = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (bad) s_bad = 1;
     }
     __syncthreads();
     if (s_bad) return false;
     for (uint32_t s = tid; s < nl + nd; s += nthreads) {
-        const int t = s >= nl;
+        const uint32_t t = s >= nl;
         const uint32_t sym = t ? s - nl : s;
         const uint8_t *bw = t ? dw : lw;
         const uint32_t w = bw[sym];
         if (w == 0) continue;
         uint32_t rank = 0;
         for (uint32_t q = 0; q < sym; ++q) rank += bw[q] == w;
-        const uint32_t code = s_first[t][w] + rank;
         (t ? T.dist_sorted : T.lit_sorted)[s_off[t][w] + rank] = (uint16_t)sym;
-        const uint32_t pri = t ? DIST_BITS : LIT_BITS;
-        const uint32_t r = __brev(code) >> (32 - w);
-        uint32_t *tab = t ? T.dist : T.lit;
-        if (w <= pri) {
-            const uint32_t e = t ? dist_entry_of(sym, w) : lit_entry_of(sym, w);
-            for (uint32_t i = r; i < (1u << pri); i += (1u << w)) tab[i] = e;
-        } else {
-            tab[r & ((1u << pri) - 1)] = E_LONG;
-        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < (1u << LIT_BITS) + (1u << DIST_BITS); i += nthreads) {
+        const uint32_t t = i >= (1u << LIT_BITS);
+        const uint32_t idx = t ? i - (1u << LIT_BITS) : i;
+        uint32_t w = 0;
+        const uint32_t sym = short_decode(t ? T.dist_count : T.lit_count, t ? T.dist_sorted : T.lit_sorted, idx,
+                                          t ? DIST_BITS : LIT_BITS, w);
+        uint32_t e;
+        if (w) e = t ? (sym < 30 ? (T.dist_info[sym] | w) : 0) : (sym < 286 ? (T.lit_info[sym] | w) : 0);
+        else e = s_long[t] ? E_LONG : 0;             // a longer code may start with these bits
+        (t ? T.dist : T.lit)[idx] = e;
     }
     __syncthreads();
     return true;
@@ -237,10 +265,13 @@ struct FastBits {
 
 // One lane decodes symbols from bit `start` until a symbol would start at or after `limit`, or
 // EndOfBlock.  EMIT: write code words.  Returns 0 ok / 1 EOB / 2 undecodable; `endpos` = bit reached.
+// EMIT also tracks the earliest cut of the slice: (cut_code, cut_out) = first code / byte such that no later
+// code OF THIS SLICE reads a byte produced before it.  A back-reference that reads below the current
+// candidate kills it and every later one up to itself, so the candidate moves to just behind it.
 template <bool EMIT>
 __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
                                            uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
-                                           int64_t &reach, uint64_t &endpos) {
+                                           int64_t &reach, uint64_t &endpos, uint32_t &cut_code, uint32_t &cut_out) {
     FastBits b;
     b.init(in, nbytes, start);
     const uint64_t span = limit > start ? limit - start : 0;
@@ -281,6 +312,7 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
                 codes[ncodes] = (length << 16) | distance;
                 const int64_t srcpos = (int64_t)(nout + no) - (int64_t)distance;   // first byte this match reads
                 if (srcpos < reach) reach = srcpos;
+                if ((int32_t)no - (int32_t)distance < (int32_t)cut_out) { cut_code = ncodes + 1; cut_out = no + length; }
             }
             ncodes++;
             no += length;
@@ -353,51 +385,76 @@ struct ClenCode {
 constexpr int SCAN_THREADS = 1024;   // lanes per block: 16 wavefronts, 4 per SIMD hide each other's latency
 
 // parse the block header at job.start_bit and build T.  → btype in hdr[0], bfinal hdr[1],
-// data start bit hdr64[0]; status in hdr[2] (0 ok, 1 undecodable header)
+// data start bit hdr64[0]; status in hdr[2] (0 ok, 1 undecodable header).
+// The code-length sequence itself is a serial Huffman stream (one lane), everything around it is spread
+// over the workgroup: a 128-entry lookup table for the code-length code, pre-zeroed widths (zero runs
+// only advance the cursor) and the table build.
 __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_bit, FastTabs &T,
                              uint8_t *lens, uint32_t *hdr, uint64_t *hdr64, uint32_t tid) {
+    __shared__ uint8_t cl_tab[128];   // symbol | width << 5 ; 0xFF = no code
+    for (uint32_t i = tid; i < 640 / 4; i += SCAN_THREADS) ((uint32_t *)lens)[i] = 0;
     if (tid == 0) {
         HdrBits hb;
         hb.init(in, nbytes, start_bit);
-        hdr[2] = 0;
+        uint32_t bad = 0;
         const uint32_t bfinal = hb.get(1), btype = hb.get(2);
         hdr[0] = btype; hdr[1] = bfinal;
-        if (hb.bad || btype == 3) hdr[2] = 1;
-        else if (btype == 1) {
-            for (uint32_t s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-            for (uint32_t s = 0; s < 30; ++s) lens[288 + s] = 5;
-            hdr[3] = 288; hdr[4] = 30;
-        } else if (btype == 2) {
+        hdr64[1] = 0;
+        if (hb.bad || btype == 3) bad = 1;
+        else if (btype == 2) {
             const uint32_t nl = hb.get(5) + 257, nd = hb.get(5) + 1, nc = hb.get(4) + 4;
             hdr[3] = nl; hdr[4] = nd;
             uint64_t clw = 0;
             for (uint32_t k = 0; k < nc; ++k) clw |= (uint64_t)hb.get(3) << (3 * clen_order(k));
-            ClenCode cc;
-            cc.build(clw);
-            uint32_t have = 0, last = 0;
-            const uint32_t total = nl + nd;
-            if (nd > 30 || hb.bad) hdr[2] = 1;
-            while (have < total && !hdr[2]) {
-                if (hb.b.pos + 7 > hb.nbits && hb.b.pos >= hb.nbits) { hdr[2] = 1; break; }
-                hb.b.refill();
-                uint32_t used = 0;
-                const uint32_t sym = cc.decode((uint32_t)hb.b.buf & 127, used);
-                if (sym == 99 || hb.b.pos + used > hb.nbits) { hdr[2] = 1; break; }
-                hb.b.skip(used);
-                uint32_t rep = 1, val = sym;
-                if (sym == 16) { if (have == 0) { hdr[2] = 1; break; } rep = 3 + hb.get(2); val = last; }
-                else if (sym == 17) { rep = 3 + hb.get(3); val = 0; }
-                else if (sym == 18) { rep = 11 + hb.get(7); val = 0; }
-                if (have + rep > total || hb.bad) { hdr[2] = 1; break; }
-                for (uint32_t k = 0; k < rep; ++k) lens[have + k] = (uint8_t)val;
-                have += rep;
-                last = val;
-            }
+            hdr64[1] = clw;
+            if (nd > 30 || hb.bad) bad = 1;
         }
+        hdr[2] = bad;
         hdr64[0] = hb.b.pos;
     }
     __syncthreads();
-    if (hdr[2] || hdr[0] == 0) return;
+    const uint32_t btype = hdr[0];
+    if (hdr[2] || btype == 0) return;
+    if (btype == 1) {
+        for (uint32_t s = tid; s < 288 + 30; s += SCAN_THREADS)
+            lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
+        if (tid == 0) { hdr[3] = 288; hdr[4] = 30; }
+    } else {
+        if (tid < 128) {
+            ClenCode cc;
+            cc.build(hdr64[1]);
+            uint32_t used = 0;
+            const uint32_t sym = cc.decode(tid, used);
+            cl_tab[tid] = sym == 99 ? 0xFF : (uint8_t)(sym | used << 5);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            HdrBits hb;
+            hb.init(in, nbytes, hdr64[0]);
+            const uint32_t nl = hdr[3], nd = hdr[4], total = nl + nd;
+            uint32_t have = 0, last = 0, bad = 0;
+            while (have < total) {
+                if (hb.b.pos >= hb.nbits) { bad = 1; break; }
+                hb.b.refill();
+                const uint32_t e = cl_tab[(uint32_t)hb.b.buf & 127];
+                const uint32_t sym = e & 31, used = e >> 5;
+                if (e == 0xFF || hb.b.pos + used > hb.nbits) { bad = 1; break; }
+                hb.b.skip(used);
+                uint32_t rep = 1, val = sym;
+                if (sym == 16) { if (have == 0) { bad = 1; break; } rep = 3 + hb.get(2); val = last; }
+                else if (sym == 17) { rep = 3 + hb.get(3); val = 0; }
+                else if (sym == 18) { rep = 11 + hb.get(7); val = 0; }
+                if (have + rep > total || hb.bad) { bad = 1; break; }
+                if (val) for (uint32_t k = 0; k < rep; ++k) lens[have + k] = (uint8_t)val;
+                have += rep;
+                last = val;
+            }
+            hdr[2] = bad;
+            hdr64[0] = hb.b.pos;
+        }
+    }
+    __syncthreads();
+    if (hdr[2]) return;
     const uint32_t nl = hdr[3], nd = hdr[4];
     if (!build_fast(T, lens, nl, lens + nl, nd, tid, SCAN_THREADS)) {
         if (tid == 0) hdr[2] = 1;
@@ -412,7 +469,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_scan_kernel(const uint8_t *_
                                                                 BlkInfo *__restrict__ infos,
                                                                 BlkLanes *__restrict__ lanes) {
     __shared__ FastTabs T;
-    __shared__ uint8_t lens[640];
+    __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
     __shared__ uint64_t s_start[SCAN_THREADS + 1];
@@ -464,7 +521,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_scan_kernel(const uint8_t *_
         if (tid < nl && st != ~0ull) {
             // the last lane keeps going to the end of the stream range (the block may end exactly at e)
             const uint64_t lim = tid + 1 == nl ? e + 64 : my_bound;
-            const int r = lane_decode<false>(T, in, nbytes, st, lim, nc, no, nullptr, dummy, exitpos);
+            uint32_t cc = 0, co = 0;
+            const int r = lane_decode<false>(T, in, nbytes, st, lim, nc, no, nullptr, dummy, exitpos, cc, co);
             flag = r == 1 ? 1 : r == 2 ? 2 : 0;
         } else flag = 4;
         s_nc[tid] = nc; s_no[tid] = no; s_flag[tid] = flag; s_exit[tid] = exitpos;
@@ -542,10 +600,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
                                                                 uint32_t *__restrict__ flags,
                                                                 BlkUnits *__restrict__ units) {
     __shared__ FastTabs T;
-    __shared__ uint8_t lens[640];
+    __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
-    __shared__ int64_t s_reach[SCAN_THREADS];
     const uint32_t tid = threadIdx.x;
     const BlkEmit job = jobs[blockIdx.x];
     BlkUnits *U = &units[blockIdx.x];
@@ -553,60 +610,68 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
         if (tid == 0) { U->n = 1; U->code0[0] = 0; U->code0[1] = 0; U->out0[0] = 0; U->out0[1] = job.n_out; }
         return;
     }
+    const uint64_t t_begin = clock64();
     parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
+    const uint64_t t_hdr = clock64();
     const BlkLanes *L = &lanes[job.cand];
     int64_t reach = INT64_MAX;
-    if (tid < job.nlanes) {
-        const uint64_t st = L->start[tid];
-        const uint64_t lim = tid + 1 < job.nlanes ? L->start[tid + 1] : ~0ull >> 1;
-        uint32_t nc = 0;
-        uint64_t no = L->out_off[tid], endpos;   // bytes of this block produced before my slice
-        lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos);
-        if (reach < 0) atomicOr(&flags[0], 1u);   // a back-reference reaches before the block start
-    }
-    s_reach[tid] = reach;
-    __syncthreads();
-    // suffix minimum over LATER lanes (serial, 1024 short steps once per block)
-    __shared__ int64_t s_later[SCAN_THREADS];
-    __shared__ uint32_t s_cut_code[SCAN_THREADS];
-    __shared__ uint64_t s_cut_pos[SCAN_THREADS];
-    if (tid == 0) {
-        int64_t m = INT64_MAX;
-        for (int k = (int)job.nlanes - 1; k >= 0; --k) { s_later[k] = m; if (s_reach[k] < m) m = s_reach[k]; }
-    }
-    __syncthreads();
-    // every lane walks its codes backwards: a cut before code i is legal iff no code at or after i
-    // (in this lane or any later one) reads a byte produced before code i's first byte
     uint32_t cut_code = 0xFFFFFFFFu;
     uint64_t cut_pos = 0;
     if (tid < job.nlanes) {
-        const uint32_t cbeg = L->code_off[tid];
-        const uint32_t cend = tid + 1 < job.nlanes ? L->code_off[tid + 1] : job.n_codes;
-        uint64_t pos = tid + 1 < job.nlanes ? L->out_off[tid + 1] : job.n_out;
-        int64_t m = s_later[tid];
-        const uint32_t *cp = codes + job.code_off;
-        for (uint32_t i = cend; i > cbeg; --i) {
-            const uint32_t c = cp[i - 1];
-            const uint32_t dist = c & 0xFFFFu, val = c >> 16;
-            pos -= dist ? val : 1u;
-            if (dist) { const int64_t sp = (int64_t)pos - (int64_t)dist; if (sp < m) m = sp; }
-            if (m >= (int64_t)pos) { cut_code = i - 1; cut_pos = pos; }   // keeps the earliest cut of the lane
-        }
+        const uint64_t st = L->start[tid];
+        const uint64_t lim = tid + 1 < job.nlanes ? L->start[tid + 1] : ~0ull >> 1;
+        uint32_t nc = 0, cc = 0, co = 0;
+        const uint64_t out0 = L->out_off[tid];   // bytes of this block produced before my slice
+        uint64_t no = out0, endpos;
+        lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co);
+        if (reach < 0) atomicOr(&flags[0], 1u);   // a back-reference reaches before the block start
+        if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
     }
+    const uint64_t t_dec = clock64();
+    // suffix minimum of `reach` over LATER lanes: within the wavefront by shuffles, then across wavefronts
+    __shared__ int64_t s_wmin[SCAN_THREADS / 64];
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    int64_t sfx = reach;   // inclusive suffix min
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t y = __shfl_down(sfx, o);
+        if (lane + o < 64 && y < sfx) sfx = y;
+    }
+    if (lane == 0) s_wmin[wave] = sfx;
+    __syncthreads();
+    int64_t later = __shfl_down(sfx, 1);            // min over the later lanes of my wavefront
+    if (lane == 63) later = INT64_MAX;
+    for (uint32_t w = wave + 1; w < SCAN_THREADS / 64; ++w) { const int64_t y = s_wmin[w]; if (y < later) later = y; }
+    // the lane's cut is legal iff no later lane reads a byte in front of it either (a later candidate of
+    // this lane lies even further right, so it cannot be legal when this one is not)
+    if (cut_code != 0xFFFFFFFFu && later < (int64_t)cut_pos) cut_code = 0xFFFFFFFFu;
+    __shared__ uint32_t s_cut_code[SCAN_THREADS];
+    __shared__ uint64_t s_cut_pos[SCAN_THREADS];
     s_cut_code[tid] = cut_code;
     s_cut_pos[tid] = cut_pos;
+    __shared__ uint64_t s_legal[SCAN_THREADS / 64];
+    const uint64_t legal = __ballot(cut_code != 0xFFFFFFFFu);
+    if (lane == 0) s_legal[wave] = legal;
     __syncthreads();
+    const uint64_t t_cut = clock64();
     if (tid == 0) {
+        // legal cuts are few (reference-made blocks: the LZ77 chunk boundaries): visit only those
         uint32_t nu = 0, last = 0;
         const uint32_t want = job.n_codes / MAX_UNITS + 1;
         U->code0[0] = 0; U->out0[0] = 0;
-        for (uint32_t k = 0; k < job.nlanes && nu + 1 < MAX_UNITS; ++k) {
-            const uint32_t cc = s_cut_code[k];
-            if (cc != 0xFFFFFFFFu && cc != 0 && cc - last >= want) { nu++; U->code0[nu] = cc; U->out0[nu] = s_cut_pos[k]; last = cc; }
+        for (uint32_t w = 0; w < SCAN_THREADS / 64 && nu + 1 < MAX_UNITS; ++w) {
+            uint64_t m = s_legal[w];
+            while (m && nu + 1 < MAX_UNITS) {
+                const uint32_t k = w * 64 + (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const uint32_t cc = s_cut_code[k];
+                if (cc != 0 && cc - last >= want) { nu++; U->code0[nu] = cc; U->out0[nu] = s_cut_pos[k]; last = cc; }
+            }
         }
         nu++;
         U->code0[nu] = job.n_codes; U->out0[nu] = job.n_out;
         U->n = nu;
+        U->cyc[0] = (uint32_t)(t_hdr - t_begin); U->cyc[1] = (uint32_t)(t_dec - t_hdr);
+        U->cyc[2] = (uint32_t)(t_cut - t_dec); U->cyc[3] = (uint32_t)(clock64() - t_cut);
     }
 }
 
