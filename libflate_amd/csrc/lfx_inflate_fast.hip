@@ -512,18 +512,53 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_scan_kernel(const uint8_t *_
     if (tid == 0) s_start[SCAN_THREADS] = ~0ull;
     __syncthreads();
     uint32_t rounds = 0;
+    // Round 1 decodes every slice from its guessed start: a short head [start, checkpoint) and the rest
+    // [checkpoint, bound).  A corrected start (round 2+) only re-decodes the head: when it lands exactly on
+    // the checkpoint — a speculative decode is in step after a few symbols — the rest is bit for bit the
+    // decode already done, so its counts are reused.
+    constexpr uint64_t CP_BITS = 768;
+    uint32_t nc = 0, flag = 4;
+    uint64_t no = 0, exitpos = ~0ull;
+    uint64_t decoded_from = ~0ull, cp_pos = 0, rest_no = 0, rest_exit = 0;
+    uint32_t rest_nc = 0, rest_flag = 0;
+    bool have_cp = false;
     for (;;) {
-        uint32_t nc = 0;
         int64_t dummy = 0;
-        uint64_t no = 0, exitpos = ~0ull;
-        uint32_t flag = 0;  // 1 EOB hit, 2 undecodable, 4 not started
+        uint32_t cc = 0, co = 0;
         const uint64_t st = s_start[tid];
         if (tid < nl && st != ~0ull) {
-            // the last lane keeps going to the end of the stream range (the block may end exactly at e)
-            const uint64_t lim = tid + 1 == nl ? e + 64 : my_bound;
-            uint32_t cc = 0, co = 0;
-            const int r = lane_decode<false>(T, in, nbytes, st, lim, nc, no, nullptr, dummy, exitpos, cc, co);
-            flag = r == 1 ? 1 : r == 2 ? 2 : 0;
+            if (st != decoded_from) {
+                // the last lane keeps going to the end of the stream range (the block may end exactly at e)
+                const uint64_t lim = tid + 1 == nl ? e + 64 : my_bound;
+                nc = 0; no = 0;
+                uint64_t at = st;
+                int r = 0;
+                bool reuse = false;
+                if (have_cp && st < cp_pos) {
+                    r = lane_decode<false>(T, in, nbytes, st, cp_pos, nc, no, nullptr, dummy, at, cc, co);
+                    reuse = r == 0 && at == cp_pos;
+                    if (!reuse) have_cp = false;
+                } else {
+                    have_cp = false;
+                    const uint64_t cpl = st + CP_BITS < lim ? st + CP_BITS : lim;
+                    r = lane_decode<false>(T, in, nbytes, st, cpl, nc, no, nullptr, dummy, at, cc, co);
+                    if (r == 0 && at < lim) {
+                        have_cp = true;
+                        cp_pos = at;
+                        rest_nc = 0; rest_no = 0;
+                        const int rr = lane_decode<false>(T, in, nbytes, at, lim, rest_nc, rest_no, nullptr, dummy, rest_exit, cc, co);
+                        rest_flag = rr == 1 ? 1 : rr == 2 ? 2 : 0;
+                        reuse = true;
+                    }
+                }
+                if (reuse) { nc += rest_nc; no += rest_no; exitpos = rest_exit; flag = rest_flag; }
+                else {
+                    if (r == 0 && at < lim) r = lane_decode<false>(T, in, nbytes, at, lim, nc, no, nullptr, dummy, at, cc, co);
+                    exitpos = at;
+                    flag = r == 1 ? 1 : r == 2 ? 2 : 0;
+                }
+                decoded_from = st;
+            }
         } else flag = 4;
         s_nc[tid] = nc; s_no[tid] = no; s_flag[tid] = flag; s_exit[tid] = exitpos;
         __syncthreads();
