@@ -246,6 +246,15 @@ extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) {
         return nullptr;
     }
     c->stream = c->own_stream;
+    (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        if (status) *status = LFX_E_DEVICE;
+        return nullptr;
+    }
     if (hipHostMalloc((void **)&c->h_res, 4096, hipHostMallocDefault) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
@@ -263,6 +272,9 @@ extern "C" void lfx_ctx_free(lfx_ctx *cc) {
     for (DevBuf *b : c->all_bufs()) b->release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -373,6 +385,15 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                             (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
                             (uint32_t *)c->d_ncodes.p));
     c->phase("lz77_parse");
+    if (want_checksum) {
+        // the container checksum reads only the input: it runs on the side stream, beside the histogram
+        // and the one-wavefront-per-block Huffman kernel, which leave most of the GPU idle
+        uint32_t *ck = (uint32_t *)c->d_ck.p;
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        LAUNCH_TRY(launch_checksum(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p));
+        HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
+    }
     uint32_t split = nchunks && nchunks < 512 ? std::min<uint32_t>(64, 1024 / nchunks + 1) : 1;
     LAUNCH_TRY(launch_histogram(st, (const ChunkDesc *)c->d_chunks.p, nchunks, split, (const uint32_t *)c->d_codes.p,
                                 (const uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_hist.p));
@@ -381,8 +402,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                               (BlockCodes *)c->d_bc.p));
     c->phase("huffman");
     if (want_checksum) {
-        uint32_t *ck = (uint32_t *)c->d_ck.p;
-        LAUNCH_TRY(launch_checksum(st, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p));
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         c->phase("checksum");
     }
     return LFX_OK;

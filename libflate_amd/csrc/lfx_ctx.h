@@ -19,7 +19,12 @@ struct DevBuf {
 
 struct Ctx {
     int device = 0;
+    int n_cu = 0;   // compute units of the device
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // work that only depends on the input (the container checksum) runs beside the thin kernels of the
+    // main stream: fork / join through these two events
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     void set_error(const std::string &e) { err = e; }
 

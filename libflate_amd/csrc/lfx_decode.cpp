@@ -250,8 +250,11 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 }
                 HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
                 HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
+                // K3 keeps four units resident per CU (LDS): size the units so that all of them are resident at once
+                const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
+                const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
-                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p));
+                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target));
                 c->phase("blk_emit");
                 LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                   (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
                                                                 const BlkLanes *__restrict__ lanes,
                                                                 uint32_t *__restrict__ codes,
                                                                 uint32_t *__restrict__ flags,
-                                                                BlkUnits *__restrict__ units) {
+                                                                BlkUnits *__restrict__ units, uint32_t unit_target) {
     __shared__ FastTabs T;
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
@@ -689,18 +689,42 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
     __syncthreads();
     const uint64_t t_cut = clock64();
     if (tid == 0) {
-        // legal cuts are few (reference-made blocks: the LZ77 chunk boundaries): visit only those
+        // The block is cut into about n_codes / unit_target units (the host sizes unit_target so that all
+        // units of the stream are resident in K3 at once): for every ideal boundary take the nearest legal
+        // cut — legal cuts are few (reference-made blocks: the LZ77 chunk boundaries), lanes hold about the
+        // same number of codes, so the search starts at the lane the boundary falls into.
         uint32_t nu = 0, last = 0;
-        const uint32_t want = job.n_codes / MAX_UNITS + 1;
+        uint32_t want_units = (job.n_codes + unit_target / 2) / unit_target;
+        if (want_units < 1) want_units = 1;
+        if (want_units > MAX_UNITS) want_units = MAX_UNITS;
+        const uint32_t tol = job.n_codes / (2 * want_units);
         U->code0[0] = 0; U->out0[0] = 0;
-        for (uint32_t w = 0; w < SCAN_THREADS / 64 && nu + 1 < MAX_UNITS; ++w) {
-            uint64_t m = s_legal[w];
-            while (m && nu + 1 < MAX_UNITS) {
-                const uint32_t k = w * 64 + (uint32_t)__builtin_ctzll(m);
-                m &= m - 1;
-                const uint32_t cc = s_cut_code[k];
-                if (cc != 0 && cc - last >= want) { nu++; U->code0[nu] = cc; U->out0[nu] = s_cut_pos[k]; last = cc; }
+        for (uint32_t b = 1; b < want_units; ++b) {
+            const uint32_t ideal = (uint32_t)((uint64_t)job.n_codes * b / want_units);
+            uint32_t l0 = (uint32_t)((uint64_t)job.nlanes * b / want_units);
+            if (l0 >= SCAN_THREADS) l0 = SCAN_THREADS - 1;
+            // nearest legal lane at or above l0, and below l0
+            int up = -1, dn = -1;
+            for (uint32_t w = l0 >> 6; w < SCAN_THREADS / 64 && up < 0; ++w) {
+                uint64_t m = s_legal[w];
+                if (w == (l0 >> 6)) m &= ~0ull << (l0 & 63);
+                if (m) up = (int)(w * 64 + (uint32_t)__builtin_ctzll(m));
             }
+            for (int w = (int)(l0 >> 6); w >= 0 && dn < 0; --w) {
+                uint64_t m = s_legal[w];
+                if (w == (int)(l0 >> 6)) m &= (l0 & 63) ? ~0ull >> (64 - (l0 & 63)) : 0ull;
+                if (m) dn = w * 64 + 63 - __builtin_clzll(m);
+            }
+            int pick = -1;
+            uint32_t best = 0xFFFFFFFFu;
+            if (up >= 0) { const uint32_t cc = s_cut_code[up]; const uint32_t d = cc > ideal ? cc - ideal : ideal - cc; if (d < best) { best = d; pick = up; } }
+            if (dn >= 0) { const uint32_t cc = s_cut_code[dn]; const uint32_t d = cc > ideal ? cc - ideal : ideal - cc; if (d < best) { best = d; pick = dn; } }
+            if (pick < 0 || best > tol) continue;
+            const uint32_t cc = s_cut_code[pick];
+            if (cc == 0 || cc <= last || cc >= job.n_codes) continue;
+            nu++;
+            U->code0[nu] = cc; U->out0[nu] = s_cut_pos[pick];
+            last = cc;
         }
         nu++;
         U->code0[nu] = job.n_codes; U->out0[nu] = job.n_out;
@@ -936,9 +960,10 @@ int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
     return 0;
 }
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
-                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units) {
+                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, lanes, codes, flags, units);
+    hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, lanes, codes, flags, units,
+                       unit_target ? unit_target : 1u);
     LFX_LAUNCH_CHECK();
     return 0;
 }
