@@ -271,8 +271,18 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                                 uv[u].cyc[1], uv[u].cyc[2], uv[u].cyc[3]);
                     std::vector<uint64_t> dv(64ull * ne);
                     (void)hipMemcpy(dv.data(), dbgbuf, 64ull * 8 * ne, hipMemcpyDeviceToHost);
+                    uint32_t nunits = 0;
+                    uint64_t maxcyc = 0, tmin = ~0ull, tmax = 0;
+                    for (uint32_t u = 0; u < 8 * ne; u++) {
+                        if (!dv[u * 8 + 1]) continue;
+                        nunits++;
+                        maxcyc = std::max(maxcyc, dv[u * 8]);
+                        tmin = std::min(tmin, dv[u * 8 + 6]); tmax = std::max(tmax, dv[u * 8 + 6]);
+                    }
+                    fprintf(stderr, "[lfx]  K3: units=%u max_cycles=%llu end-time spread=%.1f us (100 MHz clock)\n", nunits,
+                            (unsigned long long)maxcyc, (double)(tmax - tmin) / 100.0);
                     for (uint32_t u = 0; u < 8 && u < 8 * ne; u++)
-                        fprintf(stderr, "[lfx]  K3 unit %u: scan=%llu par=%llu seq=%llu flush=%llu nseq=%llu ncodes=%llu\n", u,
+                        fprintf(stderr, "[lfx]  K3 unit %u: cycles=%llu batches=%llu nseq=%llu seq_cycles=%llu codes=%llu bytes=%llu\n", u,
                                 (unsigned long long)dv[u * 8], (unsigned long long)dv[u * 8 + 1], (unsigned long long)dv[u * 8 + 2],
                                 (unsigned long long)dv[u * 8 + 3], (unsigned long long)dv[u * 8 + 4], (unsigned long long)dv[u * 8 + 5]);
                 }

@@ -735,17 +735,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: one wavefront per unit turns codes into bytes through a 40 KiB LDS ring: the last 32 KiB of
-// output (the DEFLATE window) plus at most 7 KiB in flight, so that four units are resident per CU.
-// The ring size is 5 * 8192, its index is pos mod 40960.
-constexpr uint32_t MWIN = 40960;
-constexpr uint32_t MBATCH_MAX = 7168;   // bytes one batch may produce (a code produces <= 258)
+// K3: one wavefront per unit turns codes into bytes through a 36 KiB LDS ring: the last 32 KiB of
+// output (the DEFLATE window) plus at most 4 KiB in flight, so that four units are resident per CU
+// (four 40 KiB rings are exactly the CU's 160 KiB and do NOT fit next to each other).
+// The ring size is 9 * 4096, its index is pos mod 36864.
+constexpr uint32_t MWIN = 36864;
+constexpr uint32_t MBATCH_MAX = 4096;   // bytes one batch may produce (a code produces <= 258)
 constexpr uint32_t PAR_LEN = 16;        // matches up to this length that read only pre-batch bytes go in parallel
 
 __device__ __forceinline__ uint32_t ring_idx(uint32_t pos) {
-    const uint32_t x = pos >> 13;
-    const uint32_t q = (uint32_t)(((uint64_t)x * 0xCCCCCCCDull) >> 34);   // x / 5
-    return ((x - 5 * q) << 13) | (pos & 8191);
+    const uint32_t x = pos >> 12;
+    const uint32_t q = (uint32_t)(((uint64_t)x * 954437177ull) >> 33);   // x / 9
+    return ((x - 9 * q) << 12) | (pos & 4095);
 }
 __device__ __forceinline__ uint32_t ring_add(uint32_t idx, uint32_t k) {   // k < MWIN
     const uint32_t r = idx + k;
@@ -772,9 +773,12 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
                                                              const BlkLanes *__restrict__ lanes,
                                                              const BlkUnits *__restrict__ units,
                                                              const uint32_t *__restrict__ codes,
-                                                             uint8_t *__restrict__ out, uint64_t *__restrict__ dbg) {
+                                                             uint8_t *__restrict__ out, uint32_t njobs,
+                                                             uint64_t *__restrict__ dbg) {
     __shared__ __attribute__((aligned(16))) unsigned char ring[MWIN];
-    const uint32_t bidx = blockIdx.x / MAX_UNITS, u = blockIdx.x % MAX_UNITS;
+    // unit-major: workgroups go round-robin to the 8 XCDs, so consecutive indices must all carry work (with
+    // a block-major order the real units sit at indices = 0..3 mod 8 and half of the XCDs stay idle)
+    const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;
     const BlkEmit job = jobs[bidx];
     const uint32_t lane = threadIdx.x;
     if (job.btype == 0) {
@@ -798,7 +802,10 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     uint64_t produced = 0, flushed = 0;
     uint32_t base = 0;
     uint32_t c_cur = lane < n ? cp[lane] : 0;
+    const uint64_t t0 = clock64();
+    uint64_t nbatch = 0, nseq = 0, t_seq = 0;
     while (base < n) {
+        nbatch++;
         const uint32_t i = base + lane;
         const uint32_t c_pref = i + 64 < n ? cp[i + 64] : 0;   // next batch's code words, assuming 64 are taken
         const uint32_t c = c_cur;
@@ -843,6 +850,8 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
         }
         __builtin_amdgcn_wave_barrier();
         uint64_t mm = __ballot(is_match && !par);
+        nseq += __popcll(mm);
+        const uint64_t ts0 = clock64();
         while (mm) {
             const uint32_t sl = (uint32_t)__builtin_ctzll(mm);
             mm &= mm - 1;
@@ -858,10 +867,11 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
                 for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k % d)];
             }
         }
+        t_seq += clock64() - ts0;
         produced += total;
         base += take;
         __builtin_amdgcn_wave_barrier();
-        // flush early and often: history (32 KiB) + in flight (7 KiB) + unflushed must fit the ring
+        // flush early and often: the ring holds the 32 KiB history in front of the batch plus the batch itself (<= 4 KiB)
         const bool last = base >= n;
         if (produced - flushed >= 512 || last) {
             const uint64_t upto = produced;
@@ -882,7 +892,10 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
         }
         c_cur = take == 64 ? c_pref : (base + lane < n ? cp[base + lane] : 0);   // rare path: reload
     }
-    (void)dbg;
+    if (dbg && lane == 0) {
+        uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
+        d[0] = clock64() - t0; d[1] = nbatch; d[2] = nseq; d[3] = t_seq; d[4] = n; d[5] = produced; d[6] = wall_clock64();
+    }
 }
 
 // block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
@@ -971,7 +984,7 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), 0, st, in, jobs, lanes, units, codes, out, dbg);
+    hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), 0, st, in, jobs, lanes, units, codes, out, njobs, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -13,7 +13,7 @@ from libflate_amd import _ffi
 import synth
 ctx = libflate_amd.Context(0)
 ctx.enable_timing(True)
-for mib in (8, 64):
+for mib in (8, 256):
     n = mib << 20
     data = synth.text(n)
     d_in = torch.from_numpy(data).cuda()
