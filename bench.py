@@ -25,6 +25,26 @@ WRITE = 8192
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 
 
+# phase (HIP-event bracket in the library) -> the kernel that fills it
+PHASE_KERNEL = {"enc:lz77_match": "lz77_match_kernel", "dec:lz77_copy": "blk_materialize_kernel",
+                "dec:blk_scan": "blk_scan_kernel", "dec:blk_emit": "blk_emit_kernel"}
+
+
+def hbm_traffic(phase, n):
+    """HBM bytes per launch of the phase's kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, gfx950 x2 correction on FETCH_SIZE: profiles/r01_hbm_traffic.json).
+    Only valid for the workload it was measured on; None otherwise."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("workload_bytes") != n:
+            return None
+        return t["kernels"][PHASE_KERNEL[phase]]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +190,7 @@ def main():
     if dom:
         ach = algo_bytes / (avg[dom] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": hbm_traffic(dom, n),
                 "avg_launch_ms": round(avg[dom], 4), "algorithmic_bytes": algo_bytes}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
