@@ -263,6 +263,11 @@ struct FastBits {
     }
 };
 
+constexpr uint32_t EMIT_STAGE = 16;            // code words staged per lane
+constexpr uint32_t EMIT_STRIDE = EMIT_STAGE + 1;   // row stride in dwords (odd: conflict-free across lanes)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) U32x4 { u32x4 v; };   // 16-byte store at any dword address
+
 // One lane decodes symbols from bit `start` until a symbol would start at or after `limit`, or
 // EndOfBlock.  EMIT: write code words.  Returns 0 ok / 1 EOB / 2 undecodable; `endpos` = bit reached.
 // EMIT also tracks the earliest cut of the slice: (cut_code, cut_out) = first code / byte such that no later
@@ -271,8 +276,13 @@ struct FastBits {
 template <bool EMIT>
 __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
                                            uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
-                                           int64_t &reach, uint64_t &endpos, uint32_t &cut_code, uint32_t &cut_out) {
+                                           int64_t &reach, uint64_t &endpos, uint32_t &cut_code, uint32_t &cut_out,
+                                           uint32_t *stage = nullptr) {
+    // EMIT: code words are staged in this lane's LDS row (EMIT_STAGE entries) and written out as runs of
+    // 16-byte stores whenever the wavefront pauses to refill its bit FIFOs — a lane's 4-byte stores, each
+    // to a cache line of its own, cost ~6x their size in HBM traffic (partial-line evictions).
     FastBits b;
+    uint32_t staged = 0;
     b.init(in, nbytes, start);
     const uint64_t span = limit > start ? limit - start : 0;
     const uint32_t lim = span > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)span;
@@ -280,7 +290,7 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
     uint32_t no = 0;   // bytes produced by this call (added to nout at the end)
     while (b.used < lim && ret == 0) {
         // each symbol takes at most two dwords from the FIFO
-        while (b.qn >= 2 && b.used < lim) {
+        while (b.qn >= 2 && b.used < lim && (!EMIT || staged < EMIT_STAGE)) {
             b.append();
             uint32_t e = T.lit[(uint32_t)b.buf & ((1u << LIT_BITS) - 1)];
             if (__builtin_expect((e & 15) == 0, 0)) {
@@ -290,7 +300,7 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
             const uint32_t kind = (e >> 4) & 3;
             if (kind == K_LIT) {
                 b.skip(e & 15);
-                if (EMIT) codes[ncodes] = e & 0x00FF0000u;
+                if (EMIT) stage[staged++] = e & 0x00FF0000u;
                 ncodes++;
                 no++;
                 continue;
@@ -309,13 +319,32 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
             const uint32_t distance = (d >> 16) + (((uint32_t)(b.buf >> dw)) & ((1u << db) - 1));
             b.skip(dw + db);
             if (EMIT) {
-                codes[ncodes] = (length << 16) | distance;
+                stage[staged++] = (length << 16) | distance;
                 const int64_t srcpos = (int64_t)(nout + no) - (int64_t)distance;   // first byte this match reads
                 if (srcpos < reach) reach = srcpos;
                 if ((int32_t)no - (int32_t)distance < (int32_t)cut_out) { cut_code = ncodes + 1; cut_out = no + length; }
             }
             ncodes++;
             no += length;
+        }
+        if (EMIT) {
+            uint32_t *dst = codes + (ncodes - staged);
+            for (uint32_t j = 0; j < EMIT_STAGE; j += 4) {
+                if (__ballot(j < staged) == 0) break;
+                if (j < staged) {
+                    const uint32_t c0 = stage[j], c1 = stage[j + 1], c2 = stage[j + 2], c3 = stage[j + 3];
+                    if (j + 4 <= staged) {
+                        U32x4 q;
+                        q.v = u32x4{c0, c1, c2, c3};
+                        *(U32x4 *)(dst + j) = q;
+                    } else {
+                        dst[j] = c0;
+                        if (j + 1 < staged) dst[j + 1] = c1;
+                        if (j + 2 < staged) dst[j + 2] = c2;
+                    }
+                }
+            }
+            staged = 0;
         }
         if (ret == 0 && b.used < lim && b.qn < 2) b.reload();
     }
@@ -638,6 +667,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
+    extern __shared__ uint32_t emit_stage[];   // SCAN_THREADS rows of EMIT_STRIDE dwords
     const uint32_t tid = threadIdx.x;
     const BlkEmit job = jobs[blockIdx.x];
     BlkUnits *U = &units[blockIdx.x];
@@ -658,7 +688,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *_
         uint32_t nc = 0, cc = 0, co = 0;
         const uint64_t out0 = L->out_off[tid];   // bytes of this block produced before my slice
         uint64_t no = out0, endpos;
-        lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co);
+        lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
+                          emit_stage + tid * EMIT_STRIDE);
         if (reach < 0) atomicOr(&flags[0], 1u);   // a back-reference reaches before the block start
         if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
     }
@@ -975,7 +1006,13 @@ int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, lanes, codes, flags, units,
+    constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)blk_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes, flags, units,
                        unit_target ? unit_target : 1u);
     LFX_LAUNCH_CHECK();
     return 0;
