@@ -929,6 +929,31 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     }
 }
 
+// Per-lane decode table of a COMPLETE code-length code (stage 1 of the finder guarantees completeness):
+// entry e of lane l lives at tab[e * 64 + l] (consecutive lanes in consecutive bytes) and holds
+// symbol | width << 5 for the 7 stream bits e.  Canonical codes (symbol.rs:354-369) are assigned per width
+// in symbol order; a code of width w owns the 2^(7-w) entries whose low w bits are its reversed bits.
+__device__ __forceinline__ void clen_table_build(uint8_t *tab, uint32_t lane, uint64_t clw) {
+    uint64_t cnt = 0;   // symbols per width, 5 bits at 5*w
+    for (uint32_t s = 0; s < 19; ++s) { const uint32_t w = (uint32_t)(clw >> (3 * s)) & 7; if (w) cnt += 1ull << (5 * w); }
+    uint64_t next = 0;  // next code per width, 8 bits at 8*w
+    uint32_t code = 0;
+    for (uint32_t w = 1; w <= 7; ++w) {
+        code <<= 1;
+        next |= (uint64_t)code << (8 * w);
+        code += (uint32_t)(cnt >> (5 * w)) & 31;
+    }
+    for (uint32_t s = 0; s < 19; ++s) {
+        const uint32_t w = (uint32_t)(clw >> (3 * s)) & 7;
+        if (w == 0) continue;
+        const uint32_t c = (uint32_t)(next >> (8 * w)) & 255;
+        next += 1ull << (8 * w);
+        const uint32_t r = __brev(c) >> (32 - w);
+        const uint8_t e = (uint8_t)(s | w << 5);
+        for (uint32_t i = r; i < 128; i += 1u << w) tab[i * 64 + lane] = e;
+    }
+}
+
 // block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
 // decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length code must be
 // complete and the distance code complete, single or empty.
@@ -948,17 +973,17 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
     const uint32_t nl = bits(5) + 257, nd = bits(5) + 1, nc = bits(4) + 4;
     uint64_t clw = 0;
     for (uint32_t k = 0; k < nc; ++k) clw |= (uint64_t)bits(3) << (3 * clen_order(k));
-    ClenCode cc;
-    cc.build(clw);
+    __shared__ uint8_t cl_tab[128 * 64];
+    clen_table_build(cl_tab, threadIdx.x, clw);
     uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
     const uint32_t total = nl + nd;
     bool good = !hb.bad;
     while (have < total && good) {
         if (hb.b.pos >= hb.nbits) { good = false; break; }
         hb.b.refill();
-        uint32_t used = 0;
-        const uint32_t sym = cc.decode((uint32_t)hb.b.buf & 127, used);
-        if (sym == 99 || hb.b.pos + used > hb.nbits) { good = false; break; }
+        const uint32_t e = cl_tab[((uint32_t)hb.b.buf & 127) * 64 + threadIdx.x];
+        const uint32_t sym = e & 31, used = e >> 5;
+        if (hb.b.pos + used > hb.nbits) { good = false; break; }
         hb.b.skip(used);
         uint32_t rep = 1, val = sym;
         if (sym == 16) { if (have == 0) { good = false; break; } rep = 3 + bits(2); val = last; }
@@ -976,6 +1001,9 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
         }
         have += rep;
         last = val;
+        // the literal/length widths are complete once `have` passes HLIT+257: nearly every false candidate
+        // ends here (its code is not Kraft-complete) instead of after the distance widths
+        if (have >= nl && have - rep < nl && !(kl == 32768u || (nlit == 1 && kl == 16384u))) { good = false; break; }
     }
     if (hb.bad) good = false;
     if (good) {
