@@ -336,24 +336,35 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restr
     uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
     if (ch.flags & CH_LITERALS) return;   // no walk: every byte is a literal
     uint32_t pos = s0, cnt = 0;
-    uint32_t v_next = s0 + lane < end ? md[ch.in_off + s0 + lane] : 0;   // answers are prefetched one group ahead
+    // answers are prefetched four groups ahead (a group's walk is much shorter than an HBM round trip)
+    auto fetch = [&](uint32_t g) -> uint32_t {
+        const uint32_t i = s0 + g * 64 + lane;
+        return (g < PARSE_SEG / 64 && i < end) ? md[ch.in_off + i] : 0;
+    };
+    uint32_t v0 = fetch(0), v1 = fetch(1), v2 = fetch(2), v3 = fetch(3);
     for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
         const uint32_t base = s0 + g * 64;
         uint64_t m = 0;
-        const uint32_t v = v_next;
-        {
-            const uint32_t in2 = base + 64 + lane;
-            v_next = (g + 1 < PARSE_SEG / 64 && in2 < end) ? md[ch.in_off + in2] : 0;
-        }
+        const uint32_t v = v0;
+        v0 = v1; v1 = v2; v2 = v3;
+        v3 = fetch(g + 4);
         if (base < end) {
-            // the scalar unit is shared by the whole CU: keep the serial loop at readlane / bitset /
-            // add / compare by precomputing every position's step on the vector side
+            // The scalar unit is shared by the whole CU and the walk is a chain of dependent steps: the
+            // vector side precomputes, for every position, where TWO steps lead (one ds_bpermute) and the
+            // two bits they visit, so that the serial loop is three readlanes per two steps.
             const uint32_t stepv = (v & 0xFFFFu) ? (v >> 16) : 1u;
             const uint32_t stop_r = min(base + 64, end) - base;
+            const uint32_t j1 = lane + stepv;                       // group-relative position after one step
+            const bool in1 = j1 < stop_r;                           // ... still inside the group
+            const uint32_t j1n = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((in1 ? j1 : lane) << 2), (int)j1);
+            const uint32_t j2 = in1 ? j1n : j1;
+            uint32_t klo = lane < 32 ? 1u << lane : 0u, khi = lane >= 32 ? 1u << (lane - 32) : 0u;
+            if (in1) { if (j1 < 32) klo |= 1u << j1; else khi |= 1u << (j1 - 32); }
             uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
             while (r < stop_r) {
-                m |= 1ull << r;
-                r += __builtin_amdgcn_readlane(stepv, r);
+                m |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)klo, r) |
+                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, r) << 32;
+                r = (uint32_t)__builtin_amdgcn_readlane((int)j2, r);
             }
             pos = base + r;
         }
