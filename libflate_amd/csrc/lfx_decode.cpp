@@ -158,10 +158,13 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 for (uint32_t i = 0; i < nc; i++) len[i] = bj[i].end_bit - bj[i].start_bit;
                 std::vector<uint64_t> sorted = len;
                 std::nth_element(sorted.begin(), sorted.begin() + nc / 2, sorted.end());
-                const uint64_t thresh = sorted[nc / 2] / 5 * 3;
+                const uint64_t median = sorted[nc / 2], thresh = median / 5 * 3;
                 const uint32_t max_extra = nc / 4 + 4;
                 for (uint32_t i = 0; i + 1 < nc && bj.size() - nc < max_extra; i++) {
                     if (len[i] >= thresh && len[i + 1] >= thresh) continue;
+                    // a block cut in two is about one block long when put together; anything much longer
+                    // would only be a slow job that decides the kernel's duration
+                    if (len[i] + len[i + 1] > median + median / 4) continue;
                     alt[i] = (int32_t)bj.size();
                     bj.push_back(BlkJob{starts[i], start_at(i + 2)});
                 }

@@ -263,7 +263,7 @@ struct FastBits {
     }
 };
 
-constexpr uint32_t EMIT_STAGE = 16;            // code words staged per lane
+constexpr uint32_t EMIT_STAGE = 8;             // code words staged per lane (two workgroups' staging must fit one CU)
 constexpr uint32_t EMIT_STRIDE = EMIT_STAGE + 1;   // row stride in dwords (odd: conflict-free across lanes)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(4))) U32x4 { u32x4 v; };   // 16-byte store at any dword address
@@ -493,7 +493,9 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
 
 // ------------------------------------------------------------------------------------------------
 // K1: speculative scan of one candidate block: validated per-lane starts, code and byte counts
-__global__ __launch_bounds__(SCAN_THREADS) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+// (two workgroups per CU: a stream has a few more candidate blocks than the GPU has CUs, and a second
+// round of workgroups would double the kernel's time — 8 waves per SIMD = at most 64 VGPRs)
+__global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkJob *__restrict__ jobs,
                                                                 BlkInfo *__restrict__ infos,
                                                                 BlkLanes *__restrict__ lanes) {
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_scan_kernel(const uint8_t *_
 // default.rs:73) so that K3 can materialise them concurrently.
 constexpr uint32_t MAX_UNITS = 8;
 
-__global__ __launch_bounds__(SCAN_THREADS) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+__global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkEmit *__restrict__ jobs,
                                                                 const BlkLanes *__restrict__ lanes,
                                                                 uint32_t *__restrict__ codes,
