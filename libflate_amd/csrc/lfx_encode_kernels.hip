@@ -160,7 +160,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
 
     for (int it = -2; it < (int)ntiles; ++it) {
-        const uint64_t c0 = clock64();
+        const uint64_t c0 = dbg ? clock64() : 0;
         const uint32_t t_res = base + (uint32_t)it * MTILE;              // tile being resolved (it >= 0)
         const uint32_t link_idx = (uint32_t)(it + 1);                    // tile being inserted (it >= -1)
         const uint32_t t_link = base + link_idx * MTILE;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
             swept_at = t_link;
         }
         lds_barrier();
-        const uint64_t c1 = clock64();
+        const uint64_t c1 = dbg ? clock64() : 0;
         if (wave == 0) {
             if (do_link) {
                 // Duplicate collapsing: when the bucket head carries the SAME prefix as this position
@@ -293,9 +293,9 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
             }
             predigest(pre_idx);
         }
-        const uint64_t c2 = clock64();
+        const uint64_t c2 = dbg ? clock64() : 0;
         lds_barrier();
-        const uint64_t c3 = clock64();
+        const uint64_t c3 = dbg ? clock64() : 0;
         cy_load += c1 - c0; cy_work += c2 - c1; cy_wait += c3 - c2;
     }
     if (dbg && blockIdx.x == 0 && lane == 0) {

@@ -835,8 +835,8 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     uint64_t produced = 0, flushed = 0;
     uint32_t base = 0;
     uint32_t c_cur = lane < n ? cp[lane] : 0;
-    const uint64_t t0 = clock64();
-    uint64_t nbatch = 0, nseq = 0, t_seq = 0;
+    const uint64_t t0 = dbg ? clock64() : 0;
+    uint32_t nbatch = 0;
     while (base < n) {
         nbatch++;
         const uint32_t i = base + lane;
@@ -883,8 +883,6 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
         }
         __builtin_amdgcn_wave_barrier();
         uint64_t mm = __ballot(is_match && !par);
-        nseq += __popcll(mm);
-        const uint64_t ts0 = clock64();
         while (mm) {
             const uint32_t sl = (uint32_t)__builtin_ctzll(mm);
             mm &= mm - 1;
@@ -900,7 +898,6 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
                 for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k % d)];
             }
         }
-        t_seq += clock64() - ts0;
         produced += total;
         base += take;
         __builtin_amdgcn_wave_barrier();
@@ -927,7 +924,7 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     }
     if (dbg && lane == 0) {
         uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
-        d[0] = clock64() - t0; d[1] = nbatch; d[2] = nseq; d[3] = t_seq; d[4] = n; d[5] = produced; d[6] = wall_clock64();
+        d[0] = clock64() - t0; d[1] = nbatch; d[2] = 0; d[3] = 0; d[4] = n; d[5] = produced; d[6] = wall_clock64();
     }
 }
 
