@@ -88,6 +88,15 @@ __device__ __forceinline__ uint32_t wring_off(uint32_t pos) {
     const uint32_t q = (uint32_t)(((uint64_t)x * 954437177ull) >> 33);  // x / 9
     return ((x - q * 9) << 12) | (pos & 4095);
 }
+// ring arithmetic without divisions (v_mul_hi is quarter rate): offsets are derived from one per-tile
+// offset by adding a lane index or subtracting a distance (<= 32768, smaller than either ring)
+__device__ __forceinline__ uint32_t ring_fwd(uint32_t off, uint32_t add, uint32_t size) {   // add < size
+    const uint32_t r = off + add;
+    return r >= size ? r - size : r;
+}
+__device__ __forceinline__ uint32_t ring_back(uint32_t off, uint32_t sub, uint32_t size) {  // sub < size
+    return off >= sub ? off - sub : off + size - sub;
+}
 __device__ __forceinline__ uint32_t win_at(const uint32_t *win32, uint32_t off) {
     // 4 bytes at ring byte offset `off` (the 8 mirror bytes after the ring make the wrap seamless)
     const uint32_t w0 = win32[off >> 2], w1 = win32[(off >> 2) + 1];
@@ -194,9 +203,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                 // frequent one no longer walks through hundreds of useless entries.
                 const uint32_t *stl = st_k + (link_idx & 1) * MTILE;
                 uint16_t *cdw = cd + (link_idx & 1) * MTILE;
+                const uint32_t w_link = wring_off(t_link), s_link = t_link % PRING;   // wave-uniform
                 for (uint32_t sub = 0; sub < NSUB; ++sub) {
                     const uint32_t idx = sub * 64 + lane;
                     const uint32_t p = t_link + idx;
+                    const uint32_t w_p = ring_fwd(w_link, idx, WRING), s_p = ring_fwd(s_link, idx, PRING);
                     const uint32_t sk = stl[idx];
                     if (sk != 0xFFFFFFFFu) {
                         const uint32_t key = sk & 0xFFFFFFu, f = sk >> 24, hh = hash3(key);
@@ -204,17 +215,16 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                         if (pd == 0) {
                             const uint32_t d = (p - head[hh]) & 0xFFFFu;
                             if (d != 0 && d <= MAX_WINDOW) {
-                                const uint32_t q = p - d;
                                 pd = d;
-                                if ((win_at(win32, wring_off(q)) & 0xFFFFFFu) == key) {
+                                if ((win_at(win32, ring_back(w_p, d, WRING)) & 0xFFFFFFu) == key) {
                                     cdv = d;
-                                    const uint32_t pq = prevd[q % PRING];
+                                    const uint32_t pq = prevd[ring_back(s_p, d, PRING)];
                                     pd = pq ? d + pq : 0;
                                     if (pd > MAX_WINDOW) pd = 0;
                                 }
                             }
                         }
-                        prevd[p % PRING] = (uint16_t)pd;
+                        prevd[s_p] = (uint16_t)pd;
                         cdw[idx] = (uint16_t)cdv;
                         if (f & 0x80) head[hh] = (uint16_t)p;   // last lane with this hash
                     }
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
             }
         } else {
             if (it >= 0) {
+            const uint32_t w_res = wring_off(t_res), s_res = t_res % PRING;   // wave-uniform
             const uint32_t pos = t_res + (wave - 1) * 64 + lane;
             const bool act = pos >= q0 && pos < q1;
             uint32_t dist = 0, l = 0, lim = 0, oa = 0, ob = 0;
@@ -229,24 +240,25 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
             if (act) {
                 // resolve: walk the hash chain until the exact 3-byte prefix matches (the most recent
                 // occurrence) or the chain leaves the window
-                const uint32_t key = win_at(win32, wring_off(pos)) & 0xFFFFFFu;
+                const uint32_t w_pos = ring_fwd(w_res, (wave - 1) * 64 + lane, WRING);
+                const uint32_t s_pos = ring_fwd(s_res, (wave - 1) * 64 + lane, PRING);
+                const uint32_t key = win_at(win32, w_pos) & 0xFFFFFFu;
                 const uint32_t known = cd[((uint32_t)it & 1) * MTILE + (wave - 1) * 64 + lane];
-                uint32_t d = prevd[pos % PRING];
+                uint32_t d = prevd[s_pos];
                 if (known) { dist = known; found = dist <= window; d = 0; }
                 while (d != 0) {
                     dist += d;
                     hops++;
                     if (dist > window || dist > pos) break;  // default.rs:81 (inclusive window)
-                    const uint32_t j = pos - dist;
-                    if ((win_at(win32, wring_off(j)) & 0xFFFFFFu) == key) { found = true; break; }
-                    d = prevd[j % PRING];
+                    if ((win_at(win32, ring_back(w_pos, dist, WRING)) & 0xFFFFFFu) == key) { found = true; break; }
+                    d = prevd[ring_back(s_pos, dist, PRING)];
                 }
                 if (found) {
                     // longest_common_prefix default.rs:122-129: up to max_len-3 more bytes, bounded by
                     // the end of the chunk.  Phase 1: the first 16 bytes, every lane on its own.
                     lim = n - (pos + 3);
                     if (lim > max_len - 3) lim = max_len - 3;
-                    oa = wring_off(pos + 3); ob = wring_off(pos - dist + 3);
+                    oa = ring_fwd(w_pos, 3, WRING); ob = ring_back(oa, dist, WRING);
                     while (l < lim && l < 16) {
                         const uint32_t x = win_at(win32, oa) ^ win_at(win32, ob);
                         if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
