@@ -82,3 +82,36 @@ def test_s1_single_write_multi_segment(env, oracle):
     got = ctx.encode_host(ffi.GZIP, data, ffi.make_opts(), ffi.make_schedule(0))
     assert got == oracle.encode(oracle.GZIP, data, write_size=0)
     assert ctx.decode_host(ffi.GZIP, got)[:2] == (0, data)
+
+
+def test_cfg3_batch_4096_streams(env, oracle):
+    """BASELINE cfg3 at full size: 4096 independent 64 KiB zlib streams, half made by the restated reference
+    encoder (one dynamic block + the empty final block each), half by python zlib level 6 (foreign encoder);
+    bytes and Adler-32 verified (a checksum mismatch would surface as a status)."""
+    import time
+    import torch
+    ctx, ffi, synth = env
+    count, size = 4096, 65536
+    big = synth.text(count * size, seed=0x5EED0003)
+    plains = [big[i * size:(i + 1) * size].tobytes() for i in range(count)]
+    streams = [oracle.encode(oracle.ZLIB, p) if i % 2 else pyzlib.compress(p, 6) for i, p in enumerate(plains)]
+    blob = b"".join(streams)
+    in_len = np.array([len(s) for s in streams], dtype=np.uint64)
+    in_off = (np.cumsum(in_len) - in_len).astype(np.uint64)
+    out_off = (np.arange(count, dtype=np.uint64) * size)
+    out_cap = np.full(count, size, dtype=np.uint64)
+    d_in = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(count * size, dtype=torch.uint8, device="cuda")
+    out_len = np.zeros(count, dtype=np.uint64)
+    status = np.zeros(count, dtype=np.int32)
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = ffi.lib().lfx_decode_batch_device(ctx.handle, ffi.ZLIB, count, d_in.data_ptr(), in_off.ctypes.data,
+                                               in_len.ctypes.data, d_out.data_ptr(), out_off.ctypes.data,
+                                               out_cap.ctypes.data, out_len.ctypes.data, status.ctypes.data)
+        dt = time.perf_counter() - t0
+    assert rc == 0
+    assert not status.any() and (out_len == size).all()
+    assert torch.equal(d_out, torch.from_numpy(big).cuda())
+    print("cfg3: %d streams, %.1f ms, %.2f GB/s of output" % (count, dt * 1e3, count * size / dt / 1e9))
