@@ -79,7 +79,7 @@ constexpr int HASH_BITS = 14;
 constexpr uint32_t PRING = 32768 + 2048;        // prevd ring (entries)
 constexpr uint32_t WRING = 36864;               // window ring (bytes), multiple of 4096
 constexpr uint32_t HEAD_FAR = 40000;            // distance marker of a swept head entry
-constexpr size_t MATCH_LDS = (2u << HASH_BITS) + PRING * 2 + WRING + 8 + 2 * MTILE * 4 + MTILE * 4;
+constexpr size_t MATCH_LDS = (2u << HASH_BITS) + PRING * 2 + WRING + 8 + 3 * MTILE * 4 + MTILE * 4 + MTILE * 4 + MTILE * 4;
 
 __device__ __forceinline__ uint32_t hash3(uint32_t key) { return (key * 2654435761u) >> (32 - HASH_BITS); }
 __device__ __forceinline__ uint32_t wring_off(uint32_t pos) {
@@ -116,7 +116,13 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     uint32_t *st_k = (uint32_t *)(smem + (2u << HASH_BITS) + PRING * 2 + WRING + 8);
     // cd[parity][idx]: distance to the most recent same-prefix position when the insertion already
     // knows it (0 = the resolver has to walk the chain)
-    uint16_t *cd = (uint16_t *)(st_k + 2 * MTILE);
+    uint16_t *cd = (uint16_t *)(st_k + 3 * MTILE);
+    // hvs[parity][idx]: the bucket head every position of a tile saw in the ordered head pass
+    uint16_t *hvs = cd + 2 * MTILE;
+    // lk[idx]: link state of the tile being finalized: LK_DONE | distance to the link target (0 = none), or
+    // the in-tile index of the same-prefix predecessor whose link this position inherits
+    uint32_t *lk = (uint32_t *)(hvs + 2 * MTILE);
+    constexpr uint32_t LK_DONE = 0x80000000u;
 
     const SegDesc sg = segs[blockIdx.x];
     const ChunkDesc ch = chunks[sg.chunk];
@@ -137,13 +143,24 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     uint32_t swept_at = base;
     uint64_t cy_load = 0, cy_work = 0, cy_wait = 0, hops = 0, lcps = 0;
 
-    // Pipeline, three stages one tile apart.  Iteration `it`:
-    //   resolvers (waves 1..15): resolve(tile it) ; pre-digest(tile it+2)
-    //   wave 0                 : ordered insert of tile it+1
-    // pre-digest : 3-byte prefix, nearest lower same-hash lane by ballots, flags       (parallel)
-    // insert     : head read → prev link → head write, sub-tile by sub-tile             (ordered)
-    // resolve    : chain walk + match length                                            (parallel)
-    // One barrier per tile; the ordered insert is the critical path, so wave 0 runs at raised priority.
+    // Pipeline, four stages one tile apart, two barriers per iteration `it`:
+    //   before the first barrier : window extension, head sweep, finalize-init(tile it+1)
+    //   wave 0                   : ordered head pass of tile it+2
+    //   waves 1..15              : finalize-jump(tile it+1) ; resolve(tile it) ; pre-digest(tile it+3)
+    // pre-digest : 3-byte prefix, nearest lower same-hash lane by 14 ballots, flags           (parallel)
+    // head pass  : head read → head write per 64-position sub-tile, in order — the only serial part of the
+    //              insertion.  A head write does not depend on the read before it and the LDS executes a
+    //              wavefront's operations in order: the 15 read/write pairs are issued back to back.
+    // finalize   : every position now knows its raw predecessor ph (most recent earlier position with the
+    //              same hash).  Duplicate collapsing: when ph carries the SAME prefix it is this position's
+    //              answer (cd, no walk later) and the position's chain link is ph's own link — an older
+    //              occurrence of the same prefix can never be an answer again, so chains hold one entry
+    //              per run of equal prefixes and a rare prefix that shares a bucket with a frequent one
+    //              does not walk through hundreds of useless entries.  link(p) = link(ph) is resolved
+    //              without any ordering: predecessors in older tiles are final (one read); inside the tile
+    //              by pointer jumping over lk[] (log rounds, no barrier: every state a reader can see is
+    //              valid, and the oldest member of a run is final from the start).
+    // resolve    : chain walk + match length                                                  (parallel)
     constexpr uint32_t NSUB = MTILE / 64;
     auto predigest = [&](uint32_t tile_idx) {
         const uint32_t idx = (wave - 1) * 64 + lane;
@@ -164,17 +181,20 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
         uint32_t f = lower ? lane - hb : 0;                 // 1..63, 0 = none in this sub-tile
         if (lower && kprev == key) f |= 0x40;               // ... and it has the same 3-byte prefix
         if (((same >> lane) >> 1) == 0) f |= 0x80;          // last lane with this hash
-        st_k[(tile_idx & 1) * MTILE + idx] = v ? (key | (f << 24)) : 0xFFFFFFFFu;
+        st_k[(tile_idx % 3) * MTILE + idx] = v ? (key | (f << 24)) : 0xFFFFFFFFu;
     };
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
 
-    for (int it = -2; it < (int)ntiles; ++it) {
+    for (int it = -3; it < (int)ntiles; ++it) {
         const uint64_t c0 = dbg ? clock64() : 0;
         const uint32_t t_res = base + (uint32_t)it * MTILE;              // tile being resolved (it >= 0)
-        const uint32_t link_idx = (uint32_t)(it + 1);                    // tile being inserted (it >= -1)
-        const uint32_t t_link = base + link_idx * MTILE;
-        const bool do_link = it >= -1 && link_idx < ntiles;
-        const uint32_t pre_idx = (uint32_t)(it + 2);                     // tile being pre-digested
+        const uint32_t fin_idx = (uint32_t)(it + 1);                     // tile being finalized (it >= -1)
+        const uint32_t t_fin = base + fin_idx * MTILE;
+        const bool do_fin = it >= -1 && fin_idx < ntiles;
+        const uint32_t head_idx = (uint32_t)(it + 2);                    // tile of the head pass (it >= -2)
+        const uint32_t t_head = base + head_idx * MTILE;
+        const bool do_head = it >= -2 && head_idx < ntiles;
+        const uint32_t pre_idx = (uint32_t)(it + 3);                     // tile being pre-digested
         // ---- A: everyone extends the window to cover the pre-digest tile (+3 bytes)
         const uint32_t need = min(base + pre_idx * MTILE + MTILE + 4, (n + 3) & ~3u);
         for (uint32_t p = loaded_to + 4 * tid; p < need; p += 4 * MATCH_THREADS) {
@@ -184,53 +204,79 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
             if (o < 8) win32[(WRING + o) >> 2] = v;   // mirror
         }
         if (need > loaded_to) loaded_to = need;
-        if (do_link && t_link + MTILE - swept_at > 16384) {
+        if (do_head && t_head + MTILE - swept_at > 16384) {
             // stale heads (older than the window) → "far", so that 16-bit distances never alias
             for (uint32_t i = tid; i < (1u << HASH_BITS); i += MATCH_THREADS) {
-                const uint32_t d = (t_link - head[i]) & 0xFFFFu;
-                if (d == 0 || d > MAX_WINDOW) head[i] = (uint16_t)(t_link - HEAD_FAR);
+                const uint32_t d = (t_head - head[i]) & 0xFFFFu;
+                if (d == 0 || d > MAX_WINDOW) head[i] = (uint16_t)(t_head - HEAD_FAR);
             }
-            swept_at = t_link;
+            swept_at = t_head;
+        }
+        // finalize-init: raw predecessor, known answer, first link state
+        const uint32_t fidx = (wave - 1) * 64 + lane;
+        bool fin_valid = false;
+        uint32_t fin_e = LK_DONE;
+        if (wave > 0 && do_fin) {
+            const uint32_t sk = st_k[(fin_idx % 3) * MTILE + fidx];
+            if (sk != 0xFFFFFFFFu) {
+                fin_valid = true;
+                const uint32_t key = sk & 0xFFFFFFu, f = sk >> 24;
+                const uint32_t w_p = ring_fwd(wring_off(t_fin), fidx, WRING), s_p = ring_fwd(t_fin % PRING, fidx, PRING);
+                uint32_t d = f & 0x3F;                       // nearest lower same-hash lane of the sub-tile
+                bool same = (f & 0x40) != 0;
+                if (d == 0) {
+                    d = (t_fin + fidx - hvs[(fin_idx & 1) * MTILE + fidx]) & 0xFFFFu;
+                    if (d > MAX_WINDOW) d = 0;
+                    if (d) same = (win_at(win32, ring_back(w_p, d, WRING)) & 0xFFFFFFu) == key;
+                }
+                uint32_t e = LK_DONE | d;                   // a predecessor with another prefix: plain link
+                if (d && same) {
+                    if (d > fidx) {                          // the predecessor lies in an older tile: its link is final
+                        const uint32_t pq = prevd[ring_back(s_p, d, PRING)];
+                        e = LK_DONE | (pq ? d + pq : 0);
+                    } else e = fidx - d;                     // ... in this tile: inherit through pointer jumping
+                }
+                fin_e = e;
+                lk[fidx] = e;
+                cd[(fin_idx & 1) * MTILE + fidx] = (uint16_t)((d && same) ? d : 0);
+            }
         }
         lds_barrier();
         const uint64_t c1 = dbg ? clock64() : 0;
         if (wave == 0) {
-            if (do_link) {
-                // Duplicate collapsing: when the bucket head carries the SAME prefix as this position
-                // it is this position's answer (cd), and the new link bypasses it — an older
-                // occurrence of the same prefix can never be an answer again.  Chains therefore hold
-                // about one entry per distinct prefix and a rare prefix that shares a bucket with a
-                // frequent one no longer walks through hundreds of useless entries.
-                const uint32_t *stl = st_k + (link_idx & 1) * MTILE;
-                uint16_t *cdw = cd + (link_idx & 1) * MTILE;
-                const uint32_t w_link = wring_off(t_link), s_link = t_link % PRING;   // wave-uniform
+            if (do_head) {
+                const uint32_t *stl = st_k + (head_idx % 3) * MTILE;
+                uint16_t *hv_out = hvs + (head_idx & 1) * MTILE;
+                uint32_t hvv[NSUB];
+#pragma unroll
                 for (uint32_t sub = 0; sub < NSUB; ++sub) {
-                    const uint32_t idx = sub * 64 + lane;
-                    const uint32_t p = t_link + idx;
-                    const uint32_t w_p = ring_fwd(w_link, idx, WRING), s_p = ring_fwd(s_link, idx, PRING);
-                    const uint32_t sk = stl[idx];
-                    if (sk != 0xFFFFFFFFu) {
-                        const uint32_t key = sk & 0xFFFFFFu, f = sk >> 24, hh = hash3(key);
-                        uint32_t pd = f & 0x3F, cdv = (f & 0x40) ? pd : 0;
-                        if (pd == 0) {
-                            const uint32_t d = (p - head[hh]) & 0xFFFFu;
-                            if (d != 0 && d <= MAX_WINDOW) {
-                                pd = d;
-                                if ((win_at(win32, ring_back(w_p, d, WRING)) & 0xFFFFFFu) == key) {
-                                    cdv = d;
-                                    const uint32_t pq = prevd[ring_back(s_p, d, PRING)];
-                                    pd = pq ? d + pq : 0;
-                                    if (pd > MAX_WINDOW) pd = 0;
-                                }
-                            }
-                        }
-                        prevd[s_p] = (uint16_t)pd;
-                        cdw[idx] = (uint16_t)cdv;
-                        if (f & 0x80) head[hh] = (uint16_t)p;   // last lane with this hash
-                    }
+                    const uint32_t sk = stl[sub * 64 + lane];
+                    const uint32_t hh = hash3(sk & 0xFFFFFFu) & ((1u << HASH_BITS) - 1);
+                    hvv[sub] = head[hh];
+                    if (sk != 0xFFFFFFFFu && ((sk >> 24) & 0x80)) head[hh] = (uint16_t)(t_head + sub * 64 + lane);
                 }
+#pragma unroll
+                for (uint32_t sub = 0; sub < NSUB; ++sub) hv_out[sub * 64 + lane] = (uint16_t)hvv[sub];
             }
         } else {
+            if (do_fin) {
+                // finalize-jump: inherit the link of the same-prefix predecessor
+                uint32_t e = fin_e;
+                while (__ballot(fin_valid && !(e & LK_DONE))) {
+                    if (fin_valid && !(e & LK_DONE)) {
+                        const uint32_t eq = lk[e];          // e = in-tile index of the predecessor
+                        if (eq & LK_DONE) {
+                            const uint32_t dq = eq & ~LK_DONE;
+                            e = LK_DONE | (dq ? (fidx - e) + dq : 0);
+                        } else e = eq;
+                        lk[fidx] = e;
+                    }
+                }
+                if (fin_valid) {
+                    const uint32_t dist = e & ~LK_DONE;
+                    prevd[ring_fwd(t_fin % PRING, fidx, PRING)] = (uint16_t)(dist <= MAX_WINDOW ? dist : 0);
+                }
+            }
             if (it >= 0) {
             const uint32_t w_res = wring_off(t_res), s_res = t_res % PRING;   // wave-uniform
             const uint32_t pos = t_res + (wave - 1) * 64 + lane;
