@@ -60,6 +60,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # self-test of the N>1 path on a one-GPU box: every rank on GPU 0, the 32-byte exchange over gloo
+    one_gpu_test = os.environ.get("LFX_BENCH_ONE_GPU") == "1"
+    if one_gpu_test:
+        local = 0
     if rank == 0:
         g.build()
     dist = None
@@ -67,7 +71,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if one_gpu_test:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         dist.barrier()
     import libflate_amd
     from libflate_amd import _ffi, sharded
@@ -122,7 +129,12 @@ def main():
                                          n, int(rank == 0), int(rank == world - 1), C.byref(info)), "shard_prepare")
         mine = torch.tensor([info.total_bits, info.n_bytes, info.crc32, info.adler32], dtype=torch.int64, device=dev)
         allv = torch.empty(world * 4, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allv, mine)        # RCCL over xGMI: 32 B per rank
+        if one_gpu_test:
+            parts = [torch.empty(4, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(parts, mine.cpu())
+            allv = torch.cat(parts).to(dev)
+        else:
+            dist.all_gather_into_tensor(allv, mine)    # RCCL over xGMI: 32 B per rank
         infos = [tuple(int(x) for x in row) for row in allv.view(world, 4).cpu().tolist()]
         start_bits, combined, total_n = sharded.layout(infos, hdr_len, _ffi.GZIP)
         m = C.c_uint64(0)
@@ -170,7 +182,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if dist:
-        tt = torch.tensor([elapsed, enc_t, dec_t], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed, enc_t, dec_t], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, enc_t, dec_t = (float(x) for x in tt.cpu())
     if rank != 0:
