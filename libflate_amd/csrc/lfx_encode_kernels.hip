@@ -168,13 +168,17 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
         const bool v = tile_idx < ntiles && p >= l0 && p < q1;
         uint32_t key = 0, hh = 0;
         if (v) { key = win_at(win32, wring_off(p)) & 0xFFFFFFu; hh = hash3(key); }
-        uint64_t same = __ballot(v);
+        // match-any over the 14 hash bits: a lane differs from lane j in bit b iff ballot_b[j] != its own bit;
+        // per bit one sign-extending bit extract, one compare and one or-of-xor per 32-lane half
+        uint32_t dlo = 0, dhi = 0;
 #pragma unroll
         for (int b = 0; b < HASH_BITS; ++b) {
-            const bool bit = (hh >> b) & 1;
-            const uint64_t m = __ballot(bit);
-            same &= bit ? m : ~m;
+            const int32_t nb = ((int32_t)(hh << (31 - b))) >> 31;          // 0 or -1
+            const uint64_t m = __ballot(nb != 0);
+            dlo |= (uint32_t)m ^ (uint32_t)nb;
+            dhi |= (uint32_t)(m >> 32) ^ (uint32_t)nb;
         }
+        const uint64_t same = __ballot(v) & ~((uint64_t)dhi << 32 | dlo);
         const uint64_t lower = same & lanemask_lt();
         const uint32_t hb = lower ? 63 - __clzll(lower) : lane;
         const uint32_t kprev = __shfl(key, hb);
