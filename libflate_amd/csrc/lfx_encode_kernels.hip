@@ -141,7 +141,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     for (uint32_t i = tid; i < (1u << HASH_BITS); i += MATCH_THREADS) head[i] = (uint16_t)(base - HEAD_FAR);
     uint32_t loaded_to = base;      // window holds [.., loaded_to)
     uint32_t swept_at = base;
-    uint64_t cy_load = 0, cy_work = 0, cy_wait = 0, hops = 0, lcps = 0;
+    uint64_t cy_load = 0, cy_work = 0, cy_wait = 0;
 
     // Pipeline, four stages one tile apart, two barriers per iteration `it`:
     //   before the first barrier : window extension, head sweep, finalize-init(tile it+1)
@@ -292,13 +292,14 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                 // occurrence) or the chain leaves the window
                 const uint32_t w_pos = ring_fwd(w_res, (wave - 1) * 64 + lane, WRING);
                 const uint32_t s_pos = ring_fwd(s_res, (wave - 1) * 64 + lane, PRING);
-                const uint32_t key = win_at(win32, w_pos) & 0xFFFFFFu;
+                // (the prefix is still in this wavefront's own staging slots: the pre-digest of tile it+3, which
+                // reuses them, comes later in this wavefront's program order)
+                const uint32_t key = st_k[((uint32_t)it % 3) * MTILE + (wave - 1) * 64 + lane] & 0xFFFFFFu;
                 const uint32_t known = cd[((uint32_t)it & 1) * MTILE + (wave - 1) * 64 + lane];
                 uint32_t d = prevd[s_pos];
                 if (known) { dist = known; found = dist <= window; d = 0; }
                 while (d != 0) {
                     dist += d;
-                    hops++;
                     if (dist > window || dist > pos) break;  // default.rs:81 (inclusive window)
                     if ((win_at(win32, ring_back(w_pos, dist, WRING)) & 0xFFFFFFu) == key) { found = true; break; }
                     d = prevd[ring_back(s_pos, dist, PRING)];
@@ -313,7 +314,6 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                         const uint32_t x = win_at(win32, oa) ^ win_at(win32, ob);
                         if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
                         l += 4;
-                        lcps++;
                         oa += 4; if (oa >= WRING) oa -= WRING;
                         ob += 4; if (ob >= WRING) ob -= WRING;
                     }
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
     }
     if (dbg && blockIdx.x == 0 && lane == 0) {
         uint64_t *d = dbg + wave * 8;
-        d[0] = cy_load; d[1] = cy_work; d[2] = cy_wait; d[3] = hops; d[4] = lcps; d[5] = ntiles;
+        d[0] = cy_load; d[1] = cy_work; d[2] = cy_wait; d[3] = 0; d[4] = 0; d[5] = ntiles;
     }
 }
 
