@@ -977,7 +977,35 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
     uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
     const uint32_t total = nl + nd;
     bool good = !hb.bad;
-    while (have < total && good) {
+    // a header is at most 17 + 19*3 + 320*(7+7) = 4554 bits long: when every candidate of the wavefront lies
+    // further than that from the end of the stream, the walk needs no bounds checks at all
+    const bool lean = __ballot(cand[i] + 6000 > hb.nbits) == 0;
+    while (lean && have < total && good) {
+        hb.b.refill();
+        const uint32_t e = cl_tab[((uint32_t)hb.b.buf & 127) * 64 + threadIdx.x];
+        const uint32_t sym = e & 31, used = e >> 5;
+        // repeat codes 16 / 17 / 18: extra bits 2 / 3 / 7, base count 3 / 3 / 11 (packed nibble tables)
+        const uint32_t k4 = (sym > 15 ? sym - 15 : 0) * 4;
+        const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
+        const uint32_t rep = basex + (((uint32_t)(hb.b.buf >> used)) & ((1u << nbx) - 1));
+        const uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
+        hb.b.buf >>= used + nbx;
+        hb.b.nb -= used + nbx;
+        if ((sym == 16 && have == 0) || have + rep > total) { good = false; break; }
+        if (val) {
+            // [have, have+rep) split at the literal / distance boundary
+            const uint32_t nlit_part = have < nl ? (have + rep <= nl ? rep : nl - have) : 0;
+            const uint32_t ndist_part = rep - nlit_part;
+            kl += nlit_part * (32768u >> val); nlit += nlit_part;
+            kd += ndist_part * (32768u >> val); ndist += ndist_part;
+            if (have <= 256 && 256 < have + rep) eob_len = val;
+            if (kl > 32768u || kd > 32768u) { good = false; break; }   // over-subscribed
+        }
+        have += rep;
+        last = val;
+        if (have >= nl && have - rep < nl && !(kl == 32768u || (nlit == 1 && kl == 16384u))) { good = false; break; }
+    }
+    while (have < total && good) {     // (candidates near the end of the stream: every step checked)
         if (hb.b.pos >= hb.nbits) { good = false; break; }
         hb.b.refill();
         const uint32_t e = cl_tab[((uint32_t)hb.b.buf & 127) * 64 + threadIdx.x];
