@@ -462,7 +462,25 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
             hb.init(in, nbytes, hdr64[0]);
             const uint32_t nl = hdr[3], nd = hdr[4], total = nl + nd;
             uint32_t have = 0, last = 0, bad = 0;
-            while (have < total) {
+            // (a header is at most 4554 bits long: far from the end of the stream no step needs a bounds check)
+            const bool lean = hdr64[0] + 6000 <= hb.nbits;
+            while (lean && have < total) {
+                hb.b.refill();
+                const uint32_t e = cl_tab[(uint32_t)hb.b.buf & 127];
+                const uint32_t sym = e & 31, used = e >> 5;
+                const uint32_t k4 = (sym - 16u < 3u ? sym - 15 : 0) * 4;   // repeat codes 16 / 17 / 18
+                const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
+                const uint32_t rep = basex + (((uint32_t)(hb.b.buf >> used)) & ((1u << nbx) - 1));
+                const uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
+                hb.b.buf >>= used + nbx;
+                hb.b.nb -= used + nbx;
+                hb.b.pos += used + nbx;
+                if (e == 0xFF || (sym == 16 && have == 0) || have + rep > total) { bad = 1; break; }
+                if (val) for (uint32_t k = 0; k < rep; ++k) lens[have + k] = (uint8_t)val;
+                have += rep;
+                last = val;
+            }
+            while (!bad && have < total) {
                 if (hb.b.pos >= hb.nbits) { bad = 1; break; }
                 hb.b.refill();
                 const uint32_t e = cl_tab[(uint32_t)hb.b.buf & 127];
