@@ -142,7 +142,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             starts.push_back(first_bit);  // the first block's start is known
             for (uint32_t i = 0; i < nf; i++) if (cand[i] != first_bit) starts.push_back(cand[i]);
             std::sort(starts.begin(), starts.end());
-            // ---- K1: every candidate block is scanned by a 256-lane workgroup (speculative slices,
+            // ---- K1: every candidate block is scanned by a 1024-lane workgroup (speculative slices,
             //      chained exits) for its end bit, byte and code counts
             const uint32_t nc = (uint32_t)starts.size();
             auto start_at = [&](uint32_t i) { return i < nc ? starts[i] : n * 8; };

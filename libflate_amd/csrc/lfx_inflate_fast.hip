@@ -1,15 +1,16 @@
 // lfx_inflate_fast.hip — lane-parallel inflate of ONE large DEFLATE stream (gfx950).
 //
 // The reference decodes a stream strictly serially (src/deflate/decode.rs:136-164, one symbol at a
-// time through symbol.rs:193-244).  Here every candidate block (found by find_blocks_*) is decoded by
-// a 256-lane workgroup: the block's bit range is cut into 256 slices, every lane starts decoding at
-// its slice start *speculatively* (Huffman streams self-synchronise within a few symbols), and the
+// time through symbol.rs:193-244).  Here every candidate block (found by find_blocks_*) is scanned by
+// a 1024-lane workgroup (K1): the block's bit range is cut into 1024 slices, every lane starts decoding
+// at its slice start *speculatively* (Huffman streams self-synchronise within a few symbols), and the
 // exits are chained from lane 0 — whose start is exact — until nothing changes.  Validated lanes then
-// re-decode their slices into a code stream (same word format as the encoder's: (val << 16) | dist),
-// and one wavefront per block materialises literals and back-references through a 64 KiB LDS window
-// (Lz77Decoder::decode, libflate_lz77/src/lib.rs:164-194).  Any anomaly (error, cross-block
-// reference, unchained block) makes the host fall back to the exact serial kernel, which reproduces
-// the reference's error kinds and partial output.
+// re-decode their slices into a code stream (K2; same word format as the encoder's: (val << 16) | dist)
+// and the block is cut into units no back-reference crosses; one wavefront per unit materialises
+// literals and back-references through a 36 KiB LDS ring (K3; Lz77Decoder::decode,
+// libflate_lz77/src/lib.rs:164-194).  Any anomaly (error, cross-block reference, unchained block)
+// makes the host fall back to the exact serial kernel, which reproduces the reference's error kinds
+// and partial output.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
     // slices of >= 128 bits so that one symbol (<= 48 bits) never skips a whole slice
     uint64_t slice = (e - d0 + SCAN_THREADS - 1) / SCAN_THREADS;
     if (slice < 128) slice = 128;
-    const uint32_t nl = (uint32_t)((e - d0 + slice - 1) / slice);  // lanes in use (<= 256)
+    const uint32_t nl = (uint32_t)((e - d0 + slice - 1) / slice);  // lanes in use (<= SCAN_THREADS)
     const uint64_t my_bound = d0 + (uint64_t)(tid + 1) * slice;     // end of my slice
     s_start[tid] = tid == 0 ? d0 : (tid < nl ? d0 + (uint64_t)tid * slice : ~0ull);
     if (tid == 0) s_start[SCAN_THREADS] = ~0ull;
@@ -622,8 +623,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
         if (!any || rounds >= 64) break;
     }
     // the EOB lane: first lane whose (validated) decode hit EndOfBlock; every lane before it must be clean
-    __shared__ uint32_t s_eob, s_err;
-    if (tid == 0) { s_eob = 0xFFFFFFFFu; s_err = 0; }
+    __shared__ uint32_t s_eob;
+    if (tid == 0) s_eob = 0xFFFFFFFFu;
     __syncthreads();
     if (tid < nl && s_flag[tid] != 0) atomicMin(&s_eob, tid);   // first flagged lane of the chain
     __syncthreads();
