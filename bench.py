@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=N_BYTES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schedule", choices=["S8K", "S1"], default="S8K",
+                    help="write schedule of the encoder: S8K = 8192-byte writes (the metric's configuration), "
+                         "S1 = one write_all (one LZ77 chunk, one block: SURVEY cfg2's second schedule)")
     args = ap.parse_args()
 
     import numpy as np
@@ -88,7 +91,8 @@ def main():
     n = args.bytes
     data = synth.text(n, seed=synth.SEED_BASE + 2 + rank)
     d_in = torch.from_numpy(data).to(dev)
-    opts, sched = _ffi.make_opts(mtime=0), _ffi.make_schedule(WRITE)
+    write = WRITE if args.schedule == "S8K" else 0       # 0 = one write_all
+    opts, sched = _ffi.make_opts(mtime=0), _ffi.make_schedule(write)
     bound = _ffi.lib().lfx_encode_bound(n, C.byref(opts), C.byref(sched)) & ~3
     d_out = torch.empty(bound, dtype=torch.uint8, device=dev)
     d_dec = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -210,7 +214,7 @@ def main():
         sample = min(n, 64 << 20)
         buf = data[:sample].tobytes()
         t0 = time.perf_counter()
-        enc = oracle.encode(oracle.GZIP, buf, write_size=WRITE)
+        enc = oracle.encode(oracle.GZIP, buf, write_size=write)
         t1 = time.perf_counter()
         rc, out, _, _ = oracle.decode(oracle.GZIP, enc)
         t2 = time.perf_counter()
@@ -219,7 +223,7 @@ def main():
         if sample == n:
             assert enc == d_out[:m].cpu().numpy().tobytes(), "GPU output differs from the oracle"
         cpu = {"value": round(sample / (t2 - t0) / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
-               "sample": "first %d MiB of the same buffer, S8K, oracle C restatement (encode %.3f GB/s, decode %.3f GB/s)"
+               "sample": "first %d MiB of the same buffer, " + args.schedule + ", oracle C restatement (encode %.3f GB/s, decode %.3f GB/s)"
                          % (sample >> 20, sample / (t1 - t0) / 1e9, sample / (t2 - t1) / 1e9)}
     line = {
         "metric": "gzip encode+decode throughput on 256 MiB synthetic text per GPU (uncompressed bytes through the round trip)",
@@ -227,8 +231,8 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "cfg2: gzip::Encoder (DefaultLz77Encoder, default options, mtime=0) + gzip::Decoder on "
-                               "TEXT(%d B) per GPU, write schedule S8K (8192-byte writes)" % n,
-                   "bytes_per_gpu": n, "schedule": "S8K", "compressed_bytes": m,
+                               "TEXT(%d B) per GPU, write schedule %s" % (n, "S8K (8192-byte writes)" if args.schedule == "S8K" else "S1 (one write_all)"),
+                   "bytes_per_gpu": n, "schedule": args.schedule, "compressed_bytes": m,
                    "parallelism": "1 rank" if world == 1 else "%d ranks, one member, all-gather of shard infos" % world},
         "encode_GBps": round(total_bytes * args.steps / enc_t / 1e9, 4),
         "decode_GBps": round(total_bytes * args.steps / dec_t / 1e9, 4),
