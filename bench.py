@@ -223,8 +223,8 @@ def main():
         if sample == n:
             assert enc == d_out[:m].cpu().numpy().tobytes(), "GPU output differs from the oracle"
         cpu = {"value": round(sample / (t2 - t0) / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
-               "sample": "first %d MiB of the same buffer, " + args.schedule + ", oracle C restatement (encode %.3f GB/s, decode %.3f GB/s)"
-                         % (sample >> 20, sample / (t1 - t0) / 1e9, sample / (t2 - t1) / 1e9)}
+               "sample": "first %d MiB of the same buffer, %s, oracle C restatement (encode %.3f GB/s, decode %.3f GB/s)"
+                         % (sample >> 20, args.schedule, sample / (t1 - t0) / 1e9, sample / (t2 - t1) / 1e9)}
     line = {
         "metric": "gzip encode+decode throughput on 256 MiB synthetic text per GPU (uncompressed bytes through the round trip)",
         "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

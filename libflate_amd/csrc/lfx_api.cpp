@@ -339,7 +339,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
     if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
-    if ((rc = c->d_segtmp.reserve(12ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
+    if ((rc = c->d_segtmp.reserve(16ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
     if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;

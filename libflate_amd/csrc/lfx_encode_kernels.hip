@@ -436,12 +436,77 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restr
     if (lane == 0) { seg_exit[seg] = pos; seg_count[seg] = cnt; }
 }
 
-// P2: one wavefront per chunk
+// P2a: one wavefront per segment.  The true walk enters segment s where the walk of segment s-1 left it;
+// that is the speculative exit of s-1 unless s-1 itself never merged (rare: P2b repairs those).  Re-walk
+// from the entry until the walk lands on a position the speculative walk visited — from there on both
+// coincide — and rewrite the visited mask, the count and the exit of the segment accordingly.
+struct SegFix { uint32_t cnt, ex; };
+__device__ __forceinline__ SegFix parse_rewalk(const ChunkDesc &ch, const uint32_t *__restrict__ md,
+                                               uint64_t *__restrict__ vw, uint32_t s0, uint32_t s1, uint32_t end,
+                                               uint32_t e, uint32_t cnt, uint32_t ex, uint32_t lane) {
+    uint32_t pos = e, walked = 0, spec_below = 0;
+    bool merged = false;
+    for (uint32_t g = 0; g < PARSE_SEG / 64 && !merged; ++g) {
+        const uint32_t base = s0 + g * 64;
+        if (base >= s1) break;
+        const uint64_t V = vw[g];
+        if (pos >= base + 64) {          // wholly before the true entry: nothing visited here
+            spec_below += __popcll(V);
+            if (lane == 0 && V) vw[g] = 0;
+            continue;
+        }
+        const uint32_t i = base + lane;
+        const uint32_t v = i < end ? md[ch.in_off + i] : 0;
+        const uint32_t stop = min(base + 64, s1);
+        uint64_t T = 0;
+        uint32_t mr = 64;
+        while (pos < stop) {
+            const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
+            if ((V >> r) & 1) { merged = true; mr = r; break; }
+            const uint32_t mv = __builtin_amdgcn_readlane(v, r);
+            T |= 1ull << r;
+            walked++;
+            pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
+        }
+        const uint64_t keep = mr < 64 ? (V & ~((1ull << mr) - 1)) : 0;   // speculative bits from the merge on
+        spec_below += __popcll(V & ~keep);
+        if (lane == 0) vw[g] = T | keep;
+    }
+    SegFix f;
+    if (merged) { f.cnt = cnt - spec_below + walked; f.ex = ex; }   // the exit stays the one already known
+    else { f.cnt = walked; f.ex = pos; }                             // never merged inside this segment
+    return f;
+}
+
+__global__ __launch_bounds__(64) void parse_fixseg_kernel(const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
+                                                          const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
+                                                          const uint32_t *__restrict__ seg_exit,
+                                                          uint32_t *__restrict__ seg_count,
+                                                          uint32_t *__restrict__ seg_exit2) {
+    const uint32_t seg = blockIdx.x;
+    const ChunkDesc ch = chunks[find_seg_chunk(chunks, nchunks, seg)];
+    if (ch.flags & CH_LITERALS) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s = seg - ch.seg_base;
+    const uint32_t n = (uint32_t)ch.len;
+    const uint32_t end = (n > 3 ? n : 3) - 3;
+    const uint32_t s0 = s * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
+    const uint32_t e = s ? seg_exit[seg - 1] : 0;                   // assumed entry
+    SegFix f{seg_count[seg], seg_exit[seg]};
+    if (s0 >= end) { f.cnt = 0; f.ex = e; }                          // behind the last walked position: pass through
+    else if (e != s0) f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64), s0, s1, end, e, f.cnt, f.ex, lane);
+    if (lane == 0) { seg_count[seg] = f.cnt; seg_exit2[seg] = f.ex; }
+}
+
+// P2b: one wavefront per chunk: checks the assumption of P2a for 64 segments at a time (segment s was
+// entered correctly iff the exit of s-1 did not change), repairs the rare segment that was not, and turns
+// the counts into offsets; then the chunk's tail and the EndOfBlock marker.
 __global__ __launch_bounds__(64) void parse_fix_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
                                                        const ChunkDesc *__restrict__ chunks,
                                                        const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
                                                        const uint32_t *__restrict__ seg_exit,
-                                                       const uint32_t *__restrict__ seg_count,
+                                                       uint32_t *__restrict__ seg_count,
+                                                       uint32_t *__restrict__ seg_exit2,
                                                        uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
                                                        uint32_t *__restrict__ ncodes) {
     const ChunkDesc ch = chunks[blockIdx.x];
@@ -455,52 +520,42 @@ __global__ __launch_bounds__(64) void parse_fix_kernel(const uint8_t *__restrict
         total = n;
     } else {
         const uint32_t end = (n > 3 ? n : 3) - 3;
-        uint32_t e = 0;   // true entry position of the next segment (wave-uniform)
-        for (uint32_t s = 0; s < ch.n_seg; ++s) {
-            const uint32_t s0 = s * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
-            uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
-            uint32_t cnt = seg_count[ch.seg_base + s], ex = seg_exit[ch.seg_base + s];
-            if (s0 >= end) { cnt = 0; ex = e; }
-            else if (e != s0) {
-                // the true parse enters at e > s0: re-walk from e until it lands on a position the
-                // speculative walk visited (from there on both walks coincide)
-                uint32_t pos = e, walked = 0, spec_below = 0;
-                bool merged = false;
-                for (uint32_t g = 0; g < PARSE_SEG / 64 && !merged; ++g) {
-                    const uint32_t base = s0 + g * 64;
-                    if (base >= s1) break;
-                    const uint64_t V = vw[g];
-                    if (pos >= base + 64) {          // wholly before the true entry: nothing visited here
-                        spec_below += __popcll(V);
-                        if (lane == 0 && V) vw[g] = 0;
-                        continue;
-                    }
-                    const uint32_t i = base + lane;
-                    const uint32_t v = i < end ? md[ch.in_off + i] : 0;
-                    const uint32_t stop = min(base + 64, s1);
-                    uint64_t T = 0;
-                    uint32_t mr = 64;
-                    while (pos < stop) {
-                        const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
-                        if ((V >> r) & 1) { merged = true; mr = r; break; }
-                        const uint32_t mv = __builtin_amdgcn_readlane(v, r);
-                        T |= 1ull << r;
-                        walked++;
-                        pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
-                    }
-                    const uint64_t keep = mr < 64 ? (V & ~((1ull << mr) - 1)) : 0;   // speculative bits from the merge on
-                    spec_below += __popcll(V & ~keep);
-                    if (lane == 0) vw[g] = T | keep;
-                }
-                if (merged) cnt = cnt - spec_below + walked;        // exit stays the speculative one
-                else { cnt = walked; ex = pos; }                     // never merged inside this segment
+        const uint32_t *sx = seg_exit + ch.seg_base;
+        uint32_t *sx2 = seg_exit2 + ch.seg_base, *sc = seg_count + ch.seg_base;
+        uint32_t e_last = 0;   // true exit of the segment before the current batch
+        for (uint32_t b0 = 0; b0 < ch.n_seg; ) {
+            const uint32_t s = b0 + lane;
+            const bool have = s < ch.n_seg;
+            // entry assumed by P2a vs the true exit of the predecessor
+            const uint32_t assumed = have ? (s ? sx[s - 1] : 0) : 0;
+            const uint32_t actual = have ? (s == b0 ? e_last : sx2[s - 1]) : 0;
+            const uint64_t bad = __ballot(have && assumed != actual);
+            const uint32_t nok = bad ? (uint32_t)__builtin_ctzll(bad) : min(64u, ch.n_seg - b0);   // leading good segments
+            // offsets of the good prefix
+            const uint32_t c = (have && lane < nok) ? sc[s] : 0;
+            uint32_t x = c;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
+            if (have && lane < nok) seg_off[ch.seg_base + s] = total + x - c;
+            if (nok) {
+                total += __shfl(x, nok - 1);
+                e_last = __shfl(have ? sx2[s] : 0, nok - 1);
             }
-            if (lane == 0) seg_off[ch.seg_base + s] = total;
-            total += cnt;
-            e = ex;
+            b0 += nok;
+            if (bad) {
+                // segment b0 was entered at the wrong position: redo it from the true entry
+                const uint32_t sb = b0;
+                const uint32_t s0 = sb * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
+                SegFix f{sc[sb], sx2[sb]};
+                if (s0 >= end) { f.cnt = 0; f.ex = e_last; }
+                else f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)sb * (PARSE_SEG / 64), s0, s1, end, e_last, f.cnt, f.ex, lane);
+                if (lane == 0) { sc[sb] = f.cnt; sx2[sb] = f.ex; seg_off[ch.seg_base + sb] = total; }
+                total += f.cnt;
+                e_last = f.ex;
+                b0 += 1;
+            }
         }
         // default.rs:105-107: the rest are literals (at most 3 bytes)
-        const uint32_t pos = ch.n_seg ? e : 0;
+        const uint32_t pos = ch.n_seg ? e_last : 0;
         for (uint32_t i = pos + lane; i < n; i += 64) out[total + (i - pos)] = src.load1(i) << 16;
         if (n > pos) total += n - pos;
     }
@@ -1117,12 +1172,18 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                  uint32_t *codes, uint32_t *ncodes) {
     if (nchunks == 0) return 0;
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
+    uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs;
     if (nsegs) {
         hipLaunchKernelGGL(parse_spec_kernel, dim3(nsegs), dim3(64), 0, st, chunks, nchunks, md, vis, seg_exit, seg_count);
         LFX_LAUNCH_CHECK();
     }
+    if (nsegs) {
+        hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, chunks, nchunks, md, vis, seg_exit, seg_count,
+                           seg_exit2);
+        LFX_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(64), 0, st, in, in_bytes, chunks, md, vis, seg_exit,
-                       seg_count, seg_off, codes, ncodes);
+                       seg_count, seg_exit2, seg_off, codes, ncodes);
     LFX_LAUNCH_CHECK();
     if (nsegs) {
         hipLaunchKernelGGL(parse_emit_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis,
