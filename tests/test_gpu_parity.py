@@ -342,3 +342,53 @@ def test_sharded_encode_virtual_ranks(lfx, ffi, oracle, synth):
                                        int(r == world - 1), d_dec.data_ptr(), n, C.byref(ol))
         assert rc == 0 and ol.value == n, ctxs[r].last_error()
         assert torch.equal(d_dec, d_ins[r])
+
+
+def test_differential_random(ctx, ffi, oracle, synth):
+    """Seeded differential sweep: random data kinds, sizes, write sizes and options, encode compared with the
+    oracle byte for byte, the result decoded on the GPU (and by python zlib, an independent inflater)."""
+    rng = np.random.default_rng(20260927)
+    text = synth.text(600000).tobytes()
+    low = synth.lowent(600000).tobytes()
+
+    def sample(n):
+        kind = int(rng.integers(0, 6))
+        if n == 0:
+            return b""
+        if kind == 0:
+            o = int(rng.integers(0, len(text) - n + 1)); return text[o:o + n]
+        if kind == 1:
+            o = int(rng.integers(0, len(low) - n + 1)); return low[o:o + n]
+        if kind == 2:
+            return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if kind == 3:
+            return rng.integers(0, int(rng.integers(2, 6)), n, dtype=np.uint8).tobytes()
+        if kind == 4:
+            period = int(rng.integers(1, 400))
+            unit = rng.integers(0, 256, period, dtype=np.uint8).tobytes()
+            return (unit * (n // period + 1))[:n]
+        return bytes([int(rng.integers(0, 256))]) * n
+
+    sizes = [0, 1, 2, 3, 4, 5, 63, 64, 65, 257, 258, 259, 4095, 4096, 4097, 32767, 32768, 32769, 65535, 65536,
+             262143, 262144, 262145, 262147, 300001]
+    for trial in range(60):
+        n = int(sizes[trial % len(sizes)] if trial < len(sizes) else rng.integers(0, 400000))
+        data = sample(n)
+        ws = int(rng.choice([0, 1, 7, 100, 4096, 8192, 65536, 262144, 300000]))
+        if ws == 1 and n > 20000:
+            ws = 1000
+        kw = {}
+        r = int(rng.integers(0, 8))
+        if r == 0: kw["dynamic_huffman"] = 0
+        if r == 1: kw["no_compression"] = 1
+        if r == 2: kw["lz77_kind"] = 1
+        if r == 3: kw["block_size"] = int(rng.choice([1000, 65536, 100000]))
+        if r == 4: kw["window_size"] = int(rng.choice([256, 1024, 4096, 32768]))
+        if r == 5: kw["max_length"] = int(rng.choice([3, 4, 16, 64, 258]))
+        fmt = (ffi.DEFLATE, ffi.ZLIB, ffi.GZIP)[trial % 3]
+        got = enc(ctx, ffi, fmt, data, ws, **kw)
+        want = oracle.encode(fmt, data, write_size=ws, **kw)
+        assert got == want, (trial, n, ws, kw, fmt)
+        assert pyzlib.decompress(got, {ffi.DEFLATE: -15, ffi.ZLIB: 15, ffi.GZIP: 31}[fmt]) == data, (trial, "pyzlib")
+        rc, out = ctx.decode_host(fmt, got)[:2]
+        assert rc == 0 and out == data, (trial, n, ws, kw, fmt, "gpu decode")
