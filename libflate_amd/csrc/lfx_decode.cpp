@@ -472,6 +472,111 @@ extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const vo
     return rc;
 }
 
+// Batch fast path: every stream's blocks go through the lane-parallel kernels, one block per stream and
+// round (a block's start is only known once the block before it has been scanned; reference-made streams
+// have two blocks).  A stream leaves the fast path — and is decoded again, exactly, by the serial kernel —
+// on any anomaly: undecodable block, a block that runs past the stream's end or its output capacity, a
+// back-reference that reaches in front of its block, more than MAX_ROUNDS blocks.
+// fast[i] = 1: d_out holds the stream's bytes and res[i] is filled in.
+namespace lfx {
+static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out, uint32_t count,
+                      const std::vector<InflateJob> &jobs, std::vector<uint8_t> &fast, std::vector<InflateResult> &res) {
+    constexpr uint32_t MAX_ROUNDS = 4;
+    hipStream_t st = c->stream;
+    struct Live { uint32_t stream; uint64_t bit, produced; uint32_t nblocks; };
+    std::vector<Live> live;
+    fast.assign(count, 0);
+    res.assign(count, InflateResult{});
+    for (uint32_t i = 0; i < count; i++)
+        if (jobs[i].in_len >= 64 && jobs[i].in_off + jobs[i].in_len <= n_in)
+            live.push_back(Live{i, jobs[i].in_off * 8 + jobs[i].start_bit, 0, 0});
+    int rc;
+    for (uint32_t round = 0; round < MAX_ROUNDS && !live.empty(); round++) {
+        const uint32_t nj = (uint32_t)live.size();
+        std::vector<BlkJob> bj(nj);
+        for (uint32_t k = 0; k < nj; k++) {
+            const InflateJob &j = jobs[live[k].stream];
+            bj[k] = BlkJob{live[k].bit, (j.in_off + j.in_len) * 8};
+        }
+        if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * nj))) return rc;
+        if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * nj))) return rc;
+        if ((rc = c->d_dec_cand.reserve(sizeof(BlkLanes) * (size_t)nj))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
+        LAUNCH_TRY(launch_blk_scan(st, d_in, n_in, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
+                                   (BlkLanes *)c->d_dec_cand.p));
+        std::vector<BlkInfo> bi(nj);
+        HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // blocks that scanned cleanly and fit are emitted; the others drop their stream out of the fast path
+        std::vector<BlkEmit> emit;
+        std::vector<uint32_t> owner;
+        uint64_t total_codes = 0;
+        for (uint32_t k = 0; k < nj; k++) {
+            const InflateJob &j = jobs[live[k].stream];
+            const BlkInfo &r = bi[k];
+            if (r.status != BLK_OK || r.end_bit <= live[k].bit || r.end_bit > (j.in_off + j.in_len) * 8 ||
+                live[k].produced + r.n_out > j.out_cap)
+                continue;
+            BlkEmit e{};
+            e.start_bit = live[k].bit; e.data_bit = r.data_bit; e.code_off = total_codes;
+            e.out_off = j.out_off + live[k].produced;
+            e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
+            e.hist = live[k].produced;
+            emit.push_back(e);
+            owner.push_back(k);
+            total_codes += r.n_codes;
+        }
+        const uint32_t ne = (uint32_t)emit.size();
+        std::vector<uint32_t> jf(ne, 0);
+        if (ne) {
+            if ((rc = c->d_dec_tmp.reserve(sizeof(BlkEmit) * ne + 4ull * ne + 128))) return rc;
+            if ((rc = c->d_hist.reserve(sizeof(BlkUnits) * (size_t)ne + 64))) return rc;
+            if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(total_codes, 1)))) return rc;
+            uint32_t *d_flags = (uint32_t *)c->d_dec_tmp.p;
+            uint32_t *d_jf = d_flags + 16;
+            BlkEmit *d_emit = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64 + 4ull * ne + (8 - (4ull * ne) % 8) % 8);
+            HIP_TRY(hipMemsetAsync(d_flags, 0, 64 + 4ull * ne, st));
+            HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
+            const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
+            const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
+            LAUNCH_TRY(launch_blk_emit(st, d_in, n_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p, (uint32_t *)c->d_codes.p,
+                                       d_flags, (BlkUnits *)c->d_hist.p, unit_target, d_jf));
+            LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p,
+                                              (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, nullptr));
+            HIP_TRY(hipMemcpyAsync(jf.data(), d_jf, 4ull * ne, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        std::vector<Live> next;
+        for (uint32_t q = 0; q < ne; q++) {
+            if (jf[q]) continue;                                 // reads in front of the block: serial kernel
+            Live l = live[owner[q]];
+            const BlkInfo &r = bi[owner[q]];
+            l.produced += r.n_out;
+            l.nblocks++;
+            if (r.bfinal) {
+                const InflateJob &j = jobs[l.stream];
+                InflateResult &o = res[l.stream];
+                o.end_bit = r.end_bit - j.in_off * 8;
+                o.out_len = l.produced;
+                o.blk_out_start = l.produced;
+                o.final_seen = 1;
+                o.nblocks = l.nblocks;
+                fast[l.stream] = 1;
+            } else { l.bit = r.end_bit; next.push_back(l); }
+        }
+        if (getenv("LFX_DEBUG")) {
+            uint32_t bad = 0, nfl = 0;
+            for (uint32_t k = 0; k < nj; k++) bad += bi[k].status != BLK_OK;
+            for (uint32_t q = 0; q < ne; q++) nfl += jf[q];
+            fprintf(stderr, "[lfx] batch round %u: jobs=%u scan-not-ok=%u emitted=%u cross-block=%u continuing=%zu\n", round, nj, bad,
+                    ne, nfl, next.size());
+        }
+        live.swap(next);
+    }
+    return LFX_OK;
+}
+}  // namespace lfx
+
 extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, const void *d_in,
                                        const uint64_t *in_off, const uint64_t *in_len, void *d_out,
                                        const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
@@ -515,11 +620,32 @@ extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, 
         j.flags = 0;
         jobs[i] = j;
     }
-    if ((rc = c->d_dec_streams.reserve(sizeof(InflateJob) * count))) return rc;
-    if ((rc = c->d_dec_state.reserve(sizeof(InflateResult) * count))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, jobs.data(), sizeof(InflateJob) * count, hipMemcpyHostToDevice, st));
-    LAUNCH_TRY(launch_inflate(st, (const uint8_t *)d_in, (uint8_t *)d_out, (const InflateJob *)c->d_dec_streams.p,
-                              (InflateResult *)c->d_dec_state.p, count));
+    // ---- lane-parallel path first; whatever it could not take goes through the exact serial kernel
+    uint64_t n_in = 0;
+    for (uint32_t i = 0; i < count; i++) n_in = std::max(n_in, in_off[i] + in_len[i]);
+    std::vector<uint8_t> fast;
+    std::vector<InflateResult> fres;
+    if (getenv("LFX_BATCH_SERIAL")) { fast.assign(count, 0); fres.assign(count, InflateResult{}); }
+    else if ((rc = batch_fast(c, (const uint8_t *)d_in, n_in, (uint8_t *)d_out, count, jobs, fast, fres))) return rc;
+    c->phase("fast");
+    std::vector<InflateJob> slow_jobs;
+    std::vector<uint32_t> slow_idx;
+    for (uint32_t i = 0; i < count; i++)
+        if (!fast[i]) { slow_jobs.push_back(jobs[i]); slow_idx.push_back(i); }
+    const uint32_t nslow = (uint32_t)slow_jobs.size();
+    // d_dec_state holds the per-stream results the checksum / trailer kernels read: [count] then [nslow] scratch
+    if ((rc = c->d_dec_streams.reserve(sizeof(InflateJob) * std::max<uint32_t>(nslow, 1)))) return rc;
+    if ((rc = c->d_dec_state.reserve(sizeof(InflateResult) * ((size_t)count + nslow)))) return rc;
+    InflateResult *d_res = (InflateResult *)c->d_dec_state.p, *d_slow = d_res + count;
+    HIP_TRY(hipMemcpyAsync(d_res, fres.data(), sizeof(InflateResult) * count, hipMemcpyHostToDevice, st));
+    if (nslow) {
+        HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, slow_jobs.data(), sizeof(InflateJob) * nslow, hipMemcpyHostToDevice, st));
+        LAUNCH_TRY(launch_inflate(st, (const uint8_t *)d_in, (uint8_t *)d_out, (const InflateJob *)c->d_dec_streams.p, d_slow, nslow));
+        if (nslow == count) HIP_TRY(hipMemcpyAsync(d_res, d_slow, sizeof(InflateResult) * count, hipMemcpyDeviceToDevice, st));
+        else for (uint32_t q = 0; q < nslow; q++)
+            HIP_TRY(hipMemcpyAsync(d_res + slow_idx[q], d_slow + q, sizeof(InflateResult), hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));   // (host vectors above must outlive the copies)
     c->phase("inflate");
     if (format != LFX_DEFLATE)
         LAUNCH_TRY(launch_stream_checksum(st, (const uint8_t *)d_out, d_streams, (const InflateResult *)c->d_dec_state.p,

@@ -87,6 +87,7 @@ struct BlkEmit {
     uint64_t out_off;    // first output byte of the block
     uint64_t n_out;
     uint32_t n_codes, nlanes, btype, cand;
+    uint64_t hist;       // output bytes of the same stream already materialised in front of the block (batch rounds)
 };
 struct BlkUnits {
     uint32_t n;          // independent units of the block (no back-reference crosses a cut)
@@ -97,7 +98,8 @@ struct BlkUnits {
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
                     BlkInfo *infos, BlkLanes *lanes);
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
-                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target);
+                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
+                    uint32_t *job_flags = nullptr);   // job_flags[j] = 1: block j reads bytes in front of itself
 int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg);

@@ -683,7 +683,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
                                                                 const BlkLanes *__restrict__ lanes,
                                                                 uint32_t *__restrict__ codes,
                                                                 uint32_t *__restrict__ flags,
-                                                                BlkUnits *__restrict__ units, uint32_t unit_target) {
+                                                                BlkUnits *__restrict__ units, uint32_t unit_target,
+                                                                uint32_t *__restrict__ job_flags) {
     __shared__ FastTabs T;
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
@@ -711,7 +712,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         uint64_t no = out0, endpos;
         lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
                           emit_stage + tid * EMIT_STRIDE);
-        if (reach < 0) atomicOr(&flags[0], 1u);   // a back-reference reaches before the block start
+        if (reach < -(int64_t)job.hist) {         // a back-reference reaches before the block start (and its history)
+            atomicOr(&flags[0], 1u);              // ... summary, and per job (batch decode)
+            if (job_flags) job_flags[blockIdx.x] = 1u;
+        }
         if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
     }
     const uint64_t t_dec = clock64();
@@ -850,7 +854,12 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     const uint32_t n = c1 - c0;
     // byte `pos` of the unit lives at ring_idx(pos + shift): ring and output share their 4-byte alignment,
     // so the flush moves aligned dwords
-    const uint32_t shift = (uint32_t)(gbase & 3);
+    // history in front of the block (batch rounds: earlier blocks of the stream are already in `out`): the first
+    // unit preloads up to 32 KiB of it, so that back-references may reach across the block start
+    const uint32_t hist = u == 0 ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
+    const uint32_t shift = (uint32_t)((gbase - hist) & 3) + hist;
+    for (uint32_t k = lane; k < hist; k += 64) ring[ring_idx(shift - hist + k)] = o[(int64_t)k - (int64_t)hist];
+    __builtin_amdgcn_wave_barrier();
     uint64_t produced = 0, flushed = 0;
     uint32_t base = 0;
     uint32_t c_cur = lane < n ? cp[lane] : 0;
@@ -1078,7 +1087,8 @@ int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
     return 0;
 }
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
-                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target) {
+                    const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
+                    uint32_t *job_flags) {
     if (!njobs) return 0;
     constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
     static bool attr_set = false;
@@ -1087,7 +1097,7 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
         attr_set = true;
     }
     hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes, flags, units,
-                       unit_target ? unit_target : 1u);
+                       unit_target ? unit_target : 1u, job_flags);
     LFX_LAUNCH_CHECK();
     return 0;
 }
