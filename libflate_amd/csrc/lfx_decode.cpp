@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,9 @@
 
 #include "lfx_ctx.h"
 #include "lfx_decode.h"
+
+static_assert(offsetof(lfx::DecStream, out_off) == 16 && sizeof(lfx::DecStream) % 8 == 0, "checksum_ranges stride");
+static_assert(offsetof(lfx::InflateResult, out_len) == 8 && sizeof(lfx::InflateResult) % 8 == 0, "checksum_ranges stride");
 #include "lfx_device.h"
 
 using namespace lfx;
@@ -648,8 +652,9 @@ extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, 
     HIP_TRY(hipStreamSynchronize(st));   // (host vectors above must outlive the copies)
     c->phase("inflate");
     if (format != LFX_DEFLATE)
-        LAUNCH_TRY(launch_stream_checksum(st, (const uint8_t *)d_out, d_streams, (const InflateResult *)c->d_dec_state.p,
-                                          count, d_crc, d_adler));
+        LAUNCH_TRY(launch_checksum_ranges(st, (const uint8_t *)d_out, count, (const uint64_t *)d_streams + 2,
+                                          sizeof(DecStream) / 8, (const uint64_t *)c->d_dec_state.p + 1,
+                                          sizeof(InflateResult) / 8, d_crc, d_adler));   // out_off / out_len fields
     LAUNCH_TRY(launch_verify_trailers(st, format, count, (const uint8_t *)d_in, d_streams, d_hdrs,
                                       (InflateResult *)c->d_dec_state.p, d_crc, d_adler, d_consumed));
     std::vector<InflateResult> res(count);

@@ -120,7 +120,4 @@ int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const
 int launch_verify_trailers(hipStream_t st, int format, uint32_t count, const uint8_t *in,
                            const DecStream *streams, const DecHeader *hdrs, InflateResult *results,
                            const uint32_t *crc, const uint32_t *adler, uint64_t *consumed);
-int launch_stream_checksum(hipStream_t st, const uint8_t *out, const DecStream *streams,
-                           const InflateResult *results, uint32_t count, uint32_t *crc, uint32_t *adler);
-
 }  // namespace lfx

@@ -651,75 +651,6 @@ __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-stream checksums of the decoded output: one workgroup per stream
-__global__ __launch_bounds__(256) void stream_checksum_kernel(const uint8_t *__restrict__ out,
-                                                              const DecStream *__restrict__ streams,
-                                                              const InflateResult *__restrict__ results,
-                                                              uint32_t *__restrict__ crc_out,
-                                                              uint32_t *__restrict__ adler_out) {
-    __shared__ uint32_t tab[256];
-    __shared__ uint32_t s_crc[256], s_a[256], s_b[256];
-    __shared__ uint64_t s_len[256];
-    {
-        uint32_t c = threadIdx.x;
-        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
-        tab[threadIdx.x] = c;
-    }
-    __syncthreads();
-    const uint32_t sidx = blockIdx.x;
-    const uint8_t *p = out + streams[sidx].out_off;
-    const uint64_t n = results[sidx].out_len;
-    const uint64_t per = div_up(n, 256);
-    const uint64_t lo = (uint64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    uint32_t crc = 0, a = 0, b = 0;
-    for (uint64_t i = lo; i < hi; ++i) {
-        const uint32_t byte = p[i];
-        crc = (crc >> 8) ^ tab[(crc ^ byte) & 0xFF];
-        a += byte;
-        if (a >= 65521u) a -= 65521u;
-        b += a;
-        if (b >= 65521u) b -= 65521u;
-    }
-    s_crc[threadIdx.x] = crc; s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
-    s_len[threadIdx.x] = hi > lo ? hi - lo : 0;
-    __syncthreads();
-    auto mul = [](uint32_t x, uint32_t y) {
-        uint32_t pp = 0;
-        for (int i = 0; i < 32; ++i) {
-            if (x & 0x80000000u) pp ^= y;
-            x <<= 1;
-            y = (y >> 1) ^ (0xEDB88320u & (0u - (y & 1)));
-        }
-        return pp;
-    };
-    auto xpow = [&](uint64_t e) {
-        uint32_t r = 0x80000000u, sq = 0x00800000u;
-        while (e) { if (e & 1) r = mul(r, sq); sq = mul(sq, sq); e >>= 1; }
-        return r;
-    };
-    for (uint32_t step = 1; step < 256; step <<= 1) {
-        const bool act = (threadIdx.x % (2 * step)) == 0 && threadIdx.x + step < 256;
-        uint32_t c2 = 0, a2 = 0, b2 = 0;
-        uint64_t l2 = 0;
-        if (act) { c2 = s_crc[threadIdx.x + step]; a2 = s_a[threadIdx.x + step]; b2 = s_b[threadIdx.x + step]; l2 = s_len[threadIdx.x + step]; }
-        __syncthreads();
-        if (act) {
-            const uint32_t c1 = s_crc[threadIdx.x], a1 = s_a[threadIdx.x], b1 = s_b[threadIdx.x];
-            s_crc[threadIdx.x] = (l2 ? mul(c1, xpow(l2)) : c1) ^ c2;
-            s_b[threadIdx.x] = (uint32_t)((b1 + b2 + (l2 % 65521u) * (uint64_t)a1) % 65521u);
-            s_a[threadIdx.x] = (a1 + a2) % 65521u;
-            s_len[threadIdx.x] += l2;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        crc_out[sidx] = s_crc[0] ^ mul(0xFFFFFFFFu, xpow(n)) ^ 0xFFFFFFFFu;
-        const uint32_t AA = (1u + s_a[0]) % 65521u;
-        const uint32_t BB = (uint32_t)((n % 65521u + s_b[0]) % 65521u);
-        adler_out[sidx] = (BB << 16) | AA;
-    }
-}
-
 // trailer verification per stream (gzip.rs:1030-1042: CRC-32 checked, ISIZE ignored;
 // zlib.rs:387-401: Adler-32 big-endian).  One lane per stream.
 __global__ void verify_trailers_kernel(int format, uint32_t count, const uint8_t *__restrict__ in,
@@ -797,12 +728,4 @@ int launch_verify_trailers(hipStream_t st, int format, uint32_t count, const uin
     LFX_LAUNCH_CHECK();
     return 0;
 }
-int launch_stream_checksum(hipStream_t st, const uint8_t *out, const DecStream *streams,
-                           const InflateResult *results, uint32_t count, uint32_t *crc, uint32_t *adler) {
-    if (!count) return 0;
-    hipLaunchKernelGGL(stream_checksum_kernel, dim3(count), dim3(256), 0, st, out, streams, results, crc, adler);
-    LFX_LAUNCH_CHECK();
-    return 0;
-}
-
 }  // namespace lfx

@@ -965,12 +965,8 @@ __device__ uint32_t gf2_xpow8n(uint64_t nbytes) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__restrict__ in,
-                                                            uint64_t n, uint32_t *__restrict__ crc_part,
-                                                            uint32_t *__restrict__ a_part,
-                                                            uint32_t *__restrict__ b_part) {
-    __shared__ uint32_t tab[4][256];   // slice-by-4: four independent lookups per input dword
-    __shared__ uint32_t s_adv;
+// checksum tables of a 256-thread workgroup: slice-by-4 CRC tables and x^(8*4032) (see ck_span_partial)
+__device__ __forceinline__ void ck_tables(uint32_t (*tab)[256], uint32_t *s_adv) {
     {
         uint32_t c = threadIdx.x;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1)));
@@ -982,17 +978,20 @@ __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__res
         tab[t][threadIdx.x] = (pv >> 8) ^ tab[0][pv & 0xFF];
         __syncthreads();
     }
-    if (threadIdx.x == 0) s_adv = gf2_xpow8n(4096 - 64);
+    if (threadIdx.x == 0) *s_adv = gf2_xpow8n(4096 - 64);
     __syncthreads();
-    const uint32_t adv = s_adv;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t region = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t r0 = region * CK_SPAN;
-    if (r0 >= n) return;
-    const uint32_t rlen = (uint32_t)min((uint64_t)CK_SPAN, n - r0);
-    const ByteSrc src = make_src(in + r0, rlen);
-    // Invariant: `crc` is the raw register (init 0, no xorout — linear in the data) of this lane's
-    // bytes with zeros everywhere else, standing at region offset `stand`.
+}
+
+// One wavefront, one region of at most CK_SPAN bytes: raw CRC register (init 0, no xorout — linear in the
+// data), sum of bytes mod 65521 and sum of (rlen - i) * byte_i mod 65521.  The wavefront sweeps the region
+// 4 KiB at a time (coalesced); a lane advances its register over the 4032 bytes of the other lanes with
+// one multiplication by x^(8*4032) mod P.  Results are valid in every lane.
+struct CkPartial { uint32_t crc, a, b; };
+__device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t rlen, uint32_t lane,
+                                                     const uint32_t (*tab)[256], uint32_t adv) {
+    const ByteSrc src = make_src(p, rlen);
+    // Invariant: `crc` is the raw register of this lane's bytes with zeros everywhere else, standing at
+    // region offset `stand`.
     uint32_t crc = 0, stand = 0;
     uint32_t s1 = 0, s1_before = 0;   // sum of bytes
     uint64_t s2 = 0;                  // sum of (offset in region) * byte
@@ -1032,13 +1031,61 @@ __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__res
     for (int o = 32; o > 0; o >>= 1) reg ^= __shfl_xor(reg, o);
     uint64_t t1 = s1, t2 = s2 % 65521u;
     for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+    CkPartial r;
+    r.crc = reg;
+    r.a = (uint32_t)(t1 % 65521u);
+    // sum over i of (rlen - i) * byte_i = rlen * S1 - S2
+    r.b = (uint32_t)(((uint64_t)(rlen % 65521u) * r.a + 65521ull * 65521ull - (t2 % 65521u)) % 65521u);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__restrict__ in,
+                                                            uint64_t n, uint32_t *__restrict__ crc_part,
+                                                            uint32_t *__restrict__ a_part,
+                                                            uint32_t *__restrict__ b_part) {
+    __shared__ uint32_t tab[4][256];   // slice-by-4: four independent lookups per input dword
+    __shared__ uint32_t s_adv;
+    ck_tables(tab, &s_adv);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t region = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t r0 = region * CK_SPAN;
+    if (r0 >= n) return;
+    const uint32_t rlen = (uint32_t)min((uint64_t)CK_SPAN, n - r0);
+    const CkPartial r = ck_span_partial(in + r0, rlen, lane, tab, s_adv);
+    if (lane == 0) { crc_part[region] = r.crc; a_part[region] = r.a; b_part[region] = r.b; }
+}
+
+// CRC-32 and Adler-32 of many independent byte ranges (batch decode): one wavefront per range, which folds
+// its CK_SPAN pieces in order.  off[i] / len[i] are read with the given strides (in 8-byte units) so that the
+// caller's own descriptor arrays can be used.
+__global__ __launch_bounds__(256) void checksum_ranges_kernel(const uint8_t *__restrict__ data, uint32_t count,
+                                                              const uint64_t *__restrict__ off, uint32_t off_stride,
+                                                              const uint64_t *__restrict__ len, uint32_t len_stride,
+                                                              uint32_t *__restrict__ crc_out,
+                                                              uint32_t *__restrict__ adler_out) {
+    __shared__ uint32_t tab[4][256];
+    __shared__ uint32_t s_adv;
+    ck_tables(tab, &s_adv);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= count) return;
+    const uint8_t *p = data + off[(uint64_t)i * off_stride];
+    const uint64_t n = len[(uint64_t)i * len_stride];
+    uint32_t crc = 0, a = 0, b = 0;
+    const uint32_t xs = gf2_xpow8n(CK_SPAN);
+    for (uint64_t o = 0; o < n; o += CK_SPAN) {
+        const uint32_t sl = (uint32_t)min((uint64_t)CK_SPAN, n - o);
+        const CkPartial r = ck_span_partial(p + o, sl, lane, tab, s_adv);
+        crc = gf2_mulmod(crc, sl == CK_SPAN ? xs : gf2_xpow8n(sl)) ^ r.crc;
+        b = (uint32_t)((b + r.b + (sl % 65521u) * (uint64_t)a) % 65521u);   // B += b2 + len2 * A_before
+        a = (a + r.a) % 65521u;
+    }
     if (lane == 0) {
-        crc_part[region] = reg;
-        const uint32_t a = (uint32_t)(t1 % 65521u);
-        // sum over i of (rlen - i) * byte_i = rlen * S1 - S2
-        const uint64_t bb = ((uint64_t)(rlen % 65521u) * a + 65521ull * 65521ull - (t2 % 65521u)) % 65521u;
-        a_part[region] = a;
-        b_part[region] = (uint32_t)bb;
+        // raw register of the data; apply init 0xFFFFFFFF over n bytes and the final xor; Adler with A0 = 1
+        crc_out[i] = crc ^ gf2_mulmod(0xFFFFFFFFu, gf2_xpow8n(n)) ^ 0xFFFFFFFFu;
+        const uint32_t A = (1u + a) % 65521u;
+        const uint32_t B = (uint32_t)((n % 65521u + b) % 65521u);
+        adler_out[i] = (B << 16) | A;
     }
 }
 
@@ -1246,6 +1293,14 @@ int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc
     }
     hipLaunchKernelGGL(checksum_combine_kernel, dim3(1), dim3(1024), 0, st, crc_part, a_part, b_part,
                        n, res);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_checksum_ranges(hipStream_t st, const uint8_t *data, uint32_t count, const uint64_t *off,
+                           uint32_t off_stride, const uint64_t *len, uint32_t len_stride, uint32_t *crc, uint32_t *adler) {
+    if (!count) return 0;
+    hipLaunchKernelGGL(checksum_ranges_kernel, dim3((count + 3) / 4), dim3(256), 0, st, data, count, off, off_stride, len,
+                       len_stride, crc, adler);
     LFX_LAUNCH_CHECK();
     return 0;
 }

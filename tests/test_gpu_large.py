@@ -104,6 +104,7 @@ def test_cfg3_batch_4096_streams(env, oracle):
     d_out = torch.zeros(count * size, dtype=torch.uint8, device="cuda")
     out_len = np.zeros(count, dtype=np.uint64)
     status = np.zeros(count, dtype=np.int32)
+    ctx.enable_timing(True)
     for _ in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -114,4 +115,4 @@ def test_cfg3_batch_4096_streams(env, oracle):
     assert rc == 0
     assert not status.any() and (out_len == size).all()
     assert torch.equal(d_out, torch.from_numpy(big).cuda())
-    print("cfg3: %d streams, %.1f ms, %.2f GB/s of output" % (count, dt * 1e3, count * size / dt / 1e9))
+    print("cfg3: %d streams, %.1f ms, %.2f GB/s of output" % (count, dt * 1e3, count * size / dt / 1e9), ctx.last_timing())
