@@ -177,9 +177,11 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * nj))) return rc;
             if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * nj))) return rc;
             if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)nj))) return rc;
+            const size_t tab_bytes = blk_tabs_bytes();
+            if ((rc = c->d_dec_tabs.reserve(tab_bytes * nj))) return rc;
             HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
             LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
-                                       (BlkLanes *)c->d_dec_blocks.p));
+                                       (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
             std::vector<BlkInfo> bi(nj);
             HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -213,7 +215,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 for (size_t q = 0; q < redo.size(); q++) {
                     slot[redo[q]] = redo[q];
                     LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_rj + q, 1, (BlkInfo *)c->d_dec_state.p + redo[q],
-                                               (BlkLanes *)c->d_dec_blocks.p + redo[q]));
+                                               (BlkLanes *)c->d_dec_blocks.p + redo[q],
+                                               (uint8_t *)c->d_dec_tabs.p + tab_bytes * redo[q]));
                 }
                 for (size_t q = 0; q < redo.size(); q++)
                     HIP_TRY(hipMemcpyAsync(&bi[redo[q]], (BlkInfo *)c->d_dec_state.p + redo[q], sizeof(BlkInfo), hipMemcpyDeviceToHost, st));
@@ -261,7 +264,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
                 const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
-                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target));
+                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
+                                           c->d_dec_tabs.p));
                 c->phase("blk_emit");
                 LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                   (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
@@ -505,9 +509,10 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
         if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * nj))) return rc;
         if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * nj))) return rc;
         if ((rc = c->d_dec_cand.reserve(sizeof(BlkLanes) * (size_t)nj))) return rc;
+        if ((rc = c->d_dec_tabs.reserve(blk_tabs_bytes() * nj))) return rc;
         HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
         LAUNCH_TRY(launch_blk_scan(st, d_in, n_in, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
-                                   (BlkLanes *)c->d_dec_cand.p));
+                                   (BlkLanes *)c->d_dec_cand.p, c->d_dec_tabs.p));
         std::vector<BlkInfo> bi(nj);
         HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -544,7 +549,7 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
             const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
             const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
             LAUNCH_TRY(launch_blk_emit(st, d_in, n_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p, (uint32_t *)c->d_codes.p,
-                                       d_flags, (BlkUnits *)c->d_hist.p, unit_target, d_jf));
+                                       d_flags, (BlkUnits *)c->d_hist.p, unit_target, d_jf, c->d_dec_tabs.p));
             LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p,
                                               (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, nullptr));
             HIP_TRY(hipMemcpyAsync(jf.data(), d_jf, 4ull * ne, hipMemcpyDeviceToHost, st));

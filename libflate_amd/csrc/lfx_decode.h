@@ -95,11 +95,14 @@ struct BlkUnits {
     uint64_t out0[9];    // ... and bytes [out0[u], out0[u+1]) of the block's output
     uint32_t cyc[4];     // diagnostics: header, decode, cut search, unit selection (clock64 ticks)
 };
+// tabs: njobs * blk_tabs_bytes() bytes: the decode tables of every scanned block, reused by launch_blk_emit
+size_t blk_tabs_bytes();
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
-                    BlkInfo *infos, BlkLanes *lanes);
+                    BlkInfo *infos, BlkLanes *lanes, void *tabs = nullptr);
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
-                    uint32_t *job_flags = nullptr);   // job_flags[j] = 1: block j reads bytes in front of itself
+                    uint32_t *job_flags = nullptr,   // job_flags[j] = 1: block j reads bytes in front of itself
+                    const void *tabs = nullptr);     // tables from launch_blk_scan, indexed by BlkEmit::cand
 int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg);

@@ -517,7 +517,8 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
 __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkJob *__restrict__ jobs,
                                                                 BlkInfo *__restrict__ infos,
-                                                                BlkLanes *__restrict__ lanes) {
+                                                                BlkLanes *__restrict__ lanes,
+                                                                FastTabs *__restrict__ tabs) {
     __shared__ FastTabs T;
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
@@ -548,6 +549,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
         }
         if (tid == 0) infos[blockIdx.x] = bi;
         return;
+    }
+    if (tabs) {   // the emit kernel takes the block's tables from here instead of parsing the header again
+        uint32_t *dst = (uint32_t *)&tabs[blockIdx.x];
+        const uint32_t *srcw = (const uint32_t *)&T;
+        for (uint32_t i = tid; i < sizeof(FastTabs) / 4; i += SCAN_THREADS) dst[i] = srcw[i];
     }
     const uint64_t d0 = hdr64[0];
     uint64_t e = job.end_bit;
@@ -684,7 +690,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
                                                                 uint32_t *__restrict__ codes,
                                                                 uint32_t *__restrict__ flags,
                                                                 BlkUnits *__restrict__ units, uint32_t unit_target,
-                                                                uint32_t *__restrict__ job_flags) {
+                                                                uint32_t *__restrict__ job_flags,
+                                                                const FastTabs *__restrict__ tabs) {
     __shared__ FastTabs T;
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
@@ -698,7 +705,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         return;
     }
     const uint64_t t_begin = clock64();
-    parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
+    if (tabs) {   // the tables the scan kernel built for this block
+        const uint32_t *srcw = (const uint32_t *)&tabs[job.cand];
+        uint32_t *dst = (uint32_t *)&T;
+        for (uint32_t i = tid; i < sizeof(FastTabs) / 4; i += SCAN_THREADS) dst[i] = srcw[i];
+        __syncthreads();
+    } else parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
     const uint64_t t_hdr = clock64();
     const BlkLanes *L = &lanes[job.cand];
     int64_t reach = INT64_MAX;
@@ -1079,16 +1091,17 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
         if (e_ != hipSuccess) return (int)e_;       \
     } while (0)
 
+size_t blk_tabs_bytes() { return sizeof(FastTabs); }
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
-                    BlkInfo *infos, BlkLanes *lanes) {
+                    BlkInfo *infos, BlkLanes *lanes, void *tabs) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_scan_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes);
+    hipLaunchKernelGGL(blk_scan_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes, (FastTabs *)tabs);
     LFX_LAUNCH_CHECK();
     return 0;
 }
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
-                    uint32_t *job_flags) {
+                    uint32_t *job_flags, const void *tabs) {
     if (!njobs) return 0;
     constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
     static bool attr_set = false;
@@ -1097,7 +1110,7 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
         attr_set = true;
     }
     hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes, flags, units,
-                       unit_target ? unit_target : 1u, job_flags);
+                       unit_target ? unit_target : 1u, job_flags, (const FastTabs *)tabs);
     LFX_LAUNCH_CHECK();
     return 0;
 }
