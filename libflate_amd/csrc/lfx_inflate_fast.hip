@@ -247,12 +247,13 @@ struct FastBits {
         used = 0;
     }
     __device__ __forceinline__ void append() {   // needs qn >= 1
-        if (nb <= 32) {
-            buf |= (uint64_t)q0 << nb;
-            nb += 32;
-            q0 = q1; q1 = q2; q2 = q3; q3 = q4;
-            qn--;
-        }
+        // branch-free: a divergent branch here costs an exec-mask round trip and a register copy per FIFO slot
+        const bool need = nb <= 32;
+        const uint64_t add = (uint64_t)q0 << (nb & 63);
+        buf |= need ? add : 0ull;
+        nb += need ? 32u : 0u;
+        q0 = need ? q1 : q0; q1 = need ? q2 : q1; q2 = need ? q3 : q2; q3 = need ? q4 : q3;
+        qn -= need ? 1u : 0u;
     }
     __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; nb -= k; used += k; }
     __device__ __forceinline__ void reload() {   // qn is 0 or 1 here
