@@ -300,34 +300,32 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
                 if (e == 0) { ret = 2; break; }
             }
             const uint32_t kind = (e >> 4) & 3;
-            if (kind == K_LIT) {
-                b.skip(e & 15);
-                if (EMIT) stage[staged++] = e & 0x00FF0000u;
-                ncodes++;
-                no++;
-                continue;
-            }
-            if (kind == K_EOB) { b.skip(e & 15); ret = 1; break; }
+            if (__builtin_expect(kind == K_EOB, 0)) { b.skip(e & 15); ret = 1; break; }
+            // Literals and matches share one straight-line path (a literal is a symbol without extra bits and
+            // without a distance): nearly every wavefront iteration holds both kinds, and a divergent branch
+            // costs exec-mask round trips and a register copy per live value.  A literal lane also tops up
+            // its bit window and looks up a distance entry; both are harmless and ignored.
+            const bool is_match = kind == K_LEN;
             const uint32_t w = e & 15, eb = (e >> 6) & 31;
-            const uint32_t length = (e >> 16) + (((uint32_t)(b.buf >> w)) & ((1u << eb) - 1));
+            const uint32_t val = (e >> 16) + (((uint32_t)(b.buf >> w)) & ((1u << eb) - 1));   // byte, or length
             b.skip(w + eb);
             b.append();
             uint32_t d = T.dist[(uint32_t)b.buf & ((1u << DIST_BITS) - 1)];
-            if (__builtin_expect((d & 15) == 0, 0)) {
+            if (__builtin_expect(is_match && (d & 15) == 0, 0)) {
                 d = d == E_LONG ? long_lookup(T.dist_count, T.dist_sorted, T.dist_info, 30, b.buf) : 0;
                 if (d == 0) { ret = 2; break; }
             }
             const uint32_t dw = d & 15, db = (d >> 6) & 31;
             const uint32_t distance = (d >> 16) + (((uint32_t)(b.buf >> dw)) & ((1u << db) - 1));
-            b.skip(dw + db);
+            b.skip(is_match ? dw + db : 0u);
             if (EMIT) {
-                stage[staged++] = (length << 16) | distance;
-                const int64_t srcpos = (int64_t)(nout + no) - (int64_t)distance;   // first byte this match reads
-                if (srcpos < reach) reach = srcpos;
-                if ((int32_t)no - (int32_t)distance < (int32_t)cut_out) { cut_code = ncodes + 1; cut_out = no + length; }
+                stage[staged++] = (val << 16) | (is_match ? distance : 0u);
+                const int64_t srcpos = (int64_t)(nout + no) - (int64_t)distance;   // first byte a match reads
+                if (is_match && srcpos < reach) reach = srcpos;
+                if (is_match && (int32_t)no - (int32_t)distance < (int32_t)cut_out) { cut_code = ncodes + 1; cut_out = no + val; }
             }
             ncodes++;
-            no += length;
+            no += is_match ? val : 1u;
         }
         if (EMIT) {
             uint32_t *dst = codes + (ncodes - staged);
