@@ -369,7 +369,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     } while (0)
 
     uint64_t *mdbg = nullptr;
-    if (getenv("LFX_DEBUG")) { mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768); (void)hipMemsetAsync(mdbg - 512 / 8 * 0, 0, 0, st); }
+    if (getenv("LFX_DEBUG")) mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768);   // per-wavefront cycle counters of workgroup 0
     LAUNCH_TRY(launch_match(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                             (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
     if (mdbg) {

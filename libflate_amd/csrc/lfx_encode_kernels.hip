@@ -953,15 +953,37 @@ __device__ __forceinline__ uint32_t gf2_mulmod(uint32_t a, uint32_t b) {
     }
     return p;
 }
-__device__ uint32_t gf2_xpow8n(uint64_t nbytes) {
-    // x^(8*nbytes) mod P, reflected representation (x^0 = 0x80000000)
-    uint32_t r = 0x80000000u;
-    uint32_t sq = 0x00800000u;  // x^8
-    while (nbytes) {
-        if (nbytes & 1) r = gf2_mulmod(r, sq);
-        sq = gf2_mulmod(sq, sq);
-        nbytes >>= 1;
+// x^(8 * 2^k) mod P for k = 0..47, reflected representation (x^0 = 0x80000000), built at compile time:
+// x^(8n) is then one multiplication per set bit of n instead of two per bit (a multiplication is a
+// 32-step shift/xor loop, ~1000 cycles for a lone lane).
+struct Xp8Table { uint32_t v[48]; };
+constexpr uint32_t cx_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (a & 0x80000000u) p ^= b;
+        a <<= 1;
+        b = (b >> 1) ^ (0xEDB88320u & (0u - (b & 1)));
     }
+    return p;
+}
+constexpr Xp8Table cx_xp8_table() {
+    Xp8Table t{};
+    uint32_t sq = 0x00800000u;  // x^8
+    for (int k = 0; k < 48; ++k) { t.v[k] = sq; sq = cx_mulmod(sq, sq); }
+    return t;
+}
+__constant__ Xp8Table XP8 = cx_xp8_table();
+
+__device__ __forceinline__ uint32_t gf2_xpow8n(uint64_t nbytes) {
+    // x^(8*nbytes) mod P
+    uint32_t r = 0x80000000u;
+    bool first = true;
+    for (uint32_t k = 0; nbytes; ++k, nbytes >>= 1)
+        if (nbytes & 1) {
+            const uint32_t f = XP8.v[k < 47 ? k : 47];
+            r = first ? f : gf2_mulmod(r, f);
+            first = false;
+        }
     return r;
 }
 
@@ -978,7 +1000,7 @@ __device__ __forceinline__ void ck_tables(uint32_t (*tab)[256], uint32_t *s_adv)
         tab[t][threadIdx.x] = (pv >> 8) ^ tab[0][pv & 0xFF];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *s_adv = gf2_xpow8n(4096 - 64);
+    if (threadIdx.x == 0) *s_adv = gf2_xpow8n(4096 - 64);   // (five table factors)
     __syncthreads();
 }
 
@@ -1204,10 +1226,13 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                  const SegDesc *segs, uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint64_t *dbg) {
     if (nsegs == 0) return 0;
     const size_t lds = MATCH_LDS;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // (a function attribute is per device: one flag per device ordinal)
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
         (void)hipFuncSetAttribute((const void *)lz77_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+        attr_set[dev_ & 63] = true;
     }
     hipLaunchKernelGGL(lz77_match_kernel, dim3(nsegs), dim3(MATCH_THREADS), lds, st, in, in_bytes,
                        chunks, segs, window, max_len, md, dbg);

@@ -1103,10 +1103,13 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
                     uint32_t *job_flags, const void *tabs) {
     if (!njobs) return 0;
     constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // (a function attribute is per device: one flag per device ordinal)
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
         (void)hipFuncSetAttribute((const void *)blk_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
-        attr_set = true;
+        attr_set[dev_ & 63] = true;
     }
     hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes, flags, units,
                        unit_target ? unit_target : 1u, job_flags, (const FastTabs *)tabs);
