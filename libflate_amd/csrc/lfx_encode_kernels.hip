@@ -974,6 +974,23 @@ constexpr Xp8Table cx_xp8_table() {
 }
 __constant__ Xp8Table XP8 = cx_xp8_table();
 
+// multiplication by the constant x^(8*4032) (a lane's step over the other lanes' bytes of a 4 KiB row) as
+// four byte-indexed lookups: the product is linear in the register, T[k][b] = (b << 8k) * x^(8*4032)
+struct AdvTable { uint32_t t[4][256]; };
+constexpr uint32_t cx_xpow8n(uint64_t n) {
+    uint32_t r = 0x80000000u, sq = 0x00800000u;
+    while (n) { if (n & 1) r = cx_mulmod(r, sq); sq = cx_mulmod(sq, sq); n >>= 1; }
+    return r;
+}
+constexpr AdvTable cx_adv_table() {
+    AdvTable a{};
+    const uint32_t adv = cx_xpow8n(4096 - 64);
+    for (int k = 0; k < 4; ++k)
+        for (uint32_t b = 0; b < 256; ++b) a.t[k][b] = cx_mulmod(b << (8 * k), adv);
+    return a;
+}
+__constant__ AdvTable ADV = cx_adv_table();
+
 __device__ __forceinline__ uint32_t gf2_xpow8n(uint64_t nbytes) {
     // x^(8*nbytes) mod P
     uint32_t r = 0x80000000u;
@@ -987,21 +1004,20 @@ __device__ __forceinline__ uint32_t gf2_xpow8n(uint64_t nbytes) {
     return r;
 }
 
-// checksum tables of a 256-thread workgroup: slice-by-4 CRC tables and x^(8*4032) (see ck_span_partial)
-__device__ __forceinline__ void ck_tables(uint32_t (*tab)[256], uint32_t *s_adv) {
+// checksum tables of a 256-thread workgroup: slice-by-4 CRC tables and the multiply-by-x^(8*4032) tables
+__device__ __forceinline__ void ck_tables(uint32_t (*tab)[256], uint32_t (*advt)[256]) {
     {
         uint32_t c = threadIdx.x;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (CRC_POLY & (0u - (c & 1)));
         tab[0][threadIdx.x] = c;
     }
+    for (int k = 0; k < 4; ++k) advt[k][threadIdx.x] = ADV.t[k][threadIdx.x];
     __syncthreads();
     for (int t = 1; t < 4; ++t) {
         const uint32_t pv = tab[t - 1][threadIdx.x];
         tab[t][threadIdx.x] = (pv >> 8) ^ tab[0][pv & 0xFF];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *s_adv = gf2_xpow8n(4096 - 64);   // (five table factors)
-    __syncthreads();
 }
 
 // One wavefront, one region of at most CK_SPAN bytes: raw CRC register (init 0, no xorout — linear in the
@@ -1010,7 +1026,7 @@ __device__ __forceinline__ void ck_tables(uint32_t (*tab)[256], uint32_t *s_adv)
 // one multiplication by x^(8*4032) mod P.  Results are valid in every lane.
 struct CkPartial { uint32_t crc, a, b; };
 __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t rlen, uint32_t lane,
-                                                     const uint32_t (*tab)[256], uint32_t adv) {
+                                                     const uint32_t (*tab)[256], const uint32_t (*advt)[256]) {
     const ByteSrc src = make_src(p, rlen);
     // Invariant: `crc` is the raw register of this lane's bytes with zeros everywhere else, standing at
     // region offset `stand`.
@@ -1019,7 +1035,8 @@ __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t 
     uint64_t s2 = 0;                  // sum of (offset in region) * byte
     const uint32_t first = 64 * lane;
     for (uint32_t o = first; o < rlen; o += 4096) {
-        if (o != first) crc = gf2_mulmod(crc, adv);      // over the other lanes' 4032 bytes
+        if (o != first)                                  // over the other lanes' 4032 bytes
+            crc = advt[0][crc & 0xFF] ^ advt[1][(crc >> 8) & 0xFF] ^ advt[2][(crc >> 16) & 0xFF] ^ advt[3][crc >> 24];
         const uint32_t len = min(64u, rlen - o);         // only the last piece can be short
         // all sixteen loads are issued before the (serially dependent) table walk starts
         uint32_t w[16];
@@ -1066,14 +1083,14 @@ __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__res
                                                             uint32_t *__restrict__ a_part,
                                                             uint32_t *__restrict__ b_part) {
     __shared__ uint32_t tab[4][256];   // slice-by-4: four independent lookups per input dword
-    __shared__ uint32_t s_adv;
-    ck_tables(tab, &s_adv);
+    __shared__ uint32_t advt[4][256];
+    ck_tables(tab, advt);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t region = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t r0 = region * CK_SPAN;
     if (r0 >= n) return;
     const uint32_t rlen = (uint32_t)min((uint64_t)CK_SPAN, n - r0);
-    const CkPartial r = ck_span_partial(in + r0, rlen, lane, tab, s_adv);
+    const CkPartial r = ck_span_partial(in + r0, rlen, lane, tab, advt);
     if (lane == 0) { crc_part[region] = r.crc; a_part[region] = r.a; b_part[region] = r.b; }
 }
 
@@ -1086,8 +1103,8 @@ __global__ __launch_bounds__(256) void checksum_ranges_kernel(const uint8_t *__r
                                                               uint32_t *__restrict__ crc_out,
                                                               uint32_t *__restrict__ adler_out) {
     __shared__ uint32_t tab[4][256];
-    __shared__ uint32_t s_adv;
-    ck_tables(tab, &s_adv);
+    __shared__ uint32_t advt[4][256];
+    ck_tables(tab, advt);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= count) return;
@@ -1097,7 +1114,7 @@ __global__ __launch_bounds__(256) void checksum_ranges_kernel(const uint8_t *__r
     const uint32_t xs = gf2_xpow8n(CK_SPAN);
     for (uint64_t o = 0; o < n; o += CK_SPAN) {
         const uint32_t sl = (uint32_t)min((uint64_t)CK_SPAN, n - o);
-        const CkPartial r = ck_span_partial(p + o, sl, lane, tab, s_adv);
+        const CkPartial r = ck_span_partial(p + o, sl, lane, tab, advt);
         crc = gf2_mulmod(crc, sl == CK_SPAN ? xs : gf2_xpow8n(sl)) ^ r.crc;
         b = (uint32_t)((b + r.b + (sl % 65521u) * (uint64_t)a) % 65521u);   // B += b2 + len2 * A_before
         a = (a + r.a) % 65521u;
