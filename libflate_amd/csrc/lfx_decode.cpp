@@ -237,6 +237,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 BlkEmit e{};
                 e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
                 e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
+                e.hist = total;      // (hist0 = 0: a member starts with an empty window)
                 emit.push_back(e);
                 total += r.n_out;
                 total_codes += r.n_codes;
@@ -247,8 +248,9 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             if (ok_chain && total <= cap) {
                 // ---- K2 + K3: validated lanes emit codes, one wavefront per block materialises them
                 const uint32_t ne = (uint32_t)emit.size();
-                if ((rc = c->d_dec_tmp.reserve(sizeof(BlkEmit) * ne + 64))) return rc;
-                if ((rc = c->d_hist.reserve(sizeof(BlkUnits) * (size_t)ne + 64))) return rc;
+                // (room for a second set: the ordered runs of the cross-block case below)
+                if ((rc = c->d_dec_tmp.reserve(sizeof(BlkEmit) * 2 * (size_t)ne + 64))) return rc;
+                if ((rc = c->d_hist.reserve(sizeof(BlkUnits) * 2 * (size_t)ne + 64))) return rc;
                 if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(total_codes, 1)))) return rc;
                 uint32_t *d_flags = (uint32_t *)c->d_dec_tmp.p;
                 BlkEmit *d_emit = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64);
@@ -296,6 +298,46 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                         fprintf(stderr, "[lfx]  K3 unit %u: cycles=%llu batches=%llu nseq=%llu seq_cycles=%llu codes=%llu bytes=%llu\n", u,
                                 (unsigned long long)dv[u * 8], (unsigned long long)dv[u * 8 + 1], (unsigned long long)dv[u * 8 + 2],
                                 (unsigned long long)dv[u * 8 + 3], (unsigned long long)dv[u * 8 + 4], (unsigned long long)dv[u * 8 + 5]);
+                }
+                if (fl == 2) {
+                    // Blocks read the output of earlier blocks (streams of other encoders; the reference's own
+                    // blocks never do): every block cannot be materialised at once.  The codes are all there, so
+                    // the blocks are materialised again IN ORDER — each run of consecutive compressed blocks as
+                    // one unit on one wavefront, its 32 KiB of history loaded from the output in front of it;
+                    // stored blocks in between are plain copies.  Slow (one wavefront) but ~40x the serial kernel.
+                    std::vector<BlkEmit> runs;
+                    for (uint32_t q = 0; q < ne; ) {
+                        BlkEmit r = emit[q];
+                        uint32_t q2 = q + 1;
+                        if (r.btype != 0) {
+                            r.btype = 2;
+                            uint64_t nco = r.n_codes;
+                            while (q2 < ne && emit[q2].btype != 0 && nco + emit[q2].n_codes < 0xFFFFFFFFull) {
+                                nco += emit[q2].n_codes; r.n_out += emit[q2].n_out; q2++;
+                            }
+                            r.n_codes = (uint32_t)nco;
+                        }
+                        r.preload = r.hist != 0;
+                        runs.push_back(r);
+                        q = q2;
+                    }
+                    const uint32_t nr = (uint32_t)runs.size();
+                    std::vector<BlkUnits> ru(nr);
+                    for (uint32_t q = 0; q < nr; q++) {
+                        ru[q] = BlkUnits{};
+                        ru[q].n = 1; ru[q].code0[0] = 0; ru[q].code0[1] = runs[q].n_codes; ru[q].out0[0] = 0; ru[q].out0[1] = runs[q].n_out;
+                    }
+                    BlkEmit *d_runs = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64) + ne;
+                    BlkUnits *d_ru = (BlkUnits *)c->d_hist.p + ne;
+                    HIP_TRY(hipMemcpyAsync(d_runs, runs.data(), sizeof(BlkEmit) * nr, hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(d_ru, ru.data(), sizeof(BlkUnits) * nr, hipMemcpyHostToDevice, st));
+                    for (uint32_t q = 0; q < nr; q++)
+                        LAUNCH_TRY(launch_blk_materialize(st, d_in, d_runs + q, 1, (const BlkLanes *)c->d_dec_blocks.p, d_ru + q,
+                                                          (const uint32_t *)c->d_codes.p, d_out, nullptr));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    c->phase("lz77_chain");
+                    if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  cross-block references: %u blocks re-materialised in %u ordered runs\n", ne, nr);
+                    fl = 0;
                 }
                 if (fl == 0) {   // no back-reference reached before its block's first byte
                     mr.status = LFX_OK;
@@ -531,6 +573,7 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
             e.out_off = j.out_off + live[k].produced;
             e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
             e.hist = live[k].produced;
+            e.preload = live[k].produced != 0;
             emit.push_back(e);
             owner.push_back(k);
             total_codes += r.n_codes;

@@ -87,7 +87,9 @@ struct BlkEmit {
     uint64_t out_off;    // first output byte of the block
     uint64_t n_out;
     uint32_t n_codes, nlanes, btype, cand;
-    uint64_t hist;       // output bytes of the same stream already materialised in front of the block (batch rounds)
+    uint64_t hist;       // output bytes of the same member in front of the block (bounds its back-references)
+    uint32_t preload;    // materialise: those bytes are already final in `out` — load up to 32 KiB of them as history
+    uint32_t _pad;
 };
 struct BlkUnits {
     uint32_t n;          // independent units of the block (no back-reference crosses a cut)

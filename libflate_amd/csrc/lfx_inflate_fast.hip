@@ -723,10 +723,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         uint64_t no = out0, endpos;
         lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
                           emit_stage + tid * EMIT_STRIDE);
-        if (reach < -(int64_t)job.hist) {         // a back-reference reaches before the block start (and its history)
+        if (reach < -(int64_t)job.hist) {         // a back-reference reaches in front of the member's first byte
             atomicOr(&flags[0], 1u);              // ... summary, and per job (batch decode)
             if (job_flags) job_flags[blockIdx.x] = 1u;
-        }
+        } else if (reach < 0) atomicOr(&flags[0], 2u);   // ... in front of the block: it needs the earlier output
         if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
     }
     const uint64_t t_dec = clock64();
@@ -867,7 +867,7 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     // so the flush moves aligned dwords
     // history in front of the block (batch rounds: earlier blocks of the stream are already in `out`): the first
     // unit preloads up to 32 KiB of it, so that back-references may reach across the block start
-    const uint32_t hist = u == 0 ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
+    const uint32_t hist = (u == 0 && job.preload) ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
     const uint32_t shift = (uint32_t)((gbase - hist) & 3) + hist;
     for (uint32_t k = lane; k < hist; k += 64) ring[ring_idx(shift - hist + k)] = o[(int64_t)k - (int64_t)hist];
     __builtin_amdgcn_wave_barrier();

@@ -116,3 +116,28 @@ def test_cfg3_batch_4096_streams(env, oracle):
     assert not status.any() and (out_len == size).all()
     assert torch.equal(d_out, torch.from_numpy(big).cuda())
     print("cfg3: %d streams, %.1f ms, %.2f GB/s of output" % (count, dt * 1e3, count * size / dt / 1e9), ctx.last_timing())
+
+
+def test_foreign_streams_cross_block(env):
+    """Streams of another encoder (python zlib, levels 1 / 6 / 9, and python gzip): their blocks read the output
+    of earlier blocks, which the reference's own blocks never do.  They must stay on the GPU's block-parallel
+    scan/emit path (ordered materialisation), not fall back to the serial kernel."""
+    import gzip as pygzip
+    import os
+    import torch
+    ctx, ffi, synth = env
+    n = 8 << 20
+    data = synth.text(n, seed=0x5EED0007)
+    raw = data.tobytes()
+    d_want = torch.from_numpy(data).cuda()
+    os.environ["LFX_NO_SERIAL"] = "1"
+    try:
+        for fmt, comp in ((ffi.ZLIB, pyzlib.compress(raw, 1)), (ffi.ZLIB, pyzlib.compress(raw, 6)),
+                          (ffi.ZLIB, pyzlib.compress(raw, 9)), (ffi.GZIP, pygzip.compress(raw, 6, mtime=0))):
+            d_in = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+            d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            rc, ol, used, msg = ctx.decode_device(fmt, d_in.data_ptr(), len(comp), d_out.data_ptr(), n)
+            assert (rc, ol, used) == (0, n, len(comp)), msg
+            assert torch.equal(d_out, d_want)
+    finally:
+        os.environ.pop("LFX_NO_SERIAL", None)
