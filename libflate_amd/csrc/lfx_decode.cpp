@@ -174,11 +174,14 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 }
             }
             const uint32_t nj = (uint32_t)bj.size();
-            if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * nj))) return rc;
-            if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * nj))) return rc;
-            if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)nj))) return rc;
+            // (+ EXTRA slots for blocks the finder cannot see — fixed-Huffman and stored blocks of other encoders —
+            // which the chain walk below scans on demand)
+            constexpr uint32_t EXTRA = 64, MAX_ON_DEMAND = 1u << 16;
+            if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * (nj + 1)))) return rc;
+            if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * (nj + EXTRA + 1)))) return rc;
+            if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)(nj + EXTRA + 1)))) return rc;
             const size_t tab_bytes = blk_tabs_bytes();
-            if ((rc = c->d_dec_tabs.reserve(tab_bytes * nj))) return rc;
+            if ((rc = c->d_dec_tabs.reserve(tab_bytes * (nj + EXTRA + 1)))) return rc;
             HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
             LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
                                        (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
@@ -227,12 +230,28 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             std::vector<BlkEmit> emit;
             uint64_t pos = first_bit, total = 0, total_codes = 0;
             bool ok_chain = false;
+            uint32_t n_extra = 0, n_on_demand = 0;
+            uint64_t last_end = 0;   // end bit of the last block of the chain
             for (;;) {
                 if (pos == stop_bit && !emit.empty()) { ok_chain = true; break; }
                 auto it = std::lower_bound(starts.begin(), starts.end(), pos);
-                if (it == starts.end() || *it != pos) break;
-                const uint32_t k = slot[(uint32_t)(it - starts.begin())];
-                const BlkInfo &r = bi[k];
+                uint32_t k;
+                BlkInfo r;
+                if (it != starts.end() && *it == pos) { k = slot[(uint32_t)(it - starts.begin())]; r = bi[k]; }
+                else {
+                    // not a dynamic-block start the finder knows: scan the block that starts here on demand
+                    // (stored blocks need no slot; fixed / late dynamic ones keep one of the EXTRA slots)
+                    if (pos >= n * 8 || n_on_demand++ >= MAX_ON_DEMAND || n_extra >= EXTRA) break;
+                    k = nj + n_extra;
+                    const BlkJob one{pos, it != starts.end() ? *it : n * 8};
+                    BlkJob *d_one = (BlkJob *)c->d_dec_streams.p + nj;
+                    HIP_TRY(hipMemcpyAsync(d_one, &one, sizeof one, hipMemcpyHostToDevice, st));
+                    LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_one, 1, (BlkInfo *)c->d_dec_state.p + k,
+                                               (BlkLanes *)c->d_dec_blocks.p + k, (uint8_t *)c->d_dec_tabs.p + tab_bytes * k));
+                    HIP_TRY(hipMemcpyAsync(&r, (BlkInfo *)c->d_dec_state.p + k, sizeof r, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    if (r.status == BLK_OK && r.btype != 0) n_extra++;   // the slot stays in use
+                }
                 if (r.status != BLK_OK || r.end_bit <= pos) break;
                 BlkEmit e{};
                 e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
@@ -241,6 +260,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 emit.push_back(e);
                 total += r.n_out;
                 total_codes += r.n_codes;
+                last_end = r.end_bit;
                 if (r.bfinal) { ok_chain = true; break; }
                 pos = r.end_bit;
             }
@@ -343,8 +363,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     mr.status = LFX_OK;
                     mr.out_len = total;
                     mr.blk_out_start = total;
-                    mr.end_byte = (pos == stop_bit ? pos : bi[emit.back().cand].end_bit) / 8 +
-                                  (((pos == stop_bit ? pos : bi[emit.back().cand].end_bit) & 7) ? 1 : 0);
+                    const uint64_t eb = pos == stop_bit ? pos : last_end;
+                    mr.end_byte = eb / 8 + ((eb & 7) ? 1 : 0);
                     parallel_done = true;
                 }
             }

@@ -141,3 +141,35 @@ def test_foreign_streams_cross_block(env):
             assert torch.equal(d_out, d_want)
     finally:
         os.environ.pop("LFX_NO_SERIAL", None)
+
+
+def test_foreign_streams_stored_and_fixed_blocks(env):
+    """Blocks the finder cannot see (it looks for dynamic-block headers): sync-flush markers (empty stored
+    blocks) inside a stream, an all-stored stream and a short fixed-Huffman stream are scanned on demand while
+    the chain is walked — still no serial kernel."""
+    import os
+    import torch
+    ctx, ffi, synth = env
+    raw = synth.text(6 << 20, seed=0x5EED0008).tobytes()
+    streams = []
+    co = pyzlib.compressobj(6)
+    parts = []
+    for i in range(0, len(raw), 1 << 20):
+        parts.append(co.compress(raw[i:i + (1 << 20)]))
+        parts.append(co.flush(pyzlib.Z_SYNC_FLUSH))
+    parts.append(co.flush())
+    streams.append((raw, b"".join(parts)))
+    streams.append((raw[:2 << 20], pyzlib.compress(raw[:2 << 20], 0)))                       # stored blocks only
+    cf = pyzlib.compressobj(6, pyzlib.DEFLATED, 15, 8, pyzlib.Z_FIXED)
+    streams.append((raw[:300000], cf.compress(raw[:300000]) + cf.flush()))                  # fixed-Huffman blocks
+    os.environ["LFX_NO_SERIAL"] = "1"
+    try:
+        for plain, comp in streams:
+            n = len(plain)
+            d_in = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+            d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            rc, ol, used, msg = ctx.decode_device(ffi.ZLIB, d_in.data_ptr(), len(comp), d_out.data_ptr(), n)
+            assert (rc, ol, used) == (0, n, len(comp)), (msg, len(comp))
+            assert d_out.cpu().numpy().tobytes() == plain
+    finally:
+        os.environ.pop("LFX_NO_SERIAL", None)
