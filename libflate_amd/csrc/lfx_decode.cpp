@@ -319,7 +319,43 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                                 (unsigned long long)dv[u * 8], (unsigned long long)dv[u * 8 + 1], (unsigned long long)dv[u * 8 + 2],
                                 (unsigned long long)dv[u * 8 + 3], (unsigned long long)dv[u * 8 + 4], (unsigned long long)dv[u * 8 + 5]);
                 }
+                if (fl == 2 && !getenv("LFX_NO_MARKERS")) {
+                    // Blocks read the output of earlier blocks (streams of other encoders; the reference's own
+                    // blocks never do).  Marker-based materialisation: every block, cut into units at slice
+                    // boundaries, is materialised at once into 16-bit symbols (a byte, or a reference into the
+                    // unknown 32 KiB in front of the unit); one workgroup then walks the units in order resolving
+                    // only each unit's last 32 KiB; a last pass replaces every marker.
+                    std::vector<BlkUnits> uv(ne);
+                    HIP_TRY(hipMemcpyAsync(uv.data(), c->d_hist.p, sizeof(BlkUnits) * ne, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    std::vector<SymUnit> su;
+                    uint64_t max_len = 0;
+                    for (uint32_t q = 0; q < ne; q++)
+                        for (uint32_t b = 0; b < uv[q].fn && b < 8; b++) {
+                            const uint64_t len = uv[q].fout0[b + 1] - uv[q].fout0[b];
+                            if (!len) continue;
+                            su.push_back(SymUnit{emit[q].out_off + uv[q].fout0[b], len});
+                            max_len = std::max(max_len, len);
+                        }
+                    const uint32_t nsu = (uint32_t)su.size();
+                    if ((rc = c->d_dec_sym.reserve(2 * std::max<uint64_t>(total, 1)))) return rc;
+                    if ((rc = c->d_dec_win.reserve(32768ull * std::max<uint32_t>(nsu, 1) + sizeof(SymUnit) * (size_t)nsu + 64))) return rc;
+                    uint8_t *d_win = (uint8_t *)c->d_dec_win.p;
+                    SymUnit *d_su = (SymUnit *)(d_win + 32768ull * std::max<uint32_t>(nsu, 1));
+                    HIP_TRY(hipMemcpyAsync(d_su, su.data(), sizeof(SymUnit) * nsu, hipMemcpyHostToDevice, st));
+                    LAUNCH_TRY(launch_blk_materialize_sym(st, d_in, d_emit, ne, (const BlkUnits *)c->d_hist.p,
+                                                          (const uint32_t *)c->d_codes.p, (uint16_t *)c->d_dec_sym.p));
+                    c->phase("lz77_sym");
+                    LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win));
+                    c->phase("win_chain");
+                    LAUNCH_TRY(launch_sym_substitute(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, d_out, max_len));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    c->phase("substitute");
+                    if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  cross-block references: %u blocks, %u units through markers\n", ne, nsu);
+                    fl = 0;
+                }
                 if (fl == 2) {
+                    // (LFX_NO_MARKERS) the same blocks materialised IN ORDER instead:
                     // Blocks read the output of earlier blocks (streams of other encoders; the reference's own
                     // blocks never do): every block cannot be materialised at once.  The codes are all there, so
                     // the blocks are materialised again IN ORDER — each run of consecutive compressed blocks as

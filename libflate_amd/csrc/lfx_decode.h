@@ -96,6 +96,15 @@ struct BlkUnits {
     uint32_t code0[9];   // unit u covers codes [code0[u], code0[u+1]) of the block
     uint64_t out0[9];    // ... and bytes [out0[u], out0[u+1]) of the block's output
     uint32_t cyc[4];     // diagnostics: header, decode, cut search, unit selection (clock64 ticks)
+    // the same block cut at slice boundaries WITHOUT regard to back-references (marker-based materialisation)
+    uint32_t fn;
+    uint32_t fcode0[9];
+    uint64_t fout0[9];
+};
+// one unit of the marker-based path, in stream order
+struct SymUnit {
+    uint64_t start;      // first output byte
+    uint64_t len;        // output bytes
 };
 // tabs: njobs * blk_tabs_bytes() bytes: the decode tables of every scanned block, reused by launch_blk_emit
 size_t blk_tabs_bytes();
@@ -108,6 +117,16 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
 int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg);
+
+// marker-based materialisation (streams whose blocks read earlier blocks):
+//  sym: one 16-bit symbol per output byte — a byte value, or 256 + j = byte j of the 32 KiB in front of the unit
+int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
+                               const BlkUnits *units, const uint32_t *codes, uint16_t *sym);
+//  windows[u] = the final 32 KiB of output up to the end of unit u (units in stream order, one workgroup walks them)
+int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows);
+//  out = sym with every marker replaced through the window in front of its unit
+int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits,
+                          const uint8_t *windows, uint8_t *out, uint64_t max_len);   // max_len: longest unit
 
 int launch_container(hipStream_t st, int format, uint32_t count, const uint8_t *in,
                      const DecStream *streams, DecHeader *hdrs);

@@ -700,7 +700,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
     const BlkEmit job = jobs[blockIdx.x];
     BlkUnits *U = &units[blockIdx.x];
     if (job.btype == 0) {
-        if (tid == 0) { U->n = 1; U->code0[0] = 0; U->code0[1] = 0; U->out0[0] = 0; U->out0[1] = job.n_out; }
+        if (tid == 0) {
+            U->n = 1; U->code0[0] = 0; U->code0[1] = 0; U->out0[0] = 0; U->out0[1] = job.n_out;
+            U->fn = 1; U->fcode0[0] = 0; U->fcode0[1] = 0; U->fout0[0] = 0; U->fout0[1] = job.n_out;
+        }
         return;
     }
     const uint64_t t_begin = clock64();
@@ -796,6 +799,20 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         nu++;
         U->code0[nu] = job.n_codes; U->out0[nu] = job.n_out;
         U->n = nu;
+        // ... and cut at slice boundaries without regard to back-references (marker-based materialisation)
+        uint32_t fn = 0;
+        U->fcode0[0] = 0; U->fout0[0] = 0;
+        for (uint32_t b = 1; b < want_units; ++b) {
+            const uint32_t l = (uint32_t)((uint64_t)job.nlanes * b / want_units);
+            if (l == 0 || l >= job.nlanes) continue;
+            const uint32_t cc = L->code_off[l];
+            if (cc <= U->fcode0[fn] || cc >= job.n_codes) continue;
+            fn++;
+            U->fcode0[fn] = cc; U->fout0[fn] = L->out_off[l];
+        }
+        fn++;
+        U->fcode0[fn] = job.n_codes; U->fout0[fn] = job.n_out;
+        U->fn = fn;
         U->cyc[0] = (uint32_t)(t_hdr - t_begin); U->cyc[1] = (uint32_t)(t_dec - t_hdr);
         U->cyc[2] = (uint32_t)(t_cut - t_dec); U->cyc[3] = (uint32_t)(clock64() - t_cut);
     }
@@ -967,6 +984,141 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Marker-based materialisation (pugz / rapidgzip style) for streams whose blocks read the output of earlier
+// blocks.  Pass 1 — this kernel, every unit at once: the 32 KiB in front of a unit are unknown, so the unit
+// works on 16-bit SYMBOLS: a byte value, or 256 + j = "byte j of the 32 KiB in front of me".  The ring starts
+// out holding the markers 256 + 0 .. 256 + 32767; back-references then copy symbols exactly as K3 copies
+// bytes, and the symbols go to `sym` (one per output byte).  Pass 2 (window_chain_kernel) walks the units in
+// order and resolves only each unit's LAST 32 KiB; pass 3 (sym_substitute_kernel) replaces every marker.
+constexpr uint32_t SWIN = 36864;        // ring entries: 32 Ki of history + 4 Ki in flight
+__global__ __launch_bounds__(64) void blk_materialize_sym_kernel(const uint8_t *__restrict__ in,
+                                                                 const BlkEmit *__restrict__ jobs,
+                                                                 const BlkUnits *__restrict__ units,
+                                                                 const uint32_t *__restrict__ codes,
+                                                                 uint16_t *__restrict__ sym, uint32_t njobs) {
+    extern __shared__ uint16_t ring[];   // SWIN entries (72 KiB: two units per CU)
+    const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;   // unit-major (XCD balance, see K3)
+    const BlkEmit job = jobs[bidx];
+    const uint32_t lane = threadIdx.x;
+    if (job.btype == 0) {
+        if (u != 0) return;
+        uint16_t *o = sym + job.out_off;
+        const uint8_t *src = in + (job.data_bit >> 3);
+        for (uint64_t k = lane; k < job.n_out; k += 64) o[k] = src[k];
+        return;
+    }
+    const BlkUnits *U = &units[bidx];
+    if (u >= U->fn) return;
+    const uint32_t c0 = U->fcode0[u], c1 = U->fcode0[u + 1];
+    uint16_t *o = sym + job.out_off + U->fout0[u];
+    const uint32_t *cp = codes + job.code_off + c0;
+    const uint32_t n = c1 - c0;
+    constexpr uint32_t H = 32768;       // unit byte `pos` lives at ring_idx(pos + H)
+    for (uint32_t k = lane; k < H; k += 64) ring[ring_idx(k)] = (uint16_t)(256 + k);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t produced = 0, flushed = 0, base = 0;
+    uint32_t c_cur = lane < n ? cp[lane] : 0;
+    while (base < n) {
+        const uint32_t i = base + lane;
+        const uint32_t c_pref = i + 64 < n ? cp[i + 64] : 0;
+        const uint32_t c = c_cur;
+        const uint32_t dist = c & 0xFFFFu, val = c >> 16;
+        bool valid = i < n;
+        uint32_t mylen = valid ? (dist ? val : 1u) : 0u;
+        uint32_t x = wave_inclusive_sum(mylen);
+        uint32_t take = 64;
+        if (__builtin_amdgcn_readlane(x, 63) > MBATCH_MAX) {
+            take = (uint32_t)__popcll(__ballot(x <= MBATCH_MAX));
+            if (lane >= take) { valid = false; mylen = 0; x = 0; }
+        }
+        const uint32_t total = __builtin_amdgcn_readlane(x, take - 1);
+        const bool is_match = valid && dist != 0;
+        const uint32_t rel = x - mylen;
+        const uint32_t at_i = ring_idx(produced + H + rel);
+        if (valid && !is_match) ring[at_i] = (uint16_t)val;
+        // matches that read only symbols older than this batch: every lane copies its own (<= PAR_LEN symbols)
+        const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
+        const bool par = far && mylen <= PAR_LEN && dist >= mylen;
+        if (par) {
+            const uint32_t src_i = at_i >= dist ? at_i - dist : at_i + SWIN - dist;
+            uint16_t t[PAR_LEN];
+#pragma unroll
+            for (uint32_t k = 0; k < PAR_LEN; ++k) t[k] = k < mylen ? ring[ring_add(src_i, k)] : (uint16_t)0;
+#pragma unroll
+            for (uint32_t k = 0; k < PAR_LEN; ++k)
+                if (k < mylen) ring[ring_add(at_i, k)] = t[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint64_t mm = __ballot(is_match && !par);
+        while (mm) {                       // everything else cooperatively, in order (see K3)
+            const uint32_t sl = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint32_t mc = __builtin_amdgcn_readlane(c, sl);
+            const uint32_t mat_i = __builtin_amdgcn_readlane(at_i, sl);
+            const uint32_t len = mc >> 16, d = mc & 0xFFFFu;
+            const uint32_t src_i = mat_i >= d ? mat_i - d : mat_i + SWIN - d;
+            if (d >= len) {
+                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k)];
+            } else {
+                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k % d)];
+            }
+        }
+        produced += total;
+        base += take;
+        __builtin_amdgcn_wave_barrier();
+        const bool last = base >= n;
+        if (produced - flushed >= 512 || last) {
+            for (uint32_t k = flushed + lane; k < produced; k += 64) o[k] = ring[ring_idx(k + H)];
+            flushed = produced;
+            __builtin_amdgcn_wave_barrier();
+        }
+        c_cur = take == 64 ? c_pref : (base + lane < n ? cp[base + lane] : 0);
+    }
+}
+
+// Pass 2: one workgroup walks the units in stream order.  win[u] = the final 32 KiB of output that end where
+// unit u ends; byte i of it is a symbol of the unit's own tail resolved through win[u-1], or (for a unit
+// shorter than 32 KiB) byte i + len of win[u-1].  The two windows in flight live in LDS.
+__global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__restrict__ sym,
+                                                            const SymUnit *__restrict__ units, uint32_t nunits,
+                                                            uint8_t *__restrict__ windows) {
+    extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
+    uint8_t *prev = wbuf, *cur = wbuf + 32768;
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = 0;
+    __syncthreads();
+    for (uint32_t u = 0; u < nunits; ++u) {
+        const SymUnit su = units[u];
+        uint8_t *wout = windows + (uint64_t)u * 32768;
+        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
+            uint8_t b;
+            if (su.len + i >= 32768) {                       // a byte of this unit
+                const uint32_t s = sym[su.start + su.len - 32768 + i];
+                b = s < 256 ? (uint8_t)s : prev[s - 256];
+            } else b = prev[i + (uint32_t)su.len];           // still a byte of the window in front of it
+            cur[i] = b;
+            wout[i] = b;
+        }
+        __syncthreads();
+        uint8_t *t = prev; prev = cur; cur = t;
+    }
+}
+
+// Pass 3: every marker is replaced through the window in front of its unit.
+__global__ __launch_bounds__(256) void sym_substitute_kernel(const uint16_t *__restrict__ sym,
+                                                             const SymUnit *__restrict__ units,
+                                                             const uint8_t *__restrict__ windows,
+                                                             uint8_t *__restrict__ out) {
+    const uint32_t u = blockIdx.x;
+    const SymUnit su = units[u];
+    const uint8_t *w = u ? windows + (uint64_t)(u - 1) * 32768 : windows;   // (unit 0 holds no markers)
+    const uint64_t lo = (uint64_t)blockIdx.y * 16384, hi = lo + 16384 < su.len ? lo + 16384 : su.len;
+    for (uint64_t k = lo + threadIdx.x; k < hi; k += 256) {
+        const uint32_t s = sym[su.start + k];
+        out[su.start + k] = s < 256 ? (uint8_t)s : w[s - 256];
+    }
+}
+
 // Per-lane decode table of a COMPLETE code-length code (stage 1 of the finder guarantees completeness):
 // entry e of lane l lives at tab[e * 64 + l] (consecutive lanes in consecutive bytes) and holds
 // symbol | width << 5 for the 7 stream bits e.  Canonical codes (symbol.rs:354-369) are assigned per width
@@ -1121,6 +1273,41 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
                            uint64_t *dbg) {
     if (!njobs) return 0;
     hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), 0, st, in, jobs, lanes, units, codes, out, njobs, dbg);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
+                               const BlkUnits *units, const uint32_t *codes, uint16_t *sym) {
+    if (!njobs) return 0;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
+        (void)hipFuncSetAttribute((const void *)blk_materialize_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SWIN * 2));
+        attr_set[dev_ & 63] = true;
+    }
+    hipLaunchKernelGGL(blk_materialize_sym_kernel, dim3(njobs * MAX_UNITS), dim3(64), SWIN * 2, st, in, jobs, units, codes, sym, njobs);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows) {
+    if (!nunits) return 0;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
+        (void)hipFuncSetAttribute((const void *)window_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set[dev_ & 63] = true;
+    }
+    hipLaunchKernelGGL(window_chain_kernel, dim3(1), dim3(1024), 65536, st, sym, units, nunits, windows);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits,
+                          const uint8_t *windows, uint8_t *out, uint64_t max_len) {
+    if (!nunits) return 0;
+    const uint32_t gy = (uint32_t)((max_len + 16383) / 16384);
+    hipLaunchKernelGGL(sym_substitute_kernel, dim3(nunits, gy ? gy : 1), dim3(256), 0, st, sym, units, windows, out);
     LFX_LAUNCH_CHECK();
     return 0;
 }
