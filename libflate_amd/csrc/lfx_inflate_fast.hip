@@ -800,10 +800,14 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         U->code0[nu] = job.n_codes; U->out0[nu] = job.n_out;
         U->n = nu;
         // ... and cut at slice boundaries without regard to back-references (marker-based materialisation)
+        // (units of about 128 KiB: every unit costs the in-order window chain 32 Ki lookups, and a unit's own
+        // materialisation is a serial walk — the two balance around 100 KiB)
         uint32_t fn = 0;
+        uint32_t fwant = (uint32_t)(job.n_out >> 17);
+        fwant = fwant < 1 ? 1 : fwant > MAX_UNITS ? MAX_UNITS : fwant;
         U->fcode0[0] = 0; U->fout0[0] = 0;
-        for (uint32_t b = 1; b < want_units; ++b) {
-            const uint32_t l = (uint32_t)((uint64_t)job.nlanes * b / want_units);
+        for (uint32_t b = 1; b < fwant; ++b) {
+            const uint32_t l = (uint32_t)((uint64_t)job.nlanes * b / fwant);
             if (l == 0 || l >= job.nlanes) continue;
             const uint32_t cc = L->code_off[l];
             if (cc <= U->fcode0[fn] || cc >= job.n_codes) continue;
@@ -1086,18 +1090,49 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
     extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
     uint8_t *prev = wbuf, *cur = wbuf + 32768;
     for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = 0;
+    // Thread t owns the four window bytes 4 (t + 1024 k) .. +3 of row k = 0..7: one 8-byte symbol load, four LDS
+    // gathers, one dword LDS store and one dword global store per row.  The symbols of unit u+1's tail do not
+    // depend on the chain: they are loaded while unit u is being resolved, so the walk itself only touches LDS.
+    uint32_t sn[16];                    // two symbols per register
+    auto fetch = [&](uint32_t u) {
+        if (u >= nunits) return;
+        const SymUnit su = units[u];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t i = 4 * (threadIdx.x + 1024 * k);
+            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            const uint16_t *p = sym + (su.start + su.len - 32768 + i);   // (only dereferenced when inside the unit)
+            if (su.len + i >= 32768) s0 = p[0];
+            if (su.len + i + 1 >= 32768) s1 = p[1];
+            if (su.len + i + 2 >= 32768) s2 = p[2];
+            if (su.len + i + 3 >= 32768) s3 = p[3];
+            sn[2 * k] = s0 | s1 << 16;
+            sn[2 * k + 1] = s2 | s3 << 16;
+        }
+    };
+    fetch(0);
     __syncthreads();
     for (uint32_t u = 0; u < nunits; ++u) {
-        const SymUnit su = units[u];
-        uint8_t *wout = windows + (uint64_t)u * 32768;
-        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
-            uint8_t b;
-            if (su.len + i >= 32768) {                       // a byte of this unit
-                const uint32_t s = sym[su.start + su.len - 32768 + i];
-                b = s < 256 ? (uint8_t)s : prev[s - 256];
-            } else b = prev[i + (uint32_t)su.len];           // still a byte of the window in front of it
-            cur[i] = b;
-            wout[i] = b;
+        const uint64_t len = units[u].len;
+        uint32_t sc[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) sc[k] = sn[k];
+        fetch(u + 1);
+        uint32_t *wout = (uint32_t *)(windows + (uint64_t)u * 32768);
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t i = 4 * (threadIdx.x + 1024 * k);
+            uint32_t packed = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) {
+                const uint32_t s = (sc[2 * k + (q >> 1)] >> (16 * (q & 1))) & 0xFFFFu;
+                uint32_t b;
+                if (len + i + q >= 32768) b = s < 256 ? s : prev[s - 256];   // a byte of this unit
+                else b = prev[i + q + (uint32_t)len];                          // still a byte of the window in front of it
+                packed |= b << (8 * q);
+            }
+            ((uint32_t *)cur)[i >> 2] = packed;
+            wout[i >> 2] = packed;
         }
         __syncthreads();
         uint8_t *t = prev; prev = cur; cur = t;
