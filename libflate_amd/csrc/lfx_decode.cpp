@@ -173,6 +173,12 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     bj.push_back(BlkJob{starts[i], start_at(i + 2)});
                 }
             }
+            // few candidates = few, huge blocks (schedule S1: one): a false candidate would cost a full rescan of
+            // such a block, so the known first block also gets a job that runs to the end of the stream
+            if (nc > 1 && nc <= 8 && alt[0] < 0) {
+                alt[0] = (int32_t)bj.size();
+                bj.push_back(BlkJob{starts[0], n * 8});
+            }
             const uint32_t nj = (uint32_t)bj.size();
             // (+ EXTRA slots for blocks the finder cannot see — fixed-Huffman and stored blocks of other encoders —
             // which the chain walk below scans on demand)
@@ -289,11 +295,22 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                                            (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
                                            c->d_dec_tabs.p));
                 c->phase("blk_emit");
-                LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
-                                                  (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
+                // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
+                // the marker path, which may cut anywhere
+                bool giant = false;
+                for (const BlkEmit &e : emit) giant |= e.n_out >= (8ull << 20);
+                if (!giant)
+                    LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
+                                                      (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
                 uint32_t fl = 0;
                 HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
+                if (giant && !(fl & 1) && !getenv("LFX_NO_MARKERS")) fl = 2;
+                else if (giant) {   // (markers switched off, or an invalid reference: materialise normally / fall back)
+                    LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
+                                                      (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
+                    HIP_TRY(hipStreamSynchronize(st));
+                }
                 c->phase("lz77_copy");
                 if (getenv("LFX_DEBUG")) {
                     fprintf(stderr, "[lfx]  emit flags=%u\n", fl);
@@ -331,7 +348,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     std::vector<SymUnit> su;
                     uint64_t max_len = 0;
                     for (uint32_t q = 0; q < ne; q++)
-                        for (uint32_t b = 0; b < uv[q].fn && b < 8; b++) {
+                        for (uint32_t b = 0; b < uv[q].fn && b < MAX_FREE_UNITS; b++) {
                             const uint64_t len = uv[q].fout0[b + 1] - uv[q].fout0[b];
                             if (!len) continue;
                             su.push_back(SymUnit{emit[q].out_off + uv[q].fout0[b], len});

@@ -91,6 +91,7 @@ struct BlkEmit {
     uint32_t preload;    // materialise: those bytes are already final in `out` — load up to 32 KiB of them as history
     uint32_t _pad;
 };
+constexpr uint32_t MAX_FREE_UNITS = 64;   // marker units per block (a schedule-S1 stream is ONE block)
 struct BlkUnits {
     uint32_t n;          // independent units of the block (no back-reference crosses a cut)
     uint32_t code0[9];   // unit u covers codes [code0[u], code0[u+1]) of the block
@@ -98,8 +99,8 @@ struct BlkUnits {
     uint32_t cyc[4];     // diagnostics: header, decode, cut search, unit selection (clock64 ticks)
     // the same block cut at slice boundaries WITHOUT regard to back-references (marker-based materialisation)
     uint32_t fn;
-    uint32_t fcode0[9];
-    uint64_t fout0[9];
+    uint32_t fcode0[MAX_FREE_UNITS + 1];
+    uint64_t fout0[MAX_FREE_UNITS + 1];
 };
 // one unit of the marker-based path, in stream order
 struct SymUnit {

@@ -804,7 +804,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         // materialisation is a serial walk — the two balance around 100 KiB)
         uint32_t fn = 0;
         uint32_t fwant = (uint32_t)(job.n_out >> 17);
-        fwant = fwant < 1 ? 1 : fwant > MAX_UNITS ? MAX_UNITS : fwant;
+        fwant = fwant < 1 ? 1 : fwant > MAX_FREE_UNITS ? MAX_FREE_UNITS : fwant;
         U->fcode0[0] = 0; U->fout0[0] = 0;
         for (uint32_t b = 1; b < fwant; ++b) {
             const uint32_t l = (uint32_t)((uint64_t)job.nlanes * b / fwant);
@@ -1321,7 +1321,7 @@ int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit 
         (void)hipFuncSetAttribute((const void *)blk_materialize_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SWIN * 2));
         attr_set[dev_ & 63] = true;
     }
-    hipLaunchKernelGGL(blk_materialize_sym_kernel, dim3(njobs * MAX_UNITS), dim3(64), SWIN * 2, st, in, jobs, units, codes, sym, njobs);
+    hipLaunchKernelGGL(blk_materialize_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(64), SWIN * 2, st, in, jobs, units, codes, sym, njobs);
     LFX_LAUNCH_CHECK();
     return 0;
 }
