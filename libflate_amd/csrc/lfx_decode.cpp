@@ -299,10 +299,18 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 // the marker path, which may cut anywhere
                 bool giant = false;
                 for (const BlkEmit &e : emit) giant |= e.n_out >= (8ull << 20);
-                if (!giant)
+                // small blocks smell of another encoder (zlib cuts every ~50-100 KiB of output; the reference at
+                // block_size = 1 MiB): look at the emit flags BEFORE materialising, so that a stream which needs
+                // the marker path does not pay for a discarded direct pass (costs one round trip otherwise saved)
+                const bool probe = !giant && total / ne < (256u << 10);
+                uint32_t fl = 0;
+                if (probe) {
+                    HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                }
+                if (!giant && !(probe && fl == 2 && !getenv("LFX_NO_MARKERS")))
                     LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                       (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
-                uint32_t fl = 0;
                 HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 if (giant && !(fl & 1) && !getenv("LFX_NO_MARKERS")) fl = 2;
@@ -363,7 +371,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     LAUNCH_TRY(launch_blk_materialize_sym(st, d_in, d_emit, ne, (const BlkUnits *)c->d_hist.p,
                                                           (const uint32_t *)c->d_codes.p, (uint16_t *)c->d_dec_sym.p));
                     c->phase("lz77_sym");
-                    LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win));
+                    if (nsu >= 128 && !getenv("LFX_WINDOW_CHAIN")) {   // long stream: blocked parallel prefix over the units
+                        if ((rc = c->d_dec_maps.reserve(window_prefix_scratch_bytes(nsu)))) return rc;
+                        LAUNCH_TRY(launch_window_prefix(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, d_win));
+                    } else LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win));
                     c->phase("win_chain");
                     LAUNCH_TRY(launch_sym_substitute(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, d_out, max_len));
                     HIP_TRY(hipStreamSynchronize(st));

@@ -125,6 +125,10 @@ int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit 
                                const BlkUnits *units, const uint32_t *codes, uint16_t *sym);
 //  windows[u] = the final 32 KiB of output up to the end of unit u (units in stream order, one workgroup walks them)
 int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows);
+//  the same windows by a blocked parallel prefix over the units' index maps (long streams)
+size_t window_prefix_scratch_bytes(uint32_t nunits);
+int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch,
+                         uint8_t *windows);
 //  out = sym with every marker replaced through the window in front of its unit
 int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits,
                           const uint8_t *windows, uint8_t *out, uint64_t max_len);   // max_len: longest unit

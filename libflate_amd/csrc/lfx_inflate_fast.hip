@@ -1139,6 +1139,71 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
     }
 }
 
+// Pass 2 as a blocked parallel prefix (long streams).  A unit acts on the 32 KiB window in front of it as an
+// index map F_u: window byte i behind the unit is a literal, or byte j of the window in front — exactly the
+// unit's tail symbols (for a unit shorter than 32 KiB the head of the map is the shift i -> i + len).  Maps
+// compose by a gather: (F_v o F_u)[i] = F_v[i] if literal, else F_u[F_v[i] - 256].
+//  (a) window_compose_kernel: one workgroup per group of WC_GROUP units composes the group's maps in order,
+//      C_k = F_k o ... o F_first, and stores every C_k (64 KiB each);
+//  (b) window_groups_kernel: one workgroup walks the GROUPS in order: window after group g = C_last(window
+//      after group g-1);
+//  (c) window_apply_kernel: every unit's window = its C_k applied to the window in front of its group.
+constexpr uint32_t WC_GROUP = 32;
+__device__ __forceinline__ uint32_t unit_map_symbol(const uint16_t *__restrict__ sym, const SymUnit &su, uint32_t i) {
+    return su.len + i >= 32768 ? (uint32_t)sym[su.start + su.len - 32768 + i] : 256u + i + (uint32_t)su.len;
+}
+__global__ __launch_bounds__(1024) void window_compose_kernel(const uint16_t *__restrict__ sym,
+                                                              const SymUnit *__restrict__ units, uint32_t nunits,
+                                                              uint16_t *__restrict__ maps) {
+    extern __shared__ uint16_t mbuf[];   // 2 x 32 Ki entries
+    uint16_t *prev = mbuf, *cur = mbuf + 32768;
+    const uint32_t u0 = blockIdx.x * WC_GROUP, u1 = u0 + WC_GROUP < nunits ? u0 + WC_GROUP : nunits;
+    for (uint32_t u = u0; u < u1; ++u) {
+        const SymUnit su = units[u];
+        uint16_t *mout = maps + (uint64_t)u * 32768;
+        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
+            uint32_t s = unit_map_symbol(sym, su, i);
+            if (u != u0 && s >= 256) s = prev[s - 256];
+            cur[i] = (uint16_t)s;
+            mout[i] = (uint16_t)s;
+        }
+        __syncthreads();
+        uint16_t *t = prev; prev = cur; cur = t;
+    }
+}
+__global__ __launch_bounds__(1024) void window_groups_kernel(const uint16_t *__restrict__ maps, uint32_t nunits,
+                                                             uint8_t *__restrict__ gwin) {
+    extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
+    uint8_t *prev = wbuf, *cur = wbuf + 32768;
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = 0;
+    __syncthreads();
+    const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        const uint32_t last = (g + 1) * WC_GROUP < nunits ? (g + 1) * WC_GROUP - 1 : nunits - 1;
+        const uint16_t *m = maps + (uint64_t)last * 32768;
+        uint8_t *wout = gwin + (uint64_t)g * 32768;
+        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
+            const uint32_t s = m[i];
+            const uint8_t b = s < 256 ? (uint8_t)s : prev[s - 256];
+            cur[i] = b;
+            wout[i] = b;
+        }
+        __syncthreads();
+        uint8_t *t = prev; prev = cur; cur = t;
+    }
+}
+__global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__restrict__ maps, const uint8_t *__restrict__ gwin,
+                                                           uint8_t *__restrict__ windows) {
+    const uint32_t u = blockIdx.x, g = u / WC_GROUP;
+    const uint16_t *m = maps + (uint64_t)u * 32768;
+    const uint8_t *w = g ? gwin + (uint64_t)(g - 1) * 32768 : gwin;   // (group 0: nothing in front, no markers left)
+    uint8_t *wout = windows + (uint64_t)u * 32768;
+    for (uint32_t i = threadIdx.x; i < 32768; i += 256) {
+        const uint32_t s = m[i];
+        wout[i] = s < 256 ? (uint8_t)s : (g ? w[s - 256] : (uint8_t)0);
+    }
+}
+
 // Pass 3: every marker is replaced through the window in front of its unit.
 __global__ __launch_bounds__(256) void sym_substitute_kernel(const uint16_t *__restrict__ sym,
                                                              const SymUnit *__restrict__ units,
@@ -1335,6 +1400,33 @@ int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *unit
         attr_set[dev_ & 63] = true;
     }
     hipLaunchKernelGGL(window_chain_kernel, dim3(1), dim3(1024), 65536, st, sym, units, nunits, windows);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+// blocked parallel prefix of the window chain (see window_compose_kernel); scratch: nunits * 64 KiB of maps and
+// ceil(nunits / WC_GROUP) * 32 KiB of group windows
+size_t window_prefix_scratch_bytes(uint32_t nunits) {
+    return (size_t)nunits * 65536 + (size_t)((nunits + WC_GROUP - 1) / WC_GROUP) * 32768;
+}
+int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch,
+                         uint8_t *windows) {
+    if (!nunits) return 0;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
+        (void)hipFuncSetAttribute((const void *)window_compose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void *)window_groups_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set[dev_ & 63] = true;
+    }
+    uint16_t *maps = (uint16_t *)scratch;
+    uint8_t *gwin = (uint8_t *)scratch + (size_t)nunits * 65536;
+    const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
+    hipLaunchKernelGGL(window_compose_kernel, dim3(ngroups), dim3(1024), 131072, st, sym, units, nunits, maps);
+    LFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 65536, st, maps, nunits, gwin);
+    LFX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(256), 0, st, maps, gwin, windows);
     LFX_LAUNCH_CHECK();
     return 0;
 }
