@@ -1043,15 +1043,22 @@ __global__ __launch_bounds__(64) void blk_materialize_sym_kernel(const uint8_t *
         if (valid && !is_match) ring[at_i] = (uint16_t)val;
         // matches that read only symbols older than this batch: every lane copies its own (<= PAR_LEN symbols)
         const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
-        const bool par = far && mylen <= PAR_LEN && dist >= mylen;
+        const uint32_t src_i = is_match ? (at_i >= dist ? at_i - dist : at_i + SWIN - dist) : 0;
+        const bool par = far && mylen <= PAR_LEN && dist >= mylen && src_i + PAR_LEN <= SWIN && at_i + PAR_LEN <= SWIN;
         if (par) {
-            const uint32_t src_i = at_i >= dist ? at_i - dist : at_i + SWIN - dist;
-            uint16_t t[PAR_LEN];
+            // two symbols per dword (the LDS takes a dword at any 2-byte address): pairs [0,2) [2,4) ... as far
+            // as they fit, then the last two symbols (overlapping the previous store when the length is even);
+            // all loads come before the stores, the source is older than this batch
+            const unsigned char *sp = (const unsigned char *)(ring + src_i);
+            unsigned char *dp = (unsigned char *)(ring + at_i);
+            uint32_t t[PAR_LEN / 2];
+            const uint32_t tail = lds_ld32(sp + 2 * mylen - 4);
 #pragma unroll
-            for (uint32_t k = 0; k < PAR_LEN; ++k) t[k] = k < mylen ? ring[ring_add(src_i, k)] : (uint16_t)0;
+            for (uint32_t k = 0; k < PAR_LEN / 2; ++k) t[k] = 2 * k + 2 <= mylen ? lds_ld32(sp + 4 * k) : 0u;
 #pragma unroll
-            for (uint32_t k = 0; k < PAR_LEN; ++k)
-                if (k < mylen) ring[ring_add(at_i, k)] = t[k];
+            for (uint32_t k = 0; k < PAR_LEN / 2; ++k)
+                if (2 * k + 2 <= mylen) lds_st32(dp + 4 * k, t[k]);
+            lds_st32(dp + 2 * mylen - 4, tail);
         }
         __builtin_amdgcn_wave_barrier();
         uint64_t mm = __ballot(is_match && !par);
