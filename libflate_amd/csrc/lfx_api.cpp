@@ -394,7 +394,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         LAUNCH_TRY(launch_checksum(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p));
         HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
     }
-    uint32_t split = nchunks && nchunks < 512 ? std::min<uint32_t>(64, 1024 / nchunks + 1) : 1;
+    // enough workgroups to fill the GPU even when there are few chunks (schedule S1: one)
+    uint32_t split = nchunks && nchunks < 1024 ? std::min<uint32_t>(1024, 2048 / nchunks + 1) : 1;
     LAUNCH_TRY(launch_histogram(st, (const ChunkDesc *)c->d_chunks.p, nchunks, split, (const uint32_t *)c->d_codes.p,
                                 (const uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_hist.p));
     c->phase("histogram");

@@ -150,6 +150,79 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             //      chained exits) for its end bit, byte and code counts
             const uint32_t nc = (uint32_t)starts.size();
             auto start_at = [&](uint32_t i) { return i < nc ? starts[i] : n * 8; };
+            std::vector<BlkEmit> emit;
+            uint64_t pos = first_bit, total = 0, total_codes = 0;
+            bool ok_chain = false;
+            uint64_t last_end = 0;   // end bit of the last block of the chain
+            bool pieces_mode = false;
+            const size_t tab_bytes = blk_tabs_bytes();
+            // ---- few candidates in a long stream = few, huge blocks (schedule S1: ONE block for the whole input).
+            // One workgroup per block would scan it alone; instead the block is scanned in PIECES of 4 Mbit, one
+            // workgroup each, all with the block's tables.  A piece finds its first symbol boundary by a warm-up
+            // decode that starts a few Kbit early; it is accepted iff that boundary equals the exit of the piece in
+            // front of it (piece 0 starts exactly behind the header), so the chain of pieces is proven, not assumed.
+            // Pieces behave like blocks from here on (their back-references cross pieces: marker path).
+            if (nc <= 8 && comp >= (8u << 20) && stop_bit == ~0ull && !getenv("LFX_NO_PIECES")) {
+                constexpr uint64_t PIECE_BITS = 4ull << 20, OVERLAP = 8192;
+                const uint64_t end_bits = n * 8;
+                const uint32_t cap_slots = (uint32_t)std::min<uint64_t>((end_bits - first_bit) / PIECE_BITS * 2 + 64, 1u << 20);
+                int rc2;
+                if ((rc2 = c->d_dec_streams.reserve(sizeof(BlkJob) * cap_slots))) return rc2;
+                if ((rc2 = c->d_dec_state.reserve(sizeof(BlkInfo) * cap_slots))) return rc2;
+                if ((rc2 = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)cap_slots))) return rc2;
+                if ((rc2 = c->d_dec_tabs.reserve(tab_bytes * cap_slots))) return rc2;
+                uint32_t base = 0;
+                bool fail = false;
+                for (uint32_t iter = 0; iter < 64 && !fail && !ok_chain; iter++) {
+                    const uint32_t np = (uint32_t)((end_bits - pos + PIECE_BITS - 1) / PIECE_BITS);
+                    if (np == 0 || base + np > cap_slots) { fail = true; break; }
+                    std::vector<BlkJob> pj(np);
+                    for (uint32_t q = 0; q < np; q++) {
+                        const uint64_t lo = pos + q * PIECE_BITS;
+                        pj[q] = BlkJob{pos, std::min(lo + PIECE_BITS, end_bits), q ? lo : 0, q ? lo - OVERLAP : 0, 1u, 0u};
+                    }
+                    HIP_TRY(hipMemcpyAsync((BlkJob *)c->d_dec_streams.p + base, pj.data(), sizeof(BlkJob) * np, hipMemcpyHostToDevice, st));
+                    LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p + base, np, (BlkInfo *)c->d_dec_state.p + base,
+                                               (BlkLanes *)c->d_dec_blocks.p + base, (uint8_t *)c->d_dec_tabs.p + tab_bytes * base));
+                    std::vector<BlkInfo> pi(np);
+                    HIP_TRY(hipMemcpyAsync(pi.data(), (BlkInfo *)c->d_dec_state.p + base, sizeof(BlkInfo) * np, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    uint32_t used = 0;
+                    bool closed = false;
+                    uint64_t prev_end = 0;
+                    for (uint32_t q = 0; q < np && !closed; q++) {
+                        const BlkInfo &r = pi[q];
+                        if (getenv("LFX_DEBUG") && (q < 3 || r.status != BLK_NO_EOB))
+                            fprintf(stderr, "[lfx]   piece %u/%u: status=%u btype=%u data=%llu end=%llu prev_end=%llu lanes=%u codes=%u out=%llu\n", q, np,
+                                    r.status, r.btype, (unsigned long long)r.data_bit, (unsigned long long)r.end_bit,
+                                    (unsigned long long)prev_end, r.nlanes, r.n_codes, (unsigned long long)r.n_out);
+                        if (r.status == BLK_BAD || (q && r.data_bit != prev_end) || r.end_bit <= pos) { fail = true; break; }
+                        if (q == 0 && r.btype == 0 && r.status != BLK_OK) { fail = true; break; }
+                        BlkEmit e{};
+                        e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
+                        e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = base + q;
+                        e.hist = total;
+                        e.end_limit = r.status == BLK_NO_EOB ? r.end_bit : 0;   // an open piece ends where its last lane stopped
+                        emit.push_back(e);
+                        total += r.n_out;
+                        total_codes += r.n_codes;
+                        used = q + 1;
+                        prev_end = r.end_bit;
+                        if (r.status == BLK_OK) {          // the piece that holds EndOfBlock (or a whole stored block)
+                            closed = true;
+                            last_end = r.end_bit;
+                            if (r.bfinal) ok_chain = true; else pos = r.end_bit;
+                        }
+                    }
+                    if (!closed) fail = true;
+                    base += used;
+                }
+                if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  pieces: ok=%d fail=%d pieces=%zu total=%llu\n", (int)ok_chain, (int)fail, emit.size(), (unsigned long long)total);
+                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; last_end = 0; }
+                else pieces_mode = true;
+                c->phase("pieces");
+            }
+            if (!pieces_mode) {
             std::vector<BlkJob> bj(nc);
             for (uint32_t i = 0; i < nc; i++) bj[i] = BlkJob{starts[i], start_at(i + 1)};
             // A false candidate inside a block cuts that block's range in two, and the first part then has
@@ -186,7 +259,6 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * (nj + 1)))) return rc;
             if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * (nj + EXTRA + 1)))) return rc;
             if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)(nj + EXTRA + 1)))) return rc;
-            const size_t tab_bytes = blk_tabs_bytes();
             if ((rc = c->d_dec_tabs.reserve(tab_bytes * (nj + EXTRA + 1)))) return rc;
             HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
             LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
@@ -233,11 +305,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
             c->phase("repair");
             // ---- chain from the known first block
-            std::vector<BlkEmit> emit;
-            uint64_t pos = first_bit, total = 0, total_codes = 0;
-            bool ok_chain = false;
             uint32_t n_extra = 0, n_on_demand = 0;
-            uint64_t last_end = 0;   // end bit of the last block of the chain
             for (;;) {
                 if (pos == stop_bit && !emit.empty()) { ok_chain = true; break; }
                 auto it = std::lower_bound(starts.begin(), starts.end(), pos);
@@ -270,6 +338,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 if (r.bfinal) { ok_chain = true; break; }
                 pos = r.end_bit;
             }
+            }   // !pieces_mode
             if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  chain ok=%d blocks=%zu pos=%llu total=%llu\n", (int)ok_chain, emit.size(), (unsigned long long)pos, (unsigned long long)total);
             if (ok_chain && total <= cap) {
                 // ---- K2 + K3: validated lanes emit codes, one wavefront per block materialises them
@@ -297,7 +366,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 c->phase("blk_emit");
                 // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
                 // the marker path, which may cut anywhere
-                bool giant = false;
+                bool giant = pieces_mode;   // (pieces of one block read each other's output)
                 for (const BlkEmit &e : emit) giant |= e.n_out >= (8ull << 20);
                 // small blocks smell of another encoder (zlib cuts every ~50-100 KiB of output; the reference at
                 // block_size = 1 MiB): look at the emit flags BEFORE materialising, so that a stream which needs

@@ -66,6 +66,14 @@ enum : uint32_t { BLK_OK = 0, BLK_BAD = 1, BLK_NO_EOB = 2 };
 struct BlkJob {
     uint64_t start_bit;  // block header bit
     uint64_t end_bit;    // range end guess: the next candidate's start (or the end of the input)
+    // PIECE of a huge block (piece != 0): the job scans [first symbol boundary >= lo_bit, end_bit) with the tables
+    // of the block whose header is at start_bit.  That boundary is found by a warm-up decode from warm_bit
+    // (a few Kbit earlier, a speculative start that is in step long before lo_bit); the host accepts the piece
+    // only if the boundary equals the exit of the piece before it.  A piece without EndOfBlock is "open":
+    // status BLK_NO_EOB, but lanes / counts / end_bit (exit of its last lane) are valid.
+    // Piece 0 starts behind the header like any job (warm_bit = 0).
+    uint64_t lo_bit, warm_bit;
+    uint32_t piece, _pad;
 };
 struct BlkInfo {
     uint64_t end_bit;    // bit after EndOfBlock (stored: after the data)
@@ -88,6 +96,7 @@ struct BlkEmit {
     uint64_t n_out;
     uint32_t n_codes, nlanes, btype, cand;
     uint64_t hist;       // output bytes of the same member in front of the block (bounds its back-references)
+    uint64_t end_limit;  // 0: the last lane decodes up to EndOfBlock; else (an open piece) up to this bit
     uint32_t preload;    // materialise: those bytes are already final in `out` — load up to 32 KiB of them as history
     uint32_t _pad;
 };

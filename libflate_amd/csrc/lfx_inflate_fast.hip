@@ -554,6 +554,21 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
         const uint32_t *srcw = (const uint32_t *)&T;
         for (uint32_t i = tid; i < sizeof(FastTabs) / 4; i += SCAN_THREADS) dst[i] = srcw[i];
     }
+    const bool piece = job.piece != 0;
+    if (piece && job.warm_bit) {
+        // warm-up: the first symbol boundary at or behind lo_bit (one lane; ~500 symbols)
+        if (tid == 0) {
+            uint32_t wn = 0, wcc = 0, wco = 0;
+            uint64_t wo = 0, at = 0;
+            int64_t wr = 0;
+            const int r = lane_decode<false>(T, in, nbytes, job.warm_bit, job.lo_bit, wn, wo, nullptr, wr, at, wcc, wco);
+            hdr64[0] = at;
+            hdr[2] = r != 0;          // EndOfBlock or an undecodable code before the piece: the block ended earlier
+        }
+        __syncthreads();
+        bi.data_bit = hdr64[0];
+        if (hdr[2]) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
+    }
     const uint64_t d0 = hdr64[0];
     uint64_t e = job.end_bit;
     if (e > nbytes * 8) e = nbytes * 8;
@@ -584,7 +599,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
         if (tid < nl && st != ~0ull) {
             if (st != decoded_from) {
                 // the last lane keeps going to the end of the stream range (the block may end exactly at e)
-                const uint64_t lim = tid + 1 == nl ? e + 64 : my_bound;
+                // (a piece's last lane stops at the first symbol boundary >= e: the next piece starts exactly there)
+                const uint64_t lim = tid + 1 == nl ? (piece ? e : e + 64) : my_bound;
                 nc = 0; no = 0;
                 uint64_t at = st;
                 int r = 0;
@@ -633,14 +649,16 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
     __syncthreads();
     if (tid < nl && s_flag[tid] != 0) atomicMin(&s_eob, tid);   // first flagged lane of the chain
     __syncthreads();
-    const uint32_t eobl = s_eob;
+    uint32_t eobl = s_eob;
     bi.rounds = rounds;
-    if (eobl == 0xFFFFFFFFu || rounds >= 64) {
-        bi.status = rounds >= 64 ? BLK_BAD : BLK_NO_EOB;
-        if (tid == 0) infos[blockIdx.x] = bi;
-        return;
-    }
-    if (s_flag[eobl] != 1) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
+    if (rounds >= 64) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
+    if (eobl == 0xFFFFFFFFu) {
+        // no EndOfBlock inside the range.  An ordinary job reports just that (its range was cut short by a false
+        // candidate); a piece is "open": all its lanes count and its end is the exit of the last lane
+        bi.status = BLK_NO_EOB;
+        if (!piece || nl == 0) { if (tid == 0) infos[blockIdx.x] = bi; return; }
+        eobl = nl - 1;
+    } else if (s_flag[eobl] != 1) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
     // exclusive scans of code / byte counts over lanes <= eobl
     const uint32_t mync = tid <= eobl ? s_nc[tid] : 0;
     const uint64_t myno = tid <= eobl ? s_no[tid] : 0;
@@ -720,7 +738,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
     uint64_t cut_pos = 0;
     if (tid < job.nlanes) {
         const uint64_t st = L->start[tid];
-        const uint64_t lim = tid + 1 < job.nlanes ? L->start[tid + 1] : ~0ull >> 1;
+        const uint64_t lim = tid + 1 < job.nlanes ? L->start[tid + 1] : (job.end_limit ? job.end_limit : ~0ull >> 1);
         uint32_t nc = 0, cc = 0, co = 0;
         const uint64_t out0 = L->out_off[tid];   // bytes of this block produced before my slice
         uint64_t no = out0, endpos;

@@ -173,3 +173,30 @@ def test_foreign_streams_stored_and_fixed_blocks(env):
             assert d_out.cpu().numpy().tobytes() == plain
     finally:
         os.environ.pop("LFX_NO_SERIAL", None)
+
+
+def test_s1_huge_block_pieces(env, oracle):
+    """Schedule S1 on 24 MiB: ONE LZ77 chunk and ONE block.  Encode is compared with the oracle byte for byte;
+    decode must scan the block in pieces (a proven chain of workgroups) and materialise it through markers —
+    no serial kernel."""
+    import os
+    import torch
+    ctx, ffi, synth = env
+    n = 24 << 20
+    data = synth.text(n, seed=0x5EED0009)
+    d_in = torch.from_numpy(data).cuda()
+    sched, opts = ffi.make_schedule(0), ffi.make_opts()
+    bound = ffi.lib().lfx_encode_bound(n, None, None)
+    d_out = torch.empty(bound, dtype=torch.uint8, device="cuda")
+    m = ctx.encode_device(ffi.GZIP, d_in.data_ptr(), n, d_out.data_ptr(), bound, opts, sched)
+    got = d_out[:m].cpu().numpy().tobytes()
+    assert got == oracle.encode(oracle.GZIP, data.tobytes(), write_size=0)
+    assert len(oracle.scan_blocks(got[10:-8])) == 2          # the block + the empty final block
+    os.environ["LFX_NO_SERIAL"] = "1"
+    try:
+        d_dec = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        rc, ol, used, msg = ctx.decode_device(ffi.GZIP, d_out.data_ptr(), m, d_dec.data_ptr(), n)
+        assert (rc, ol, used) == (0, n, m), msg
+        assert torch.equal(d_dec, d_in)
+    finally:
+        os.environ.pop("LFX_NO_SERIAL", None)
