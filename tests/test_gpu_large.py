@@ -200,3 +200,25 @@ def test_s1_huge_block_pieces(env, oracle):
         assert torch.equal(d_dec, d_in)
     finally:
         os.environ.pop("LFX_NO_SERIAL", None)
+
+
+def test_s1_huge_block_corrupted(env, oracle):
+    """A damaged huge-block stream: the piece chain (or the scan behind it) refuses it and the exact serial kernel
+    must report what the reference reports — same status, same bytes produced so far."""
+    ctx, ffi, synth = env
+    n = 12 << 20
+    data = synth.text(n, seed=0x5EED000A).tobytes()
+    good = oracle.encode(oracle.ZLIB, data, write_size=0)
+    assert len(good) > (4 << 20)
+    bad = bytearray(good)
+    bad[len(bad) * 3 // 5] ^= 0x10
+    want = oracle.decode(oracle.ZLIB, bytes(bad))
+    rc, out, used, msg = ctx.decode_host(ffi.ZLIB, bytes(bad))
+    assert rc == want[0] and rc != 0
+    assert out == want[1]
+    # truncation
+    cut = bytes(good[:len(good) * 2 // 3])
+    want = oracle.decode(oracle.ZLIB, cut)
+    rc, out, used, msg = ctx.decode_host(ffi.ZLIB, cut)
+    assert rc == want[0] == ffi.E_UNEXPECTED_EOF
+    assert out == want[1]
