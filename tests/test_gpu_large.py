@@ -222,3 +222,38 @@ def test_s1_huge_block_corrupted(env, oracle):
     rc, out, used, msg = ctx.decode_host(ffi.ZLIB, cut)
     assert rc == want[0] == ffi.E_UNEXPECTED_EOF
     assert out == want[1]
+
+
+def test_foreign_streams_fuzz(env):
+    """python zlib as a stand-in for "any other encoder": levels, strategies, window sizes and flush points chosen
+    at random; every stream must decode to its input (whichever internal path it takes)."""
+    import torch
+    ctx, ffi, synth = env
+    rng = np.random.default_rng(77)
+    text = synth.text(6 << 20, seed=0x5EED000B).tobytes()
+    low = synth.lowent(3 << 20, seed=0x5EED000C).tobytes()
+    strategies = [pyzlib.Z_DEFAULT_STRATEGY, pyzlib.Z_FILTERED, pyzlib.Z_HUFFMAN_ONLY, pyzlib.Z_RLE, pyzlib.Z_FIXED]
+    for trial in range(24):
+        src = text if trial % 3 else low
+        n = int(rng.integers(300000, min(len(src), 4 << 20)))
+        o = int(rng.integers(0, len(src) - n + 1))
+        plain = src[o:o + n]
+        level = int(rng.integers(0, 10))
+        wbits = int(rng.integers(9, 16))
+        strat = strategies[int(rng.integers(0, len(strategies)))]
+        co = pyzlib.compressobj(level, pyzlib.DEFLATED, wbits, 8, strat)
+        parts, at = [], 0
+        while at < n:
+            step = int(rng.integers(20000, 900000))
+            parts.append(co.compress(plain[at:at + step]))
+            at += step
+            r = int(rng.integers(0, 6))
+            if r == 0: parts.append(co.flush(pyzlib.Z_SYNC_FLUSH))
+            if r == 1: parts.append(co.flush(pyzlib.Z_FULL_FLUSH))
+        parts.append(co.flush())
+        comp = b"".join(parts)
+        d_in = torch.frombuffer(bytearray(comp), dtype=torch.uint8).cuda()
+        d_out = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        rc, ol, used, msg = ctx.decode_device(ffi.ZLIB, d_in.data_ptr(), len(comp), d_out.data_ptr(), n)
+        assert (rc, ol, used) == (0, n, len(comp)), (trial, level, wbits, strat, msg)
+        assert d_out.cpu().numpy().tobytes() == plain, (trial, level, wbits, strat)

@@ -371,7 +371,7 @@ def test_differential_random(ctx, ffi, oracle, synth):
 
     sizes = [0, 1, 2, 3, 4, 5, 63, 64, 65, 257, 258, 259, 4095, 4096, 4097, 32767, 32768, 32769, 65535, 65536,
              262143, 262144, 262145, 262147, 300001]
-    for trial in range(60):
+    for trial in range(int(__import__("os").environ.get("LFX_FUZZ_TRIALS", "60"))):
         n = int(sizes[trial % len(sizes)] if trial < len(sizes) else rng.integers(0, 400000))
         data = sample(n)
         ws = int(rng.choice([0, 1, 7, 100, 4096, 8192, 65536, 262144, 300000]))
