@@ -319,12 +319,23 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         }
     const uint32_t nchunks = (uint32_t)plan.chunks.size(), nblocks = (uint32_t)plan.blocks.size();
     // segments for the match search
+    // A segment is one workgroup's serial walk (plus a 32 KiB warm-up when it does not start a chunk).  Small
+    // inputs are cut finer so that the GPU still fills: halve the segment length until there are >= 512 of them
+    // (never below 32 Ki positions: the warm-up would dominate).
+    uint64_t seg_len = SEG_POSITIONS;
+    for (;;) {
+        uint64_t cnt = 0;
+        for (const ChunkDesc &ch : plan.chunks)
+            if (!(ch.flags & CH_LITERALS) && ch.len > 3) cnt += div_up(ch.len - 3, seg_len);
+        if (cnt >= 512 || seg_len <= 32768) break;
+        seg_len /= 2;
+    }
     std::vector<SegDesc> segs;
     for (uint32_t ci = 0; ci < nchunks; ci++) {
         const ChunkDesc &ch = plan.chunks[ci];
         if (ch.flags & CH_LITERALS) continue;
-        for (uint64_t s = 0; s + 3 < ch.len; s += SEG_POSITIONS)
-            segs.push_back(SegDesc{ci, (uint32_t)s, (uint32_t)std::min<uint64_t>(SEG_POSITIONS, ch.len - s), 0});
+        for (uint64_t s = 0; s + 3 < ch.len; s += seg_len)
+            segs.push_back(SegDesc{ci, (uint32_t)s, (uint32_t)std::min<uint64_t>(seg_len, ch.len - s), 0});
     }
     c->cur_nchunks = nchunks;
     c->cur_nblocks = nblocks;
