@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -318,24 +319,40 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             return LFX_E_ARG;
         }
     const uint32_t nchunks = (uint32_t)plan.chunks.size(), nblocks = (uint32_t)plan.blocks.size();
-    // segments for the match search
+    // ---- which match stage (lfx_match2.hip vs the first-generation kernel) and how the work is cut
+    // FUSED: a workgroup owns a whole chunk and also walks / emits it — the per-position intermediate never leaves
+    // the chip.  Needs enough chunks to fill the GPU and chunks short enough for one workgroup's serial walk.
+    const bool match_v1 = c->force_match_v1 || getenv("LFX_MATCH_V1") != nullptr || !getenv("LFX_MATCH_V2");   // (opt-in while it is being tuned)
+    uint64_t n_match_chunks = 0, max_chunk = 0;
+    for (const ChunkDesc &ch : plan.chunks)
+        if (!(ch.flags & CH_LITERALS)) { n_match_chunks++; max_chunk = std::max<uint64_t>(max_chunk, ch.len); }
+    // (LFX_FUSED_MIN_CHUNKS: tests force the fused path on small inputs)
+    const char *fm = getenv("LFX_FUSED_MIN_CHUNKS");
+    const uint64_t fused_min = fm ? strtoull(fm, nullptr, 10) : (uint64_t)std::max(c->n_cu / 2, 1);
+    const bool fused = !match_v1 && po.lz77_kind == 0 && !getenv("LFX_NO_FUSED") && max_chunk <= (512u << 10) &&
+                       n_match_chunks >= fused_min;
     // A segment is one workgroup's serial walk (plus a 32 KiB warm-up when it does not start a chunk).  Small
     // inputs are cut finer so that the GPU still fills: halve the segment length until there are >= 512 of them
     // (never below 32 Ki positions: the warm-up would dominate).
-    uint64_t seg_len = SEG_POSITIONS;
-    for (;;) {
-        uint64_t cnt = 0;
-        for (const ChunkDesc &ch : plan.chunks)
-            if (!(ch.flags & CH_LITERALS) && ch.len > 3) cnt += div_up(ch.len - 3, seg_len);
-        if (cnt >= 512 || seg_len <= 32768) break;
-        seg_len /= 2;
-    }
     std::vector<SegDesc> segs;
-    for (uint32_t ci = 0; ci < nchunks; ci++) {
-        const ChunkDesc &ch = plan.chunks[ci];
-        if (ch.flags & CH_LITERALS) continue;
-        for (uint64_t s = 0; s + 3 < ch.len; s += seg_len)
-            segs.push_back(SegDesc{ci, (uint32_t)s, (uint32_t)std::min<uint64_t>(seg_len, ch.len - s), 0});
+    if (fused) {
+        for (uint32_t ci = 0; ci < nchunks; ci++)
+            segs.push_back(SegDesc{ci, 0, (uint32_t)plan.chunks[ci].len, 0});   // (also empty chunks: they emit EndOfBlock)
+    } else {
+        uint64_t seg_len = SEG_POSITIONS;
+        for (;;) {
+            uint64_t cnt = 0;
+            for (const ChunkDesc &ch : plan.chunks)
+                if (!(ch.flags & CH_LITERALS) && ch.len > 3) cnt += div_up(ch.len - 3, seg_len);
+            if (cnt >= 512 || seg_len <= 32768) break;
+            seg_len /= 2;
+        }
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            const ChunkDesc &ch = plan.chunks[ci];
+            if (ch.flags & CH_LITERALS) continue;
+            for (uint64_t s = 0; s + 3 < ch.len; s += seg_len)
+                segs.push_back(SegDesc{ci, (uint32_t)s, (uint32_t)std::min<uint64_t>(seg_len, ch.len - s), 0});
+        }
     }
     c->cur_nchunks = nchunks;
     c->cur_nblocks = nblocks;
@@ -346,17 +363,17 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_chunks.reserve(sizeof(ChunkDesc) * std::max<size_t>(nchunks, 1)))) return rc;
     if ((rc = c->d_blocks.reserve(sizeof(BlockDesc) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
-    if ((rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;
+    if (!fused && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
-    if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
-    if ((rc = c->d_segtmp.reserve(16ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
+    if (!fused && (rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
+    if (!fused && (rc = c->d_segtmp.reserve(16ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
     if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_tile_bits.reserve(4 * std::max<uint64_t>(plan.n_tiles, 1)))) return rc;
     if ((rc = c->d_tile_start.reserve(8 * std::max<uint64_t>(plan.n_tiles, 1)))) return rc;
-    const uint64_t nspans = div_up(std::max<uint64_t>(n, 1), 1024);
+    const uint64_t nspans = div_up(std::max<uint64_t>(n, 1), 65536);   // CK_SPAN of the checksum kernels
     if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
     if ((rc = c->d_res.reserve(256))) return rc;
     if ((rc = c->d_small.reserve(70000))) return rc;
@@ -381,20 +398,27 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
 
     uint64_t *mdbg = nullptr;
     if (getenv("LFX_DEBUG")) mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768);   // per-wavefront cycle counters of workgroup 0
-    LAUNCH_TRY(launch_match(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                            (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
+    uint32_t *d_match_flags = (uint32_t *)((uint8_t *)c->d_res.p + offsetof(EncodeResult, match_flags));
+    if (match_v1)
+        LAUNCH_TRY(launch_match(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
+    else
+        LAUNCH_TRY(launch_match2(st, fused, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p,
+                                 (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, d_match_flags, mdbg));
     if (mdbg) {
         uint64_t hv[128];
         (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
         for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[lfx] match wave%d: load=%llu work=%llu wait=%llu hops=%llu lcp_iters=%llu tiles=%llu\n", w,
-                    (unsigned long long)hv[w * 8], (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2],
-                    (unsigned long long)hv[w * 8 + 3], (unsigned long long)hv[w * 8 + 4], (unsigned long long)hv[w * 8 + 5]);
+            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : (fused ? "2f" : "2"), w,
+                    match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
+                    (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
     }
     c->phase("lz77_match");
-    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
-                            (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
-                            (uint32_t *)c->d_ncodes.p));
+    if (!fused)
+        LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
+                                (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
+                                (uint32_t *)c->d_ncodes.p));
     c->phase("lz77_parse");
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the histogram
@@ -445,13 +469,14 @@ int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, b
                            (uint32_t *)d_out));
     c->phase("pack");
     if (prefix_len) {
-        HIP_TRY(hipMemcpyAsync(c->d_small.p, prefix, prefix_len, hipMemcpyHostToDevice, st));
-        LAUNCH_TRY(launch_put_bytes(st, (const uint8_t *)c->d_small.p, prefix_len, 0, (uint32_t *)d_out));
+        // (a gzip header holds an unbounded file name / comment: its own buffer, sized to fit)
+        int rcp = c->d_hdr.reserve(prefix_len);
+        if (rcp) return rcp;
+        HIP_TRY(hipMemcpyAsync(c->d_hdr.p, prefix, prefix_len, hipMemcpyHostToDevice, st));
+        LAUNCH_TRY(launch_put_bytes(st, (const uint8_t *)c->d_hdr.p, prefix_len, 0, (uint32_t *)d_out));
     }
     if (!use_device_check) {
         // combined checksum supplied by the caller (sharded encode): patch the device result
-        EncodeResult tmp{};
-        (void)tmp;
         HIP_TRY(hipMemcpyAsync((uint8_t *)dres + offsetof(EncodeResult, crc32), &trailer_check, 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync((uint8_t *)dres + offsetof(EncodeResult, adler32), &trailer_check, 4, hipMemcpyHostToDevice, st));
     }
@@ -466,6 +491,14 @@ int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, b
 
 }  // namespace lfx
 
+// The second-generation match kernel proves its one hardware assumption at run time; a violation voids the results
+// and makes the context fall back to the first-generation kernel for good.
+static bool match_violation(Ctx *c, const EncodeResult &res) {
+    if (!(res.match_flags & 1) || c->force_match_v1) return false;
+    c->force_match_v1 = true;
+    return true;
+}
+
 extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                                  const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len) {
     if (!cc) return LFX_E_DEVICE;
@@ -479,10 +512,14 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
     Planner pl(po);
     apply_schedule(pl, s, n);
     Plan &plan = pl.finish();
-    if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) return rc;
-    EncodeResult res;
-    rc = encode_emit(c, format, true, 0, true, n, hdr.data(), (uint32_t)hdr.size(), 8 * (uint64_t)hdr.size(),
-                     (uint8_t *)d_out, cap, &res);
+    EncodeResult res{};
+    for (;;) {
+        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) return rc;
+        rc = encode_emit(c, format, true, 0, true, n, hdr.data(), (uint32_t)hdr.size(), 8 * (uint64_t)hdr.size(),
+                         (uint8_t *)d_out, cap, &res);
+        if (match_violation(c, res)) continue;   // (never observed: see lfx_match2.hip) redo with the first-generation kernel
+        break;
+    }
     if (rc) return rc;
     if (out_len) *out_len = res.out_bytes;
     return LFX_OK;
@@ -542,21 +579,23 @@ extern "C" int lfx_encode_shard_prepare(lfx_ctx *cc, int format, const lfx_encod
     if (is_first && (rc = container_header(format, d, c->shard_hdr))) return rc;
     c->shard_format = format;
     c->shard_last = is_last != 0;
-    if ((rc = encode_prepare(c, *plan, po, (const uint8_t *)d_in, n, true))) return rc;
-    // total bits for phase 0 (compressed blocks only → phase independent)
     hipStream_t st = c->stream;
-    LAUNCH_TRY(launch_offsets(st, (const BlockDesc *)c->d_blocks.p, c->cur_nblocks, (const BlockCodes *)c->d_bc.p,
-                              0, ~0ull, (uint64_t *)c->d_block_start.p, (EncodeResult *)c->d_res.p));
-    HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    EncodeResult r = *(EncodeResult *)c->h_res;
-    info->total_bits = r.end_bit;  // for the last shard this includes alignment relative to phase 0
-    if (is_last) {
-        // report unaligned bits: recompute without the final alignment
-        // (end_bit was aligned from phase 0; the true alignment happens in emit with the real phase)
-        // body bits = sum of block bits; the last block is never a stored block here
-        info->total_bits = r.end_bit;  // corrected below by emit(); callers only need sums of non-last shards
+    EncodeResult r{};
+    for (;;) {
+        if ((rc = encode_prepare(c, *plan, po, (const uint8_t *)d_in, n, true))) return rc;
+        // total bits at bit phase 0 (compressed blocks only → independent of the phase)
+        LAUNCH_TRY(launch_offsets(st, (const BlockDesc *)c->d_blocks.p, c->cur_nblocks, (const BlockCodes *)c->d_bc.p,
+                                  0, ~0ull, (uint64_t *)c->d_block_start.p, (EncodeResult *)c->d_res.p));
+        HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        r = *(EncodeResult *)c->h_res;
+        if (match_violation(c, r)) continue;
+        break;
     }
+    // For the LAST shard the figure includes the final byte alignment as seen from phase 0; its true value depends on
+    // the shard's start phase and is settled by emit().  Layouts only ever sum the bits of the shards in front of a
+    // shard, so the last shard's own figure is informative.
+    info->total_bits = r.end_bit;
     info->n_bytes = n;
     info->crc32 = r.crc32;
     info->adler32 = r.adler32;
@@ -627,12 +666,16 @@ static int enc_run(lfx_encoder *e, bool final) {
     const uint64_t bound = n + n / 4 + 1024 * (uint64_t)plan->blocks.size() + 128;
     if ((rc = e->d_out.reserve(bound))) return rc;
     if (n && hipMemcpyAsync(e->d_in.p, e->pending.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
-    if ((rc = encode_prepare(c, *plan, e->po, (const uint8_t *)e->d_in.p, n, e->format != LFX_DEFLATE))) { e->err = c->err; return rc; }
-    EncodeResult res;
+    EncodeResult res{};
     uint8_t prefix[1] = {e->carry};
-    // the container trailer is written by the host here (the checksum spans batches)
-    rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits,
-                     (uint8_t *)e->d_out.p, bound & ~3ull, &res);
+    for (;;) {
+        if ((rc = encode_prepare(c, *plan, e->po, (const uint8_t *)e->d_in.p, n, e->format != LFX_DEFLATE))) { e->err = c->err; return rc; }
+        // the container trailer is written by the host here (the checksum spans batches)
+        rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits,
+                         (uint8_t *)e->d_out.p, bound & ~3ull, &res);
+        if (match_violation(c, res)) continue;
+        break;
+    }
     if (rc) { e->err = c->err; return rc; }
     if (e->format == LFX_GZIP) e->crc = e->total_in == n ? res.crc32 : lfx_crc32_combine(e->crc, res.crc32, n);
     if (e->format == LFX_ZLIB) e->adler = e->total_in == n ? res.adler32 : lfx_adler32_combine(e->adler, res.adler32, n);
@@ -783,9 +826,15 @@ extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
     int rc;
     if ((rc = z->d_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
     HIP_TRY(hipMemcpyAsync(z->d_in.p, z->buf.data(), n, hipMemcpyHostToDevice, c->stream));
-    if ((rc = encode_prepare(c, plan, po, (const uint8_t *)z->d_in.p, n, false))) return rc;
     uint32_t nc = 0;
-    HIP_TRY(hipMemcpy(&nc, c->d_ncodes.p, 4, hipMemcpyDeviceToHost));
+    for (;;) {
+        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)z->d_in.p, n, false))) return rc;
+        EncodeResult r{};
+        HIP_TRY(hipMemcpy(&r, c->d_res.p, sizeof r, hipMemcpyDeviceToHost));
+        if (match_violation(c, r)) continue;
+        HIP_TRY(hipMemcpy(&nc, c->d_ncodes.p, 4, hipMemcpyDeviceToHost));
+        break;
+    }
     z->host_codes.resize(nc);
     if (nc) HIP_TRY(hipMemcpy(z->host_codes.data(), c->d_codes.p, 4ull * nc, hipMemcpyDeviceToHost));
     z->buf.clear();  // default.rs:108
