@@ -53,8 +53,8 @@ constexpr int HASH_BITS = 14;
 constexpr uint32_t PRING = 32768 + 2048;      // prevd ring (entries)  >= window + TILE
 constexpr uint32_t WRING = 36864;             // window ring (bytes)   >= window + 4 TILE + 4, and the fill of
                                               // tile k+4 must not touch what R(k) reads: 4 TILE + 4 <= WRING - 32768
-constexpr uint32_t HEAD_FAR = 40000;          // distance marker of an empty / swept head field
-constexpr uint32_t SWEEP_SLICES = 16;         // the whole table is swept every 16 tiles (14336 positions)
+constexpr uint32_t HEAD_FAR = 33000;          // distance marker of an empty / swept head field
+constexpr uint32_t SWEEP_SLICES = 32;         // the whole table is swept every 32 tiles (28672 positions)
 constexpr uint32_t FUTURE = 65536 - 64;       // a distance this large can only come from a lane-order violation
 
 constexpr uint32_t LK_PTR = 32769;            // lk value >= LK_PTR: inherit the link of in-tile index (v - LK_PTR)
@@ -63,9 +63,14 @@ constexpr uint32_t LK_PTR = 32769;            // lk value >= LK_PTR: inherit the
 constexpr uint32_t OFF_HEAD = 0;                                   // 8192 dwords
 constexpr uint32_t OFF_PREVD = OFF_HEAD + (2u << HASH_BITS);       // PRING u16
 constexpr uint32_t OFF_WIN = OFF_PREVD + PRING * 2;                // WRING + 8 bytes (+ pad)
-constexpr uint32_t OFF_LK = OFF_WIN + WRING + 16;                  // 2 x TILE u16 (raw predecessor, then link state)
-constexpr uint32_t OFF_CODE = OFF_LK + 2 * TILE * 2;               // 2 x TILE u32 (fused mode)
-constexpr uint32_t LDS_BYTES = OFF_CODE + 2 * TILE * 4;
+constexpr uint32_t OFF_REQ = OFF_WIN + WRING + 16;                 // TILE u32: head-pass requests (hash, valid, position)
+constexpr uint32_t OFF_OLD = OFF_REQ + TILE * 4;                   // TILE u32: the dwords the exchanges returned
+constexpr uint32_t OFF_LK = OFF_OLD + TILE * 4;                    // TILE u16: link states of the tile being finalized
+constexpr uint32_t OFF_TABE = OFF_LK + TILE * 2;                   // fused: per group and entry lane, where the walk leaves the group
+constexpr uint32_t OFF_TABM = OFF_TABE + TILE * 2;                 // fused: ... and the 64-bit set of positions it visits
+constexpr uint32_t OFF_RES = OFF_TABM + TILE * 8;                  // fused: per group {visited mask, codes before the group}
+constexpr uint32_t LDS_BYTES = OFF_RES + NSUB * 16;
+static_assert(NSUB == 14, "the head pass issues two batches of seven exchanges");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(4 * TILE + 4 <= WRING - 32768, "window ring slack");
 static_assert(TILE <= PRING - 32768, "prevd ring slack");
@@ -86,6 +91,14 @@ struct ByteSrc2 {
     __device__ __forceinline__ uint32_t load1(uint64_t off) const {
         const uint64_t a = off + shift;
         return (w[a >> 2] >> (((uint32_t)a & 3) * 8)) & 0xFF;
+    }
+    // the two dwords load4() would combine (with alignbyte(w1, w0, shift)), for a dword-aligned `off`: the combination
+    // can then wait until the data is needed
+    __device__ __forceinline__ void load_raw(uint64_t off, uint32_t &w0, uint32_t &w1) const {
+        const uint64_t a = off + shift, idx = a >> 2;
+        const uint64_t last = (nbytes + shift + 3) >> 2;
+        w0 = idx < last ? w[idx] : 0;
+        w1 = (shift != 0 && idx + 1 < last) ? w[idx + 1] : 0;
     }
 };
 
@@ -112,34 +125,23 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64 - lane));
 }
 
-// fourteen 16-bit exchanges, in order, one wait.  old[i] = the dword that held the field before.
+// seven 16-bit exchanges, in order, one wait.  old[i] = the dword that held the field before.
 // A lane with mask 0 / value 0 leaves its dword untouched.
-__device__ __forceinline__ void mskor14(uint32_t (&old)[14], const uint32_t (&addr)[14], const uint32_t (&mask)[14],
-                                        const uint32_t (&val)[14]) {
+__device__ __forceinline__ void mskor7(uint32_t (&old)[7], const uint32_t (&addr)[7], const uint32_t (&mask)[7],
+                                       const uint32_t (&val)[7]) {
     asm volatile(
-        "ds_mskor_rtn_b32 %0, %14, %28, %42\n\t"
-        "ds_mskor_rtn_b32 %1, %15, %29, %43\n\t"
-        "ds_mskor_rtn_b32 %2, %16, %30, %44\n\t"
-        "ds_mskor_rtn_b32 %3, %17, %31, %45\n\t"
-        "ds_mskor_rtn_b32 %4, %18, %32, %46\n\t"
-        "ds_mskor_rtn_b32 %5, %19, %33, %47\n\t"
-        "ds_mskor_rtn_b32 %6, %20, %34, %48\n\t"
-        "ds_mskor_rtn_b32 %7, %21, %35, %49\n\t"
-        "ds_mskor_rtn_b32 %8, %22, %36, %50\n\t"
-        "ds_mskor_rtn_b32 %9, %23, %37, %51\n\t"
-        "ds_mskor_rtn_b32 %10, %24, %38, %52\n\t"
-        "ds_mskor_rtn_b32 %11, %25, %39, %53\n\t"
-        "ds_mskor_rtn_b32 %12, %26, %40, %54\n\t"
-        "ds_mskor_rtn_b32 %13, %27, %41, %55\n\t"
+        "ds_mskor_rtn_b32 %0, %7, %14, %21\n\t"
+        "ds_mskor_rtn_b32 %1, %8, %15, %22\n\t"
+        "ds_mskor_rtn_b32 %2, %9, %16, %23\n\t"
+        "ds_mskor_rtn_b32 %3, %10, %17, %24\n\t"
+        "ds_mskor_rtn_b32 %4, %11, %18, %25\n\t"
+        "ds_mskor_rtn_b32 %5, %12, %19, %26\n\t"
+        "ds_mskor_rtn_b32 %6, %13, %20, %27\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5]), "=&v"(old[6]),
-          "=&v"(old[7]), "=&v"(old[8]), "=&v"(old[9]), "=&v"(old[10]), "=&v"(old[11]), "=&v"(old[12]), "=&v"(old[13])
-        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]), "v"(addr[7]),
-          "v"(addr[8]), "v"(addr[9]), "v"(addr[10]), "v"(addr[11]), "v"(addr[12]), "v"(addr[13]),
-          "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]), "v"(mask[7]),
-          "v"(mask[8]), "v"(mask[9]), "v"(mask[10]), "v"(mask[11]), "v"(mask[12]), "v"(mask[13]),
-          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6]), "v"(val[7]),
-          "v"(val[8]), "v"(val[9]), "v"(val[10]), "v"(val[11]), "v"(val[12]), "v"(val[13])
+        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5]), "=&v"(old[6])
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]),
+          "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]),
+          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6])
         : "memory");
 }
 
@@ -158,8 +160,12 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     uint32_t *head32 = (uint32_t *)(smem + OFF_HEAD);
     uint16_t *prevd = (uint16_t *)(smem + OFF_PREVD);
     uint32_t *win32 = (uint32_t *)(smem + OFF_WIN);
-    uint16_t *lkb = (uint16_t *)(smem + OFF_LK);
-    uint32_t *codeb = (uint32_t *)(smem + OFF_CODE);
+    uint32_t *reqb = (uint32_t *)(smem + OFF_REQ);
+    uint32_t *oldb = (uint32_t *)(smem + OFF_OLD);
+    uint16_t *lk = (uint16_t *)(smem + OFF_LK);
+    uint16_t *tabE = (uint16_t *)(smem + OFF_TABE);
+    uint2 *tabM = (uint2 *)(smem + OFF_TABM);
+    uint32_t *resw = (uint32_t *)(smem + OFF_RES);   // per group: mask lo, mask hi, codes before, unused
     // LDS byte address of head[] for the asm exchanges (taking it from the pointer also makes the array escape)
     const uint32_t head_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)head32;
 
@@ -212,282 +218,356 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     }
     lds_barrier();
 
-    // resolver lane state carried from stage to stage (same lane index in consecutive tiles)
+    // resolver lane state carried from stage to stage (a lane keeps its index inside the tile: stage X of tile k and
+    // stage X+1 of the same tile run on the same lane one or two phases later)
     const uint32_t idx = (wave - 1) * 64 + lane;   // resolver's index inside a tile (waves 1..14)
-    uint32_t key_f = 0, key_r = 0;                 // 3-byte prefix of the F / R tile position
+    uint32_t key_p = 0, key_f = 0, key_r = 0;      // 3-byte prefix of the P / F / R tile position
+    uint32_t hh_p = 0, hh_f = 0;                   // its hash (selects the half of the exchanged dword)
+    bool val_p = false, val_f = false, val_r = false;   // position takes part in the chain structure (l0 <= p < q1)
     uint32_t cd_f = 0, cd_r = 0;                   // known answer distance (0 = walk)
     uint32_t e_f = 0, e_r = 0;                     // own final link distance (0 = none)
-    bool val_f = false, val_r = false;             // position takes part in the chain structure
     uint32_t lk_f = 0;                             // F1 → F2: first link state
     uint32_t r_dist = 0;                           // R1 → R2
     bool r_found = false;
-    // walker state (wave 15)
-    uint32_t w_pos = 0, w_cnt = 0;
+    uint32_t code_r = 0, code_t = 0, code_e = 0;   // fused: code word of the R2 / T / E tile position
+    uint32_t w_pos = 0, w_cnt = 0;                 // walker (wave 15): next position to visit, codes emitted
     // (tile 0 = position `base` sits at ring offset 0; the loop starts two tiles early)
     uint32_t wk = WRING - 2 * TILE, sk = PRING - 2 * TILE;   // window / prevd ring offset of tile `it`
-    uint32_t fill_off = loaded_to - base;          // wave 0: ring offset of position loaded_to
+    uint32_t fill_off = loaded_to - base;          // wave 15: ring offset of position loaded_to
     uint64_t cy_a = 0, cy_b = 0, cy_w = 0;
-
-    // ---- W: the greedy walk (default.rs:76-107) over one tile's code words, groups [g_lo, g_hi).  64 answers sit in
-    // a VGPR; the vector side precomputes where TWO steps lead from every position (one ds_bpermute) and the two
-    // bits they visit, so the serial chain is three readlanes per two steps; the visited code words are compacted
-    // into the chunk's code array.
-    auto walk_groups = [&](uint32_t tile, uint32_t g_lo, uint32_t g_hi) {
-        const uint32_t t_w = base + tile * TILE;
-        const uint32_t *cw = codeb + (tile & 1) * TILE;
-        const uint64_t lt = lanemask_lt();
-        for (uint32_t g = g_lo; g < g_hi; ++g) {
-            const uint32_t gb = t_w + g * 64;
-            if (gb >= n) break;
-            const uint32_t v = cw[g * 64 + lane];
-            const uint32_t stepv = (v & 0xFFFFu) ? (v >> 16) : 1u;
-            const uint32_t stop_r = min(gb + 64, n) - gb;
-            const uint32_t j1 = lane + stepv;
-            const bool in1 = j1 < stop_r;
-            const uint32_t j1n = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((in1 ? j1 : lane) << 2), (int)j1);
-            const uint32_t j2 = in1 ? j1n : j1;
-            uint32_t klo = lane < 32 ? 1u << lane : 0u, khi = lane >= 32 ? 1u << (lane - 32) : 0u;
-            if (in1) { if (j1 < 32) klo |= 1u << j1; else khi |= 1u << (j1 - 32); }
-            uint64_t m = 0;
-            uint32_t r = __builtin_amdgcn_readfirstlane(w_pos - gb);   // w_pos >= gb: steps only go forward
-            while (r < stop_r) {
-                m |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)klo, r) |
-                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, r) << 32;
-                r = (uint32_t)__builtin_amdgcn_readlane((int)j2, r);
-            }
-            w_pos = gb + r;
-            if ((m >> lane) & 1) out[w_cnt + __popcll(m & lt)] = v;
-            w_cnt += __popcll(m);
-        }
-    };
+    const uint64_t lt_mask = lanemask_lt();
 
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
-    else if (FUSED && wave == 15) __builtin_amdgcn_s_setprio(2);
+    else if (wave == 15) __builtin_amdgcn_s_setprio(2);
 
-    const int it_end = FUSED ? ntiles + 1 : ntiles;
+    // Stages of iteration `it` (tile numbers in parentheses):
+    //   phase A   resolvers: R1(it) F1(it+1) P(it+2) [E(it-2) T(it-1)]   wave 15: window loads (global → registers), sweep
+    //   phase B   resolvers: F2(it+1) R2(it)      wave 0: H(it+2)         wave 15: [W(it-1)], window stores
+    // Inside a phase the stages of a resolver are independent chains of LDS round trips; they are written
+    // interleaved — all loads of a step first (dummy addresses for lanes that do not need them), then their uses —
+    // so that several round trips are in flight per wavefront.
+    const int it_end = FUSED ? ntiles + 2 : ntiles;
     for (int it = -2; it < it_end; ++it) {
         const uint64_t c0 = dbg ? clock64() : 0;
-        // ring offsets of the tiles in flight (tile it may be "negative" during the ramp-up: only it+1 / it+2 are used then)
-        const uint32_t w1 = ring_fwd(wk, TILE, WRING), s1 = ring_fwd(sk, TILE, PRING);
-        const uint32_t w2 = ring_fwd(w1, TILE, WRING);
+        const uint32_t w1 = ring_fwd(wk, TILE, WRING), s1 = ring_fwd(sk, TILE, PRING);   // tile it+1
+        const uint32_t w2 = ring_fwd(w1, TILE, WRING);                                   // tile it+2
         const bool do_r = it >= 0 && it < ntiles;
         const bool do_f = it + 1 >= 0 && it + 1 < ntiles;
-        const bool do_h = it + 2 >= 0 && it + 2 < ntiles;
-        // (during the ramp-up wk/sk are kept at the offsets tile `it` WOULD have: tile -2 → ring offset -2*TILE mod ring)
+        const bool do_p = it + 2 >= 0 && it + 2 < ntiles;
+        const bool do_t = FUSED && it - 1 >= 0 && it - 1 < ntiles;
+        const bool do_e = FUSED && it - 2 >= 0 && it - 2 < ntiles;
         const uint32_t t_r = base + (uint32_t)it * TILE;            // only used when do_r
-        const uint32_t t_h = base + (uint32_t)(it + 2) * TILE;      // only used when do_h
-        uint32_t fill_v[4] = {0, 0, 0, 0};
+        const uint32_t t_f = base + (uint32_t)(it + 1) * TILE;      // only used when do_f
+        const uint32_t t_p = base + (uint32_t)(it + 2) * TILE;      // only used when do_p
+        uint32_t fill_w0[4] = {0, 0, 0, 0}, fill_w1[4] = {0, 0, 0, 0};
         uint32_t fill_need = loaded_to;
 
         // =================================================== phase A
-        if (wave == 0) {
-            // ---- window bytes for H(it+3): global loads now, LDS stores in phase B
-            // (always four tiles ahead of R: the last tiles' match lengths read up to 258 bytes past the segment)
+        if (wave == 15) {
+            // ---- window bytes: global loads now, LDS stores at the end of phase B.  Always four tiles ahead of R:
+            //      the last tiles' match lengths read up to 258 bytes past the segment.
             fill_need = max(loaded_to, min(base + (uint32_t)(it + 4) * TILE + 4, n_pad));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t p = loaded_to + 4 * lane + 256 * q;
-                if (p < fill_need) fill_v[q] = src.load4(p);
+                if (p < fill_need) src.load_raw(p, fill_w0[q], fill_w1[q]);
             }
-            if (do_h) {
+            if (do_p) {
                 // ---- incremental sweep: stale fields (older than the window) → "far"
-                {
-                    const uint32_t slice = (uint32_t)(it + 2) % SWEEP_SLICES;
-                    const uint32_t far = (t_h - HEAD_FAR) & 0xFFFFu;
+                const uint32_t slice = (uint32_t)(it + 2) % SWEEP_SLICES;
+                const uint32_t far = (t_p - HEAD_FAR) & 0xFFFFu;
+                constexpr uint32_t PER = (1u << (HASH_BITS - 1)) / SWEEP_SLICES / 64;
+                uint32_t hw[PER];
 #pragma unroll
-                    for (uint32_t q = 0; q < (1u << (HASH_BITS - 1)) / SWEEP_SLICES / 64; ++q) {
-                        const uint32_t wi = slice * ((1u << (HASH_BITS - 1)) / SWEEP_SLICES) + q * 64 + lane;
-                        const uint32_t v = head32[wi];
-                        uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-                        const uint32_t dlo = (t_h - lo) & 0xFFFFu, dhi = (t_h - hi) & 0xFFFFu;
-                        if (dlo == 0 || dlo > MAX_WINDOW) lo = far;
-                        if (dhi == 0 || dhi > MAX_WINDOW) hi = far;
-                        head32[wi] = lo | hi << 16;
-                    }
-                }
-                // ---- ordered head pass of tile it+2
-                uint16_t *hv = lkb + ((uint32_t)(it + 2) & 1) * TILE;
-                uint32_t old[NSUB], addr[NSUB], mask[NSUB], val[NSUB];
+                for (uint32_t q = 0; q < PER; ++q) hw[q] = head32[slice * (PER * 64) + q * 64 + lane];
 #pragma unroll
-                for (uint32_t s = 0; s < NSUB; ++s) {
-                    const uint32_t p = t_h + s * 64 + lane;
-                    const bool v = p >= l0 && p < q1;
-                    const uint32_t key = win4(win32, ring_fwd(w2, s * 64 + lane, WRING)) & 0xFFFFFFu;
-                    const uint32_t hh = hash3(key);
-                    const uint32_t sh = (hh & 1) * 16;
-                    addr[s] = head_lds + (hh >> 1) * 4;
-                    mask[s] = v ? 0xFFFFu << sh : 0u;
-                    val[s] = v ? (p & 0xFFFFu) << sh : 0u;
+                for (uint32_t q = 0; q < PER; ++q) {
+                    uint32_t lo = hw[q] & 0xFFFFu, hi = hw[q] >> 16;
+                    const uint32_t dlo = (t_p - lo) & 0xFFFFu, dhi = (t_p - hi) & 0xFFFFu;
+                    if (dlo == 0 || dlo > MAX_WINDOW) lo = far;
+                    if (dhi == 0 || dhi > MAX_WINDOW) hi = far;
+                    head32[slice * (PER * 64) + q * 64 + lane] = lo | hi << 16;
                 }
-                mskor14(old, addr, mask, val);
-                bool viol = false;
-#pragma unroll
-                for (uint32_t s = 0; s < NSUB; ++s) {
-                    const uint32_t p = t_h + s * 64 + lane;
-                    const bool v = mask[s] != 0;
-                    const uint32_t of = (mask[s] >> 16) ? old[s] >> 16 : old[s] & 0xFFFFu;
-                    uint32_t d = (p - of) & 0xFFFFu;
-                    viol |= v && d >= FUTURE;
-                    if (d > MAX_WINDOW) d = 0;
-                    hv[s * 64 + lane] = v ? (uint16_t)d : (uint16_t)0xFFFFu;
-                }
-                if (__ballot(viol) && lane == 0) atomicOr(flags, 1u);
             }
-        } else if (wave <= RW) {
-            // ---- R1(it): chain walk (only where the answer is not already known)
-            const uint32_t p_r = t_r + idx;
+        } else if (wave >= 1 && wave <= RW) {
+            const uint32_t p_r = t_r + idx, p_f = t_f + idx, p_p = t_p + idx;
+            const uint32_t w_pos_r = ring_fwd(wk, idx, WRING), s_pos_r = ring_fwd(sk, idx, PRING);
+            const uint32_t w_pos_f = ring_fwd(w1, idx, WRING), s_pos_f = ring_fwd(s1, idx, PRING);
             const bool act_r = do_r && val_r && p_r >= q0;       // (val_r implies p_r < q1)
-            uint32_t dist = 0;
-            bool found = false;
+            const bool act_f = do_f && val_f;
+            // ---- R1(it): chain walk, only where the answer is not already known (cd) — and then starting at the LINK of
+            //      the raw predecessor, which is known to carry another prefix
+            uint32_t dist = 0, d = 0;
+            bool found = false, walk = false;
             if (act_r) {
-                const uint32_t w_pos_r = ring_fwd(wk, idx, WRING), s_pos_r = ring_fwd(sk, idx, PRING);
-                uint32_t d = 0;
                 if (cd_r) { dist = cd_r; found = dist <= window; }
-                else if (e_r) {
-                    // the raw predecessor is known to carry another prefix: start at ITS link
-                    dist = e_r;
-                    if (dist <= window) d = prevd[ring_back(s_pos_r, dist, PRING)];
-                }
-                while (d != 0) {
+                else if (e_r != 0 && e_r <= window) { dist = e_r; walk = true; }
+            }
+            struct Hop { uint32_t kq, dn; bool ok; };
+            auto hop_issue = [&]() -> Hop {
+                Hop h;
+                h.ok = false;
+                uint32_t aw = w_pos_r, as = s_pos_r;
+                if (d != 0) {
                     dist += d;
-                    if (dist > window || dist > p_r) break;        // default.rs:81 (inclusive window)
-                    const uint32_t kq = win4(win32, ring_back(w_pos_r, dist, WRING)) & 0xFFFFFFu;
-                    const uint32_t dn = prevd[ring_back(s_pos_r, dist, PRING)];
-                    if (kq == key_r) { found = true; break; }
-                    d = dn;
+                    if (dist > window || dist > p_r) d = 0;            // default.rs:81 (inclusive window)
+                    else { h.ok = true; aw = ring_back(w_pos_r, dist, WRING); as = ring_back(s_pos_r, dist, PRING); }
                 }
+                h.kq = win4(win32, aw) & 0xFFFFFFu;
+                h.dn = prevd[as];
+                return h;
+            };
+            auto hop_finish = [&](const Hop &h) {
+                if (h.ok) { if (h.kq == key_r) { found = true; d = 0; } else d = h.dn; }
+            };
+            // -- step 0: loads
+            const uint32_t d0 = prevd[walk ? ring_back(s_pos_r, dist, PRING) : s_pos_r];
+            const uint32_t ow = oldb[idx];
+            const uint32_t kp_raw = win4(win32, ring_fwd(w2, idx, WRING));
+            uint32_t e_ml = 0, e_mh = 0, e_b = 0;
+            if (FUSED) { e_ml = resw[(wave - 1) * 4]; e_mh = resw[(wave - 1) * 4 + 1]; e_b = resw[(wave - 1) * 4 + 2]; }
+            // -- step 0: uses
+            d = walk ? d0 : 0u;
+            uint32_t d_f = 0;
+            if (act_f) {
+                const uint32_t of = (hh_f & 1) ? ow >> 16 : ow & 0xFFFFu;   // what the exchange returned for this field
+                d_f = (p_f - of) & 0xFFFFu;
+            }
+            if (__ballot(d_f >= FUTURE) && lane == 0) atomicOr(flags, 1u);  // lane-order violation (never observed)
+            if (d_f > MAX_WINDOW) d_f = 0;
+            // -- step 1: loads (R1 hop 1, F1 predecessor)
+            Hop h1 = hop_issue();
+            const uint32_t kqf = win4(win32, d_f ? ring_back(w_pos_f, d_f, WRING) : w_pos_f) & 0xFFFFFFu;
+            const uint32_t pqf = prevd[d_f > idx ? ring_back(s_pos_f, d_f, PRING) : s_pos_f];   // older tile: final
+            // -- step 1: uses
+            hop_finish(h1);
+            // F1(it+1): raw predecessor → known answer / first link state
+            cd_f = 0;
+            {
+                uint32_t e = d_f;                                    // plain link (or none)
+                if (d_f != 0 && kqf == key_f) {
+                    cd_f = d_f;
+                    if (d_f > idx) { e = pqf ? d_f + pqf : 0; if (e > MAX_WINDOW) e = 0; }
+                    else e = LK_PTR + (idx - d_f);                   // in this tile: inherit by pointer jumping
+                }
+                lk_f = e;
+                if (act_f) lk[idx] = (uint16_t)e;
+            }
+            // P(it+2): request word of the head pass: hash << 17 | valid << 16 | low 16 bits of the position
+            val_p = do_p && p_p >= l0 && p_p < q1;
+            key_p = kp_raw & 0xFFFFFFu;
+            hh_p = hash3(key_p);
+            if (do_p) reqb[idx] = val_p ? (hh_p << 17) | 0x10000u | (p_p & 0xFFFFu) : 0u;
+            // E(it-2): the walker's verdict for this wavefront's group → compact the visited code words
+            if (do_e) {
+                const uint64_t M = (uint64_t)e_ml | (uint64_t)e_mh << 32;
+                if ((M >> lane) & 1) out[e_b + __popcll(M & lt_mask)] = code_e;
+            }
+            // -- further R1 hops, interleaved with T(it-1): the transition table of this wavefront's group by pointer
+            //    doubling — for EVERY entry lane, where the greedy walk (default.rs:76-107) leaves the group and which
+            //    positions it visits
+            uint32_t cur = 64, mlo = 0, mhi = 0, stop_r = 0;
+            if (do_t) {
+                const uint32_t gb = base + (uint32_t)(it - 1) * TILE + (wave - 1) * 64;
+                stop_r = gb < n ? min(64u, n - gb) : 0u;
+                cur = lane + ((code_t & 0xFFFFu) ? (code_t >> 16) : 1u);
+                mlo = lane < 32 ? 1u << lane : 0u;
+                mhi = lane >= 32 ? 1u << (lane - 32) : 0u;
+            }
+            for (int round = 0;; ++round) {
+                const bool any_r = __ballot(d != 0) != 0;
+                const bool ta = cur < stop_r;
+                const bool any_t = FUSED && do_t && round < 6 && __ballot(ta) != 0;
+                if (!any_r && !any_t) break;
+                Hop h{0, 0, false};
+                if (any_r) h = hop_issue();
+                uint32_t c2 = 0, l2 = 0, h2 = 0;
+                if (any_t) {
+                    const int sl = (int)((ta ? cur : lane) << 2);
+                    c2 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)cur);
+                    l2 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)mlo);
+                    h2 = (uint32_t)__builtin_amdgcn_ds_bpermute(sl, (int)mhi);
+                }
+                if (any_r) hop_finish(h);
+                if (any_t && ta) { cur = c2; mlo |= l2; mhi |= h2; }
+            }
+            if (do_t) {
+                tabE[(wave - 1) * 64 + lane] = (uint16_t)cur;
+                tabM[(wave - 1) * 64 + lane] = make_uint2(mlo, mhi);
             }
             r_dist = dist;
             r_found = found;
-            // ---- F1(it+1): raw predecessor → known answer / first link state
-            val_f = false; cd_f = 0; lk_f = 0; key_f = 0;
-            if (do_f) {
-                uint16_t *lk = lkb + ((uint32_t)(it + 1) & 1) * TILE;
-                const uint32_t hvv = lk[idx];
-                const uint32_t w_pos_f = ring_fwd(w1, idx, WRING), s_pos_f = ring_fwd(s1, idx, PRING);
-                key_f = win4(win32, w_pos_f) & 0xFFFFFFu;
-                if (hvv != 0xFFFFu) {
-                    val_f = true;
-                    const uint32_t d = hvv;
-                    uint32_t e = d;                                  // plain link (or none)
-                    if (d) {
-                        const uint32_t kq = win4(win32, ring_back(w_pos_f, d, WRING)) & 0xFFFFFFu;
-                        const uint32_t pq = d > idx ? prevd[ring_back(s_pos_f, d, PRING)] : 0u;   // older tile: final
-                        if (kq == key_f) {
-                            cd_f = d;
-                            if (d > idx) { e = pq ? d + pq : 0; if (e > MAX_WINDOW) e = 0; }
-                            else e = LK_PTR + (idx - d);             // in this tile: inherit by pointer jumping
-                        }
-                    }
-                    lk_f = e;
-                    lk[idx] = (uint16_t)e;
-                }
-            }
-        } else if (FUSED && it >= 1) {
-            walk_groups((uint32_t)(it - 1), 0, NSUB / 2);   // W(it-1), first half of the groups
         }
         const uint64_t c1 = dbg ? clock64() : 0;
         lds_barrier();
         // =================================================== phase B
         if (wave == 0) {
+            if (do_p) {
+                // ---- H(it+2): the ordered head pass — fourteen exchanges in position order
+                // (two batches of seven: the second batch's requests are unpacked while the first is in flight)
+#pragma unroll
+                for (uint32_t h = 0; h < 2; ++h) {
+                    uint32_t old[7], addr[7], mask[7], val[7];
+#pragma unroll
+                    for (uint32_t s = 0; s < 7; ++s) {
+                        const uint32_t rq = reqb[(h * 7 + s) * 64 + lane];
+                        const uint32_t sh = (rq >> 13) & 16u;                 // (hash & 1) * 16
+                        addr[s] = head_lds + ((rq >> 18) << 2);               // dword of field hash
+                        mask[s] = (0u - ((rq >> 16) & 1u)) & (0xFFFFu << sh);
+                        val[s] = (rq & 0xFFFFu) << sh;
+                    }
+                    mskor7(old, addr, mask, val);
+#pragma unroll
+                    for (uint32_t s = 0; s < 7; ++s) oldb[(h * 7 + s) * 64 + lane] = old[s];
+                }
+            }
+        } else if (wave <= RW) {
+            const uint32_t p_r = t_r + idx;
+            const uint32_t w_pos_r = ring_fwd(wk, idx, WRING);
+            const bool act_r = do_r && val_r && p_r >= q0;
+            const bool act_f = do_f && val_f;
+            // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed: every
+            //      state a reader can observe is valid and the oldest member of a run is final from the start)
+            // ---- R2(it): longest_common_prefix (default.rs:122-129): 8 bytes per step for the first 16
+            uint32_t e = act_f ? lk_f : 0u;
+            const bool found = act_r && r_found;
+            const uint32_t dist = r_dist;
+            uint32_t l = 0, lim = 0;
+            uint32_t oa = ring_fwd(w_pos_r, 3, WRING), ob = oa;
+            if (found) {
+                lim = n - (p_r + 3);                                   // bounded by the end of the chunk
+                if (lim > max_len - 3) lim = max_len - 3;
+                ob = ring_back(oa, dist, WRING);
+            }
+            bool cmp = found && lim != 0;                              // still comparing
+#pragma unroll
+            for (int step = 0; step < 2; ++step) {
+                // loads
+                const bool ptr = e >= LK_PTR;
+                const uint32_t j = ptr ? e - LK_PTR : idx;
+                const uint32_t eq = lk[j];
+                const uint64_t xa = win8(win32, oa), xb = win8(win32, ob);
+                // uses
+                if (ptr) {
+                    if (eq < LK_PTR) { e = eq ? (idx - j) + eq : 0; if (e > MAX_WINDOW) e = 0; }
+                    else e = eq;
+                    lk[idx] = (uint16_t)e;
+                }
+                if (cmp) {
+                    const uint64_t x = xa ^ xb;
+                    if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; cmp = false; }
+                    else {
+                        l += 8;
+                        oa += 8; if (oa >= WRING) oa -= WRING;
+                        ob += 8; if (ob >= WRING) ob -= WRING;
+                        if (l >= lim) cmp = false;
+                    }
+                }
+            }
+            while (__ballot(e >= LK_PTR)) {
+                if (e >= LK_PTR) {
+                    const uint32_t j = e - LK_PTR;
+                    const uint32_t eq = lk[j];
+                    if (eq < LK_PTR) { e = eq ? (idx - j) + eq : 0; if (e > MAX_WINDOW) e = 0; }
+                    else e = eq;
+                    lk[idx] = (uint16_t)e;
+                }
+            }
+            e_f = e;
+            if (act_f) prevd[ring_fwd(s1, idx, PRING)] = (uint16_t)e;
+            // a lane still matching after 16 bytes gets the whole wavefront: lane j compares bytes
+            // [16+4j, 16+4j+4) — one step settles up to 256 more bytes
+            uint64_t lm = __ballot(cmp);                               // (cmp here ⇒ l == 16 < lim)
+            while (lm) {
+                const uint32_t sl = (uint32_t)__builtin_ctzll(lm);
+                lm &= lm - 1;
+                const uint32_t boa = __builtin_amdgcn_readlane(oa, sl), bob = __builtin_amdgcn_readlane(ob, sl);
+                const uint32_t blim = __builtin_amdgcn_readlane(lim, sl);
+                const uint32_t off = 4 * lane;
+                uint32_t x = 0;
+                if (16 + off < blim) {
+                    uint32_t a = boa + off, b = bob + off;
+                    if (a >= WRING) a -= WRING;
+                    if (b >= WRING) b -= WRING;
+                    x = win4(win32, a) ^ win4(win32, b);
+                }
+                const uint64_t mis = __ballot(x != 0);
+                uint32_t res = blim;
+                if (mis) {
+                    const uint32_t fl = (uint32_t)__builtin_ctzll(mis);
+                    const uint32_t cand = 16 + off + ((uint32_t)__builtin_ctz(x | 0x80000000u) >> 3);
+                    res = __builtin_amdgcn_readlane(cand, fl);
+                }
+                if (lane == sl) l = res;
+            }
+            uint32_t word = 0;
+            if (found) {
+                if (l > lim) l = lim;
+                word = ((3 + l) << 16) | dist;
+            }
+            if (FUSED) {
+                // every position of the chunk gets a code word: a pointer, or its own byte as a literal
+                // (positions >= end are never hashed and are always literals, default.rs:75,105-107)
+                code_r = word ? word : (key_r & 0xFFu) << 16;
+            } else if (act_r) {
+                md[ch.in_off + p_r] = word;
+            }
+        } else {
+            if (FUSED && do_t) {
+                // ---- W(it-1): the serial part of the greedy walk — one table look-up per group of 64 positions.  The
+                // tables of seven groups are fetched at a time; the chain then runs on readlanes only and leaves the
+                // groups' verdicts {visited mask, codes before} in lanes 0..13 (one store at the end).
+                const uint32_t t_w = base + (uint32_t)(it - 1) * TILE;
+                uint32_t res_l = 0, res_h = 0, res_c = 0;
+#pragma unroll
+                for (uint32_t g0 = 0; g0 < NSUB; g0 += NSUB / 2) {
+                    uint32_t tE[NSUB / 2], tL[NSUB / 2], tH[NSUB / 2];
+#pragma unroll
+                    for (uint32_t q = 0; q < NSUB / 2; ++q) {
+                        tE[q] = tabE[(g0 + q) * 64 + lane];
+                        const uint2 m = tabM[(g0 + q) * 64 + lane];
+                        tL[q] = m.x; tH[q] = m.y;
+                    }
+#pragma unroll
+                    for (uint32_t q = 0; q < NSUB / 2; ++q) {
+                        const uint32_t g = g0 + q;
+                        const uint32_t gb = t_w + g * 64;
+                        const uint32_t lim_g = min(gb + 64, n);    // (gb may lie past the chunk: then nothing is visited)
+                        uint32_t ml = 0, mh = 0;
+                        const uint32_t wp = __builtin_amdgcn_readfirstlane(w_pos);
+                        if (wp >= gb && wp < lim_g) {
+                            const uint32_t en = wp - gb;
+                            ml = (uint32_t)__builtin_amdgcn_readlane((int)tL[q], en);
+                            mh = (uint32_t)__builtin_amdgcn_readlane((int)tH[q], en);
+                            w_pos = gb + (uint32_t)__builtin_amdgcn_readlane((int)tE[q], en);
+                        }
+                        if (lane == g) { res_l = ml; res_h = mh; res_c = w_cnt; }
+                        w_cnt += __popc(ml) + __popc(mh);
+                    }
+                }
+                if (lane < NSUB) { resw[lane * 4] = res_l; resw[lane * 4 + 1] = res_h; resw[lane * 4 + 2] = res_c; }
+            }
+            // ---- window stores (their loads were issued in phase A)
+            const uint32_t sh = (uint32_t)src.shift;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t p = loaded_to + 4 * lane + 256 * q;
                 if (p < fill_need) {
+                    const uint32_t v = __builtin_amdgcn_alignbyte(fill_w1[q], fill_w0[q], sh);
                     const uint32_t o = ring_fwd(fill_off, 4 * lane + 256 * q, WRING);
-                    win32[o >> 2] = fill_v[q];
-                    if (o < 8) win32[(WRING + o) >> 2] = fill_v[q];
+                    win32[o >> 2] = v;
+                    if (o < 8) win32[(WRING + o) >> 2] = v;
                 }
             }
             fill_off = ring_fwd(fill_off, fill_need - loaded_to, WRING);
             loaded_to = fill_need;
-        } else if (wave <= RW) {
-            // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed:
-            //      every state a reader can observe is valid and the oldest member of a run is final from the start)
-            if (do_f) {
-                uint16_t *lk = lkb + ((uint32_t)(it + 1) & 1) * TILE;
-                uint32_t e = lk_f;
-                while (__ballot(val_f && e >= LK_PTR)) {
-                    if (val_f && e >= LK_PTR) {
-                        const uint32_t j = e - LK_PTR;
-                        const uint32_t eq = lk[j];
-                        if (eq < LK_PTR) {
-                            e = eq ? (idx - j) + eq : 0;
-                            if (e > MAX_WINDOW) e = 0;
-                        } else e = eq;
-                        lk[idx] = (uint16_t)e;
-                    }
-                }
-                e_f = e;
-                if (val_f) prevd[ring_fwd(s1, idx, PRING)] = (uint16_t)e;
-            }
-            // ---- R2(it): longest_common_prefix (default.rs:122-129) → code word
-            if (do_r) {
-                const uint32_t p_r = t_r + idx;
-                const bool act_r = val_r && p_r >= q0;
-                const bool found = r_found;
-                const uint32_t dist = r_dist;
-                uint32_t l = 0, lim = 0, oa = 0, ob = 0;
-                if (act_r && found) {
-                    lim = n - (p_r + 3);                               // bounded by the end of the chunk
-                    if (lim > max_len - 3) lim = max_len - 3;
-                    oa = ring_fwd(ring_fwd(wk, idx, WRING), 3, WRING);
-                    ob = ring_back(oa, dist, WRING);
-                    // the first 16 bytes, every lane on its own, 8 bytes per step
-                    while (l < lim && l < 16) {
-                        const uint64_t x = win8(win32, oa) ^ win8(win32, ob);
-                        if (x) { l += (uint32_t)__builtin_ctzll(x) >> 3; break; }
-                        l += 8;
-                        oa += 8; if (oa >= WRING) oa -= WRING;
-                        ob += 8; if (ob >= WRING) ob -= WRING;
-                    }
-                }
-                // a lane still matching after 16 bytes gets the whole wavefront: lane j compares bytes
-                // [16+4j, 16+4j+4) — one step settles up to 256 more bytes
-                uint64_t lm = __ballot(act_r && found && l == 16 && l < lim);
-                while (lm) {
-                    const uint32_t sl = (uint32_t)__builtin_ctzll(lm);
-                    lm &= lm - 1;
-                    const uint32_t boa = __builtin_amdgcn_readlane(oa, sl), bob = __builtin_amdgcn_readlane(ob, sl);
-                    const uint32_t blim = __builtin_amdgcn_readlane(lim, sl);
-                    const uint32_t off = 4 * lane;
-                    uint32_t x = 0;
-                    if (16 + off < blim) {
-                        uint32_t a = boa + off, b = bob + off;
-                        if (a >= WRING) a -= WRING;
-                        if (b >= WRING) b -= WRING;
-                        x = win4(win32, a) ^ win4(win32, b);
-                    }
-                    const uint64_t mis = __ballot(x != 0);
-                    uint32_t res = blim;
-                    if (mis) {
-                        const uint32_t fl = (uint32_t)__builtin_ctzll(mis);
-                        const uint32_t cand = 16 + off + ((uint32_t)__builtin_ctz(x | 0x80000000u) >> 3);
-                        res = __builtin_amdgcn_readlane(cand, fl);
-                    }
-                    if (lane == sl) l = res;
-                }
-                uint32_t word = 0;
-                if (act_r && found) {
-                    if (l > lim) l = lim;
-                    word = ((3 + l) << 16) | dist;
-                }
-                if (FUSED) {
-                    // every position of the chunk gets a code word: a pointer, or its own byte as a literal
-                    // (positions >= end are never hashed and are always literals, default.rs:75,105-107)
-                    if (p_r < n) {
-                        if (!word) word = (win4(win32, ring_fwd(wk, idx, WRING)) & 0xFFu) << 16;
-                        codeb[((uint32_t)it & 1) * TILE + idx] = word;
-                    }
-                } else if (act_r) {
-                    md[ch.in_off + p_r] = word;
-                }
-            }
         }
-        if (FUSED && wave == 15 && it >= 1) walk_groups((uint32_t)(it - 1), NSUB / 2, NSUB);
         const uint64_t c2 = dbg ? clock64() : 0;
         // ---- rotate the stage registers
-        key_r = key_f; cd_r = cd_f; e_r = e_f; val_r = val_f;
+        key_r = key_f; key_f = key_p; hh_f = hh_p;
+        val_r = val_f; val_f = val_p;
+        cd_r = cd_f; e_r = e_f;
+        code_e = code_t; code_t = code_r;
         wk = w1; sk = s1;
         lds_barrier();
         const uint64_t c3 = dbg ? clock64() : 0;
