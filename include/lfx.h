@@ -35,7 +35,8 @@ enum {
     LFX_E_DEVICE = 5,         /* no device / HIP failure (never a silent CPU fallback) */
     LFX_E_ARG = 6,            /* out-of-domain option */
     LFX_E_NOSPACE = 7,        /* output capacity too small */
-    LFX_E_UNSUPPORTED = 8
+    LFX_E_UNSUPPORTED = 8,
+    LFX_E_WOULD_BLOCK = 9     /* io::ErrorKind::WouldBlock: a read callback of a non-blocking decoder has nothing yet */
 };
 
 /* libflate_lz77::CompressionLevel (libflate_lz77/src/lib.rs:44-58) */
@@ -169,17 +170,48 @@ const char *lfx_encoder_last_error(const lfx_encoder *e);
 void lfx_encoder_free(lfx_encoder *e);
 
 typedef struct lfx_decoder lfx_decoder;
-/* {deflate,zlib,gzip}::Decoder::new / gzip::MultiDecoder::new — gzip/zlib parse the header
- * eagerly and can fail (gzip.rs:941-944, zlib.rs:312-320). */
+/* {deflate,zlib,gzip}::Decoder::new / gzip::MultiDecoder::new (flag LFX_DEC_MULTI).  gzip / zlib read the container
+ * header — and nothing that is not needed for it beyond the chunk the reader hands over — and can fail
+ * (gzip.rs:941-944, zlib.rs:312-320); the body is decoded by the first read().
+ * LFX_DEC_NONBLOCKING = src/non_blocking/{deflate,zlib,gzip}::Decoder: the read callback may return
+ * -LFX_E_WOULD_BLOCK at any point; read() / header() then return LFX_E_WOULD_BLOCK and can be called again
+ * (the header is read lazily, non_blocking/gzip.rs:64-113).
+ *
+ * Input is pulled in growing batches (the GPU inflates whole members); a decode is attempted when a batch is
+ * complete, the reader ends, hands over a short read, or would block.  Bytes pulled beyond the member's trailer
+ * are not decoded: lfx_decoder_surplus() hands them back (what into_inner() means for a reader that cannot be
+ * rewound, gzip.rs:987,1216-1226); a MultiDecoder continues with them.  A blocking reader that never ends and
+ * never returns short reads can make a blocking decoder ask for more than the member holds: use the
+ * non-blocking mode for sockets. */
+#define LFX_DEC_NONBLOCKING 2u
 lfx_decoder *lfx_decoder_new(lfx_ctx *c, int format, uint32_t flags, lfx_read_cb r, void *user,
                              int *status);
-/* io::Read::read: >0 bytes, 0 = end of stream, <0 = -(LFX_E_*).  A zero-capacity read returns 0
- * without latching end-of-stream (gzip.rs:1025-1027, zlib.rs:383-385). */
+/* io::Read::read: >0 bytes, 0 = end of stream, <0 = -(LFX_E_*) (reported once, after the bytes decoded in front of
+ * the error).  A zero-capacity read returns 0 without latching end-of-stream (gzip.rs:1025-1027, zlib.rs:383-385). */
 int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap);
 /* Decoder::unread_decoded_data (decode.rs:68-73) */
 int lfx_decoder_unread(lfx_decoder *d, const uint8_t **p, size_t *n);
-/* bytes of the inner reader consumed so far (Decoder::into_inner position; gzip.rs:1216-1226) */
+/* bytes of the inner reader that belong to the members decoded so far (Decoder::into_inner position;
+ * gzip.rs:1216-1226) */
 uint64_t lfx_decoder_consumed(const lfx_decoder *d);
+/* bytes pulled from the reader behind the last finished member (valid until the next read()) */
+int lfx_decoder_surplus(lfx_decoder *d, const uint8_t **p, size_t *n);
+/* gzip::Header (gzip.rs:292-341: modification_time, compression_level (XFL), os, is_text, is_verified, extra_field,
+ * filename, comment) / zlib::Header (zlib.rs:197-220: window_size, compression_level) of the current member.
+ * Pointers stay valid until the next member starts or the decoder is freed. */
+typedef struct lfx_header {
+    int32_t format;
+    uint32_t mtime;
+    uint8_t xfl, os, is_text, is_verified, has_extra;
+    uint8_t _pad[3];
+    const uint8_t *extra;     /* serialized subfields (id[2] len[2] data)*; NULL when absent */
+    uint32_t extra_len;
+    const char *filename;     /* NUL-terminated; NULL when absent */
+    const char *comment;
+    uint32_t zlib_window_size; /* 256 << CINFO */
+    uint32_t zlib_level;       /* FLEVEL 0..3 */
+} lfx_header;
+int lfx_decoder_header(lfx_decoder *d, lfx_header *h);
 const char *lfx_decoder_last_error(const lfx_decoder *d);
 void lfx_decoder_free(lfx_decoder *d);
 

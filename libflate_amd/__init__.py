@@ -6,6 +6,6 @@ CPU fallback.
 """
 from . import _ffi  # noqa: F401
 from .context import Context, default_context  # noqa: F401
-from . import deflate, gzip, lz77, zlib  # noqa: F401
+from . import deflate, gzip, lz77, non_blocking, zlib  # noqa: F401
 
-__all__ = ["Context", "default_context", "deflate", "zlib", "gzip", "lz77"]
+__all__ = ["Context", "default_context", "deflate", "zlib", "gzip", "lz77", "non_blocking"]

@@ -10,12 +10,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "liblfx.so")
 
 DEFLATE, ZLIB, GZIP = 0, 1, 2
-OK, E_INVALID_DATA, E_UNEXPECTED_EOF, E_IO, E_OOM, E_DEVICE, E_ARG, E_NOSPACE, E_UNSUPPORTED = range(9)
+OK, E_INVALID_DATA, E_UNEXPECTED_EOF, E_IO, E_OOM, E_DEVICE, E_ARG, E_NOSPACE, E_UNSUPPORTED, E_WOULD_BLOCK = range(10)
 LZ77_DEFAULT, LZ77_NOCOMPRESSION = 0, 1
 FLUSH_NONE, FLUSH_SYNC = 0, 2
 SCHED_SINGLE, SCHED_FIXED, SCHED_LIST = 0, 1, 2
 SCHED_FLUSH = (1 << 64) - 1
 DEC_MULTI = 1
+DEC_NONBLOCKING = 2
 
 # every symbol include/lfx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -25,7 +26,7 @@ EXPORTS = [
     "lfx_crc32_combine", "lfx_adler32_combine", "lfx_container_header_len", "lfx_encoder_new",
     "lfx_encoder_write", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
     "lfx_encoder_free", "lfx_decoder_new", "lfx_decoder_read", "lfx_decoder_unread",
-    "lfx_decoder_consumed", "lfx_decoder_last_error", "lfx_decoder_free", "lfx_lz77_new",
+    "lfx_decoder_consumed", "lfx_decoder_surplus", "lfx_decoder_header", "lfx_decoder_last_error", "lfx_decoder_free", "lfx_lz77_new",
     "lfx_lz77_encode", "lfx_lz77_flush", "lfx_lz77_window_size", "lfx_lz77_compression_level",
     "lfx_lz77_free", "lfx_ctx_last_timing", "lfx_ctx_enable_timing", "lfx_version",
 ]
@@ -49,6 +50,13 @@ class Schedule(C.Structure):
 class ShardInfo(C.Structure):
     _fields_ = [("total_bits", C.c_uint64), ("n_bytes", C.c_uint64), ("crc32", C.c_uint32),
                 ("adler32", C.c_uint32)]
+
+
+class Header(C.Structure):
+    _fields_ = [("format", C.c_int32), ("mtime", C.c_uint32), ("xfl", C.c_uint8), ("os", C.c_uint8),
+                ("is_text", C.c_uint8), ("is_verified", C.c_uint8), ("has_extra", C.c_uint8), ("_pad", C.c_uint8 * 3),
+                ("extra", C.POINTER(C.c_uint8)), ("extra_len", C.c_uint32), ("filename", C.c_char_p),
+                ("comment", C.c_char_p), ("zlib_window_size", C.c_uint32), ("zlib_level", C.c_uint32)]
 
 
 class Timing(C.Structure):
@@ -135,6 +143,8 @@ def lib():
     L.lfx_decoder_unread.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.lfx_decoder_consumed.restype = u64
     L.lfx_decoder_consumed.argtypes = [vp]
+    L.lfx_decoder_surplus.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    L.lfx_decoder_header.argtypes = [vp, C.POINTER(Header)]
     L.lfx_decoder_last_error.restype = C.c_char_p
     L.lfx_decoder_last_error.argtypes = [vp]
     L.lfx_decoder_free.argtypes = [vp]
@@ -153,6 +163,8 @@ def lib():
     L.lfx_debug_huff_block.argtypes = [vp, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u64)]
     L.lfx_debug_plan.argtypes = [i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), u64, vp, C.c_size_t,
                                  C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lfx_debug_plan_incremental.argtypes = [i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), u64, u32, vp, C.c_size_t,
+                                             C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lfx_debug_symbols.argtypes = [u32, u32, vp]
     _lib = L
     return L

@@ -114,8 +114,12 @@ class _DecoderBase:
     def _on_read(self, _user, p, cap):
         try:
             b = self._inner.read(cap)
+            if b is None:                      # a non-blocking raw stream with nothing to hand over
+                return -_ffi.E_WOULD_BLOCK
             C.memmove(p, b, len(b))
             return len(b)
+        except BlockingIOError:
+            return -_ffi.E_WOULD_BLOCK
         except Exception:
             return -5
 
@@ -129,6 +133,10 @@ class _DecoderBase:
             cap = 1 << 20 if want < 0 else want
             buf = C.create_string_buffer(cap)
             r = _ffi.lib().lfx_decoder_read(self._h, buf, cap)
+            if r == -_ffi.E_WOULD_BLOCK:       # io::ErrorKind::WouldBlock: call again later (non-blocking decoders)
+                if chunks:
+                    break
+                raise BlockingIOError("WouldBlock")
             if r < 0:
                 err = StreamError(-r, self._err())
                 err.partial = b"".join(chunks)
@@ -147,6 +155,29 @@ class _DecoderBase:
         p = C.POINTER(C.c_uint8)()
         n = C.c_size_t(0)
         _ffi.lib().lfx_decoder_unread(self._h, C.byref(p), C.byref(n))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def header(self):
+        """gzip::Header / zlib::Header of the current member (gzip.rs:292-341, zlib.rs:197-220) as a dict."""
+        h = _ffi.Header()
+        rc = _ffi.lib().lfx_decoder_header(self._h, C.byref(h))
+        if rc == _ffi.E_WOULD_BLOCK:
+            raise BlockingIOError("WouldBlock")
+        if rc:
+            raise StreamError(rc, self._err())
+        if self.FORMAT == _ffi.ZLIB:
+            return {"window_size": h.zlib_window_size, "compression_level": h.zlib_level}
+        return {"modification_time": h.mtime, "xfl": h.xfl, "os": h.os, "is_text": bool(h.is_text),
+                "is_verified": bool(h.is_verified),
+                "extra_field": C.string_at(h.extra, h.extra_len) if h.has_extra else None,
+                "filename": h.filename, "comment": h.comment}
+
+    def surplus(self):
+        """bytes already pulled from the inner reader that lie behind the last finished member — what a caller hands
+        to whatever reads next after into_inner() (gzip.rs:1216-1226)."""
+        p = C.POINTER(C.c_uint8)()
+        n = C.c_size_t(0)
+        _ffi.lib().lfx_decoder_surplus(self._h, C.byref(p), C.byref(n))
         return C.string_at(p, n.value) if n.value else b""
 
     def consumed(self):

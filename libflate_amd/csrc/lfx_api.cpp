@@ -289,6 +289,7 @@ extern "C" void lfx_ctx_set_stream(lfx_ctx *cc, void *s) {
 extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on != 0; }
 extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) {
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     memset(t, 0, sizeof *t);
     if (c->n_ev < 2) return LFX_E_ARG;
     (void)hipEventSynchronize(c->ev[c->n_ev - 1]);
@@ -505,6 +506,7 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
                                  const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     lfx_encode_opts d = norm_opts(o);
     int rc = check_opts(d);
     if (rc) { c->set_error("option outside the reference's domain"); return rc; }
@@ -531,6 +533,7 @@ extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o
                                const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     (void)hipSetDevice(c->device);
     uint64_t bound = lfx_encode_bound(n, o, s);
     if (bound == 0) { c->set_error("option outside the reference's domain"); return LFX_E_ARG; }
@@ -553,6 +556,7 @@ extern "C" int lfx_encode_shard_prepare(lfx_ctx *cc, int format, const lfx_encod
                                         lfx_shard_info *info) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     lfx_encode_opts d = norm_opts(o);
     int rc = check_opts(d);
     if (rc) return rc;
@@ -608,6 +612,7 @@ extern "C" int lfx_encode_shard_emit(lfx_ctx *cc, uint64_t start_bit, uint32_t c
                                      void *d_out, uint64_t cap, uint64_t *out_len) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     // d_out[0] is byte start_bit/8 of the member; a first shard carries the container header
     const uint64_t rel_start = c->shard_hdr.empty() ? (start_bit & 7) : start_bit;
     EncodeResult res;
@@ -630,9 +635,9 @@ struct lfx_encoder {
     lfx_write_cb w;
     lfx_flush_cb f;
     void *user;
-    std::vector<uint8_t> pending;       // input bytes of the blocks not yet encoded
-    std::vector<uint64_t> events;       // write sizes / LFX_SCHED_FLUSH since `pending` began
-    uint64_t total_in = 0;
+    std::vector<uint8_t> pending;       // input bytes not yet encoded: the planner's byte 0 is pending[0]
+    Planner *pl = nullptr;              // incremental write-schedule state (chunks / blocks of `pending`)
+    uint64_t total_in = 0, encoded_in = 0;
     uint32_t crc = 0, adler = 1;        // running container checksum (combined per batch)
     uint8_t carry = 0;                  // partial last byte of the bitstream so far
     uint32_t carry_bits = 0;
@@ -648,30 +653,25 @@ static int enc_emit_bytes(lfx_encoder *e, const uint8_t *p, size_t n) {
     return LFX_OK;
 }
 
-// encode everything pending as one batch; `final` closes the stream
+// Encode the closed blocks of `pending` (all of it when `final`, which first closes the stream) as one GPU batch and
+// hand the bytes to the sink; the open block's bytes stay pending.
 static int enc_run(lfx_encoder *e, bool final) {
     Ctx *c = e->c;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     (void)hipSetDevice(c->device);
-    Planner pl(e->po);
-    for (uint64_t ev : e->events) {
-        if (ev == LFX_SCHED_FLUSH) pl.flush(); else pl.write(ev);
-    }
-    Plan *plan = final ? &pl.finish() : &pl.plan();
-    if (!final) {
-        plan->n_codes_cap = 0;
-        for (auto &ch : plan->chunks) plan->n_codes_cap = std::max(plan->n_codes_cap, ch.code_off + ch.len + 1);
-        plan->n_tiles = plan->chunks.empty() ? 0 : plan->chunks.back().tile_base + div_up(plan->chunks.back().len + 1, PACK_TILE);
-    }
-    const uint64_t n = e->pending.size();
+    if (final) e->pl->finish();
+    const uint64_t n = final ? e->pending.size() : e->pl->closed_bytes();
+    Plan plan = final ? std::move(e->pl->plan()) : e->pl->take_closed();
+    if (plan.blocks.empty()) return LFX_OK;
     int rc;
     if ((rc = e->d_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
-    const uint64_t bound = n + n / 4 + 1024 * (uint64_t)plan->blocks.size() + 128;
+    const uint64_t bound = n + n / 4 + 1024 * (uint64_t)plan.blocks.size() + 128;
     if ((rc = e->d_out.reserve(bound))) return rc;
     if (n && hipMemcpyAsync(e->d_in.p, e->pending.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
     EncodeResult res{};
     uint8_t prefix[1] = {e->carry};
     for (;;) {
-        if ((rc = encode_prepare(c, *plan, e->po, (const uint8_t *)e->d_in.p, n, e->format != LFX_DEFLATE))) { e->err = c->err; return rc; }
+        if ((rc = encode_prepare(c, plan, e->po, (const uint8_t *)e->d_in.p, n, e->format != LFX_DEFLATE))) { e->err = c->err; return rc; }
         // the container trailer is written by the host here (the checksum spans batches)
         rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits,
                          (uint8_t *)e->d_out.p, bound & ~3ull, &res);
@@ -679,15 +679,15 @@ static int enc_run(lfx_encoder *e, bool final) {
         break;
     }
     if (rc) { e->err = c->err; return rc; }
-    if (e->format == LFX_GZIP) e->crc = e->total_in == n ? res.crc32 : lfx_crc32_combine(e->crc, res.crc32, n);
-    if (e->format == LFX_ZLIB) e->adler = e->total_in == n ? res.adler32 : lfx_adler32_combine(e->adler, res.adler32, n);
+    if (e->format == LFX_GZIP) e->crc = e->encoded_in == 0 ? res.crc32 : lfx_crc32_combine(e->crc, res.crc32, n);
+    if (e->format == LFX_ZLIB) e->adler = e->encoded_in == 0 ? res.adler32 : lfx_adler32_combine(e->adler, res.adler32, n);
+    e->encoded_in += n;
     const uint64_t whole = final ? (res.end_bit + 7) / 8 : res.end_bit / 8;
     std::vector<uint8_t> host(whole + 1);
     if (hipMemcpy(host.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
     e->carry_bits = final ? 0 : (uint32_t)(res.end_bit & 7);
     e->carry = e->carry_bits ? host[whole] : 0;
-    e->pending.clear();
-    e->events.clear();
+    e->pending.erase(e->pending.begin(), e->pending.begin() + (std::ptrdiff_t)n);
     return enc_emit_bytes(e, host.data(), whole);
 }
 
@@ -705,6 +705,7 @@ extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encod
     if (d.comment) { e->comment = d.comment; e->o.comment = e->comment.c_str(); }
     if (d.extra) { e->extra.assign(d.extra, d.extra + d.extra_len); e->o.extra = e->extra.data(); }
     e->po = plan_opts(format, e->o);
+    e->pl = new Planner(e->po);
     e->w = w;
     e->f = f;
     e->user = user;
@@ -712,30 +713,22 @@ extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encod
     std::vector<uint8_t> hdr;
     rc = container_header(format, e->o, hdr);
     if (!rc) rc = enc_emit_bytes(e, hdr.data(), hdr.size());
-    if (rc) { if (status) *status = rc; delete e; return nullptr; }
+    if (rc) { if (status) *status = rc; delete e->pl; delete e; return nullptr; }
     if (status) *status = LFX_OK;
     return e;
 }
 
-static bool enc_idle(const lfx_encoder *e) {
-    // nothing buffered in the reference's LZ77 / block buffers ⇔ replaying the events leaves the
-    // planner with an empty tail.  Cheap check: replay (events are few per batch).
-    Planner pl(e->po);
-    for (uint64_t ev : e->events) { if (ev == LFX_SCHED_FLUSH) pl.flush(); else pl.write(ev); }
-    Planner probe = pl;
-    size_t before = pl.plan().blocks.size();
-    Plan &fin = probe.finish();
-    return fin.blocks.size() == before + 1 && fin.blocks.back().in_len == 0 && fin.blocks.back().type != BT_RAW;
-}
+// closed blocks are encoded once this much input is waiting (a batch large enough to fill the GPU); the open
+// block's bytes — all the reference itself would be holding (encode.rs:386-426) — stay in `pending`
+static const uint64_t ENC_BATCH_BYTES = 64ull << 20;
 
 extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n) {
     if (!e || e->finished) return -(int64_t)LFX_E_ARG;
     if (e->failed) return -(int64_t)LFX_E_IO;
     e->pending.insert(e->pending.end(), p, p + n);
-    e->events.push_back(n);
+    e->pl->write(n);
     e->total_in += n;
-    // batch: encode once >= 64 MiB of whole blocks are pending and the encoder state is idle
-    if (e->pending.size() >= (64u << 20) && enc_idle(e)) {
+    if (e->pl->closed_bytes() >= ENC_BATCH_BYTES || (e->po.no_compression && e->pl->closed_blocks() >= 1024)) {
         int rc = enc_run(e, false);
         if (rc) { e->failed = true; return -(int64_t)rc; }
     }
@@ -745,7 +738,7 @@ extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n)
 extern "C" int lfx_encoder_flush(lfx_encoder *e) {
     if (!e || e->finished) return LFX_E_ARG;
     if (e->failed) return LFX_E_IO;
-    e->events.push_back(LFX_SCHED_FLUSH);
+    e->pl->flush();
     int rc = enc_run(e, false);  // io::Write::flush pushes everything to the inner writer
     if (rc) { e->failed = true; return rc; }
     if (e->f && e->f(e->user) != 0) { e->failed = true; e->err = "flush callback failed"; return LFX_E_IO; }
@@ -781,6 +774,7 @@ extern "C" void lfx_encoder_free(lfx_encoder *e) {
     (void)hipSetDevice(e->c->device);
     e->d_in.release();
     e->d_out.release();
+    delete e->pl;
     delete e;
 }
 
@@ -806,6 +800,7 @@ extern "C" lfx_lz77 *lfx_lz77_new(lfx_ctx *cc, uint32_t window_size, uint32_t ma
 extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
     // DefaultLz77Encoder::flush default.rs:69-109 — one chunk through match + parse
     Ctx *c = z->c;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     (void)hipSetDevice(c->device);
     const uint64_t n = z->buf.size();
     if (n == 0) return LFX_OK;
@@ -892,6 +887,49 @@ extern "C" int lfx_debug_plan(int format, const lfx_encode_opts *o, const lfx_sc
         block_out[6 * i] = p.blocks[i].type; block_out[6 * i + 1] = p.blocks[i].final;
         block_out[6 * i + 2] = p.blocks[i].first_chunk; block_out[6 * i + 3] = p.blocks[i].n_chunks;
         block_out[6 * i + 4] = p.blocks[i].in_off; block_out[6 * i + 5] = p.blocks[i].in_len;
+    }
+    return 0;
+}
+// the same plan, but collected the way the stream encoder does: closed blocks are taken out after every
+// `take_every`-th event and the remainder is rebased; the pieces are stitched back together here
+extern "C" int lfx_debug_plan_incremental(int format, const lfx_encode_opts *o, const lfx_schedule *s, uint64_t n,
+                                          uint32_t take_every, uint64_t *chunk_out, size_t max_chunks, size_t *n_chunks,
+                                          uint64_t *block_out, size_t max_blocks, size_t *n_blocks) {
+    lfx_encode_opts d = norm_opts(o);
+    if (check_opts(d) || !s || s->kind != LFX_SCHED_LIST) return LFX_E_ARG;
+    Planner pl(plan_opts(format, d));
+    std::vector<ChunkDesc> chunks;
+    std::vector<BlockDesc> blocks;
+    uint64_t byte0 = 0;
+    auto stitch = [&](Plan &p, uint64_t bytes) {
+        const uint32_t b0 = (uint32_t)blocks.size(), c0 = (uint32_t)chunks.size();
+        for (ChunkDesc c : p.chunks) { c.in_off += byte0; c.block += b0; chunks.push_back(c); }
+        for (BlockDesc b : p.blocks) { b.in_off += byte0; b.first_chunk += c0; blocks.push_back(b); }
+        byte0 += bytes;
+    };
+    uint64_t used = 0;
+    for (size_t i = 0; i < s->n_writes; i++) {
+        if (s->writes[i] == LFX_SCHED_FLUSH) pl.flush();
+        else { const uint64_t w = std::min(s->writes[i], n - used); pl.write(w); used += w; }
+        if (take_every && (i + 1) % take_every == 0) {
+            const uint64_t cut = pl.closed_bytes();
+            Plan p = pl.take_closed();
+            stitch(p, cut);
+        }
+    }
+    if (used < n) pl.write(n - used);
+    Plan &fin = pl.finish();
+    stitch(fin, 0);
+    *n_chunks = chunks.size();
+    *n_blocks = blocks.size();
+    for (size_t i = 0; i < chunks.size() && i < max_chunks; i++) {
+        chunk_out[4 * i] = chunks[i].in_off; chunk_out[4 * i + 1] = chunks[i].len;
+        chunk_out[4 * i + 2] = chunks[i].block; chunk_out[4 * i + 3] = chunks[i].flags;
+    }
+    for (size_t i = 0; i < blocks.size() && i < max_blocks; i++) {
+        block_out[6 * i] = blocks[i].type; block_out[6 * i + 1] = blocks[i].final;
+        block_out[6 * i + 2] = blocks[i].first_chunk; block_out[6 * i + 3] = blocks[i].n_chunks;
+        block_out[6 * i + 4] = blocks[i].in_off; block_out[6 * i + 5] = blocks[i].in_len;
     }
     return 0;
 }

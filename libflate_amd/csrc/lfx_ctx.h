@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,9 @@ struct Ctx {
     // main stream: fork / join through these two events
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Every entry point that touches the context's scratch holds this lock: handles (encoders, decoders, LZ77 plug-ins)
+    // of one context may live on different threads, they simply take turns on the GPU (SURVEY §8b threading row).
+    std::recursive_mutex mu;
     std::string err;
     void set_error(const std::string &e) { err = e; }
 

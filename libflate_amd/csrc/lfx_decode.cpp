@@ -10,10 +10,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "lfx_ctx.h"
+#include "lfx_container.h"
 #include "lfx_decode.h"
 
 static_assert(offsetof(lfx::DecStream, out_off) == 16 && sizeof(lfx::DecStream) % 8 == 0, "checksum_ranges stride");
@@ -115,7 +117,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
     const uint64_t comp = n > off0 ? n - off0 : 0;
     if (comp >= (64u << 10)) {
         // ---- speculative block-start search
-        const uint32_t shard_cap = 1u << 17, final_cap = 1u << 16;
+        // survivors of stage 1 are ~0.1 % of the bit offsets (more on incompressible data): room for 0.4 % of them, so
+        // that a gibibyte-sized stream does not overflow the lists and fall back to the serial walk
+        const uint32_t shard_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 17, comp / 1000), 1u << 26);
+        const uint32_t final_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 16, comp / 4096), 1u << 24);
         int rc;
         if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 512))) return rc;
         uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // FIND_SHARDS + 1 words, then final count
@@ -503,10 +508,6 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
         }
     }
-    if (!parallel_done && stop_bit != ~0ull) {
-        c->set_error("shard decode needs chainable (history-free) blocks");
-        return LFX_E_UNSUPPORTED;
-    }
     if (!parallel_done && getenv("LFX_NO_SERIAL")) { c->set_error("serial fallback disabled (LFX_NO_SERIAL)"); return LFX_E_UNSUPPORTED; }
     if (!parallel_done) {
         // ---- serial walk of the whole stream by one wavefront (exact error / partial-output semantics)
@@ -514,11 +515,16 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         InflateJob j{};
         j.in_off = 0; j.in_len = n; j.start_bit = first_bit;
         j.out_off = 0; j.out_cap = cap; j.hist_avail = 0; j.flags = 0;
+        j.stop_bit = stop_bit == ~0ull ? 0 : stop_bit;   // (small or irregular shards: the exact walk, ended at the shard's last bit)
         jobs.push_back(j);
         int rc;
         if ((rc = run_jobs(c, d_in, d_out, jobs, res))) return rc;
         c->phase("serial");
-        const InflateResult &r = res[0];
+        InflateResult &r = res[0];
+        if (stop_bit != ~0ull && r.status == 0 && (r.final_seen || r.end_bit != stop_bit)) {
+            // a shard without the BFINAL block must end exactly where the next shard starts
+            r.status = 1; r.err = ERR_HUFF; r.a0 = r.a1 = 0;
+        }
         mr.status = map_status(r.status);
         mr.out_len = r.out_len;
         mr.blk_out_start = r.status ? r.blk_out_start : r.out_len;
@@ -630,6 +636,7 @@ extern "C" int lfx_decode_device(lfx_ctx *cc, int format, uint32_t flags, const 
                                  void *d_out, uint64_t cap, uint64_t *out_len, uint64_t *consumed) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (format < 0 || format > 2) return LFX_E_ARG;
     DecodeOutcome oc;
     int rc = decode_stream(c, format, flags, (const uint8_t *)d_in, n, (uint8_t *)d_out, cap, oc);
@@ -646,6 +653,7 @@ extern "C" int lfx_decode_shard_device(lfx_ctx *cc, const void *d_in, uint64_t n
                                        uint64_t *out_len) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     (void)hipSetDevice(c->device);
     c->n_ev = 0;
     c->phase("start");
@@ -662,6 +670,7 @@ extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const vo
                                uint64_t cap, uint64_t *out_len, uint64_t *consumed) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     (void)hipSetDevice(c->device);
     int rc;
     if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
@@ -788,6 +797,7 @@ extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, 
                                        int32_t *status) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     c->n_ev = 0;
@@ -873,66 +883,173 @@ extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// stream decoder: io::Read shaped.  The reader is drained up front (GPU decode needs the whole
-// compressed stream); bytes read past the end of the stream are reported by lfx_decoder_consumed().
+// stream decoder: io::Read shaped ({deflate,zlib,gzip}::Decoder, gzip::MultiDecoder, src/non_blocking/*).
+//
+// Header first: the constructor pulls only what the container header needs (plus the rest of the chunk the reader
+// handed over) and reports header errors (gzip.rs:941-944, zlib.rs:312-320); the body is decoded by the first
+// read().  The GPU inflates whole members, so input is pulled in growing batches and a decode is ATTEMPTED whenever
+// a batch is complete, the reader ends, hands over a short read, or (non-blocking mode) would block; an attempt
+// that runs out of input (UnexpectedEof while the reader has not ended) simply waits for more.  Bytes pulled
+// beyond the member's trailer are never decoded: they stay in the decoder (lfx_decoder_surplus) for the caller to
+// hand to whatever reads next — what `into_inner()` amounts to for a reader that cannot be rewound
+// (gzip.rs:987,1216-1226) — and MultiDecoder continues with them.
 struct lfx_decoder {
     Ctx *c;
     int format;
     uint32_t flags;
-    std::vector<uint8_t> in;
+    lfx_read_cb r;
+    void *user;
+    std::vector<uint8_t> in;        // pulled from the reader and not yet consumed by a finished member
+    bool reader_eof = false;
+    enum State { ST_HEADER, ST_BODY, ST_SERVE, ST_DONE, ST_FAILED } state = ST_HEADER;
+    bool first_member = true;
+    // current member
+    ContainerFields hf{};
+    std::vector<uint8_t> hdr_bytes;
+    bool have_header = false;
     std::vector<uint8_t> out;
-    bool decoded = false;
-    DecodeOutcome oc;
-    uint64_t cursor = 0;
-    bool error_reported = false;
+    uint64_t cursor = 0, serve_limit = 0;
+    int pending_status = LFX_OK;    // reported once the bytes in front of it have been served
+    uint64_t consumed_total = 0;    // reader bytes that belong to finished members
+    uint64_t target = 0;            // input size at which the next attempt is due
+    uint64_t tried_at = 0;          // input size of the last attempt that ran out of input
     std::string err;
 };
 
-static int dec_run(lfx_decoder *d) {
-    Ctx *c = d->c;
-    (void)hipSetDevice(c->device);
-    int rc;
-    const uint64_t n = d->in.size();
-    // output size is unknown: try growing capacities (DEFLATE expands at most 1032:1)
-    uint64_t cap = std::max<uint64_t>(n * 8, 1 << 20);
-    for (;;) {
-        if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
-        if ((rc = c->d_io_out.reserve(cap))) return rc;
-        if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
-        rc = decode_stream(c, d->format, d->flags, (const uint8_t *)c->d_io_in.p, n, (uint8_t *)c->d_io_out.p, cap, d->oc);
-        if (rc) return rc;
-        if (d->oc.status == LFX_E_NOSPACE && cap < n * 1040 + (1 << 20)) { cap *= 8; continue; }
-        break;
-    }
-    d->out.resize(d->oc.out_len);
-    if (d->oc.out_len && hipMemcpy(d->out.data(), c->d_io_out.p, d->oc.out_len, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
-    d->decoded = true;
-    d->err = d->oc.msg;
-    return LFX_OK;
+namespace {
+
+enum { PULL_OK = 0, PULL_EOF = 1, PULL_BLOCK = 2, PULL_ERR = 3 };
+// one read() of up to `want` bytes from the inner reader
+int dec_pull(lfx_decoder *d, size_t want, size_t *got) {
+    *got = 0;
+    if (d->reader_eof) return PULL_EOF;
+    const size_t at = d->in.size();
+    d->in.resize(at + want);
+    const int64_t k = d->r(d->user, d->in.data() + at, want);
+    d->in.resize(at + (k > 0 ? (size_t)k : 0));
+    if (k == -(int64_t)LFX_E_WOULD_BLOCK) return PULL_BLOCK;
+    if (k < 0) return PULL_ERR;
+    if (k == 0) { d->reader_eof = true; return PULL_EOF; }
+    *got = (size_t)k;
+    return PULL_OK;
 }
 
+// parse the container header at the front of d->in, pulling what is missing.
+// → LFX_OK (have_header set), LFX_E_WOULD_BLOCK, LFX_E_IO, or the header's own failure (err set)
+int dec_header(lfx_decoder *d) {
+    if (d->format == LFX_DEFLATE) { d->have_header = true; d->hf = ContainerFields{}; d->hdr_bytes.clear(); return LFX_OK; }
+    for (;;) {
+        ContainerFields cf;
+        const DecHeader h = parse_container(d->format, d->in.data(), d->in.size(), &cf);
+        if (h.status == 0) {
+            d->hf = cf;                    // (a header that fails to parse leaves the previous member's in place)
+            d->hdr_bytes.assign(d->in.begin(), d->in.begin() + (size_t)h.deflate_off);
+            d->have_header = true;
+            return LFX_OK;
+        }
+        if (h.status == 2 && !d->reader_eof) {          // the header may simply not be complete yet
+            size_t got;
+            const int pr = dec_pull(d, 1 << 16, &got);
+            if (pr == PULL_BLOCK) return LFX_E_WOULD_BLOCK;
+            if (pr == PULL_ERR) { d->err = "read callback failed"; return LFX_E_IO; }
+            continue;
+        }
+        d->err = format_error(h.err, h.a0, h.a1);
+        d->consumed_total += h.deflate_off;
+        return map_status(h.status);
+    }
+}
+
+// decode the member at the front of d->in.  → LFX_OK when a verdict is in (state ST_SERVE), LFX_E_WOULD_BLOCK /
+// LFX_E_IO from the reader, or a device error
+int dec_body(lfx_decoder *d) {
+    Ctx *c = d->c;
+    const bool nonblock = (d->flags & LFX_DEC_NONBLOCKING) != 0;
+    if (d->target == 0) d->target = 1 << 16;
+    for (;;) {
+        // ---- input: up to the next attempt size; a short read or the end of the reader also triggers an attempt
+        bool attempt = d->reader_eof;
+        while (!attempt) {
+            if (d->in.size() >= d->target) { attempt = true; break; }
+            size_t got;
+            const size_t want = std::min<uint64_t>(d->target - d->in.size(), 4u << 20);
+            const int pr = dec_pull(d, want, &got);
+            if (pr == PULL_ERR) { d->err = "read callback failed"; return LFX_E_IO; }
+            if (pr == PULL_EOF) { attempt = true; break; }
+            if (pr == PULL_BLOCK) {
+                // everything the peer has sent is here: decode it if anything new arrived, else report WouldBlock
+                if (d->in.size() > d->tried_at) { attempt = true; break; }
+                return LFX_E_WOULD_BLOCK;
+            }
+            // a short read hints that the reader has no more right now (pipes, sockets): worth an attempt once the
+            // input has grown by a quarter since the last one (keeps the total work linear)
+            if (got < want && d->in.size() >= d->tried_at + d->tried_at / 4 + 1) { attempt = true; break; }
+        }
+        // ---- attempt (the context's scratch is shared: one decode at a time per context)
+        const uint64_t n = d->in.size();
+        DecodeOutcome oc;
+        {
+            std::lock_guard<std::recursive_mutex> lock(c->mu);
+            (void)hipSetDevice(c->device);
+            int rc;
+            uint64_t cap = std::max<uint64_t>(n * 8, 1 << 20);
+            for (;;) {
+                if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+                if ((rc = c->d_io_out.reserve(cap))) return rc;
+                if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
+                oc = DecodeOutcome{};       // (a fresh verdict per attempt: a retry must not inherit NOSPACE)
+                rc = decode_stream(c, d->format, 0, (const uint8_t *)c->d_io_in.p, n, (uint8_t *)c->d_io_out.p, cap, oc);
+                if (rc) return rc;
+                if (oc.status == LFX_E_NOSPACE && cap < n * 1040 + (1 << 20)) { cap *= 8; continue; }
+                break;
+            }
+            if (!(oc.status == LFX_E_UNEXPECTED_EOF && !d->reader_eof)) {
+                d->out.resize(oc.out_len);
+                if (oc.out_len && hipMemcpy(d->out.data(), c->d_io_out.p, oc.out_len, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
+            }
+        }
+        if (oc.status == LFX_E_UNEXPECTED_EOF && !d->reader_eof) {
+            // ran out of input, not out of stream: wait for more
+            d->tried_at = n;
+            d->target = std::max<uint64_t>(d->target, n) * 2;
+            if (nonblock) continue;      // (the pull loop reports WouldBlock unless new bytes arrive)
+            continue;
+        }
+        d->cursor = 0;
+        d->serve_limit = oc.status == LFX_OK ? oc.out_len : oc.delivered_len;
+        d->pending_status = oc.status;
+        d->err = oc.msg;
+        const uint64_t used = std::min<uint64_t>(oc.consumed, n);
+        d->consumed_total += used;
+        d->in.erase(d->in.begin(), d->in.begin() + (size_t)used);   // what is left is the surplus
+        d->state = lfx_decoder::ST_SERVE;
+        d->target = 0;
+        d->tried_at = 0;
+        return LFX_OK;
+    }
+}
+
+}  // namespace
+
 extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags, lfx_read_cb r, void *user, int *status) {
-    if (!cc || !r) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
+    if (!cc || !r || format < 0 || format > 2) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
     lfx_decoder *d = new lfx_decoder();
     d->c = reinterpret_cast<Ctx *>(cc);
     d->format = format;
     d->flags = flags;
-    std::vector<uint8_t> chunk(1 << 16);
-    for (;;) {
-        int64_t k = r(user, chunk.data(), chunk.size());
-        if (k < 0) { if (status) *status = LFX_E_IO; delete d; return nullptr; }
-        if (k == 0) break;
-        d->in.insert(d->in.end(), chunk.begin(), chunk.begin() + k);
-    }
-    // gzip / zlib constructors parse the header eagerly and can fail (gzip.rs:941-944, zlib.rs:312-320):
-    // decode now; a header failure is reported here, anything later by read()
-    int rc = dec_run(d);
-    if (rc) { if (status) *status = rc; delete d; return nullptr; }
-    if (d->oc.header_failed) {
-        if (status) *status = d->oc.status;
-        d->c->set_error(d->oc.msg);
-        delete d;
-        return nullptr;
+    d->r = r;
+    d->user = user;
+    if (!(flags & LFX_DEC_NONBLOCKING)) {
+        // gzip / zlib constructors read the header and can fail (gzip.rs:941-944, zlib.rs:312-320); the non-blocking
+        // decoders read it lazily (src/non_blocking/gzip.rs:64-88)
+        const int rc = dec_header(d);
+        if (rc) {
+            if (status) *status = rc;
+            d->c->set_error(d->err);
+            delete d;
+            return nullptr;
+        }
+        d->state = lfx_decoder::ST_BODY;
     }
     if (status) *status = LFX_OK;
     return d;
@@ -941,27 +1058,96 @@ extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags,
 extern "C" int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap) {
     if (!d) return -(int64_t)LFX_E_ARG;
     if (cap == 0) return 0;  // never latches end-of-stream (gzip.rs:1025-1027, zlib.rs:383-385)
-    const uint64_t limit = d->oc.status == LFX_OK ? d->oc.out_len : d->oc.delivered_len;
-    if (d->cursor < limit) {
-        const uint64_t k = std::min<uint64_t>(cap, limit - d->cursor);
-        memcpy(out, d->out.data() + d->cursor, k);
-        d->cursor += k;
-        return (int64_t)k;
+    for (;;) {
+        switch (d->state) {
+            case lfx_decoder::ST_DONE: return 0;
+            case lfx_decoder::ST_FAILED: return 0;   // (the error was reported once, like a latched io::Error)
+            case lfx_decoder::ST_SERVE: {
+                if (d->cursor < d->serve_limit) {
+                    const uint64_t k = std::min<uint64_t>(cap, d->serve_limit - d->cursor);
+                    memcpy(out, d->out.data() + d->cursor, k);
+                    d->cursor += k;
+                    return (int64_t)k;
+                }
+                if (d->pending_status != LFX_OK) { d->state = lfx_decoder::ST_FAILED; return -(int64_t)d->pending_status; }
+                if (d->format == LFX_GZIP && (d->flags & LFX_DEC_MULTI)) {   // MultiDecoder::read gzip.rs:1142-1166
+                    d->first_member = false;
+                    d->state = lfx_decoder::ST_HEADER;
+                    continue;
+                }
+                d->state = lfx_decoder::ST_DONE;
+                return 0;
+            }
+            case lfx_decoder::ST_HEADER: {
+                const uint64_t before = d->consumed_total;
+                const int rc = dec_header(d);
+                if (rc == LFX_E_WOULD_BLOCK) return -(int64_t)LFX_E_WOULD_BLOCK;
+                if (rc == LFX_E_UNEXPECTED_EOF && !d->first_member) {
+                    // a following member's header that ends early = clean end of the stream (gzip.rs:1150-1156);
+                    // the partial header bytes were read
+                    d->consumed_total = before + d->in.size();
+                    d->in.clear();
+                    d->err.clear();
+                    d->state = lfx_decoder::ST_DONE;
+                    return 0;
+                }
+                if (rc) { d->state = lfx_decoder::ST_FAILED; return -(int64_t)rc; }
+                d->state = lfx_decoder::ST_BODY;
+                continue;
+            }
+            case lfx_decoder::ST_BODY: {
+                const int rc = dec_body(d);
+                if (rc == LFX_E_WOULD_BLOCK) return -(int64_t)LFX_E_WOULD_BLOCK;
+                if (rc) { d->err = d->err.empty() ? d->c->err : d->err; d->state = lfx_decoder::ST_FAILED; return -(int64_t)rc; }
+                continue;
+            }
+        }
     }
-    if (d->oc.status != LFX_OK && !d->error_reported) {
-        d->error_reported = true;
-        return -(int64_t)d->oc.status;
-    }
-    return 0;
 }
 extern "C" int lfx_decoder_unread(lfx_decoder *d, const uint8_t **p, size_t *n) {
     if (!d) return LFX_E_ARG;
-    // data decoded but not handed out: the rest of completed blocks + the partial block
-    const uint64_t start = std::min<uint64_t>(d->cursor, d->oc.out_len);
+    // data decoded but not handed out: the rest of completed blocks + the partial block (decode.rs:68-73)
+    const uint64_t start = std::min<uint64_t>(d->cursor, d->out.size());
     *p = d->out.data() + start;
-    *n = d->oc.out_len - start;
+    *n = d->out.size() - start;
     return LFX_OK;
 }
-extern "C" uint64_t lfx_decoder_consumed(const lfx_decoder *d) { return d ? d->oc.consumed : 0; }
+extern "C" int lfx_decoder_surplus(lfx_decoder *d, const uint8_t **p, size_t *n) {
+    if (!d) return LFX_E_ARG;
+    // input pulled from the reader that lies behind the last finished member (only meaningful between members /
+    // at the end: while a member is being collected `in` holds that member's bytes)
+    const bool settled = d->state == lfx_decoder::ST_SERVE || d->state == lfx_decoder::ST_DONE || d->state == lfx_decoder::ST_FAILED;
+    *p = d->in.data();
+    *n = settled ? d->in.size() : 0;
+    return LFX_OK;
+}
+extern "C" int lfx_decoder_header(lfx_decoder *d, lfx_header *h) {
+    if (!d || !h) return LFX_E_ARG;
+    memset(h, 0, sizeof *h);
+    if (!d->have_header) {
+        if (!(d->flags & LFX_DEC_NONBLOCKING) || d->state != lfx_decoder::ST_HEADER) return LFX_E_ARG;
+        const int rc = dec_header(d);          // non-blocking decoders read the header on demand (non_blocking/gzip.rs:98-113)
+        if (rc) { if (rc != LFX_E_WOULD_BLOCK) d->state = lfx_decoder::ST_FAILED; return rc; }
+        d->state = lfx_decoder::ST_BODY;
+    }
+    const ContainerFields &f = d->hf;
+    const uint8_t *b = d->hdr_bytes.data();
+    h->format = d->format;
+    if (d->format == LFX_GZIP) {
+        h->mtime = f.mtime;
+        h->xfl = f.xfl;
+        h->os = f.os;
+        h->is_text = (f.flg & 1) != 0;
+        h->is_verified = (f.flg & 2) != 0;
+        if (f.flg & 4) { h->extra = b + f.extra_off; h->extra_len = (uint32_t)f.extra_len; h->has_extra = 1; }
+        if (f.name_len) h->filename = (const char *)(b + f.name_off);
+        if (f.comment_len) h->comment = (const char *)(b + f.comment_off);
+    } else if (d->format == LFX_ZLIB) {
+        h->zlib_window_size = 1u << (((uint32_t)f.cmf >> 4) + 8);   // Lz77WindowSize (zlib.rs:99-173)
+        h->zlib_level = (uint32_t)f.flg >> 6;                        // CompressionLevel (zlib.rs:28-58)
+    }
+    return LFX_OK;
+}
+extern "C" uint64_t lfx_decoder_consumed(const lfx_decoder *d) { return d ? d->consumed_total : 0; }
 extern "C" const char *lfx_decoder_last_error(const lfx_decoder *d) { return d ? d->err.c_str() : "null"; }
 extern "C" void lfx_decoder_free(lfx_decoder *d) { delete d; }

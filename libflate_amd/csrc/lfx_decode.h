@@ -46,6 +46,7 @@ struct InflateJob {
     uint64_t start_bit;   // first bit to decode, relative to in_off
     uint64_t out_off, out_cap;
     uint64_t hist_avail;  // bytes of this member already produced before this job
+    uint64_t stop_bit;    // != 0: the walk ends cleanly when a block ends exactly at this bit (a shard without BFINAL)
     uint32_t flags;
     uint32_t _pad;
 };

@@ -16,6 +16,7 @@
 
 #include "lfx_common.h"
 #include "lfx_decode.h"
+#include "lfx_container.h"
 
 namespace lfx {
 
@@ -27,97 +28,7 @@ __global__ void container_kernel(int format, uint32_t count, const uint8_t *__re
                                  const DecStream *__restrict__ streams, DecHeader *__restrict__ hdrs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const uint8_t *p = in + streams[i].in_off;
-    const uint64_t n = streams[i].in_len;
-    DecHeader h;
-    h.status = 0; h.err = 0; h.a0 = 0; h.a1 = 0; h.deflate_off = 0; h.flags = 0;
-    if (format == 1) {
-        // zlib Header::read_from zlib.rs:221-266
-        if (n < 2) { h.status = 2; h.err = ERR_EOF; h.deflate_off = n; }
-        else {
-            const uint32_t cmf = p[0], flg = p[1];
-            h.deflate_off = 2;
-            if (((cmf << 8) + flg) % 31 != 0) { h.status = 1; h.err = ERR_ZLIB_CHECK; h.a0 = cmf; h.a1 = flg; }
-            else if ((cmf & 15) != 8) { h.status = 1; h.err = ERR_METHOD; h.a0 = cmf & 15; }
-            else if ((cmf >> 4) > 7) { h.status = 1; h.err = ERR_CINFO; h.a0 = cmf >> 4; }
-            else if (flg & 0x20) {
-                if (n < 6) { h.status = 2; h.err = ERR_EOF; h.deflate_off = n; }
-                else { h.status = 1; h.err = ERR_FDICT; h.deflate_off = 6;
-                       h.a0 = (uint32_t)p[2] << 24 | (uint32_t)p[3] << 16 | (uint32_t)p[4] << 8 | p[5]; }
-            }
-        }
-    } else if (format == 2) {
-        // gzip Header::read_from gzip.rs:390-446
-        uint64_t pos = 0;
-        if (n < 10) { h.status = 2; h.err = ERR_EOF; pos = n; }
-        else {
-            pos = 10;
-            const uint32_t flags = p[3];
-            h.flags = flags;
-            if (p[0] != 31 || p[1] != 139) { h.status = 1; h.err = ERR_GZIP_ID; }
-            else if (p[2] != 8) { h.status = 1; h.err = ERR_METHOD; h.a0 = p[2]; }
-            else {
-                uint64_t extra_off = 0, extra_len = 0;
-                if (flags & 4) {
-                    if (n - pos < 2) { h.status = 2; h.err = ERR_EOF; pos = n; }
-                    else {
-                        uint64_t xl = (uint64_t)p[pos] | (uint64_t)p[pos + 1] << 8;
-                        pos += 2;
-                        extra_off = pos; extra_len = xl;
-                        uint64_t lim = xl, q = pos;  // ExtraField::read_from gzip.rs:470-485
-                        while (lim > 0 && h.status == 0) {
-                            if (lim < 4 || n - q < 4) { h.status = 2; h.err = ERR_EOF; q = n; break; }
-                            uint64_t dl = (uint64_t)p[q + 2] | (uint64_t)p[q + 3] << 8;
-                            q += 4; lim -= 4;
-                            if (lim < dl || n - q < dl) { h.status = 2; h.err = ERR_EOF; q = n; break; }
-                            q += dl; lim -= dl;
-                        }
-                        pos = q;
-                    }
-                }
-                uint64_t str_off[2] = {0, 0}, str_len[2] = {0, 0};
-                for (int k = 0; k < 2 && h.status == 0; ++k) {
-                    if (!(flags & (k ? 16 : 8))) continue;
-                    const uint64_t s = pos;
-                    for (;;) {
-                        if (pos >= n) { h.status = 2; h.err = ERR_EOF; break; }
-                        if (p[pos++] == 0) break;
-                    }
-                    str_off[k] = s; str_len[k] = pos - s;
-                }
-                if (h.status == 0 && (flags & 2)) {
-                    if (n - pos < 2) { h.status = 2; h.err = ERR_EOF; pos = n; }
-                    else {
-                        const uint32_t crc = (uint32_t)p[pos] | (uint32_t)p[pos + 1] << 8;
-                        pos += 2;
-                        // crc16 of the header RE-SERIALISED with only the five known flag bits and
-                        // FLG.HCRC cleared; XFL through from_u8/to_u8 (gzip.rs:343-367, 69-82)
-                        uint32_t c = 0xFFFFFFFFu;
-                        auto upd = [&](uint32_t byte) {
-                            c ^= byte;
-                            for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
-                        };
-                        for (int k = 0; k < 10; ++k) {
-                            uint32_t b = p[k];
-                            if (k == 3) b = flags & (1 | 4 | 8 | 16);
-                            if (k == 8) b = (b == 4 || b == 2) ? b : 0;
-                            upd(b);
-                        }
-                        if (flags & 4) {
-                            upd((uint32_t)extra_len & 0xFF); upd((uint32_t)(extra_len >> 8) & 0xFF);
-                            for (uint64_t k = 0; k < extra_len; ++k) upd(p[extra_off + k]);
-                        }
-                        for (int k = 0; k < 2; ++k)
-                            for (uint64_t j = 0; j < str_len[k]; ++j) upd(p[str_off[k] + j]);
-                        const uint32_t expect = (~c) & 0xFFFF;
-                        if (crc != expect) { h.status = 1; h.err = ERR_HCRC; h.a0 = crc; h.a1 = expect; }
-                    }
-                }
-            }
-        }
-        h.deflate_off = pos;
-    }
-    hdrs[i] = h;
+    hdrs[i] = parse_container(format, in + streams[i].in_off, streams[i].in_len, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -558,6 +469,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
             if (stop) break;
         }
         if (final_seen || (job.flags & JOB_SINGLE_BLOCK)) break;
+        if (job.stop_bit != 0 && b.pos == job.stop_bit) break;   // end of a shard that holds no BFINAL block
     }
     // ---- result
     b.err = __shfl(b.err, 0);

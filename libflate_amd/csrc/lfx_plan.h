@@ -7,7 +7,9 @@
 //          CompressBuf::{append,flush} (encode.rs:405-425), RawBuf::flush (encode.rs:364-382),
 //          Encoder::{flush,zlib_sync_flush} (encode.rs:225-249).
 #pragma once
+#include <cstddef>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 #include "lfx_common.h"
@@ -62,6 +64,7 @@ class Planner {
             b.type = BT_RAW;
             b.in_off = cursor_;
             b.in_len = 0;
+            b.first_chunk = (uint32_t)plan_.chunks.size();
             plan_.blocks.push_back(b);
         }
     }
@@ -75,6 +78,40 @@ class Planner {
     }
     Plan &plan() { return plan_; }
     uint64_t cursor() const { return cursor_; }
+
+    // ---- incremental use (stream encoder): blocks that are already closed can be encoded while later writes are
+    // still being collected.  closed_bytes() = input bytes covered by closed blocks; take_closed() moves those
+    // blocks (and their chunks) out and rebases what remains — the open block's finished chunks, the partial chunk
+    // and all counters — to start at byte 0, exactly as if the stream had begun there in the same state.
+    uint64_t closed_bytes() const {
+        if (raw_) return cursor_ - raw_len_;
+        return plan_.chunks.size() > first_chunk_ ? plan_.chunks[first_chunk_].in_off : cursor_ - lz_len_;
+    }
+    size_t closed_blocks() const { return plan_.blocks.size(); }
+    Plan take_closed() {
+        Plan out;
+        const uint64_t cut = closed_bytes();
+        out.blocks = std::move(plan_.blocks);
+        plan_.blocks.clear();
+        out.chunks.assign(plan_.chunks.begin(), plan_.chunks.begin() + (std::ptrdiff_t)first_chunk_);
+        plan_.chunks.erase(plan_.chunks.begin(), plan_.chunks.begin() + (std::ptrdiff_t)first_chunk_);
+        // what the closed part used of the code / tile / mask / segment spaces
+        uint64_t code0 = code_cursor_, tile0 = tile_cursor_, vis0 = plan_.n_vis;
+        uint32_t seg0 = plan_.n_segs;
+        if (!plan_.chunks.empty()) {
+            code0 = plan_.chunks[0].code_off; tile0 = plan_.chunks[0].tile_base;
+            vis0 = plan_.chunks[0].vis_base; seg0 = plan_.chunks[0].seg_base;
+        }
+        out.n_codes_cap = code0; out.n_tiles = tile0; out.n_vis = vis0; out.n_segs = seg0;
+        for (ChunkDesc &c : plan_.chunks) {
+            c.in_off -= cut; c.code_off -= code0; c.tile_base -= tile0; c.vis_base -= vis0; c.seg_base -= seg0;
+            c.block = 0;    // (the open block becomes block 0)
+        }
+        code_cursor_ -= code0; tile_cursor_ -= tile0; plan_.n_vis -= vis0; plan_.n_segs -= seg0;
+        cursor_ -= cut;
+        first_chunk_ = 0;
+        return out;
+    }
 
   private:
     void emit_chunk(uint64_t off, uint64_t len, uint32_t flags) {

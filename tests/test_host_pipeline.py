@@ -233,3 +233,38 @@ def test_structural_insight_parse_independent_candidates(oracle):
                     codes.append(data[i] << 16); i += 1
             codes.extend(b << 16 for b in data[i:])
             assert codes == [int(x) for x in oracle.lz77_chunk(data, window, maxlen)], (window, maxlen, n)
+
+
+def test_incremental_planner_equals_one_shot(ffi):
+    """The stream encoder takes closed blocks out of its planner while later writes are still arriving
+    (Planner::take_closed); stitched together, the pieces must be the plan of the whole event list."""
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        kw = {}
+        r = trial % 6
+        if r == 1: kw["no_compression"] = 1
+        if r == 2: kw["block_size"] = int(rng.choice([1000, 65536, 3 << 20]))
+        if r == 3: kw["lz77_kind"] = 1
+        if r == 4: kw["window_size"] = 1024
+        if r == 5: kw["no_compression"] = 1; kw["block_size"] = 700
+        sync = 2 if trial % 4 == 0 else 0
+        writes, total = [], 0
+        for _ in range(int(rng.integers(1, 120))):
+            if rng.integers(0, 6) == 0:
+                writes.append(None)
+            else:
+                w = int(rng.choice([0, 1, 100, 8192, 65535, 65536, 262144, 300000, 2 << 20]))
+                writes.append(w); total += w
+        fmt = ffi.ZLIB
+        o = ffi.make_opts(zlib_flush_mode=sync, **kw)
+        s = ffi.make_schedule(writes=writes)
+        want_c, want_b = plan(ffi, fmt, total, writes=writes, zlib_flush_mode=sync, **kw)
+        for every in (1, 3, 17):
+            ch = np.zeros(4 * 8192, np.uint64); bl = np.zeros(6 * 8192, np.uint64)
+            nc, nb = C.c_size_t(0), C.c_size_t(0)
+            rc = ffi.lib().lfx_debug_plan_incremental(fmt, C.byref(o), C.byref(s), total, every, ch.ctypes.data, 8192,
+                                                      C.byref(nc), bl.ctypes.data, 8192, C.byref(nb))
+            assert rc == 0
+            got_c, got_b = ch[:4 * nc.value].reshape(-1, 4), bl[:6 * nb.value].reshape(-1, 6)
+            assert got_c.shape == want_c.shape and (got_c == want_c).all(), (trial, every, kw)
+            assert got_b.shape == want_b.shape and (got_b == want_b).all(), (trial, every, kw)
