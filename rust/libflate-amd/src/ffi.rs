@@ -1,0 +1,109 @@
+//! Raw bindings of include/lfx.h (bindgen-free: the header is small and stable).  Every function declared here
+//! is driven by tests/c/shim_abi.c with the same argument shapes (tests/test_abi.py checks the two lists agree).
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const LFX_DEFLATE: c_int = 0;
+pub const LFX_ZLIB: c_int = 1;
+pub const LFX_GZIP: c_int = 2;
+
+pub const LFX_OK: c_int = 0;
+pub const LFX_E_INVALID_DATA: c_int = 1;
+pub const LFX_E_UNEXPECTED_EOF: c_int = 2;
+pub const LFX_E_IO: c_int = 3;
+pub const LFX_E_OOM: c_int = 4;
+pub const LFX_E_DEVICE: c_int = 5;
+pub const LFX_E_ARG: c_int = 6;
+pub const LFX_E_NOSPACE: c_int = 7;
+pub const LFX_E_UNSUPPORTED: c_int = 8;
+pub const LFX_E_WOULD_BLOCK: c_int = 9;
+
+pub const LFX_LZ77_DEFAULT: i32 = 0;
+pub const LFX_LZ77_NOCOMPRESSION: i32 = 1;
+pub const LFX_FLUSH_NONE: i32 = 0;
+pub const LFX_FLUSH_SYNC: i32 = 2;
+pub const LFX_DEC_MULTI: u32 = 1;
+pub const LFX_DEC_NONBLOCKING: u32 = 2;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct lfx_encode_opts {
+    pub block_size: u64,
+    pub dynamic_huffman: i32,
+    pub no_compression: i32,
+    pub lz77_kind: i32,
+    pub window_size: u32,
+    pub max_length: u32,
+    pub zlib_flush_mode: i32,
+    pub mtime: u32,
+    pub os: u8,
+    pub is_text: u8,
+    pub hcrc: u8,
+    pub _pad: u8,
+    pub extra: *const u8,
+    pub extra_len: u32,
+    pub filename: *const c_char,
+    pub comment: *const c_char,
+}
+
+#[repr(C)]
+pub struct lfx_header {
+    pub format: i32,
+    pub mtime: u32,
+    pub xfl: u8,
+    pub os: u8,
+    pub is_text: u8,
+    pub is_verified: u8,
+    pub has_extra: u8,
+    pub _pad: [u8; 3],
+    pub extra: *const u8,
+    pub extra_len: u32,
+    pub filename: *const c_char,
+    pub comment: *const c_char,
+    pub zlib_window_size: u32,
+    pub zlib_level: u32,
+}
+
+pub enum lfx_ctx {}
+pub enum lfx_encoder {}
+pub enum lfx_decoder {}
+pub enum lfx_lz77 {}
+
+pub type lfx_write_cb = extern "C" fn(user: *mut c_void, p: *const u8, n: usize) -> i64;
+pub type lfx_flush_cb = extern "C" fn(user: *mut c_void) -> c_int;
+pub type lfx_read_cb = extern "C" fn(user: *mut c_void, p: *mut u8, cap: usize) -> i64;
+pub type lfx_sink_cb = extern "C" fn(user: *mut c_void, codes: *const u32, n: usize);
+
+extern "C" {
+    pub fn lfx_version() -> u32;
+    pub fn lfx_device_count() -> c_int;
+    pub fn lfx_encode_opts_default(o: *mut lfx_encode_opts);
+    pub fn lfx_ctx_new(device: c_int, status: *mut c_int) -> *mut lfx_ctx;
+    pub fn lfx_ctx_free(c: *mut lfx_ctx);
+    pub fn lfx_ctx_last_error(c: *const lfx_ctx) -> *const c_char;
+
+    pub fn lfx_encoder_new(c: *mut lfx_ctx, format: c_int, o: *const lfx_encode_opts, w: lfx_write_cb,
+                           f: Option<lfx_flush_cb>, user: *mut c_void, status: *mut c_int) -> *mut lfx_encoder;
+    pub fn lfx_encoder_write(e: *mut lfx_encoder, p: *const u8, n: usize) -> i64;
+    pub fn lfx_encoder_flush(e: *mut lfx_encoder) -> c_int;
+    pub fn lfx_encoder_finish(e: *mut lfx_encoder) -> c_int;
+    pub fn lfx_encoder_last_error(e: *const lfx_encoder) -> *const c_char;
+    pub fn lfx_encoder_free(e: *mut lfx_encoder);
+
+    pub fn lfx_decoder_new(c: *mut lfx_ctx, format: c_int, flags: u32, r: lfx_read_cb, user: *mut c_void,
+                           status: *mut c_int) -> *mut lfx_decoder;
+    pub fn lfx_decoder_read(d: *mut lfx_decoder, out: *mut u8, cap: usize) -> i64;
+    pub fn lfx_decoder_unread(d: *mut lfx_decoder, p: *mut *const u8, n: *mut usize) -> c_int;
+    pub fn lfx_decoder_surplus(d: *mut lfx_decoder, p: *mut *const u8, n: *mut usize) -> c_int;
+    pub fn lfx_decoder_consumed(d: *const lfx_decoder) -> u64;
+    pub fn lfx_decoder_header(d: *mut lfx_decoder, h: *mut lfx_header) -> c_int;
+    pub fn lfx_decoder_last_error(d: *const lfx_decoder) -> *const c_char;
+    pub fn lfx_decoder_free(d: *mut lfx_decoder);
+
+    pub fn lfx_lz77_new(c: *mut lfx_ctx, window_size: u32, max_length: u32, status: *mut c_int) -> *mut lfx_lz77;
+    pub fn lfx_lz77_encode(z: *mut lfx_lz77, buf: *const u8, len: usize, sink: lfx_sink_cb, user: *mut c_void) -> c_int;
+    pub fn lfx_lz77_flush(z: *mut lfx_lz77, sink: lfx_sink_cb, user: *mut c_void) -> c_int;
+    pub fn lfx_lz77_window_size(z: *const lfx_lz77) -> u32;
+    pub fn lfx_lz77_compression_level(z: *const lfx_lz77) -> c_int;
+    pub fn lfx_lz77_free(z: *mut lfx_lz77);
+}

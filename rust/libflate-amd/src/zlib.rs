@@ -1,0 +1,83 @@
+//! `libflate::zlib` (reference `src/zlib.rs`).
+use crate::deflate::Lz77;
+use crate::{ffi, Finish, RawDecoder, RawEncoder};
+use std::io;
+
+/// zlib.rs:28-58
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum CompressionLevel { Fastest = 0, Fast = 1, Default = 2, Slowest = 3 }
+/// zlib.rs:184-195
+#[derive(Debug, Clone, Copy, PartialEq, Eq)]
+pub enum FlushMode { None, Sync }
+
+/// `zlib::Header` (zlib.rs:197-220); `window_size` in bytes (`Lz77WindowSize::to_u16` + 1 semantics: 256 << CINFO)
+#[derive(Debug, Clone, PartialEq, Eq)]
+pub struct Header { window_size: u32, compression_level: CompressionLevel }
+impl Header {
+    pub fn window_size(&self) -> u32 { self.window_size }
+    pub fn compression_level(&self) -> CompressionLevel { self.compression_level.clone() }
+    pub(crate) fn from_ffi(h: &ffi::lfx_header) -> Header {
+        let l = match h.zlib_level { 0 => CompressionLevel::Fastest, 1 => CompressionLevel::Fast,
+                                     2 => CompressionLevel::Default, _ => CompressionLevel::Slowest };
+        Header { window_size: h.zlib_window_size, compression_level: l }
+    }
+}
+
+/// `zlib::EncodeOptions` (zlib.rs:414-518)
+#[derive(Debug, Clone)]
+pub struct EncodeOptions { inner: crate::deflate::EncodeOptions, flush_mode: FlushMode }
+impl Default for EncodeOptions {
+    fn default() -> Self { EncodeOptions { inner: Default::default(), flush_mode: FlushMode::None } }
+}
+impl EncodeOptions {
+    pub fn new() -> Self { Self::default() }
+    pub fn with_lz77(lz77: Lz77) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), flush_mode: FlushMode::None } }
+    pub fn no_compression(mut self) -> Self { self.inner = self.inner.no_compression(); self }
+    pub fn block_size(mut self, size: usize) -> Self { self.inner = self.inner.block_size(size); self }
+    pub fn fixed_huffman_codes(mut self) -> Self { self.inner = self.inner.fixed_huffman_codes(); self }
+    pub fn flush_mode(mut self, mode: FlushMode) -> Self { self.flush_mode = mode; self }
+    fn to_ffi(&self) -> ffi::lfx_encode_opts {
+        let mut o = self.inner.to_ffi();
+        o.zlib_flush_mode = if self.flush_mode == FlushMode::Sync { ffi::LFX_FLUSH_SYNC } else { ffi::LFX_FLUSH_NONE };
+        o
+    }
+}
+
+/// `zlib::Encoder` (zlib.rs:522-681)
+pub struct Encoder<W: io::Write> { raw: RawEncoder<W> }
+impl<W: io::Write> Encoder<W> {
+    /// writes the 2-byte header immediately and can fail (zlib.rs:577-585)
+    pub fn new(inner: W) -> io::Result<Self> { Self::with_options(inner, EncodeOptions::default()) }
+    pub fn with_options(inner: W, options: EncodeOptions) -> io::Result<Self> {
+        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_ZLIB, &options.to_ffi(), inner)? })
+    }
+    pub fn finish(self) -> Finish<W, io::Error> { let (w, e) = self.raw.finish(); Finish::new(w, e) }
+    pub fn as_inner_ref(&self) -> &W { self.raw.inner_ref() }
+    pub fn as_inner_mut(&mut self) -> &mut W { self.raw.inner_mut() }
+    pub fn into_inner(self) -> W { self.raw.into_inner() }
+}
+impl<W: io::Write> io::Write for Encoder<W> {
+    fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.raw.write(buf) }
+    /// `FlushMode::Sync` appends the empty stored block `00 00 FF FF` (zlib.rs:666-671)
+    fn flush(&mut self) -> io::Result<()> { self.raw.flush() }
+}
+
+/// `zlib::Decoder` (zlib.rs:284-410)
+pub struct Decoder<R: io::Read> { raw: RawDecoder<R>, header: Header }
+impl<R: io::Read> Decoder<R> {
+    /// reads the header and can fail (zlib.rs:312-320)
+    pub fn new(inner: R) -> io::Result<Self> {
+        let mut raw = RawDecoder::new(ffi::LFX_ZLIB, 0, inner)?;
+        let header = Header::from_ffi(&raw.header()?);
+        Ok(Decoder { raw, header })
+    }
+    pub fn header(&self) -> &Header { &self.header }
+    pub fn as_inner_ref(&self) -> &R { self.raw.inner_ref() }
+    pub fn as_inner_mut(&mut self) -> &mut R { self.raw.inner_mut() }
+    pub fn into_inner(self) -> R { self.raw.into_inner() }
+    pub fn unread_decoded_data(&self) -> &[u8] { self.raw.unread_decoded_data() }
+    pub fn unread_input(&self) -> &[u8] { self.raw.surplus() }
+}
+impl<R: io::Read> io::Read for Decoder<R> {
+    fn read(&mut self, buf: &mut [u8]) -> io::Result<usize> { self.raw.read(buf) }
+}

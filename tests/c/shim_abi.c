@@ -1,0 +1,193 @@
+/* shim_abi.c — drives, from plain C, every extern "C" function the Rust shim crate (rust/libflate-amd/src/ffi.rs)
+ * declares, with the argument shapes the crate uses: callbacks over user pointers, header-first decoder construction,
+ * header getters, surplus bytes, non-blocking reads, the Lz77Encode plug-in.  The expected bytes are the reference's
+ * own known-answer vectors (src/deflate/encode.rs:152-154, src/zlib.rs:547-549, src/gzip.rs:800-802,1072-1083,
+ * src/lz77.rs:16-32).  tests/test_abi.py keeps the two lists of functions in step.
+ *
+ * Without a GPU: checks that construction fails loudly with LFX_E_DEVICE (exit 0, prints "no device").
+ * With a GPU: runs the vectors (exit 0 and "shim abi ok", or exit 1 with the failing check). */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/lfx.h"
+
+#define CHECK(cond)                                                               \
+    do {                                                                          \
+        if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
+    } while (0)
+
+typedef struct { unsigned char b[1 << 16]; size_t n; int flushes; } sink_t;
+static int64_t on_write(void *user, const uint8_t *p, size_t n) {
+    sink_t *s = (sink_t *)user;
+    if (s->n + n > sizeof s->b) return -5;
+    memcpy(s->b + s->n, p, n);
+    s->n += n;
+    return (int64_t)n;
+}
+static int on_flush(void *user) { ((sink_t *)user)->flushes++; return 0; }
+
+typedef struct { const unsigned char *p; size_t n, pos, step; int block_every; int calls; } src_t;
+static int64_t on_read(void *user, uint8_t *out, size_t cap) {
+    src_t *s = (src_t *)user;
+    s->calls++;
+    if (s->block_every && (s->calls % s->block_every) == 1) return -(int64_t)LFX_E_WOULD_BLOCK;
+    size_t k = s->n - s->pos;
+    if (k > cap) k = cap;
+    if (s->step && k > s->step) k = s->step;
+    memcpy(out, s->p + s->pos, k);
+    s->pos += k;
+    return (int64_t)k;
+}
+
+typedef struct { uint32_t w[64]; size_t n; } codes_t;
+static void on_codes(void *user, const uint32_t *codes, size_t n) {
+    codes_t *c = (codes_t *)user;
+    for (size_t i = 0; i < n && c->n < 64; i++) c->w[c->n++] = codes[i];
+}
+
+static int read_all(lfx_decoder *d, unsigned char *out, size_t cap, size_t *got, int *blocks) {
+    *got = 0;
+    for (;;) {
+        int64_t r = lfx_decoder_read(d, out + *got, cap - *got);
+        if (r == -(int64_t)LFX_E_WOULD_BLOCK) { if (blocks) (*blocks)++; continue; }
+        if (r < 0) return (int)-r;
+        if (r == 0) return 0;
+        *got += (size_t)r;
+    }
+}
+
+static const unsigned char HELLO[] = "Hello World!";
+static const unsigned char DEFLATE_HELLO[] = {5, 192, 49, 13, 0, 0, 8, 3, 65, 43, 224, 6, 7, 24, 128, 237, 147, 38, 245, 63, 244, 230, 65, 181, 50, 215, 1};
+static const unsigned char ZLIB_HELLO[] = {120, 156, 5, 192, 49, 13, 0, 0, 8, 3, 65, 43, 224, 6, 7, 24, 128, 237, 147, 38, 245, 63, 244, 230, 65, 181, 50, 215, 1, 28, 73, 4, 62};
+static const unsigned char GZIP_STORED[] = {31, 139, 8, 0, 123, 0, 0, 0, 0, 3, 1, 12, 0, 243, 255, 72, 101, 108, 108, 111, 32, 87, 111, 114, 108, 100, 33, 163, 28, 41, 28, 12, 0, 0, 0};
+static const unsigned char MEMBER_A[] = {31, 139, 8, 0, 51, 206, 75, 90, 0, 3, 5, 128, 49, 9, 0, 0, 0, 194, 170, 24, 199, 34, 126, 3, 251, 127, 163, 131, 71, 192, 252, 45, 234, 6, 0, 0, 0};
+static const unsigned char MEMBER_B[] = {31, 139, 8, 0, 227, 207, 75, 90, 0, 3, 5, 128, 49, 9, 0, 0, 0, 194, 178, 152, 202, 2, 158, 130, 96, 255, 99, 120, 111, 4, 222, 157, 40, 118, 6, 0, 0, 0};
+
+int main(void) {
+    CHECK(lfx_version() == LFX_VERSION);
+    int st = -1;
+    lfx_ctx *c = lfx_ctx_new(0, &st);
+    if (!c) {
+        CHECK(st == LFX_E_DEVICE);
+        CHECK(lfx_device_count() == 0);
+        printf("no device: lfx_ctx_new fails with LFX_E_DEVICE (no CPU fallback)\n");
+        return 0;
+    }
+    CHECK(st == LFX_OK && lfx_device_count() >= 1);
+    CHECK(lfx_ctx_last_error(c) != NULL);
+    lfx_encode_opts o;
+
+    /* ---- encoders: deflate / zlib / gzip (stored, mtime 123), write + flush + finish */
+    {
+        sink_t s = {{0}, 0, 0};
+        lfx_encode_opts_default(&o);
+        lfx_encoder *e = lfx_encoder_new(c, LFX_DEFLATE, &o, on_write, on_flush, &s, &st);
+        CHECK(e && st == LFX_OK);
+        CHECK(lfx_encoder_write(e, HELLO, 12) == 12);
+        CHECK(lfx_encoder_finish(e) == LFX_OK);
+        CHECK(lfx_encoder_last_error(e) != NULL);
+        lfx_encoder_free(e);
+        CHECK(s.n == sizeof DEFLATE_HELLO && !memcmp(s.b, DEFLATE_HELLO, s.n) && s.flushes >= 1);
+    }
+    {
+        sink_t s = {{0}, 0, 0};
+        lfx_encode_opts_default(&o);
+        lfx_encoder *e = lfx_encoder_new(c, LFX_ZLIB, &o, on_write, NULL, &s, &st);
+        CHECK(e && s.n == 2);                                   /* the header is written immediately (zlib.rs:577-585) */
+        CHECK(lfx_encoder_write(e, HELLO, 5) == 5 && lfx_encoder_write(e, HELLO + 5, 7) == 7);
+        CHECK(lfx_encoder_finish(e) == LFX_OK);
+        lfx_encoder_free(e);
+        CHECK(s.n == sizeof ZLIB_HELLO && !memcmp(s.b, ZLIB_HELLO, s.n));
+    }
+    {
+        sink_t s = {{0}, 0, 0};
+        lfx_encode_opts_default(&o);
+        o.no_compression = 1;
+        o.mtime = 123;
+        lfx_encoder *e = lfx_encoder_new(c, LFX_GZIP, &o, on_write, on_flush, &s, &st);
+        CHECK(e && s.n == 10);
+        CHECK(lfx_encoder_write(e, HELLO, 12) == 12);
+        {   /* the same options without a flush: the reference's bytes (gzip.rs:800-802) */
+            sink_t s2 = {{0}, 0, 0};
+            lfx_encoder *e2 = lfx_encoder_new(c, LFX_GZIP, &o, on_write, on_flush, &s2, &st);
+            CHECK(e2 && lfx_encoder_write(e2, HELLO, 12) == 12 && lfx_encoder_finish(e2) == LFX_OK);
+            lfx_encoder_free(e2);
+            CHECK(s2.n == sizeof GZIP_STORED && !memcmp(s2.b, GZIP_STORED, s2.n));
+        }
+        CHECK(lfx_encoder_flush(e) == LFX_OK);                  /* closes a (here: stored) block */
+        CHECK(lfx_encoder_finish(e) == LFX_OK);
+        lfx_encoder_free(e);
+        /* flush() before finish() adds an empty final stored block: decode instead of comparing bytes */
+        src_t r = {s.b, s.n, 0, 0, 0, 0};
+        lfx_decoder *d = lfx_decoder_new(c, LFX_GZIP, 0, on_read, &r, &st);
+        CHECK(d && st == LFX_OK);
+        unsigned char out[64]; size_t got;
+        CHECK(read_all(d, out, sizeof out, &got, NULL) == 0 && got == 12 && !memcmp(out, HELLO, 12));
+        lfx_decoder_free(d);
+    }
+    /* ---- decoder: header first, getters, one member of two, surplus, consumed */
+    {
+        unsigned char both[sizeof MEMBER_A + sizeof MEMBER_B];
+        memcpy(both, MEMBER_A, sizeof MEMBER_A);
+        memcpy(both + sizeof MEMBER_A, MEMBER_B, sizeof MEMBER_B);
+        src_t r = {both, sizeof both, 0, 0, 0, 0};
+        lfx_decoder *d = lfx_decoder_new(c, LFX_GZIP, 0, on_read, &r, &st);
+        CHECK(d);
+        lfx_header h;
+        CHECK(lfx_decoder_header(d, &h) == LFX_OK && h.format == LFX_GZIP && h.mtime == 0x5A4BCE33u && h.os == 3 && !h.filename);
+        unsigned char out[64]; size_t got;
+        CHECK(lfx_decoder_read(d, out, 0) == 0);                /* a zero-capacity read never latches EOS (gzip.rs:1025) */
+        CHECK(read_all(d, out, sizeof out, &got, NULL) == 0 && got == 6 && !memcmp(out, "Hello ", 6));
+        CHECK(lfx_decoder_consumed(d) == sizeof MEMBER_A);
+        const uint8_t *sp; size_t sn;
+        CHECK(lfx_decoder_surplus(d, &sp, &sn) == LFX_OK && sn == sizeof MEMBER_B && !memcmp(sp, MEMBER_B, sn));
+        CHECK(lfx_decoder_unread(d, &sp, &sn) == LFX_OK && sn == 0);
+        lfx_decoder_free(d);
+        /* MultiDecoder over a reader that hands out 5 bytes at a time */
+        src_t r2 = {both, sizeof both, 0, 5, 0, 0};
+        d = lfx_decoder_new(c, LFX_GZIP, LFX_DEC_MULTI, on_read, &r2, &st);
+        CHECK(d);
+        CHECK(read_all(d, out, sizeof out, &got, NULL) == 0 && got == 12 && !memcmp(out, HELLO, 12));
+        CHECK(lfx_decoder_consumed(d) == sizeof both);
+        lfx_decoder_free(d);
+        /* non-blocking: WouldBlock on every other call, nothing read by the constructor */
+        src_t r3 = {both, sizeof both, 0, 7, 2, 0};
+        d = lfx_decoder_new(c, LFX_GZIP, LFX_DEC_MULTI | LFX_DEC_NONBLOCKING, on_read, &r3, &st);
+        CHECK(d && r3.calls == 0);
+        int blocks = 0;
+        CHECK(read_all(d, out, sizeof out, &got, &blocks) == 0 && got == 12 && blocks > 0);
+        lfx_decoder_free(d);
+        /* a header error surfaces in the constructor (gzip.rs:941-944), with the reference's message */
+        both[0] = 30;
+        src_t r4 = {both, sizeof both, 0, 0, 0, 0};
+        d = lfx_decoder_new(c, LFX_GZIP, 0, on_read, &r4, &st);
+        CHECK(!d && st == LFX_E_INVALID_DATA && strstr(lfx_ctx_last_error(c), "Unexpected GZIP ID"));
+    }
+    /* ---- decode error text after the bytes in front of it (zlib.rs:916-934 style) */
+    {
+        src_t r = {ZLIB_HELLO, sizeof ZLIB_HELLO - 1, 0, 0, 0, 0};
+        lfx_decoder *d = lfx_decoder_new(c, LFX_ZLIB, 0, on_read, &r, &st);
+        CHECK(d);
+        lfx_header h;
+        CHECK(lfx_decoder_header(d, &h) == LFX_OK && h.zlib_window_size == 32768 && h.zlib_level == 2);
+        unsigned char out[64]; size_t got;
+        CHECK(read_all(d, out, sizeof out, &got, NULL) == LFX_E_UNEXPECTED_EOF);
+        CHECK(lfx_decoder_last_error(d)[0] != 0);
+        lfx_decoder_free(d);
+    }
+    /* ---- Lz77Encode plug-in (src/lz77.rs:16-32) */
+    {
+        lfx_lz77 *z = lfx_lz77_new(c, 32768, 258, &st);
+        CHECK(z && st == LFX_OK);
+        CHECK(lfx_lz77_window_size(z) == 32768 && lfx_lz77_compression_level(z) == LFX_LEVEL_BALANCE);
+        codes_t cs = {{0}, 0};
+        CHECK(lfx_lz77_encode(z, (const uint8_t *)"aaaaa", 5, on_codes, &cs) == LFX_OK && cs.n == 0);   /* buffers */
+        CHECK(lfx_lz77_flush(z, on_codes, &cs) == LFX_OK);
+        CHECK(cs.n == 2 && cs.w[0] == (97u << 16) && cs.w[1] == ((4u << 16) | 1u));
+        lfx_lz77_free(z);
+    }
+    lfx_ctx_free(c);
+    printf("shim abi ok\n");
+    return 0;
+}

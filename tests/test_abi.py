@@ -63,3 +63,52 @@ def test_checksum_combine(ffi, oracle):
         a, b = d[:cut], d[cut:]
         assert L.lfx_crc32_combine(oracle.crc32(a), oracle.crc32(b), len(b)) == oracle.crc32(d)
         assert L.lfx_adler32_combine(oracle.adler32(a), oracle.adler32(b), len(b)) == oracle.adler32(d)
+
+
+# ---- the Rust shim crate (rust/libflate-amd): cannot be compiled here (no Rust toolchain), so the ABI it binds is
+# exercised from C: tests/c/shim_abi.c drives every extern the crate declares.
+def _shim_binary():
+    import subprocess
+    src = os.path.join(ROOT, "tests", "c", "shim_abi.c")
+    exe = os.path.join(ROOT, "tests", "c", "shim_abi")
+    libdir = os.path.join(ROOT, "libflate_amd")
+    if not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe):
+        subprocess.check_call(["gcc", "-O1", "-Wall", "-o", exe, src, "-L" + libdir, "-llfx", "-Wl,-rpath," + libdir])
+    return exe
+
+
+def _shim_env():
+    env = dict(os.environ)
+    # same HIP runtime as the Python tests use (torch's bundled copy), found through the loader path
+    try:
+        import torch
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+        env["LD_LIBRARY_PATH"] = tl + ":" + env.get("LD_LIBRARY_PATH", "") + ":/opt/rocm/lib"
+    except ImportError:
+        env["LD_LIBRARY_PATH"] = env.get("LD_LIBRARY_PATH", "") + ":/opt/rocm/lib"
+    return env
+
+
+def test_rust_shim_binds_declared_abi(ffi):
+    rs = open(os.path.join(ROOT, "rust", "libflate-amd", "src", "ffi.rs")).read()
+    bound = set(re.findall(r"pub fn (lfx_[a-z0-9_]+)\s*\(", rs))
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lfx.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(lfx_[a-z0-9_]+)\s*\(", hdr))
+    assert bound and bound <= declared, bound - declared
+    csrc = open(os.path.join(ROOT, "tests", "c", "shim_abi.c")).read()
+    driven = set(re.findall(r"\b(lfx_[a-z0-9_]+)\s*\(", csrc))
+    assert bound <= driven, sorted(bound - driven)        # every extern of the crate is exercised from C
+    # struct layouts the crate mirrors by hand
+    assert C.sizeof(ffi.EncodeOpts) == 72 and C.sizeof(ffi.Header) == 56
+    for field, off in (("block_size", 0), ("window_size", 20), ("mtime", 32), ("os", 36), ("extra", 40), ("extra_len", 48),
+                       ("filename", 56), ("comment", 64)):
+        assert getattr(ffi.EncodeOpts, field).offset == off, field
+
+
+def test_shim_abi_program_without_gpu(ffi):
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: tests/test_gpu_round2.py runs the vectors")
+    out = subprocess.run([_shim_binary()], env=_shim_env(), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "no device" in out.stdout, out.stderr

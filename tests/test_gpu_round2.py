@@ -400,3 +400,12 @@ def test_cfg2_256mib_bit_exact_vs_oracle(env, oracle, write_size):
 def C_byref(x):
     import ctypes
     return ctypes.byref(x)
+
+
+def test_shim_abi_program(env):
+    """tests/c/shim_abi.c: every extern "C" function the Rust shim crate declares, driven from C on the reference's
+    known-answer vectors (the crate itself cannot be compiled in this image)."""
+    import subprocess
+    from test_abi import _shim_binary, _shim_env
+    out = subprocess.run([_shim_binary()], env=_shim_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "shim abi ok" in out.stdout, (out.stdout, out.stderr)
