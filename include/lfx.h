@@ -143,6 +143,12 @@ int lfx_encode_shard_emit(lfx_ctx *c, uint64_t start_bit, uint32_t combined_chec
 int lfx_decode_shard_device(lfx_ctx *c, const void *d_in, uint64_t n, uint64_t start_bit,
                             uint64_t total_bits, int is_last, void *d_out, uint64_t cap,
                             uint64_t *out_len);
+/* stream concatenation on the writer rank: places one shard's bytes (as written by emit(), already
+ * on this device — e.g. received over RCCL / xGMI) at byte start_bit/8 of the member buffer; when the shard starts
+ * inside a byte (start_bit % 8 != 0) that byte is shared with the shard in front and is OR-ed.  Place the shards in
+ * rank order. */
+int lfx_shard_place_device(lfx_ctx *c, void *d_member, uint64_t cap, const void *d_part, uint64_t part_len,
+                           uint64_t start_bit, int is_first);
 uint32_t lfx_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 uint32_t lfx_adler32_combine(uint32_t ad1, uint32_t ad2, uint64_t len2);
 uint64_t lfx_container_header_len(int format, const lfx_encode_opts *o);

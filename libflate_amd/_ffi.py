@@ -22,7 +22,7 @@ DEC_NONBLOCKING = 2
 EXPORTS = [
     "lfx_encode_opts_default", "lfx_ctx_new", "lfx_ctx_free", "lfx_ctx_last_error", "lfx_ctx_set_stream",
     "lfx_device_count", "lfx_encode_bound", "lfx_encode_device", "lfx_encode_host", "lfx_decode_device",
-    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device",
+    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device", "lfx_shard_place_device",
     "lfx_crc32_combine", "lfx_adler32_combine", "lfx_container_header_len", "lfx_encoder_new",
     "lfx_encoder_write", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
     "lfx_encoder_free", "lfx_decoder_new", "lfx_decoder_read", "lfx_decoder_unread",
@@ -121,6 +121,7 @@ def lib():
                                            i32, C.POINTER(ShardInfo)]
     L.lfx_encode_shard_emit.argtypes = [vp, u64, u32, u64, vp, u64, C.POINTER(u64)]
     L.lfx_decode_shard_device.argtypes = [vp, vp, u64, u64, u64, i32, vp, u64, C.POINTER(u64)]
+    L.lfx_shard_place_device.argtypes = [vp, vp, u64, vp, u64, u64, i32]
     L.lfx_crc32_combine.restype = u32
     L.lfx_crc32_combine.argtypes = [u32, u32, u64]
     L.lfx_adler32_combine.restype = u32

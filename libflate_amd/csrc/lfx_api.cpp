@@ -623,6 +623,28 @@ extern "C" int lfx_encode_shard_emit(lfx_ctx *cc, uint64_t start_bit, uint32_t c
     return LFX_OK;
 }
 
+extern "C" int lfx_shard_place_device(lfx_ctx *cc, void *d_member, uint64_t cap, const void *d_part, uint64_t part_len,
+                                      uint64_t start_bit, int is_first) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    const uint64_t at = is_first ? 0 : start_bit / 8;
+    if (at + part_len > cap) { c->set_error("member buffer too small"); return LFX_E_NOSPACE; }
+    if (part_len == 0) return LFX_OK;
+    uint8_t *dst = (uint8_t *)d_member + at;
+    const uint8_t *src = (const uint8_t *)d_part;
+    const bool shared = !is_first && (start_bit & 7) != 0;      // the first byte also holds the last bits of the shard in front
+    if (shared) {
+        LAUNCH_TRY(launch_or_byte(c->stream, dst, src));
+        if (part_len > 1) HIP_TRY(hipMemcpyAsync(dst + 1, src + 1, part_len - 1, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(dst, src, part_len, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LFX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // stream encoder: io::Write shaped
 struct lfx_encoder {

@@ -53,6 +53,7 @@ int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc
 // CRC-32 / Adler-32 of count byte ranges data[off[i*off_stride] .. +len[i*len_stride]) (strides in 8-byte units)
 int launch_checksum_ranges(hipStream_t st, const uint8_t *data, uint32_t count, const uint64_t *off,
                            uint32_t off_stride, const uint64_t *len, uint32_t len_stride, uint32_t *crc, uint32_t *adler);
+int launch_or_byte(hipStream_t st, uint8_t *dst, const uint8_t *src);
 int launch_put_bytes(hipStream_t st, const uint8_t *d_bytes, uint32_t n, uint64_t at_byte, uint32_t *out);
 int launch_trailer(hipStream_t st, int format, uint32_t isize, uint64_t out_base_bit,
                    EncodeResult *res, uint32_t *out);

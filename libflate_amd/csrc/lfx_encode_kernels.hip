@@ -1206,6 +1206,15 @@ __global__ void put_bytes_kernel(const uint8_t *__restrict__ bytes, uint32_t n, 
         atomicOr(&out[ob >> 2], (uint32_t)bytes[i] << (8 * (ob & 3)));
     }
 }
+// shard concatenation: the byte a shard shares with the shard in front of it
+__global__ void or_byte_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = (uint8_t)(dst[0] | src[0]);
+}
+int launch_or_byte(hipStream_t st, uint8_t *dst, const uint8_t *src) {
+    hipLaunchKernelGGL(or_byte_kernel, dim3(1), dim3(64), 0, st, dst, src);
+    const hipError_t e_ = hipGetLastError();
+    return e_ != hipSuccess ? (int)e_ : 0;
+}
 // trailer from the device-side checksum result (gzip.rs:114-121 CRC-32 LE + ISIZE LE;
 // zlib.rs:630-639 Adler-32 BE), placed at the byte after the last DEFLATE bit
 __global__ void trailer_kernel(int format, uint32_t isize, uint64_t out_base_bit,

@@ -1,7 +1,12 @@
-"""Sharded encode across ranks: one gzip/zlib/deflate member, contiguous block ranges per rank
-(SURVEY.md §8e).  The only exchange is an all-gather of (total_bits, n_bytes, crc32, adler32) per
-rank — 32 bytes each, latency-bound — from which every rank derives its start bit and the last rank
-the combined trailer.  No bulk data crosses xGMI on this path."""
+"""Sharded encode, host side: layout of the ranks' bit ranges inside ONE member, the combined
+trailer checksum, and the concatenation of the shards on the writer rank.
+
+The data path has no collective: every rank encodes its own blocks; the ranks exchange 32 bytes each
+(`lfx_shard_info`, one all-gather over RCCL / xGMI), emit at their global bit offset, and the shard bytes travel
+once to the writer rank (point-to-point over xGMI), where `lfx_shard_place_device` puts them in place — the byte at a
+shard boundary is shared by two shards and is OR-ed."""
+import ctypes as C
+
 from . import _ffi
 
 
@@ -23,8 +28,8 @@ def layout(infos, header_len, fmt):
 
 
 def assemble(parts, start_bits):
-    """Concatenate per-rank outputs (bytes) into the member: part r starts at byte start_bits[r]//8
-    and shares that byte with its predecessor when start_bits[r] % 8 != 0 (OR the halves)."""
+    """Host reference of the concatenation (tests): part r starts at byte start_bits[r]//8 and shares that byte
+    with its predecessor when start_bits[r] % 8 != 0 (OR the halves)."""
     out = bytearray()
     for r, p in enumerate(parts):
         at = start_bits[r] // 8 if r else 0
@@ -34,3 +39,40 @@ def assemble(parts, start_bits):
         else:
             out += p
     return bytes(out)
+
+
+def member_bytes(start_bits, part_lens):
+    """size of the assembled member given every rank's emitted byte count"""
+    last = len(start_bits) - 1
+    return (start_bits[last] // 8 if last else 0) + part_lens[last]
+
+
+def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
+    """Concatenate the shards on rank 0 (the writer).  d_part / d_member / staging are torch uint8 tensors on the
+    rank's device; `dist` is torch.distributed (None for world == 1).  Point-to-point transfers, in rank order; each
+    shard is placed as soon as it has arrived.  Returns the member's length on rank 0, 0 elsewhere."""
+    L = _ffi.lib()
+
+    def place(src_tensor, r):
+        rc = L.lfx_shard_place_device(ctx.handle, d_member.data_ptr(), cap, src_tensor.data_ptr(), part_lens[r],
+                                      start_bits[r], int(r == 0))
+        if rc:
+            raise _ffi.LfxError(rc, ctx.last_error())
+
+    if rank == 0:
+        place(d_part, 0)
+        for r in range(1, world):
+            buf = staging[:part_lens[r]]
+            if buf.device.type == "cpu" or dist.get_backend() == "gloo":
+                host = buf.cpu() if buf.device.type != "cpu" else buf
+                dist.recv(host, src=r)
+                buf.copy_(host)
+            else:
+                dist.recv(buf, src=r)
+            place(buf, r)
+        return member_bytes(start_bits, part_lens)
+    send = d_part[:part_len]
+    if dist.get_backend() == "gloo":
+        send = send.cpu()
+    dist.send(send, dst=0)
+    return 0

@@ -309,7 +309,17 @@ def shard_roundtrip(env, oracle, world, n, fake_lead_bits=0):
         outs.append((d_out, m.value, sb))
     member = sharded.assemble(parts, start_bits)
     whole = b"".join(d.tobytes() for d in datas)
-    assert member == oracle.encode(oracle.GZIP, whole, write_size=8192)
+    want = oracle.encode(oracle.GZIP, whole, write_size=8192)
+    assert member == want
+    # the same concatenation on the device (what the writer rank does with the shards it received over xGMI)
+    real_bits = [start_bits[r] for r in range(world)]
+    cap = len(want) + 64
+    d_member = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        rc = L.lfx_shard_place_device(ctxs[0].handle, d_member.data_ptr(), cap, outs[r][0].data_ptr(), outs[r][1],
+                                      real_bits[r], int(r == 0))
+        assert rc == 0, ctxs[0].last_error()
+    assert d_member[:sharded.member_bytes(real_bits, [o[1] for o in outs])].cpu().numpy().tobytes() == want
     for r in range(world):
         d_dec = torch.zeros(n, dtype=torch.uint8, device="cuda")
         ol = C.c_uint64(0)
