@@ -320,28 +320,13 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             return LFX_E_ARG;
         }
     const uint32_t nchunks = (uint32_t)plan.chunks.size(), nblocks = (uint32_t)plan.blocks.size();
-    // ---- which match stage (lfx_match2.hip vs the first-generation kernel) and how the work is cut
-    // FUSED: a workgroup owns a whole chunk and also walks / emits it — the per-position intermediate never leaves
-    // the chip.  Needs enough chunks to fill the GPU and chunks short enough for one workgroup's serial walk.
+    // ---- which match stage: lfx_match2.hip unless it once reported a lane-order violation (or LFX_MATCH_V1 is set)
     const bool match_v1 = c->force_match_v1 || getenv("LFX_MATCH_V1") != nullptr;
-    uint64_t n_match_chunks = 0, max_chunk = 0;
-    for (const ChunkDesc &ch : plan.chunks)
-        if (!(ch.flags & CH_LITERALS)) { n_match_chunks++; max_chunk = std::max<uint64_t>(max_chunk, ch.len); }
-    // Measured on 256 MiB of text (S8K): separate match + parse kernels 4.4 + 1.5 ms, fused 7.0 ms — the table
-    // building and the walker sit on the critical path of the same 16 wavefronts.  The fused mode therefore stays
-    // opt-in (LFX_FUSED=1; LFX_FUSED_MIN_CHUNKS lets the tests force it on small inputs).
-    const char *fm = getenv("LFX_FUSED_MIN_CHUNKS");
-    const uint64_t fused_min = fm ? strtoull(fm, nullptr, 10) : (uint64_t)std::max(c->n_cu / 2, 1);
-    const bool fused = !match_v1 && po.lz77_kind == 0 && (getenv("LFX_FUSED") || fm) && max_chunk <= (512u << 10) &&
-                       n_match_chunks >= fused_min;
     // A segment is one workgroup's serial walk (plus a 32 KiB warm-up when it does not start a chunk).  Small
     // inputs are cut finer so that the GPU still fills: halve the segment length until there are >= 512 of them
     // (never below 32 Ki positions: the warm-up would dominate).
     std::vector<SegDesc> segs;
-    if (fused) {
-        for (uint32_t ci = 0; ci < nchunks; ci++)
-            segs.push_back(SegDesc{ci, 0, (uint32_t)plan.chunks[ci].len, 0});   // (also empty chunks: they emit EndOfBlock)
-    } else {
+    {
         uint64_t seg_len = SEG_POSITIONS;
         for (;;) {
             uint64_t cnt = 0;
@@ -366,11 +351,11 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_chunks.reserve(sizeof(ChunkDesc) * std::max<size_t>(nchunks, 1)))) return rc;
     if ((rc = c->d_blocks.reserve(sizeof(BlockDesc) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
-    if (!fused && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;
+    if ((rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
-    if (!fused && (rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
-    if (!fused && (rc = c->d_segtmp.reserve(16ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
+    if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
+    if ((rc = c->d_segtmp.reserve(16ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
     if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;
@@ -406,22 +391,20 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         LAUNCH_TRY(launch_match(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
     else
-        LAUNCH_TRY(launch_match2(st, fused, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p,
-                                 (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, d_match_flags, mdbg));
+        LAUNCH_TRY(launch_match2(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, d_match_flags, mdbg));
     if (mdbg) {
         uint64_t hv[128];
         (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
         for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : (fused ? "2f" : "2"), w,
+            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "2", w,
                     match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
     }
     c->phase("lz77_match");
-    if (!fused)
-        LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
-                                (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
-                                (uint32_t *)c->d_ncodes.p));
+    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
+                            (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
+                            (uint32_t *)c->d_ncodes.p));
     c->phase("lz77_parse");
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the histogram
