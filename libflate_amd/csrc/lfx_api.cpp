@@ -365,10 +365,6 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
     if ((rc = c->d_res.reserve(256))) return rc;
     if ((rc = c->d_small.reserve(70000))) return rc;
-    // the chain walks the match kernel's helpers hand on (lfx_match2.hip): room for one position in 128
-    const uint32_t deep_cap = (uint32_t)std::min<uint64_t>(n / 128 + 4096, 1u << 26);
-    if ((rc = c->d_deep.reserve(8ull * deep_cap + 8))) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_deep.p, 0, 8, st));
 
     if (nchunks) HIP_TRY(hipMemcpyAsync(c->d_chunks.p, plan.chunks.data(), sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
     if (nblocks) HIP_TRY(hipMemcpyAsync(c->d_blocks.p, plan.blocks.data(), sizeof(BlockDesc) * nblocks, hipMemcpyHostToDevice, st));
@@ -396,21 +392,14 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
     else
         LAUNCH_TRY(launch_match2(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, d_match_flags,
-                                 (uint32_t *)c->d_deep.p, deep_cap, mdbg));
-    if (mdbg && !match_v1) {
-        uint32_t dc = 0;
-        (void)hipMemcpy(&dc, c->d_deep.p, 4, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[lfx] match2: %u walks went to the deep list (capacity %u)\n", dc, deep_cap);
-    }
+                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, d_match_flags, mdbg));
     if (mdbg) {
         uint64_t hv[128];
         (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
         for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu last_at_barrier1=%llu last_at_barrier2=%llu wait1=%llu\n",
-                    match_v1 ? "1" : "2", w, match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
-                    (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5],
-                    (unsigned long long)hv[w * 8 + 3], (unsigned long long)hv[w * 8 + 4], (unsigned long long)hv[w * 8 + 6]);
+            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "2", w,
+                    match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
+                    (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
     }
     c->phase("lz77_match");
     LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,

@@ -31,8 +31,7 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                  uint64_t *dbg = nullptr);
 // second-generation match stage (lfx_match2.hip): per-position answers → md.  flags[0] |= 1 on a lane-order violation.
 int launch_match2(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint32_t *flags, uint32_t *deep,
-                  uint32_t deep_cap, uint64_t *dbg = nullptr);   // deep: 2 + 2 * deep_cap words, deep[0] zeroed by the caller
+                  uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint32_t *flags, uint64_t *dbg = nullptr);
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                  uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
                  uint32_t *codes, uint32_t *ncodes);
