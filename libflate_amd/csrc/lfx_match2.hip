@@ -6,7 +6,7 @@
 // reference inserts EVERY position < end exactly once and in order (default.rs:78,92-97), so
 // cand(i) = max{ j < i : buf[j..j+3] == buf[i..i+3] } does not depend on which positions the walk visits.
 //
-// One workgroup of 16 wavefronts per segment, a software pipeline over tiles of 896 positions (14 resolver
+// One workgroup of 16 wavefronts per segment, a software pipeline over tiles of 960 positions (15 resolver
 // wavefronts x 64 lanes), two LDS-only barriers per tile:
 //
 //   phase A   resolvers: R1(k)   chain walk for the positions whose answer is not known yet
@@ -52,16 +52,17 @@ namespace lfx {
 namespace m2 {
 
 constexpr int THREADS = 1024;
-constexpr uint32_t RW = 14;                   // resolver wavefronts (waves 1..14; wave 0: head pass + window, wave 15 idle)
-constexpr uint32_t TILE = RW * 64;            // 896 positions
+constexpr uint32_t RW = 15;                   // resolver wavefronts (waves 1..15; wave 0: head pass + window)
+constexpr uint32_t TILE = RW * 64;            // 960 positions
 constexpr uint32_t NSUB = RW;                 // 64-position sub-tiles per tile (= exchanges of the head pass)
 constexpr int HASH_BITS = 14;
 // ONE ring modulus for the window bytes and the link distances: a position's ring offset indexes both.  A multiple
 // of the tile size, so that a tile never straddles the end of the ring; >= window + 4 tiles + 4 (the fill of tile k+4
 // must not touch what R(k) reads).
-constexpr uint32_t RING = 41 * TILE;          // 36736
+constexpr uint32_t RING = 39 * TILE;          // 37440
 constexpr uint32_t HEAD_FAR = 33000;          // distance marker of an empty / swept head field
-constexpr uint32_t SWEEP_SLICES = 32;         // the whole table is swept every 32 tiles (28672 positions)
+constexpr uint32_t SWEEP_SLICES = 32;         // the whole table is swept every 32 tiles (30720 positions)
+constexpr uint32_t HB = 5;                    // exchanges per batch of the head pass (one wait per batch)
 constexpr uint32_t FUTURE = 65536 - 64;       // a distance this large can only come from a lane-order violation
 constexpr uint32_t FILL_LOADS = (TILE + 255) / 256;   // dword loads per lane of wave 0 and tile
 constexpr uint32_t LK_PTR = 32769;            // lk value >= LK_PTR: inherit the link of in-tile index (v - LK_PTR)
@@ -74,7 +75,7 @@ constexpr uint32_t OFF_REQ = OFF_WIN + RING + 16;                  // TILE u32: 
 constexpr uint32_t OFF_OLD = OFF_REQ + TILE * 4;                   // TILE u32: the dwords the exchanges returned
 constexpr uint32_t OFF_LK = OFF_OLD + TILE * 4;                    // TILE u16: link states of the tile being finalized
 constexpr uint32_t LDS_BYTES = OFF_LK + TILE * 2;
-static_assert(NSUB % 7 == 0, "the head pass issues batches of seven exchanges");
+static_assert(NSUB % HB == 0, "the head pass issues whole batches");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(RING % 4 == 0 && 4 * TILE + 4 <= RING - 32768, "ring slack");
 static_assert(SWEEP_SLICES * TILE + 32768 + TILE + 64 < FUTURE, "head ages must stay below the violation zone");
@@ -125,23 +126,22 @@ __device__ __forceinline__ uint64_t win8(const uint32_t *win32, uint32_t off) { 
     return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, off & 3) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, off & 3) << 32;
 }
 
-// seven 16-bit exchanges, in order, one wait.  old[i] = the dword that held the field before.
+// HB 16-bit exchanges, in order, one wait.  old[i] = the dword that held the field before.
 // A lane with mask 0 / value 0 leaves its dword untouched.
-__device__ __forceinline__ void mskor7(uint32_t (&old)[7], const uint32_t (&addr)[7], const uint32_t (&mask)[7],
-                                       const uint32_t (&val)[7]) {
+__device__ __forceinline__ void mskor_batch(uint32_t (&old)[HB], const uint32_t (&addr)[HB], const uint32_t (&mask)[HB],
+                                            const uint32_t (&val)[HB]) {
+    static_assert(HB == 5, "operand list below");
     asm volatile(
-        "ds_mskor_rtn_b32 %0, %7, %14, %21\n\t"
-        "ds_mskor_rtn_b32 %1, %8, %15, %22\n\t"
-        "ds_mskor_rtn_b32 %2, %9, %16, %23\n\t"
-        "ds_mskor_rtn_b32 %3, %10, %17, %24\n\t"
-        "ds_mskor_rtn_b32 %4, %11, %18, %25\n\t"
-        "ds_mskor_rtn_b32 %5, %12, %19, %26\n\t"
-        "ds_mskor_rtn_b32 %6, %13, %20, %27\n\t"
+        "ds_mskor_rtn_b32 %0, %5, %10, %15\n\t"
+        "ds_mskor_rtn_b32 %1, %6, %11, %16\n\t"
+        "ds_mskor_rtn_b32 %2, %7, %12, %17\n\t"
+        "ds_mskor_rtn_b32 %3, %8, %13, %18\n\t"
+        "ds_mskor_rtn_b32 %4, %9, %14, %19\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5]), "=&v"(old[6])
-        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]),
-          "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]),
-          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6])
+        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4])
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]),
+          "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]),
+          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4])
         : "memory");
 }
 
@@ -340,21 +340,21 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
         // =================================================== phase B
         if (wave == 0) {
             if (do_p) {
-                // ---- H(it+2): the ordered head pass — NSUB exchanges in position order, in batches of seven
+                // ---- H(it+2): the ordered head pass — NSUB exchanges in position order, in batches of HB
 #pragma unroll
-                for (uint32_t h = 0; h < NSUB / 7; ++h) {
-                    uint32_t old[7], addr[7], mask[7], val[7];
+                for (uint32_t h = 0; h < NSUB / HB; ++h) {
+                    uint32_t old[HB], addr[HB], mask[HB], val[HB];
 #pragma unroll
-                    for (uint32_t s = 0; s < 7; ++s) {
-                        const uint32_t rq = reqb[(h * 7 + s) * 64 + lane];
+                    for (uint32_t s = 0; s < HB; ++s) {
+                        const uint32_t rq = reqb[(h * HB + s) * 64 + lane];
                         const uint32_t sh = (rq >> 13) & 16u;                 // (hash & 1) * 16
                         addr[s] = head_lds + ((rq >> 18) << 2);               // dword of field hash
                         mask[s] = (0u - ((rq >> 16) & 1u)) & (0xFFFFu << sh);
                         val[s] = (rq & 0xFFFFu) << sh;
                     }
-                    mskor7(old, addr, mask, val);
+                    mskor_batch(old, addr, mask, val);
 #pragma unroll
-                    for (uint32_t s = 0; s < 7; ++s) oldb[(h * 7 + s) * 64 + lane] = old[s];
+                    for (uint32_t s = 0; s < HB; ++s) oldb[(h * HB + s) * 64 + lane] = old[s];
                 }
             }
             // ---- window stores (their loads were issued in phase A)
