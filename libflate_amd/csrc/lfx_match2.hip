@@ -65,22 +65,28 @@ constexpr uint32_t SWEEP_SLICES = 32;         // the whole table is swept every 
 constexpr uint32_t HB = 5;                    // exchanges per batch of the head pass (one wait per batch)
 constexpr uint32_t FUTURE = 65536 - 64;       // a distance this large can only come from a lane-order violation
 constexpr uint32_t FILL_LOADS = (TILE + 255) / 256;   // dword loads per lane of wave 0 and tile
-constexpr uint32_t LK_PTR = 32769;            // lk value >= LK_PTR: inherit the link of in-tile index (v - LK_PTR)
+// link values (16 bits, in lk[] and prevd[]): 1..32768 a distance; NONE..LK_PTR-1 no link (every sum of a distance and a
+// link is clamped to NONE with one v_min — no compare, no select); >= LK_PTR (lk[] only) inherit the link of in-tile
+// index (v - LK_PTR)
+constexpr uint32_t NONE = MAX_WINDOW + 1;
+constexpr uint32_t LK_PTR = 0xC000;
 
-// LDS layout (bytes)
-constexpr uint32_t OFF_HEAD = 0;                                   // 8192 dwords
-constexpr uint32_t OFF_PREVD = OFF_HEAD + (2u << HASH_BITS);       // RING u16
-constexpr uint32_t OFF_WIN = OFF_PREVD + RING * 2;                 // RING + 8 bytes (+ pad)
-constexpr uint32_t OFF_REQ = OFF_WIN + RING + 16;                  // TILE u32: head-pass requests (hash, valid, position)
+// LDS layout (bytes), static so that the offsets fold into the ds instructions: the window at 0 (ds_read2_b32 offsets
+// are dword indices below 256), the arrays addressed by computed indices below 64 KiB (16-bit offset field)
+constexpr uint32_t OFF_WIN = 0;                                    // RING + 8 bytes (+ pad)
+constexpr uint32_t OFF_LK = OFF_WIN + RING + 16;                   // TILE u16: link states of the tile being finalized
+constexpr uint32_t OFF_PREVD = OFF_LK + TILE * 2;                  // RING u16
+constexpr uint32_t OFF_REQ = OFF_PREVD + RING * 2;                 // TILE u32: head-pass requests (hash, valid, position)
 constexpr uint32_t OFF_OLD = OFF_REQ + TILE * 4;                   // TILE u32: the dwords the exchanges returned
-constexpr uint32_t OFF_LK = OFF_OLD + TILE * 4;                    // TILE u16: link states of the tile being finalized
-constexpr uint32_t LDS_BYTES = OFF_LK + TILE * 2;
+constexpr uint32_t OFF_HEAD = OFF_OLD + TILE * 4;                  // 8192 dwords
+constexpr uint32_t LDS_BYTES = OFF_HEAD + (2u << HASH_BITS);
+static_assert(OFF_PREVD < 65536 && OFF_LK < 65536, "offset field");
 static_assert(NSUB % HB == 0, "the head pass issues whole batches");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(RING % 4 == 0 && 4 * TILE + 4 <= RING - 32768, "ring slack");
 static_assert(SWEEP_SLICES * TILE + 32768 + TILE + 64 < FUTURE, "head ages must stay below the violation zone");
 static_assert(HEAD_FAR + SWEEP_SLICES * TILE + TILE < FUTURE && HEAD_FAR > 32768, "far marker range");
-static_assert(LK_PTR + TILE <= 65536, "link states are 16 bits");
+static_assert(LK_PTR + TILE <= 65536 && NONE < LK_PTR, "link states are 16 bits; every stored non-pointer is clamped to NONE");
 static_assert(((1u << (HASH_BITS - 1)) / SWEEP_SLICES) % 64 == 0, "sweep slice per lane");
 
 struct ByteSrc2 {
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     const SegDesc *__restrict__ segs, uint32_t window, uint32_t max_len, uint32_t *__restrict__ md,
     uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg) {
     using namespace m2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     uint32_t *head32 = (uint32_t *)(smem + OFF_HEAD);
     uint16_t *prevd = (uint16_t *)(smem + OFF_PREVD);
     uint32_t *win32 = (uint32_t *)(smem + OFF_WIN);
@@ -211,8 +217,8 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     uint32_t hh_p = 0, hh_f = 0;                   // its hash (selects the half of the exchanged dword)
     bool val_p = false, val_f = false, val_r = false;   // position takes part in the chain structure (l0 <= p < q1)
     uint32_t cd_f = 0, cd_r = 0;                   // known answer distance (0 = walk)
-    uint32_t e_f = 0, e_r = 0;                     // own final link distance (0 = none)
-    uint32_t lk_f = 0;                             // F1 → F2: first link state
+    uint32_t e_f = NONE, e_r = NONE;               // own final link distance
+    uint32_t lk_f = NONE;                          // F1 → F2: first link state
     uint32_t r_dist = 0;                           // R1 → R2
     bool r_found = false;
     bool viol = false;                             // a lane-order violation seen by this lane (reported once, at the end)
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
             //      the raw predecessor, which is known to carry another prefix.  (A link never reaches in front of the
             //      first inserted position, so the distance needs no check against the position itself.)
             const bool known = act_r && cd_r != 0;
-            const bool walk = act_r && cd_r == 0 && e_r != 0 && e_r <= window;
+            const bool walk = act_r && cd_r == 0 && e_r <= window;          // (NONE > every window)
             uint32_t dist = known ? cd_r : (walk ? e_r : 0u);
             uint32_t found = (known && dist <= window) ? 1u : 0u;
             // -- step 0: loads
@@ -283,16 +289,17 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
             // -- step 0: uses
             uint32_t d = walk ? d0 : 0u;
             const uint32_t of = (hh_f & 1) ? ow >> 16 : ow & 0xFFFFu;   // what the exchange returned for this field
-            uint32_t d_f = act_f ? (t_f + idx - of) & 0xFFFFu : 0u;
+            uint32_t d_f = act_f ? (t_f + idx - of) & 0xFFFFu : NONE;   // (never 0: the sweep retires a field long before)
             viol |= d_f >= FUTURE;
-            d_f = d_f > MAX_WINDOW ? 0u : d_f;
+            d_f = min(d_f, NONE);
+            const bool has_f = d_f < NONE;
             // -- step 1: loads (R1 hop 1, F1 predecessor)
             dist += d;
             d = dist > window ? 0u : d;                          // default.rs:81 (inclusive window)
             const uint32_t a1 = d ? ring_back(o_r, dist) : o_r;
             const uint32_t kq1 = win4(win32, a1) & 0xFFFFFFu;
             const uint32_t dn1 = prevd[a1];
-            const uint32_t af = d_f ? ring_back(o_f, d_f) : o_f;
+            const uint32_t af = has_f ? ring_back(o_f, d_f) : o_f;
             const uint32_t kqf = win4(win32, af) & 0xFFFFFFu;
             uint32_t pqf = prevd[af];                            // (final when the predecessor lies in an older tile)
             pin(pqf);
@@ -304,10 +311,10 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
             }
             // F1(it+1): raw predecessor → known answer / first link state
             {
-                const bool same = d_f != 0 && kqf == key_f;
+                const bool same = has_f && kqf == key_f;
                 cd_f = same ? d_f : 0u;
-                uint32_t e_old = pqf ? d_f + pqf : 0u;               // predecessor in an older tile: inherit its final link
-                e_old = e_old > MAX_WINDOW ? 0u : e_old;
+                uint32_t e_old = min(d_f + pqf, NONE);                // predecessor in an older tile: inherit its final link
+                pin(e_old);
                 const uint32_t e_same = d_f > idx ? e_old : LK_PTR + (idx - d_f);   // in this tile: by pointer jumping
                 const uint32_t e = same ? e_same : d_f;               // another prefix: plain link (or none)
                 lk_f = e;
@@ -375,11 +382,10 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
             const uint32_t p_r = t_r + idx;
             const uint32_t o_r = ok + idx, o_f = o1 + idx;
             const bool act_r = do_r && val_r && p_r >= q0;
-            const bool act_f = do_f && val_f;
             // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed: every
             //      state a reader can observe is valid and the oldest member of a run is final from the start)
             // ---- R2(it): longest_common_prefix (default.rs:122-129): 8 bytes per step for the first 16
-            uint32_t e = act_f ? lk_f : 0u;
+            uint32_t e = lk_f;                                         // (NONE where the position takes no part)
             const bool found = act_r && r_found;
             const uint32_t dist = r_dist;
             uint32_t l = 0;
@@ -392,16 +398,14 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
 #pragma unroll
             for (int step = 0; step < 2; ++step) {
                 // loads
-                const bool ptr = e >= LK_PTR;
-                const uint32_t j = ptr ? e - LK_PTR : idx;
+                // (a lane whose state is final reads its own slot, which holds that state: the update is the identity)
+                const uint32_t j = min(e - LK_PTR, idx);
                 const uint32_t eq = lk[j];
                 const uint64_t xa = win8(win32, oa), xb = win8(win32, ob);
                 // uses
                 {
-                    uint32_t en = eq ? (idx - j) + eq : 0u;            // the predecessor's link is final: make it ours
-                    en = en > MAX_WINDOW ? 0u : en;
-                    en = eq < LK_PTR ? en : eq;                        // ... or it still points on: jump
-                    e = ptr ? en : e;
+                    const uint32_t en = min((idx - j) + eq, NONE);     // the predecessor's link is final: make it ours
+                    e = eq < LK_PTR ? en : eq;                         // ... or it still points on: jump
                     lk[idx] = (uint16_t)e;
                 }
                 {
@@ -414,13 +418,10 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
                 }
             }
             while (__ballot(e >= LK_PTR)) {
-                const bool ptr = e >= LK_PTR;
-                const uint32_t j = ptr ? e - LK_PTR : idx;
+                const uint32_t j = min(e - LK_PTR, idx);
                 const uint32_t eq = lk[j];
-                uint32_t en = eq ? (idx - j) + eq : 0u;
-                en = en > MAX_WINDOW ? 0u : en;
-                en = eq < LK_PTR ? en : eq;
-                e = ptr ? en : e;
+                const uint32_t en = min((idx - j) + eq, NONE);
+                e = eq < LK_PTR ? en : eq;
                 lk[idx] = (uint16_t)e;
             }
             e_f = e;
@@ -469,20 +470,11 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
 int launch_match2(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint32_t *flags, uint64_t *dbg) {
     if (nsegs == 0) return 0;
-    const size_t lds = m2::LDS_BYTES;
-    static bool attr_set[64] = {};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    if (!attr_set[dev_ & 63]) {
-        (void)hipFuncSetAttribute((const void *)lz77_match2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)lz77_match2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set[dev_ & 63] = true;
-    }
     if (dbg)
-        hipLaunchKernelGGL(lz77_match2_kernel<true>, dim3(nsegs), dim3(m2::THREADS), lds, st, in, in_bytes, chunks, segs, window,
+        hipLaunchKernelGGL(lz77_match2_kernel<true>, dim3(nsegs), dim3(m2::THREADS), 0, st, in, in_bytes, chunks, segs, window,
                            max_len, md, flags, dbg);
     else
-        hipLaunchKernelGGL(lz77_match2_kernel<false>, dim3(nsegs), dim3(m2::THREADS), lds, st, in, in_bytes, chunks, segs, window,
+        hipLaunchKernelGGL(lz77_match2_kernel<false>, dim3(nsegs), dim3(m2::THREADS), 0, st, in, in_bytes, chunks, segs, window,
                            max_len, md, flags, dbg);
     const hipError_t e_ = hipGetLastError();
     return e_ != hipSuccess ? (int)e_ : 0;
