@@ -1,6 +1,7 @@
 // lfx_api.cpp — C ABI (include/lfx.h) over the HIP kernels.  Host side = framing bytes, the write
 // schedule planner and kernel orchestration; every byte of compression work runs on the GPU.
 #include "../../include/lfx.h"
+#include "../../include/lfx_testhooks.h"
 
 #include <hip/hip_runtime.h>
 
@@ -858,7 +859,7 @@ extern "C" void lfx_lz77_free(lfx_lz77 *z) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// debug hooks for the CPU test-suite: run the SAME host/device-shared code on the host.
+// test hooks (include/lfx_testhooks.h) for the CPU test-suite: run the SAME host/device-shared code on the host.
 // Not a product path (no compression work can be reached through them).
 extern "C" int lfx_debug_huff_block(const uint32_t *hist320, uint32_t type, uint32_t *lit288, uint32_t *dist32,
                                     uint32_t *hdr160, uint32_t *hdr_bits, uint64_t *body_bits) {

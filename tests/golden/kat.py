@@ -2,7 +2,7 @@
 
 Every entry cites the reference file:line (relative to sile/libflate v2.3.0) that holds it.
 They pin the oracle (tests/test_oracle_kat.py) and, through the same tables, the HIP path
-(tests/test_gpu_kat.py).
+(tests/test_gpu_parity.py::test_kat_*).
 """
 import os
 

@@ -3,6 +3,7 @@ calls fail loudly without a GPU (no CPU fallback)."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import pytest
 
@@ -17,15 +18,24 @@ def ffi():
     return _ffi
 
 
-def test_exports_match_header(ffi):
-    hdr = open(os.path.join(ROOT, "include", "lfx.h")).read()
+def _declared(name):
+    hdr = open(os.path.join(ROOT, "include", name)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(lfx_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"lfx_write_cb", "lfx_flush_cb", "lfx_read_cb", "lfx_sink_cb"}
+    return set(re.findall(r"\b(lfx_[a-z0-9_]+)\s*\(", hdr)) - {"lfx_write_cb", "lfx_flush_cb", "lfx_read_cb", "lfx_sink_cb"}
+
+
+def test_exports_match_header(ffi):
+    declared = _declared("lfx.h")
     L = ffi.lib()
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
     assert declared == set(ffi.EXPORTS), declared ^ set(ffi.EXPORTS)
+    # the library exports nothing beyond the boundary and the four host-only test hooks (include/lfx_testhooks.h)
+    hooks = _declared("lfx_testhooks.h")
+    assert hooks and not (hooks & declared) and all(h.startswith("lfx_debug_") for h in hooks)
+    out = subprocess.run(["nm", "-D", "--defined-only", ffi.SO_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("lfx_")}
+    assert exported == declared | hooks, exported ^ (declared | hooks)
     assert L.lfx_version() == 0x000100
 
 
