@@ -13,6 +13,7 @@
 // and partial output.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "lfx_common.h"
 #include "lfx_decode.h"
@@ -1007,6 +1008,212 @@ __global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__re
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3, second generation: a 256-lane workgroup per unit, the copy itself data-parallel over BYTES.
+//
+// The first-generation kernel above gives a unit to ONE wavefront: lanes = codes, back-references that read bytes of
+// their own batch are executed one after the other, and with a single wavefront per SIMD every instruction's latency is
+// exposed (measured: 3360 cycles per batch of 64 codes = 234 bytes).  Here a tile of 256 codes (<= M2_TILE bytes) is
+// expanded to bytes: every lane owns four output bytes, finds the code that covers them (binary search in the codes'
+// end offsets), and
+//   * a literal, or a byte whose source lies in front of the tile (final, in the ring), is written at once;
+//   * a byte whose source lies inside the tile gets a POINTER to it: P[i] = i - distance.  Rounds of pointer jumping
+//     (P[i] = P[P[i]] until the target is resolved) settle these in log2(chain depth) rounds — the overlapping
+//     forward copy of rle_decode (libflate_lz77/src/lib.rs:186-190) is just a chain of depth length / distance.
+// In-place jumping is safe without a second buffer: every value a reader can observe in P[j] is either "resolved" —
+// and then the byte is already in the ring, because the LDS executes a wavefront's instructions in order — or an
+// earlier byte with the same content.
+// Four units per CU (39.5 KB of LDS each), 16 wavefronts per CU instead of 4.
+constexpr uint32_t M2_THREADS = 256;
+constexpr uint32_t M2_TILE = 1536;                        // bytes one tile may produce
+constexpr uint32_t M2_RING = 32768 + M2_TILE;             // the DEFLATE window + the tile in flight
+constexpr uint32_t M2_PASSES = (M2_TILE + 4 * M2_THREADS - 1) / (4 * M2_THREADS);
+constexpr uint32_t M2_DONE = 0xFFFFu;
+static_assert(M2_RING % 4 == 0 && M2_TILE >= 258 && M2_TILE < M2_DONE, "tile");
+
+__device__ __forceinline__ uint32_t m2_wrap(uint32_t x) { return min(x, x - M2_RING); }          // x in [0, 2 RING)
+__device__ __forceinline__ uint32_t m2_back(uint32_t idx, uint32_t d) {                           // idx, d < RING
+    const uint32_t a = idx - d;
+    return min(a, a + M2_RING);
+}
+
+__global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint8_t *__restrict__ in,
+                                                                      const BlkEmit *__restrict__ jobs,
+                                                                      const BlkUnits *__restrict__ units,
+                                                                      const uint32_t *__restrict__ codes,
+                                                                      uint8_t *__restrict__ out, uint32_t njobs,
+                                                                      uint64_t *__restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) unsigned char ring[M2_RING + 64];   // (+ a dump for the stores of idle bytes)
+    __shared__ __attribute__((aligned(8))) uint16_t P[M2_PASSES * 4 * M2_THREADS];
+    // per code of the tile: x = inclusive end offset, y = code word; four sentinels behind the last (never passed)
+    __shared__ __attribute__((aligned(8))) uint2 XC[M2_THREADS + 4];
+    __shared__ uint32_t s_w[8];
+    __shared__ uint32_t s_any[2][4];
+    const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;   // unit-major (XCD balance, see K3)
+    const BlkEmit job = jobs[bidx];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (job.btype == 0) {
+        if (u != 0) return;
+        uint8_t *o = out + job.out_off;
+        const uint8_t *src = in + (job.data_bit >> 3);
+        for (uint64_t k = tid; k < job.n_out; k += M2_THREADS) o[k] = src[k];
+        return;
+    }
+    const BlkUnits *U = &units[bidx];
+    if (u >= U->n) return;
+    const uint32_t c0 = U->code0[u], c1 = U->code0[u + 1];
+    const uint64_t ob = U->out0[u];
+    const uint64_t gbase = job.out_off + ob;
+    uint8_t *o = out + gbase;
+    const uint32_t *cp = codes + job.code_off + c0;
+    const uint32_t n = c1 - c0;
+    // unit byte p lives at ring index (p + shift) mod M2_RING; ring and output share their 4-byte alignment.
+    // History in front of the block (batch rounds / ordered runs: already final in `out`): up to 32 KiB preloaded.
+    const uint32_t hist = (u == 0 && job.preload) ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
+    const uint32_t shift = (uint32_t)((gbase - hist) & 3) + hist;       // < M2_RING
+    for (uint32_t k = tid; k < hist; k += M2_THREADS) ring[shift - hist + k] = o[(int64_t)k - (int64_t)hist];
+    if (tid < 4) XC[M2_THREADS + tid] = make_uint2(0xFFFFFFFFu, 0u);
+    uint64_t produced = 0, flushed = 0;
+    uint32_t tr = shift;                       // ring index of the tile's first byte
+    uint32_t fr = shift;                       // ring index of byte `flushed`
+    uint32_t base = 0, ntiles = 0, nrounds = 0;
+    uint32_t c_cur = tid < n ? cp[tid] : 0;
+    const uint64_t t0 = dbg ? clock64() : 0;
+    uint32_t par = 0;
+    while (base < n) {
+        ntiles++;
+        const uint32_t i = base + tid;
+        const uint32_t c_pref = (uint64_t)i + M2_THREADS < n ? cp[i + M2_THREADS] : 0;   // assuming the whole tile is taken
+        const uint32_t c = c_cur;
+        const uint32_t mylen = i < n ? ((c & 0xFFFFu) ? c >> 16 : 1u) : 0u;
+        uint32_t x = wave_inclusive_sum(mylen);
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();       // (also: the previous tile's flush has read the ring before this tile writes it)
+        const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
+        x += (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+        const uint32_t tot = w0 + w1 + w2 + w3;
+        XC[tid] = make_uint2(x, c);
+        if (tot > M2_TILE) {   // (uniform) only the codes whose output fits are taken; a code is at most 258 bytes
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(x <= M2_TILE));
+            if (lane == 0) s_w[4 + wave] = cnt;
+        }
+        __syncthreads();
+        uint32_t take = M2_THREADS, total = tot;
+        if (tot > M2_TILE) {
+            take = s_w[4] + s_w[5] + s_w[6] + s_w[7];
+            total = XC[take - 1].x;
+        }
+        // ---- round 0: bytes -> owner code -> literal / final source / pointer.  Branch-free: every byte loads from the
+        //      ring (its own slot when there is nothing to fetch) and stores (to the dump when it lies behind the tile).
+        uint32_t pp[M2_PASSES][4];
+        bool pend = false;
+#pragma unroll
+        for (uint32_t ps = 0; ps < M2_PASSES; ++ps) {
+            const uint32_t b = ps * 4 * M2_THREADS + 4 * tid;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) pp[ps][q] = M2_DONE;
+            if (ps == 0 || __ballot(b < total)) {   // (pass 1 and later: whole wavefronts skip)
+                uint32_t k = 0;   // smallest k with X[k] > b  (zero-length slots behind the last code are never chosen)
+#pragma unroll
+                for (uint32_t step = M2_THREADS / 2; step; step >>= 1) k += XC[k + step - 1].x <= b ? step : 0u;
+                uint32_t src[4], dst[4], cwq[4];
+                bool lit[4], fin[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) {
+                    const uint32_t bi = b + q;
+                    if (q) k += bi >= cwq[q - 1] ? 1u : 0u;        // (cwq[q-1] still holds the previous owner's end offset)
+                    const uint2 xc = XC[k];
+                    const uint32_t d = xc.y & 0xFFFFu;
+                    const uint32_t t = m2_wrap(tr + bi);
+                    const bool in = bi < total;
+                    lit[q] = d == 0;
+                    fin[q] = lit[q] || d > bi;
+                    src[q] = (d > bi && in) ? m2_back(t, d) : t;
+                    dst[q] = in ? t : M2_RING + (tid & 63u);
+                    pp[ps][q] = (fin[q] || !in) ? M2_DONE : bi - d;
+                    cwq[q] = xc.x;                                  // end offset now, code word's literal below
+                    src[q] |= xc.y & 0xFFFF0000u;                   // (ring indices are below 2^16: the value rides along)
+                }
+                uint32_t hv[4];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) hv[q] = ring[src[q] & 0xFFFFu];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; ++q) ring[dst[q]] = (unsigned char)(lit[q] ? src[q] >> 16 : hv[q]);
+                pend |= (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) != M2_DONE;
+            }
+            *(uint64_t *)&P[b] = (uint64_t)pp[ps][0] | (uint64_t)pp[ps][1] << 16 | (uint64_t)pp[ps][2] << 32 | (uint64_t)pp[ps][3] << 48;
+        }
+        // ---- rounds of pointer jumping.  Per byte: load the target's state, then the target's byte (in this order: a
+        //      target seen resolved has its byte in the ring), store the byte, then the state.  A byte fetched from an
+        //      unresolved target is garbage in a slot nobody reads yet.
+        for (;;) {
+            const uint64_t bal = __ballot(pend);
+            if (lane == 0) s_any[par][wave] = bal != 0;
+            __syncthreads();
+            const uint32_t any = s_any[par][0] | s_any[par][1] | s_any[par][2] | s_any[par][3];
+            par ^= 1;
+            if (!any) break;
+            nrounds++;
+            if (pend) {
+#pragma unroll
+                for (uint32_t ps = 0; ps < M2_PASSES; ++ps) {
+                    const uint32_t b = ps * 4 * M2_THREADS + 4 * tid;
+                    if (ps && (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) == M2_DONE) continue;
+                    uint32_t nx[4], hv[4], jj[4];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        jj[q] = pp[ps][q] != M2_DONE ? pp[ps][q] : b + q;
+                        nx[q] = P[jj[q]];
+                    }
+                    asm volatile("" ::: "memory");   // the states are loaded BEFORE the bytes (the LDS keeps a wavefront's order)
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) hv[q] = ring[m2_wrap(tr + jj[q])];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) {
+                        // (a byte that was final before reads itself — also one behind the tile — and writes the same
+                        //  byte and the same state back)
+                        ring[m2_wrap(tr + b + q)] = (unsigned char)hv[q];
+                        pp[ps][q] = nx[q];
+                    }
+                    asm volatile("" ::: "memory");   // ... and the bytes are stored BEFORE the states
+                    *(uint64_t *)&P[b] = (uint64_t)nx[0] | (uint64_t)nx[1] << 16 | (uint64_t)nx[2] << 32 | (uint64_t)nx[3] << 48;
+                }
+                pend = false;
+#pragma unroll
+                for (uint32_t ps = 0; ps < M2_PASSES; ++ps) pend |= (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) != M2_DONE;
+            }
+        }
+        // ---- flush: whole dwords; what is left over waits for the next tile
+        const uint64_t upto = produced + total;
+        base += take;
+        const bool last = base >= n;
+        if ((gbase + flushed) & 3) {   // (only in front of the first aligned dword)
+            uint32_t hb = 4 - (uint32_t)((gbase + flushed) & 3);
+            if (hb > upto - flushed) hb = (uint32_t)(upto - flushed);
+            if (tid < hb) o[flushed + tid] = ring[m2_wrap(fr + tid)];
+            flushed += hb;
+            fr = m2_wrap(fr + hb);
+        }
+        const uint32_t ndw = (uint32_t)((upto - flushed) >> 2);
+        uint32_t *o32 = (uint32_t *)(o + flushed);
+        for (uint32_t k = tid; k < ndw; k += M2_THREADS) o32[k] = *(const uint32_t *)&ring[m2_wrap(fr + 4 * k)];
+        flushed += 4ull * ndw;
+        fr = m2_wrap(fr + 4 * ndw);
+        if (last) {
+            const uint32_t rest = (uint32_t)(upto - flushed);
+            if (tid < rest) o[flushed + tid] = ring[m2_wrap(fr + tid)];
+            flushed = upto;
+        }
+        produced = upto;
+        tr = m2_wrap(tr + total);
+        c_cur = take == M2_THREADS ? c_pref : ((uint64_t)base + tid < n ? cp[base + tid] : 0);   // rare path: reload
+    }
+    if (dbg && tid == 0) {
+        uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
+        d[0] = clock64() - t0; d[1] = ntiles; d[2] = nrounds; d[3] = 0; d[4] = n; d[5] = produced; d[6] = wall_clock64();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Marker-based materialisation (pugz / rapidgzip style) for streams whose blocks read the output of earlier
 // blocks.  Pass 1 — this kernel, every unit at once: the 32 KiB in front of a unit are unknown, so the unit
 // works on 16-bit SYMBOLS: a byte value, or 256 + j = "byte j of the 32 KiB in front of me".  The ring starts
@@ -1397,7 +1604,11 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), 0, st, in, jobs, lanes, units, codes, out, njobs, dbg);
+    static const bool first_gen = getenv("LFX_MAT_V1") != nullptr;   // (A/B measurements)
+    if (first_gen)
+        hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), 0, st, in, jobs, lanes, units, codes, out, njobs, dbg);
+    else
+        hipLaunchKernelGGL(blk_materialize2_kernel, dim3(njobs * MAX_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
