@@ -383,6 +383,7 @@ __device__ __forceinline__ uint32_t find_seg_chunk(const ChunkDesc *chunks, uint
     return lo;
 }
 
+constexpr int SPEC_ROUNDS = 3;
 __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
                                                         const uint32_t *__restrict__ md,
                                                         uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit,
@@ -412,21 +413,29 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restr
         v3 = fetch(g + 4);
         if (base < end) {
             // The scalar unit is shared by the whole CU and the walk is a chain of dependent steps: the
-            // vector side precomputes, for every position, where TWO steps lead (one ds_bpermute) and the
-            // two bits they visit, so that the serial loop is three readlanes per two steps.
+            // vector side precomputes, for every position, where 2^SPEC_ROUNDS steps lead and the bits they
+            // visit (pointer doubling, three ds_bpermute per round), so that the serial loop is three readlanes
+            // per eight steps.
             const uint32_t stepv = (v & 0xFFFFu) ? (v >> 16) : 1u;
             const uint32_t stop_r = min(base + 64, end) - base;
-            const uint32_t j1 = lane + stepv;                       // group-relative position after one step
-            const bool in1 = j1 < stop_r;                           // ... still inside the group
-            const uint32_t j1n = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((in1 ? j1 : lane) << 2), (int)j1);
-            const uint32_t j2 = in1 ? j1n : j1;
-            uint32_t klo = lane < 32 ? 1u << lane : 0u, khi = lane >= 32 ? 1u << (lane - 32) : 0u;
-            if (in1) { if (j1 < 32) klo |= 1u << j1; else khi |= 1u << (j1 - 32); }
+            uint32_t j = lane + stepv;                              // group-relative position after 2^k steps
+            uint32_t klo = lane < 32 ? 1u << lane : 0u, khi = lane >= 32 ? 1u << (lane - 32) : 0u;   // positions visited on the way
+#pragma unroll
+            for (int rd = 0; rd < SPEC_ROUNDS; ++rd) {
+                const bool inside = j < stop_r;                     // ... still inside the group
+                const int from = (int)((inside ? j : lane) << 2);
+                const uint32_t jn = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)j);
+                const uint32_t ln = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)klo);
+                const uint32_t hn = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)khi);
+                klo |= inside ? ln : 0u;
+                khi |= inside ? hn : 0u;
+                j = inside ? jn : j;
+            }
             uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
             while (r < stop_r) {
                 m |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)klo, r) |
                      (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, r) << 32;
-                r = (uint32_t)__builtin_amdgcn_readlane((int)j2, r);
+                r = (uint32_t)__builtin_amdgcn_readlane((int)j, r);
             }
             pos = base + r;
         }
@@ -648,14 +657,15 @@ __global__ __launch_bounds__(256) void histogram_kernel(const ChunkDesc *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void huffman_kernel(const BlockDesc *__restrict__ blocks,
-                                                     const uint32_t *__restrict__ hist,
-                                                     BlockCodes *__restrict__ bc) {
+constexpr int HUFF_THREADS = 256;   // four wavefronts per block: the rank / merge / code passes stride over the lanes
+__global__ __launch_bounds__(HUFF_THREADS) void huffman_kernel(const BlockDesc *__restrict__ blocks,
+                                                               const uint32_t *__restrict__ hist,
+                                                               BlockCodes *__restrict__ bc) {
     __shared__ HuffScratch S;
     const uint32_t b = blockIdx.x;
     const uint32_t type = blocks[b].type;
     if (type == BT_RAW) return;
-    huff_block_build(hist + (uint64_t)b * HIST_STRIDE, type, &bc[b], S, (int)threadIdx.x, 64);
+    huff_block_build(hist + (uint64_t)b * HIST_STRIDE, type, &bc[b], S, (int)threadIdx.x, HUFF_THREADS);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1300,7 +1310,7 @@ int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, 
 int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,
                    BlockCodes *bc) {
     if (nblocks == 0) return 0;
-    hipLaunchKernelGGL(huffman_kernel, dim3(nblocks), dim3(64), 0, st, blocks, hist, bc);
+    hipLaunchKernelGGL(huffman_kernel, dim3(nblocks), dim3(HUFF_THREADS), 0, st, blocks, hist, bc);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -76,6 +76,7 @@ struct HuffScratch {
     uint16_t clc[19];
     uint8_t lw[HMAX];            // saved literal widths while the clen code is built
     uint8_t dw[32];
+    uint32_t hdrw[160];          // the header bits are assembled here (not by read-modify-write on global memory)
 };
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -351,8 +352,8 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
             if (S.freq[i] != 0 && S.clw[i] > 0) { bcc = k + 1; break; }
         }
         if (bcc < 4) bcc = 4;
-        for (int i = 0; i < 160; i++) out->hdr[i] = 0;
-        HdrWriter hw{out->hdr, 0};
+        for (int i = 0; i < 160; i++) S.hdrw[i] = 0;
+        HdrWriter hw{S.hdrw, 0};
         hw.put(5, (uint32_t)(nl - 257));
         hw.put(5, (uint32_t)(nd - 1));
         hw.put(4, (uint32_t)(bcc - 4));
@@ -365,11 +366,23 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
             if (S.rl_bits[i]) hw.put(S.rl_bits[i], S.rl_extra[i]);
         }
         out->hdr_bits = hw.nbits;
-        uint64_t bits = 3 + (uint64_t)hw.nbits;
-        for (int s = 0; s < 286; s++)
-            bits += (uint64_t)hist[s] * (S.lw[s] + (s > 256 ? len_extra_bits_of_symbol((uint32_t)s) : 0));
-        for (int d = 0; d < 30; d++)
-            bits += (uint64_t)hist[288 + d] * (S.dw[d] + dist_extra_bits_of_symbol((uint32_t)d));
+        S.rl_n = (int32_t)hw.nbits;   // (for the sum below)
+    }
+    LFX_SYNC();
+    // header words out; body size = 3 + header + Σ count · (width + extra bits), partial sums per lane
+    for (int i = lane; i < 160; i += nlanes) out->hdr[i] = S.hdrw[i];
+    {
+        uint64_t part = 0;
+        for (int s = lane; s < 286; s += nlanes)
+            part += (uint64_t)hist[s] * (S.lw[s] + (s > 256 ? len_extra_bits_of_symbol((uint32_t)s) : 0));
+        for (int d = lane; d < 30; d += nlanes)
+            part += (uint64_t)hist[288 + d] * (S.dw[d] + dist_extra_bits_of_symbol((uint32_t)d));
+        S.cur[lane] = part;           // (the weighted lists are no longer needed)
+    }
+    LFX_SYNC();
+    if (lane == 0) {
+        uint64_t bits = 3 + (uint64_t)(uint32_t)S.rl_n;
+        for (int l = 0; l < nlanes; l++) bits += S.cur[l];
         out->body_bits = bits;
     }
     LFX_SYNC();
