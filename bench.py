@@ -38,7 +38,7 @@ WRITE = 8192
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 
 # phase (HIP-event bracket in the library) -> the kernel that fills it
-PHASE_KERNEL = {"enc:lz77_match": "lz77_match2_kernel", "dec:lz77_copy": "blk_materialize_kernel",
+PHASE_KERNEL = {"enc:lz77_match": "lz77_match2_kernel", "dec:lz77_copy": "blk_materialize2_kernel",
                 "dec:blk_scan": "blk_scan_kernel", "dec:blk_emit": "blk_emit_kernel", "enc:lz77_parse": "parse_spec_kernel"}
 CALIBRATION_KERNEL = "checksum_span_kernel"   # reads its input exactly once with wide coalesced loads
 
@@ -76,6 +76,7 @@ def measure_traffic(kernel, n, schedule):
             for (name, _), v in acc.items():
                 per.setdefault(name, []).append(v)
             out[counter] = {k: sum(v) / len(v) for k, v in per.items()}     # KiB per dispatch
+            out[counter + ":step"] = {k: sum(v) for k, v in per.items()}    # KiB per step (the child runs ONE step)
     except Exception as e:  # noqa: BLE001
         return {"error": "traffic measurement failed: %r" % (e,)}
     finally:
@@ -91,8 +92,21 @@ def measure_traffic(kernel, n, schedule):
     if not cal or fetch is None or write is None:
         return {"error": "kernel %s not in the counter output" % kernel}
     factor = n / (cal * 1024.0)           # ≈ 2 on gfx950
+    # every lfx kernel of one encode+decode step: HBM bytes (same correction), largest first
+    per_kernel = {}
+    for name, kib in out["FETCH_SIZE:step"].items():
+        if "lfx::" in name:
+            per_kernel[name.replace("lfx::", "")] = kib * 1024 * factor
+    for name, kib in out["WRITE_SIZE:step"].items():
+        if "lfx::" in name:
+            key = name.replace("lfx::", "")
+            per_kernel[key] = per_kernel.get(key, 0.0) + kib * 1024
+    step_total = int(sum(per_kernel.values()))
+    top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:12]
     return {"hbm_bytes": int(fetch * 1024 * factor + write * 1024), "fetch_bytes": int(fetch * 1024 * factor),
             "write_bytes": int(write * 1024), "fetch_size_correction": round(factor, 3),
+            "step_hbm_bytes_all_kernels": step_total,
+            "step_hbm_bytes_by_kernel": {k: int(v) for k, v in top},
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child passes of this run"}
 
 
@@ -350,6 +364,7 @@ def main():
     dom = max(kernel_phases, key=kernel_phases.get) if kernel_phases else None
     algo_bytes = n + m     # encode N read + C written; decode C read + N written
     roof = None
+    step_traffic = None
     if dom:
         ach = algo_bytes / (avg[dom] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "kernel_name": PHASE_KERNEL.get(dom), "achieved": round(ach, 2),
@@ -362,11 +377,14 @@ def main():
             if t and "hbm_bytes" in t:
                 roof["traffic"] = t["hbm_bytes"]
                 roof["traffic_detail"] = t
+                step_traffic = t.get("step_hbm_bytes_all_kernels")
             else:
                 roof["traffic_error"] = (t or {}).get("error", "unknown")
     whole_ach = 2.0 * algo_bytes * world / (elapsed / args.steps) / 1e9
     whole = {"achieved": round(whole_ach, 2), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
-             "frac": round(whole_ach / (HBM_PEAK_GBPS * world), 5), "algorithmic_bytes_per_step": 2 * algo_bytes * world}
+             "frac": round(whole_ach / (HBM_PEAK_GBPS * world), 5), "algorithmic_bytes_per_step": 2 * algo_bytes * world,
+             "traffic": step_traffic,
+             "traffic_over_algorithmic": round(step_traffic / (2.0 * algo_bytes), 2) if step_traffic else None}
     # ---- the other write schedule of SURVEY cfg2 in the same run (fewer steps: it is a sub-record, not the metric)
     s1 = None
     if world == 1 and not sharded_path and not args.no_s1:

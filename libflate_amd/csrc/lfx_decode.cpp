@@ -115,7 +115,9 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
     std::vector<InflateResult> res;
     bool parallel_done = false;
     const uint64_t comp = n > off0 ? n - off0 : 0;
-    if (comp >= (64u << 10)) {
+    // (below a few KiB the exact serial kernel is faster than the parallel path's fixed cost of about 2 ms; measured:
+    //  a 32 KiB stream takes 17 ms on the serial kernel)
+    if (comp >= (4u << 10)) {
         // ---- speculative block-start search
         // survivors of stage 1 are ~0.1 % of the bit offsets (more on incompressible data): room for 0.4 % of them, so
         // that a gibibyte-sized stream does not overflow the lists and fall back to the serial walk
