@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lfx_common.h"
 #include "lfx_decode.h"
 
@@ -1036,13 +1038,18 @@ __device__ __forceinline__ uint32_t m2_back(uint32_t idx, uint32_t d) {         
     return min(a, a + M2_RING);
 }
 
-__global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint8_t *__restrict__ in,
-                                                                      const BlkEmit *__restrict__ jobs,
-                                                                      const BlkUnits *__restrict__ units,
-                                                                      const uint32_t *__restrict__ codes,
-                                                                      uint8_t *__restrict__ out, uint32_t njobs,
-                                                                      uint64_t *__restrict__ dbg) {
-    __shared__ __attribute__((aligned(16))) unsigned char ring[M2_RING + 64];   // (+ a dump for the stores of idle bytes)
+// One body for both materialisations: SYM = false writes BYTES (direct path: the unit's history is known or empty),
+// SYM = true writes 16-bit SYMBOLS for the marker path (below): the 32 Ki entries in front of the unit start out as the
+// markers 256 + j, and the units are the ones cut without regard to back-references (fcode0 / fout0).
+template <bool SYM>
+__device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in, const BlkEmit *__restrict__ jobs,
+                                                  const BlkUnits *__restrict__ units,
+                                                  const uint32_t *__restrict__ codes,
+                                                  typename std::conditional<SYM, uint16_t, uint8_t>::type *__restrict__ out,
+                                                  uint32_t njobs, uint64_t *__restrict__ dbg) {
+    using elem_t = typename std::conditional<SYM, uint16_t, uint8_t>::type;
+    constexpr uint32_t EPD = 4 / sizeof(elem_t);                                // elements per dword (flush granule)
+    __shared__ __attribute__((aligned(16))) elem_t ring[M2_RING + 64];   // (+ a dump for the stores of idle bytes)
     __shared__ __attribute__((aligned(8))) uint16_t P[M2_PASSES * 4 * M2_THREADS];
     // per code of the tile: x = inclusive end offset, y = code word; four sentinels behind the last (never passed)
     __shared__ __attribute__((aligned(8))) uint2 XC[M2_THREADS + 4];
@@ -1053,24 +1060,26 @@ __global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (job.btype == 0) {
         if (u != 0) return;
-        uint8_t *o = out + job.out_off;
+        elem_t *o = out + job.out_off;
         const uint8_t *src = in + (job.data_bit >> 3);
         for (uint64_t k = tid; k < job.n_out; k += M2_THREADS) o[k] = src[k];
         return;
     }
     const BlkUnits *U = &units[bidx];
-    if (u >= U->n) return;
-    const uint32_t c0 = U->code0[u], c1 = U->code0[u + 1];
-    const uint64_t ob = U->out0[u];
+    if (u >= (SYM ? U->fn : U->n)) return;
+    const uint32_t c0 = SYM ? U->fcode0[u] : U->code0[u], c1 = SYM ? U->fcode0[u + 1] : U->code0[u + 1];
+    const uint64_t ob = SYM ? U->fout0[u] : U->out0[u];
     const uint64_t gbase = job.out_off + ob;
-    uint8_t *o = out + gbase;
+    elem_t *o = out + gbase;
     const uint32_t *cp = codes + job.code_off + c0;
     const uint32_t n = c1 - c0;
-    // unit byte p lives at ring index (p + shift) mod M2_RING; ring and output share their 4-byte alignment.
-    // History in front of the block (batch rounds / ordered runs: already final in `out`): up to 32 KiB preloaded.
-    const uint32_t hist = (u == 0 && job.preload) ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
-    const uint32_t shift = (uint32_t)((gbase - hist) & 3) + hist;       // < M2_RING
-    for (uint32_t k = tid; k < hist; k += M2_THREADS) ring[shift - hist + k] = o[(int64_t)k - (int64_t)hist];
+    // unit element p lives at ring index (p + shift) mod M2_RING; ring and output share their dword alignment.
+    // History in front of the block (batch rounds / ordered runs: already final in `out`): up to 32 KiB preloaded;
+    // SYM: the 32 Ki markers "entry j of the window in front of this unit".
+    const uint32_t hist = SYM ? 32768u : (u == 0 && job.preload) ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
+    const uint32_t shift = (uint32_t)((gbase - hist) & (EPD - 1)) + hist;       // < M2_RING
+    for (uint32_t k = tid; k < hist; k += M2_THREADS)
+        ring[shift - hist + k] = SYM ? (elem_t)(256 + k) : (elem_t)o[(int64_t)k - (int64_t)hist];
     if (tid < 4) XC[M2_THREADS + tid] = make_uint2(0xFFFFFFFFu, 0u);
     uint64_t produced = 0, flushed = 0;
     uint32_t tr = shift;                       // ring index of the tile's first byte
@@ -1137,7 +1146,7 @@ __global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint
 #pragma unroll
                 for (uint32_t q = 0; q < 4; ++q) hv[q] = ring[src[q] & 0xFFFFu];
 #pragma unroll
-                for (uint32_t q = 0; q < 4; ++q) ring[dst[q]] = (unsigned char)(lit[q] ? src[q] >> 16 : hv[q]);
+                for (uint32_t q = 0; q < 4; ++q) ring[dst[q]] = (elem_t)(lit[q] ? src[q] >> 16 : hv[q]);
                 pend |= (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) != M2_DONE;
             }
             *(uint64_t *)&P[b] = (uint64_t)pp[ps][0] | (uint64_t)pp[ps][1] << 16 | (uint64_t)pp[ps][2] << 32 | (uint64_t)pp[ps][3] << 48;
@@ -1171,7 +1180,7 @@ __global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint
                     for (uint32_t q = 0; q < 4; ++q) {
                         // (a byte that was final before reads itself — also one behind the tile — and writes the same
                         //  byte and the same state back)
-                        ring[m2_wrap(tr + b + q)] = (unsigned char)hv[q];
+                        ring[m2_wrap(tr + b + q)] = (elem_t)hv[q];
                         pp[ps][q] = nx[q];
                     }
                     asm volatile("" ::: "memory");   // ... and the bytes are stored BEFORE the states
@@ -1186,18 +1195,18 @@ __global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint
         const uint64_t upto = produced + total;
         base += take;
         const bool last = base >= n;
-        if ((gbase + flushed) & 3) {   // (only in front of the first aligned dword)
-            uint32_t hb = 4 - (uint32_t)((gbase + flushed) & 3);
+        if ((gbase + flushed) & (EPD - 1)) {   // (only in front of the first aligned dword)
+            uint32_t hb = EPD - (uint32_t)((gbase + flushed) & (EPD - 1));
             if (hb > upto - flushed) hb = (uint32_t)(upto - flushed);
             if (tid < hb) o[flushed + tid] = ring[m2_wrap(fr + tid)];
             flushed += hb;
             fr = m2_wrap(fr + hb);
         }
-        const uint32_t ndw = (uint32_t)((upto - flushed) >> 2);
+        const uint32_t ndw = (uint32_t)((upto - flushed) / EPD);
         uint32_t *o32 = (uint32_t *)(o + flushed);
-        for (uint32_t k = tid; k < ndw; k += M2_THREADS) o32[k] = *(const uint32_t *)&ring[m2_wrap(fr + 4 * k)];
-        flushed += 4ull * ndw;
-        fr = m2_wrap(fr + 4 * ndw);
+        for (uint32_t k = tid; k < ndw; k += M2_THREADS) o32[k] = *(const uint32_t *)&ring[m2_wrap(fr + EPD * k)];
+        flushed += (uint64_t)EPD * ndw;
+        fr = m2_wrap(fr + EPD * ndw);
         if (last) {
             const uint32_t rest = (uint32_t)(upto - flushed);
             if (tid < rest) o[flushed + tid] = ring[m2_wrap(fr + tid)];
@@ -1207,10 +1216,20 @@ __global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint
         tr = m2_wrap(tr + total);
         c_cur = take == M2_THREADS ? c_pref : ((uint64_t)base + tid < n ? cp[base + tid] : 0);   // rare path: reload
     }
-    if (dbg && tid == 0) {
+    if (!SYM && dbg && tid == 0) {
         uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
         d[0] = clock64() - t0; d[1] = ntiles; d[2] = nrounds; d[3] = 0; d[4] = n; d[5] = produced; d[6] = wall_clock64();
     }
+}
+
+
+__global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint8_t *__restrict__ in,
+                                                                      const BlkEmit *__restrict__ jobs,
+                                                                      const BlkUnits *__restrict__ units,
+                                                                      const uint32_t *__restrict__ codes,
+                                                                      uint8_t *__restrict__ out, uint32_t njobs,
+                                                                      uint64_t *__restrict__ dbg) {
+    materialize2_body<false>(in, jobs, units, codes, out, njobs, dbg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1567,6 +1586,16 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
     }
 }
 
+// marker path, pass 1, second generation: the byte kernel's tiles on 16-bit symbols (75 KB of LDS: two units per CU,
+// eight wavefronts per CU where the first-generation kernel above runs two)
+__global__ __launch_bounds__(M2_THREADS) void blk_materialize2_sym_kernel(const uint8_t *__restrict__ in,
+                                                                          const BlkEmit *__restrict__ jobs,
+                                                                          const BlkUnits *__restrict__ units,
+                                                                          const uint32_t *__restrict__ codes,
+                                                                          uint16_t *__restrict__ sym, uint32_t njobs) {
+    materialize2_body<true>(in, jobs, units, codes, sym, njobs, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------
 #define LFX_LAUNCH_CHECK()                          \
     do {                                            \
@@ -1621,6 +1650,12 @@ int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit 
     if (!attr_set[dev_ & 63]) {
         (void)hipFuncSetAttribute((const void *)blk_materialize_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SWIN * 2));
         attr_set[dev_ & 63] = true;
+    }
+    static const bool first_gen = getenv("LFX_MAT_V1") != nullptr;   // (A/B measurements)
+    if (!first_gen) {
+        hipLaunchKernelGGL(blk_materialize2_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, sym, njobs);
+        LFX_LAUNCH_CHECK();
+        return 0;
     }
     hipLaunchKernelGGL(blk_materialize_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(64), SWIN * 2, st, in, jobs, units, codes, sym, njobs);
     LFX_LAUNCH_CHECK();
