@@ -367,9 +367,16 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 // K3 keeps four units resident per CU (LDS): size the units so that all of them are resident at once
                 const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
                 const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
+                // marker units (used only when blocks read earlier blocks): two symbol units are resident per CU and the
+                // symbol kernel's time does not depend on the unit size as long as every slot has a unit, while every
+                // unit costs the window resolution 32 Ki lookups (256 MiB: 128 KiB units 1.31 + 0.74 ms, 512 KiB units
+                // 0.59 + 0.64 ms for window resolution + substitution)
+                uint32_t free_shift = 17;
+                while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
+                if (const char *fs = getenv("LFX_FREE_SHIFT")) free_shift = (uint32_t)atoi(fs);
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                            (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
-                                           c->d_dec_tabs.p));
+                                           c->d_dec_tabs.p, free_shift));
                 c->phase("blk_emit");
                 // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
                 // the marker path, which may cut anywhere

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
                                                                 const BlkLanes *__restrict__ lanes,
                                                                 uint32_t *__restrict__ codes,
                                                                 uint32_t *__restrict__ flags,
-                                                                BlkUnits *__restrict__ units, uint32_t unit_target,
+                                                                BlkUnits *__restrict__ units, uint32_t unit_target, uint32_t free_shift,
                                                                 uint32_t *__restrict__ job_flags,
                                                                 const FastTabs *__restrict__ tabs) {
     __shared__ FastTabs T;
@@ -821,10 +821,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         U->code0[nu] = job.n_codes; U->out0[nu] = job.n_out;
         U->n = nu;
         // ... and cut at slice boundaries without regard to back-references (marker-based materialisation)
-        // (units of about 128 KiB: every unit costs the in-order window chain 32 Ki lookups, and a unit's own
-        // materialisation is a serial walk — the two balance around 100 KiB)
+        // (units of 2^free_shift bytes, 128 KiB and up: every unit costs the window resolution 32 Ki lookups; the host
+        // sizes them so that the stream still has a few units per resident slot)
         uint32_t fn = 0;
-        uint32_t fwant = (uint32_t)(job.n_out >> 17);
+        uint32_t fwant = (uint32_t)(job.n_out >> free_shift);
         fwant = fwant < 1 ? 1 : fwant > MAX_FREE_UNITS ? MAX_FREE_UNITS : fwant;
         U->fcode0[0] = 0; U->fout0[0] = 0;
         for (uint32_t b = 1; b < fwant; ++b) {
@@ -1613,7 +1613,7 @@ int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
 }
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
-                    uint32_t *job_flags, const void *tabs) {
+                    uint32_t *job_flags, const void *tabs, uint32_t free_shift) {
     if (!njobs) return 0;
     constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
     // (a function attribute is per device: one flag per device ordinal)
@@ -1625,7 +1625,7 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
         attr_set[dev_ & 63] = true;
     }
     hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes, flags, units,
-                       unit_target ? unit_target : 1u, job_flags, (const FastTabs *)tabs);
+                       unit_target ? unit_target : 1u, free_shift < 17 ? 17u : free_shift, job_flags, (const FastTabs *)tabs);
     LFX_LAUNCH_CHECK();
     return 0;
 }
