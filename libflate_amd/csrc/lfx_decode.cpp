@@ -606,7 +606,8 @@ int decode_stream(Ctx *c, int format, uint32_t flags, const uint8_t *d_in, uint6
             const uint64_t nspans = div_up(std::max<uint64_t>(mr.out_len, 1), 65536);   // CK_SPAN
             if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
             uint32_t *ck = (uint32_t *)c->d_ck.p;
-            LAUNCH_TRY(launch_checksum(st, d_out + out_at, mr.out_len, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p));
+            LAUNCH_TRY(launch_checksum(st, d_out + out_at, mr.out_len, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,
+                                       format == LFX_GZIP ? 1 : format == LFX_ZLIB ? 2 : 3));
             HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(t, d_in + tpos, need, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

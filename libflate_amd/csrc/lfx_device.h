@@ -47,7 +47,8 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
                 const uint64_t *block_start, uint32_t *tile_bits, uint64_t *tile_start,
                 const EncodeResult *res, uint64_t out_base_bit, uint32_t *out);
 int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
-                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res);
+                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res,
+                    int mode = 3)   /* bit 0: CRC-32, bit 1: Adler-32 (the other result is then 0) */;
 // CRC-32 / Adler-32 of count byte ranges data[off[i*off_stride] .. +len[i*len_stride]) (strides in 8-byte units)
 int launch_checksum_ranges(hipStream_t st, const uint8_t *data, uint32_t count, const uint64_t *off,
                            uint32_t off_stride, const uint64_t *len, uint32_t len_stride, uint32_t *crc, uint32_t *adler);

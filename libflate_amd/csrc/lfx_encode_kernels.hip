@@ -1035,8 +1035,12 @@ __device__ __forceinline__ void ck_tables(uint32_t (*tab)[256], uint32_t (*advt)
 // 4 KiB at a time (coalesced); a lane advances its register over the 4032 bytes of the other lanes with
 // one multiplication by x^(8*4032) mod P.  Results are valid in every lane.
 struct CkPartial { uint32_t crc, a, b; };
+// MODE bit 0: CRC-32, bit 1: Adler-32 (a caller that needs one of them does not pay for the other: the kernel is
+// bound by its instruction count, not by the 64 KiB it reads)
+template <int MODE = 3>
 __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t rlen, uint32_t lane,
                                                      const uint32_t (*tab)[256], const uint32_t (*advt)[256]) {
+    constexpr bool CRC = (MODE & 1) != 0, ADL = (MODE & 2) != 0;
     const ByteSrc src = make_src(p, rlen);
     // Invariant: `crc` is the raw register of this lane's bytes with zeros everywhere else, standing at
     // region offset `stand`.
@@ -1045,7 +1049,7 @@ __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t 
     uint64_t s2 = 0;                  // sum of (offset in region) * byte
     const uint32_t first = 64 * lane;
     for (uint32_t o = first; o < rlen; o += 4096) {
-        if (o != first)                                  // over the other lanes' 4032 bytes
+        if (CRC && o != first)                           // over the other lanes' 4032 bytes
             crc = advt[0][crc & 0xFF] ^ advt[1][(crc >> 8) & 0xFF] ^ advt[2][(crc >> 16) & 0xFF] ^ advt[3][crc >> 24];
         const uint32_t len = min(64u, rlen - o);         // only the last piece can be short
         // all sixteen loads are issued before the (serially dependent) table walk starts
@@ -1057,17 +1061,20 @@ __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t 
         for (uint32_t q = 0; q < 16; ++q) {
             const uint32_t m = len > 4 * q ? min(4u, len - 4 * q) : 0u;
             if (m == 4) {
-                const uint32_t x = crc ^ w[q];
-                crc = tab[3][x & 0xFF] ^ tab[2][(x >> 8) & 0xFF] ^ tab[1][(x >> 16) & 0xFF] ^ tab[0][x >> 24];
-                const uint32_t b0 = w[q] & 0xFF, b1 = (w[q] >> 8) & 0xFF, b2 = (w[q] >> 16) & 0xFF, b3 = w[q] >> 24;
-                s1 += b0 + b1 + b2 + b3;
-                wsum += 4 * q * (b0 + b1 + b2 + b3) + b1 + 2 * b2 + 3 * b3;
+                if (CRC) {
+                    const uint32_t x = crc ^ w[q];
+                    crc = tab[3][x & 0xFF] ^ tab[2][(x >> 8) & 0xFF] ^ tab[1][(x >> 16) & 0xFF] ^ tab[0][x >> 24];
+                }
+                if (ADL) {
+                    const uint32_t b0 = w[q] & 0xFF, b1 = (w[q] >> 8) & 0xFF, b2 = (w[q] >> 16) & 0xFF, b3 = w[q] >> 24;
+                    s1 += b0 + b1 + b2 + b3;
+                    wsum += 4 * q * (b0 + b1 + b2 + b3) + b1 + 2 * b2 + 3 * b3;
+                }
             } else {
                 for (uint32_t k = 0; k < m; ++k) {
                     const uint32_t byte = (w[q] >> (8 * k)) & 0xFF;
-                    crc = (crc >> 8) ^ tab[0][(crc ^ byte) & 0xFF];
-                    s1 += byte;
-                    wsum += (4 * q + k) * byte;
+                    if (CRC) crc = (crc >> 8) ^ tab[0][(crc ^ byte) & 0xFF];
+                    if (ADL) { s1 += byte; wsum += (4 * q + k) * byte; }
                 }
             }
         }
@@ -1076,18 +1083,24 @@ __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t 
         stand = o + len;
     }
     // every lane's register is brought to the region end; then they simply XOR together
-    uint32_t reg = first < rlen ? gf2_mulmod(crc, gf2_xpow8n(rlen - stand)) : 0u;
-    for (int o = 32; o > 0; o >>= 1) reg ^= __shfl_xor(reg, o);
-    uint64_t t1 = s1, t2 = s2 % 65521u;
-    for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
     CkPartial r;
-    r.crc = reg;
-    r.a = (uint32_t)(t1 % 65521u);
-    // sum over i of (rlen - i) * byte_i = rlen * S1 - S2
-    r.b = (uint32_t)(((uint64_t)(rlen % 65521u) * r.a + 65521ull * 65521ull - (t2 % 65521u)) % 65521u);
+    r.crc = 0; r.a = 0; r.b = 0;
+    if (CRC) {
+        uint32_t reg = first < rlen ? gf2_mulmod(crc, gf2_xpow8n(rlen - stand)) : 0u;
+        for (int o = 32; o > 0; o >>= 1) reg ^= __shfl_xor(reg, o);
+        r.crc = reg;
+    }
+    if (ADL) {
+        uint64_t t1 = s1, t2 = s2 % 65521u;
+        for (int o = 32; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o); t2 += __shfl_xor(t2, o); }
+        r.a = (uint32_t)(t1 % 65521u);
+        // sum over i of (rlen - i) * byte_i = rlen * S1 - S2
+        r.b = (uint32_t)(((uint64_t)(rlen % 65521u) * r.a + 65521ull * 65521ull - (t2 % 65521u)) % 65521u);
+    }
     return r;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__restrict__ in,
                                                             uint64_t n, uint32_t *__restrict__ crc_part,
                                                             uint32_t *__restrict__ a_part,
@@ -1100,7 +1113,7 @@ __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__res
     const uint64_t r0 = region * CK_SPAN;
     if (r0 >= n) return;
     const uint32_t rlen = (uint32_t)min((uint64_t)CK_SPAN, n - r0);
-    const CkPartial r = ck_span_partial(in + r0, rlen, lane, tab, advt);
+    const CkPartial r = ck_span_partial<MODE>(in + r0, rlen, lane, tab, advt);
     if (lane == 0) { crc_part[region] = r.crc; a_part[region] = r.a; b_part[region] = r.b; }
 }
 
@@ -1345,11 +1358,13 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
     return 0;
 }
 int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
-                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res) {
+                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res, int mode) {
     const uint64_t nspans = div_up(n, CK_SPAN);
     if (nspans) {
-        hipLaunchKernelGGL(checksum_span_kernel, dim3((uint32_t)div_up(nspans, 4)), dim3(256), 0, st,
-                           in, n, crc_part, a_part, b_part);
+        const dim3 grid((uint32_t)div_up(nspans, 4));
+        if (mode == 1) hipLaunchKernelGGL(checksum_span_kernel<1>, grid, dim3(256), 0, st, in, n, crc_part, a_part, b_part);
+        else if (mode == 2) hipLaunchKernelGGL(checksum_span_kernel<2>, grid, dim3(256), 0, st, in, n, crc_part, a_part, b_part);
+        else hipLaunchKernelGGL(checksum_span_kernel<3>, grid, dim3(256), 0, st, in, n, crc_part, a_part, b_part);
         LFX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(checksum_combine_kernel, dim3(1), dim3(1024), 0, st, crc_part, a_part, b_part,
