@@ -76,7 +76,9 @@ def measure_traffic(kernel, n, schedule):
             for (name, _), v in acc.items():
                 per.setdefault(name, []).append(v)
             out[counter] = {k: sum(v) / len(v) for k, v in per.items()}     # KiB per dispatch
-            out[counter + ":step"] = {k: sum(v) for k, v in per.items()}    # KiB per step (the child runs ONE step)
+            # KiB per encode+decode step: the child's steps = dispatches of a kernel that runs exactly once per step
+            nsteps = max([len(v) for k, v in per.items() if CALIBRATION_KERNEL + "<3>" in k or "lz77_match" in k] or [1])
+            out[counter + ":step"] = {k: sum(v) / nsteps for k, v in per.items()}
     except Exception as e:  # noqa: BLE001
         return {"error": "traffic measurement failed: %r" % (e,)}
     finally:
@@ -106,6 +108,8 @@ def measure_traffic(kernel, n, schedule):
     return {"hbm_bytes": int(fetch * 1024 * factor + write * 1024), "fetch_bytes": int(fetch * 1024 * factor),
             "write_bytes": int(write * 1024), "fetch_size_correction": round(factor, 3),
             "step_hbm_bytes_all_kernels": step_total,
+            "fetch_calibration": "x%.3f on %s in this run; profiles/r02_fetch_calibration.txt: the same x2 for 16 B/lane and "
+                                 "4 B/lane coalesced reads, x2 with 17 %% real re-fetch for 4 B/lane strided reads" % (factor, CALIBRATION_KERNEL),
             "step_hbm_bytes_by_kernel": {k: int(v) for k, v in top},
             "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child passes of this run"}
 

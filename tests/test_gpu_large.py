@@ -1,5 +1,6 @@
 """GPU: BASELINE.json-size checks through size-independent properties (round trip, checksum of the
 round trip, python-zlib as an independent inflater) plus a 64 MiB byte-for-byte oracle comparison."""
+import os
 import zlib as pyzlib
 
 import numpy as np
@@ -233,7 +234,7 @@ def test_foreign_streams_fuzz(env):
     text = synth.text(6 << 20, seed=0x5EED000B).tobytes()
     low = synth.lowent(3 << 20, seed=0x5EED000C).tobytes()
     strategies = [pyzlib.Z_DEFAULT_STRATEGY, pyzlib.Z_FILTERED, pyzlib.Z_HUFFMAN_ONLY, pyzlib.Z_RLE, pyzlib.Z_FIXED]
-    for trial in range(24):
+    for trial in range(int(os.environ.get("LFX_FOREIGN_TRIALS", "24"))):
         src = text if trial % 3 else low
         n = int(rng.integers(300000, min(len(src), 4 << 20)))
         o = int(rng.integers(0, len(src) - n + 1))
