@@ -1484,15 +1484,23 @@ __device__ __forceinline__ void clen_table_build(uint8_t *tab, uint32_t lane, ui
         next |= (uint64_t)code << (8 * w);
         code += (uint32_t)(cnt >> (5 * w)) & 31;
     }
+    // base entries: a code of width w sits at entry r = its reversed bits (r < 2^w) ...
     for (uint32_t s = 0; s < 19; ++s) {
         const uint32_t w = (uint32_t)(clw >> (3 * s)) & 7;
-        if (w == 0) continue;
         const uint32_t c = (uint32_t)(next >> (8 * w)) & 255;
-        next += 1ull << (8 * w);
+        next += w ? 1ull << (8 * w) : 0ull;
         const uint32_t r = __brev(c) >> (32 - w);
-        const uint8_t e = (uint8_t)(s | w << 5);
-        for (uint32_t i = r; i < 128; i += 1u << w) tab[i * 64 + lane] = e;
+        if (w) tab[r * 64 + lane] = (uint8_t)(s | w << 5);
     }
+    // ... and is replicated upward: entry i + 2^k (i < 2^k) decodes like entry i iff that code is at most k bits wide
+    // (otherwise bit k belongs to the code and i + 2^k is a base entry of its own).  127 uniform steps instead of one
+    // divergent fill loop per symbol; the code is complete (stage 1), so every entry ends up written.
+#pragma unroll 1
+    for (uint32_t k = 0; k < 7; ++k)
+        for (uint32_t i = 0; i < (1u << k); ++i) {
+            const uint8_t e = tab[i * 64 + lane];
+            if ((uint32_t)(e >> 5) <= k) tab[(i + (1u << k)) * 64 + lane] = e;
+        }
 }
 
 // block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
@@ -1522,30 +1530,58 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
     // a header is at most 17 + 19*3 + 320*(7+7) = 4554 bits long: when every candidate of the wavefront lies
     // further than that from the end of the stream, the walk needs no bounds checks at all
     const bool lean = __ballot(cand[i] + 6000 > hb.nbits) == 0;
-    while (lean && have < total && good) {
-        hb.b.refill();
-        const uint32_t e = cl_tab[((uint32_t)hb.b.buf & 127) * 64 + threadIdx.x];
-        const uint32_t sym = e & 31, used = e >> 5;
-        // repeat codes 16 / 17 / 18: extra bits 2 / 3 / 7, base count 3 / 3 / 11 (packed nibble tables)
-        const uint32_t k4 = (sym > 15 ? sym - 15 : 0) * 4;
-        const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
-        const uint32_t rep = basex + (((uint32_t)(hb.b.buf >> used)) & ((1u << nbx) - 1));
-        const uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
-        hb.b.buf >>= used + nbx;
-        hb.b.nb -= used + nbx;
-        if ((sym == 16 && have == 0) || have + rep > total) { good = false; break; }
-        if (val) {
+    if (lean) {
+        // Branch-free walk, one uniform loop for the wavefront: nearly every false candidate runs until its literal /
+        // length widths are complete (their Kraft sum only then shows), so the wavefront's time is its instruction
+        // count per step.  A lane that is done or dead is frozen (zero-length step) instead of masked off.
+        // Bit source: the position behind the fixed header fields is known arithmetically; a 64-bit window topped up
+        // from a one-dword-ahead pointer, no bounds checks (lean).
+        const uint64_t a = (uint64_t)in;
+        const uint64_t abs = cand[i] + 17 + 3ull * nc + (a & 3) * 8;
+        gptr_u32 p = (gptr_u32)(a & ~3ull) + (abs >> 5);
+        const uint32_t off = (uint32_t)abs & 31;
+        uint64_t buf = ((uint64_t)p[1] << 32 | p[0]) >> off;
+        uint32_t nb = 64 - off;
+        uint32_t nxt = p[2];
+        p += 3;
+        bool run = good && have < total;
+        while (__ballot(run)) {
+            if (nb <= 32) {
+                buf |= (uint64_t)nxt << nb;
+                nb += 32;
+                nxt = *p++;
+            }
+            const uint32_t e = cl_tab[((uint32_t)buf & 127) * 64 + threadIdx.x];
+            const uint32_t sym = e & 31, used = e >> 5;
+            // repeat codes 16 / 17 / 18: extra bits 2 / 3 / 7, base count 3 / 3 / 11 (packed nibble tables)
+            const uint32_t k4 = (sym > 15 ? sym - 15 : 0) * 4;
+            const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
+            uint32_t rep = basex + (((uint32_t)(buf >> used)) & ((1u << nbx) - 1));
+            uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
+            uint32_t adv = used + nbx;
+            bool bad = run && ((sym == 16 && have == 0) || have + rep > total);
+            rep = run ? rep : 0u;
+            val = run ? val : 0u;
+            adv = run ? adv : 0u;
+            buf >>= adv;
+            nb -= adv;
             // [have, have+rep) split at the literal / distance boundary
-            const uint32_t nlit_part = have < nl ? (have + rep <= nl ? rep : nl - have) : 0;
+            const uint32_t nlit_part = have < nl ? min(rep, nl - have) : 0u;
             const uint32_t ndist_part = rep - nlit_part;
-            kl += nlit_part * (32768u >> val); nlit += nlit_part;
-            kd += ndist_part * (32768u >> val); ndist += ndist_part;
-            if (have <= 256 && 256 < have + rep) eob_len = val;
-            if (kl > 32768u || kd > 32768u) { good = false; break; }   // over-subscribed
+            const uint32_t wgt = val ? 32768u >> val : 0u;
+            kl += __umul24(nlit_part, wgt);
+            kd += __umul24(ndist_part, wgt);
+            nlit += val ? nlit_part : 0u;
+            ndist += val ? ndist_part : 0u;
+            eob_len = (val && have <= 256 && 256 < have + rep) ? val : eob_len;
+            bad |= kl > 32768u || kd > 32768u;                       // over-subscribed
+            // the literal / length widths are complete once `have` passes HLIT+257
+            bad |= have + rep >= nl && have < nl && !(kl == 32768u || (nlit == 1 && kl == 16384u));
+            have += rep;
+            last = val;
+            good = good && !bad;
+            run = good && have < total;
         }
-        have += rep;
-        last = val;
-        if (have >= nl && have - rep < nl && !(kl == 32768u || (nlit == 1 && kl == 16384u))) { good = false; break; }
     }
     while (have < total && good) {     // (candidates near the end of the stream: every step checked)
         if (hb.b.pos >= hb.nbits) { good = false; break; }
