@@ -356,7 +356,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
     if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
-    if ((rc = c->d_segtmp.reserve(16ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
+    if ((rc = c->d_segtmp.reserve(24ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
+    if ((rc = c->d_stage.reserve(4ull * (n + 64)))) return rc;   // code words staged by the speculative parse walk
     if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;
@@ -405,7 +406,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     c->phase("lz77_match");
     LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
                             (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
-                            (uint32_t *)c->d_ncodes.p));
+                            (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p));
     c->phase("lz77_parse");
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the histogram

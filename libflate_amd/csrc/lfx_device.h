@@ -34,7 +34,7 @@ int launch_match2(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Ch
                   uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint32_t *flags, uint64_t *dbg = nullptr);
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                  uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
-                 uint32_t *codes, uint32_t *ncodes);
+                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage /* 4 bytes per input byte */);
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
                      const uint32_t *codes, const uint32_t *ncodes, uint32_t *hist);
 int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,

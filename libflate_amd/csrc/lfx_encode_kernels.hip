@@ -384,10 +384,15 @@ __device__ __forceinline__ uint32_t find_seg_chunk(const ChunkDesc *chunks, uint
 }
 
 constexpr int SPEC_ROUNDS = 3;
-__global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
+// The walk also STAGES its code words (stage[], indexed like md: a segment's codes, compacted, from its first
+// position on): the answers are in registers here, and everything behind the point where the true walk merges into
+// the speculative one is final — parse_emit then copies it instead of reading md (4 B per position) a second time.
+__global__ __launch_bounds__(64) void parse_spec_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                        const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
                                                         const uint32_t *__restrict__ md,
                                                         uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit,
-                                                        uint32_t *__restrict__ seg_count) {
+                                                        uint32_t *__restrict__ seg_count,
+                                                        uint32_t *__restrict__ stage) {
     const uint32_t seg = blockIdx.x;
     const uint32_t c = find_seg_chunk(chunks, nchunks, seg);
     const ChunkDesc ch = chunks[c];
@@ -399,18 +404,29 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restr
     uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
     if (ch.flags & CH_LITERALS) return;   // no walk: every byte is a literal
     uint32_t pos = s0, cnt = 0;
-    // answers are prefetched four groups ahead (a group's walk is much shorter than an HBM round trip)
+    const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
+    uint32_t *st = stage + ch.in_off + s0;
+    const uint64_t lt = lanemask_lt();
+    // answers (and the bytes, for the literals) are prefetched four groups ahead (a group's walk is much shorter
+    // than an HBM round trip)
     auto fetch = [&](uint32_t g) -> uint32_t {
         const uint32_t i = s0 + g * 64 + lane;
         return (g < PARSE_SEG / 64 && i < end) ? md[ch.in_off + i] : 0;
     };
+    auto fetch_b = [&](uint32_t g) -> uint32_t {
+        const uint32_t i = s0 + g * 64 + lane;
+        return (g < PARSE_SEG / 64 && i < end) ? src.load1(i) : 0;
+    };
     uint32_t v0 = fetch(0), v1 = fetch(1), v2 = fetch(2), v3 = fetch(3);
+    uint32_t b0 = fetch_b(0), b1 = fetch_b(1), b2 = fetch_b(2), b3 = fetch_b(3);
     for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
         const uint32_t base = s0 + g * 64;
         uint64_t m = 0;
-        const uint32_t v = v0;
+        const uint32_t v = v0, byte = b0;
         v0 = v1; v1 = v2; v2 = v3;
+        b0 = b1; b1 = b2; b2 = b3;
         v3 = fetch(g + 4);
+        b3 = fetch_b(g + 4);
         if (base < end) {
             // The scalar unit is shared by the whole CU and the walk is a chain of dependent steps: the
             // vector side precomputes, for every position, where 2^SPEC_ROUNDS steps lead and the bits they
@@ -440,6 +456,7 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restr
             pos = base + r;
         }
         if (lane == 0) vw[g] = m;
+        if ((m >> lane) & 1) st[cnt + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (byte << 16);
         cnt += __popcll(m);
     }
     if (lane == 0) { seg_exit[seg] = pos; seg_count[seg] = cnt; }
@@ -449,11 +466,11 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const ChunkDesc *__restr
 // that is the speculative exit of s-1 unless s-1 itself never merged (rare: P2b repairs those).  Re-walk
 // from the entry until the walk lands on a position the speculative walk visited — from there on both
 // coincide — and rewrite the visited mask, the count and the exit of the segment accordingly.
-struct SegFix { uint32_t cnt, ex; };
+struct SegFix { uint32_t cnt, ex, mpos, kspec; };   // codes, exit; merge position, staged codes in front of it
 __device__ __forceinline__ SegFix parse_rewalk(const ChunkDesc &ch, const uint32_t *__restrict__ md,
                                                uint64_t *__restrict__ vw, uint32_t s0, uint32_t s1, uint32_t end,
                                                uint32_t e, uint32_t cnt, uint32_t ex, uint32_t lane) {
-    uint32_t pos = e, walked = 0, spec_below = 0;
+    uint32_t pos = e, walked = 0, spec_below = 0, merge_pos = s1;
     bool merged = false;
     for (uint32_t g = 0; g < PARSE_SEG / 64 && !merged; ++g) {
         const uint32_t base = s0 + g * 64;
@@ -471,7 +488,7 @@ __device__ __forceinline__ SegFix parse_rewalk(const ChunkDesc &ch, const uint32
         uint32_t mr = 64;
         while (pos < stop) {
             const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
-            if ((V >> r) & 1) { merged = true; mr = r; break; }
+            if ((V >> r) & 1) { merged = true; mr = r; merge_pos = base + r; break; }
             const uint32_t mv = __builtin_amdgcn_readlane(v, r);
             T |= 1ull << r;
             walked++;
@@ -482,8 +499,8 @@ __device__ __forceinline__ SegFix parse_rewalk(const ChunkDesc &ch, const uint32
         if (lane == 0) vw[g] = T | keep;
     }
     SegFix f;
-    if (merged) { f.cnt = cnt - spec_below + walked; f.ex = ex; }   // the exit stays the one already known
-    else { f.cnt = walked; f.ex = pos; }                             // never merged inside this segment
+    if (merged) { f.cnt = cnt - spec_below + walked; f.ex = ex; f.mpos = merge_pos; f.kspec = spec_below; }   // the exit stays the one already known
+    else { f.cnt = walked; f.ex = pos; f.mpos = s1; f.kspec = cnt; }     // never merged inside this segment: nothing staged survives
     return f;
 }
 
@@ -491,7 +508,9 @@ __global__ __launch_bounds__(64) void parse_fixseg_kernel(const ChunkDesc *__res
                                                           const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
                                                           const uint32_t *__restrict__ seg_exit,
                                                           uint32_t *__restrict__ seg_count,
-                                                          uint32_t *__restrict__ seg_exit2) {
+                                                          uint32_t *__restrict__ seg_exit2,
+                                                          uint32_t *__restrict__ seg_mpos,
+                                                          uint32_t *__restrict__ seg_kspec) {
     const uint32_t seg = blockIdx.x;
     const ChunkDesc ch = chunks[find_seg_chunk(chunks, nchunks, seg)];
     if (ch.flags & CH_LITERALS) return;
@@ -501,10 +520,10 @@ __global__ __launch_bounds__(64) void parse_fixseg_kernel(const ChunkDesc *__res
     const uint32_t end = (n > 3 ? n : 3) - 3;
     const uint32_t s0 = s * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
     const uint32_t e = s ? seg_exit[seg - 1] : 0;                   // assumed entry
-    SegFix f{seg_count[seg], seg_exit[seg]};
+    SegFix f{seg_count[seg], seg_exit[seg], s0, 0u};                 // (entered where assumed: every staged code is final)
     if (s0 >= end) { f.cnt = 0; f.ex = e; }                          // behind the last walked position: pass through
     else if (e != s0) f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64), s0, s1, end, e, f.cnt, f.ex, lane);
-    if (lane == 0) { seg_count[seg] = f.cnt; seg_exit2[seg] = f.ex; }
+    if (lane == 0) { seg_count[seg] = f.cnt; seg_exit2[seg] = f.ex; seg_mpos[seg] = f.mpos; seg_kspec[seg] = f.kspec; }
 }
 
 // P2b: one wavefront per chunk: checks the assumption of P2a for 64 segments at a time (segment s was
@@ -517,7 +536,7 @@ __global__ __launch_bounds__(64) void parse_fix_kernel(const uint8_t *__restrict
                                                        uint32_t *__restrict__ seg_count,
                                                        uint32_t *__restrict__ seg_exit2,
                                                        uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
-                                                       uint32_t *__restrict__ ncodes) {
+                                                       uint32_t *__restrict__ ncodes, uint32_t *__restrict__ seg_mpos) {
     const ChunkDesc ch = chunks[blockIdx.x];
     const uint32_t lane = threadIdx.x;
     const uint32_t n = (uint32_t)ch.len;
@@ -554,10 +573,12 @@ __global__ __launch_bounds__(64) void parse_fix_kernel(const uint8_t *__restrict
                 // segment b0 was entered at the wrong position: redo it from the true entry
                 const uint32_t sb = b0;
                 const uint32_t s0 = sb * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
-                SegFix f{sc[sb], sx2[sb]};
+                SegFix f{sc[sb], sx2[sb], 0u, 0u};
                 if (s0 >= end) { f.cnt = 0; f.ex = e_last; }
                 else f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)sb * (PARSE_SEG / 64), s0, s1, end, e_last, f.cnt, f.ex, lane);
-                if (lane == 0) { sc[sb] = f.cnt; sx2[sb] = f.ex; seg_off[ch.seg_base + sb] = total; }
+                // (walked a second time: the staged codes no longer line up with the visit bits — emit all of this
+                //  segment from the bits)
+                if (lane == 0) { sc[sb] = f.cnt; sx2[sb] = f.ex; seg_off[ch.seg_base + sb] = total; seg_mpos[ch.seg_base + sb] = 0xFFFFFFFFu; }
                 total += f.cnt;
                 e_last = f.ex;
                 b0 += 1;
@@ -581,7 +602,11 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
                                                         const uint32_t *__restrict__ md,
                                                         const uint64_t *__restrict__ vis,
                                                         const uint32_t *__restrict__ seg_off,
-                                                        uint32_t *__restrict__ codes) {
+                                                        uint32_t *__restrict__ codes,
+                                                        const uint32_t *__restrict__ stage,
+                                                        const uint32_t *__restrict__ seg_count,
+                                                        const uint32_t *__restrict__ seg_mpos,
+                                                        const uint32_t *__restrict__ seg_kspec) {
     const uint32_t seg = blockIdx.x;
     const uint32_t c = find_seg_chunk(chunks, nchunks, seg);
     const ChunkDesc ch = chunks[c];
@@ -600,26 +625,26 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
     const uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
     const uint64_t lt = lanemask_lt();
     uint32_t nout = 0;
-    // the segment's 64 mask words are read once (lane g holds word g); answers and bytes of the next
-    // group are in flight while the current one is compacted
-    const uint64_t my_word = s0 + lane * 64 < end ? vw[lane] : 0;
-    uint32_t v_next = s0 + lane < end ? md[ch.in_off + s0 + lane] : 0;
-    uint32_t b_next = s0 + lane < n ? src.load1(s0 + lane) : 0;
+    // positions in front of the merge point: from the (repaired) visit bits and md, as far as they go — usually less
+    // than one 64-position group, none at all when the segment was entered where the speculative walk assumed
+    const uint32_t mpos = min(seg_mpos[seg], min(s0 + PARSE_SEG, end));
     for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
         const uint32_t base = s0 + g * 64;
-        if (base >= end) break;
-        const uint64_t m = __shfl(my_word, g);
-        const uint32_t v = v_next, byte = b_next;
-        {
-            const uint32_t in2 = base + 64 + lane;
-            const bool more = g + 1 < PARSE_SEG / 64;
-            v_next = (more && in2 < end) ? md[ch.in_off + in2] : 0;
-            b_next = (more && in2 < n) ? src.load1(in2) : 0;
-        }
+        if (base >= mpos) break;
+        uint64_t m = vw[g];
+        if (mpos - base < 64) m &= (1ull << (mpos - base)) - 1;
         if (m == 0) continue;
-        if ((m >> lane) & 1) out[nout + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (byte << 16);
+        if ((m >> lane) & 1) {
+            const uint32_t i = base + lane;
+            const uint32_t v = md[ch.in_off + i];
+            out[nout + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (src.load1(i) << 16);
+        }
         nout += __popcll(m);
     }
+    // everything behind it: the codes the speculative walk staged, behind the kspec it visited in front of the merge
+    const uint32_t n2 = seg_count[seg] - nout;
+    const uint32_t *st = stage + ch.in_off + s0 + seg_kspec[seg];
+    for (uint32_t j = lane; j < n2; j += 64) out[nout + j] = st[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1290,25 +1315,28 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
 }
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                  uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
-                 uint32_t *codes, uint32_t *ncodes) {
+                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage) {
     if (nchunks == 0) return 0;
+    // seg_tmp: six arrays of nsegs words
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
-    uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs;
+    uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs, *seg_mpos = seg_tmp + 4 * (size_t)nsegs;
+    uint32_t *seg_kspec = seg_tmp + 5 * (size_t)nsegs;
     if (nsegs) {
-        hipLaunchKernelGGL(parse_spec_kernel, dim3(nsegs), dim3(64), 0, st, chunks, nchunks, md, vis, seg_exit, seg_count);
+        hipLaunchKernelGGL(parse_spec_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis, seg_exit,
+                           seg_count, stage);
         LFX_LAUNCH_CHECK();
     }
     if (nsegs) {
         hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, chunks, nchunks, md, vis, seg_exit, seg_count,
-                           seg_exit2);
+                           seg_exit2, seg_mpos, seg_kspec);
         LFX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(64), 0, st, in, in_bytes, chunks, md, vis, seg_exit,
-                       seg_count, seg_exit2, seg_off, codes, ncodes);
+                       seg_count, seg_exit2, seg_off, codes, ncodes, seg_mpos);
     LFX_LAUNCH_CHECK();
     if (nsegs) {
         hipLaunchKernelGGL(parse_emit_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis,
-                           seg_off, codes);
+                           seg_off, codes, stage, seg_count, seg_mpos, seg_kspec);
         LFX_LAUNCH_CHECK();
     }
     return 0;
