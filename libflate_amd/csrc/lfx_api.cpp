@@ -358,6 +358,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
     if ((rc = c->d_segtmp.reserve(24ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
     if ((rc = c->d_stage.reserve(4ull * (n + 64)))) return rc;   // code words staged by the speculative parse walk
+    if ((rc = c->d_chunkmap.reserve(4ull * (plan.n_tiles + plan.n_segs + 2)))) return rc;   // tile → chunk, segment → chunk
     if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;
@@ -376,6 +377,12 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     // the host vectors must outlive the async copies: synchronise the (tiny) uploads now
     HIP_TRY(hipStreamSynchronize(st));
     c->phase("upload");
+    uint32_t *tile_map = (uint32_t *)c->d_chunkmap.p, *seg_map = tile_map + plan.n_tiles;
+    c->cur_tile_map = tile_map;
+    if (int e_ = launch_chunk_maps(st, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_tiles, plan.n_segs, tile_map, seg_map)) {
+        c->set_error(hipGetErrorString((hipError_t)e_));
+        return LFX_E_DEVICE;
+    }
 
 #define LAUNCH_TRY(call)                                                              \
     do {                                                                              \
@@ -406,7 +413,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     c->phase("lz77_match");
     LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
                             (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
-                            (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p));
+                            (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map));
     c->phase("lz77_parse");
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the histogram
@@ -454,7 +461,7 @@ int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, b
                            (const uint32_t *)c->d_codes.p, (const uint32_t *)c->d_ncodes.p,
                            (const BlockCodes *)c->d_bc.p, (const uint64_t *)c->d_block_start.p,
                            (uint32_t *)c->d_tile_bits.p, (uint64_t *)c->d_tile_start.p, dres, 0,
-                           (uint32_t *)d_out));
+                           (uint32_t *)d_out, c->cur_tile_map));
     c->phase("pack");
     if (prefix_len) {
         // (a gzip header holds an unbounded file name / comment: its own buffer, sized to fit)

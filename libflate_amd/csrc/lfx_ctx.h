@@ -34,12 +34,12 @@ struct Ctx {
 
     // encode scratch
     DevBuf d_chunks, d_blocks, d_segs, d_md, d_codes, d_ncodes, d_hist, d_bc, d_block_start, d_tile_bits,
-        d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage;
+        d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage, d_chunkmap;
     // decode scratch
     DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks, d_dec_tabs, d_dec_sym, d_dec_win, d_dec_maps;
     std::vector<DevBuf *> all_bufs() {
         return {&d_chunks, &d_blocks, &d_segs, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
-                &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage,
+                &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage, &d_chunkmap,
                 &d_dec_streams, &d_dec_state, &d_dec_tmp, &d_dec_cand, &d_dec_blocks, &d_dec_tabs, &d_dec_sym, &d_dec_win, &d_dec_maps};
     }
     void *h_res = nullptr;  // pinned, 4 KiB
@@ -47,6 +47,7 @@ struct Ctx {
     // state between encode_prepare and encode_emit
     uint32_t cur_nchunks = 0, cur_nblocks = 0;
     uint64_t cur_ntiles = 0, cur_n = 0;
+    const uint32_t *cur_tile_map = nullptr;   // tile → chunk table of the prepared encode (lives in d_chunkmap)
     const uint8_t *cur_in = nullptr;
     bool force_match_v1 = false;   // sticky: the second-generation match kernel reported a lane-order violation
     std::vector<uint8_t> shard_hdr;

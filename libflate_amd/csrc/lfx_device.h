@@ -34,7 +34,9 @@ int launch_match2(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Ch
                   uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint32_t *flags, uint64_t *dbg = nullptr);
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                  uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
-                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage /* 4 bytes per input byte */);
+                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage /* 4 bytes per input byte */, const uint32_t *seg_map);
+int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
+                      uint32_t *tile_map, uint32_t *seg_map);
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
                      const uint32_t *codes, const uint32_t *ncodes, uint32_t *hist);
 int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,
@@ -45,7 +47,7 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
                 uint32_t nchunks, const BlockDesc *blocks, uint32_t nblocks, uint64_t ntiles,
                 const uint32_t *codes, const uint32_t *ncodes, const BlockCodes *bc,
                 const uint64_t *block_start, uint32_t *tile_bits, uint64_t *tile_start,
-                const EncodeResult *res, uint64_t out_base_bit, uint32_t *out);
+                const EncodeResult *res, uint64_t out_base_bit, uint32_t *out, const uint32_t *tile_map);
 int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
                     uint32_t *a_part, uint32_t *b_part, EncodeResult *res,
                     int mode = 3)   /* bit 0: CRC-32, bit 1: Adler-32 (the other result is then 0) */;

@@ -374,13 +374,18 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
 // points through the segments, re-walking only from a segment's true entry to the merge point, and
 // turns the per-segment counts into offsets; every segment finally emits its codes (P3).
 // The walk itself keeps 64 per-position answers in a VGPR and steps through them with v_readlane.
-__device__ __forceinline__ uint32_t find_seg_chunk(const ChunkDesc *chunks, uint32_t nchunks, uint32_t seg) {
-    uint32_t lo = 0, hi = nchunks;  // last chunk with seg_base <= seg and n_seg > 0 reachable
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (chunks[mid].seg_base <= seg) lo = mid; else hi = mid;
-    }
-    return lo;
+// tile → chunk and segment → chunk tables (one workgroup per chunk): the tile / segment kernels start with one load
+// instead of a binary search over the chunk list (ten dependent L2 round trips per workgroup, also in the many
+// workgroups of tiles that hold no code)
+__global__ __launch_bounds__(256) void chunk_maps_kernel(const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
+                                                         uint64_t ntiles, uint32_t nsegs,
+                                                         uint32_t *__restrict__ tile_map, uint32_t *__restrict__ seg_map) {
+    const uint32_t c = blockIdx.x;
+    const ChunkDesc ch = chunks[c];
+    const uint64_t t1 = c + 1 < nchunks ? chunks[c + 1].tile_base : ntiles;
+    const uint32_t s1 = c + 1 < nchunks ? chunks[c + 1].seg_base : nsegs;
+    for (uint64_t t = ch.tile_base + blockIdx.y * 256 + threadIdx.x; t < t1; t += 256ull * gridDim.y) tile_map[t] = c;
+    for (uint32_t q = ch.seg_base + blockIdx.y * 256 + threadIdx.x; q < s1; q += 256u * gridDim.y) seg_map[q] = c;
 }
 
 constexpr int SPEC_ROUNDS = 3;
@@ -392,9 +397,10 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const uint8_t *__restric
                                                         const uint32_t *__restrict__ md,
                                                         uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit,
                                                         uint32_t *__restrict__ seg_count,
-                                                        uint32_t *__restrict__ stage) {
+                                                        uint32_t *__restrict__ stage,
+                                                        const uint32_t *__restrict__ seg_map) {
     const uint32_t seg = blockIdx.x;
-    const uint32_t c = find_seg_chunk(chunks, nchunks, seg);
+    const uint32_t c = seg_map[seg];   // (a table, not a binary search over the chunk list: ten dependent loads less)
     const ChunkDesc ch = chunks[c];
     const uint32_t lane = threadIdx.x;
     const uint32_t s = seg - ch.seg_base;
@@ -510,9 +516,10 @@ __global__ __launch_bounds__(64) void parse_fixseg_kernel(const ChunkDesc *__res
                                                           uint32_t *__restrict__ seg_count,
                                                           uint32_t *__restrict__ seg_exit2,
                                                           uint32_t *__restrict__ seg_mpos,
-                                                          uint32_t *__restrict__ seg_kspec) {
+                                                          uint32_t *__restrict__ seg_kspec,
+                                                          const uint32_t *__restrict__ seg_map) {
     const uint32_t seg = blockIdx.x;
-    const ChunkDesc ch = chunks[find_seg_chunk(chunks, nchunks, seg)];
+    const ChunkDesc ch = chunks[seg_map[seg]];
     if (ch.flags & CH_LITERALS) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t s = seg - ch.seg_base;
@@ -606,9 +613,10 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
                                                         const uint32_t *__restrict__ stage,
                                                         const uint32_t *__restrict__ seg_count,
                                                         const uint32_t *__restrict__ seg_mpos,
-                                                        const uint32_t *__restrict__ seg_kspec) {
+                                                        const uint32_t *__restrict__ seg_kspec,
+                                                        const uint32_t *__restrict__ seg_map) {
     const uint32_t seg = blockIdx.x;
-    const uint32_t c = find_seg_chunk(chunks, nchunks, seg);
+    const uint32_t c = seg_map[seg];
     const ChunkDesc ch = chunks[c];
     const uint32_t lane = threadIdx.x;
     const uint32_t s = seg - ch.seg_base;
@@ -664,15 +672,22 @@ __global__ __launch_bounds__(256) void histogram_kernel(const ChunkDesc *__restr
     const uint32_t per = (uint32_t)div_up(n, gridDim.y);
     const uint32_t lo = blockIdx.y * per, hi = min(n, lo + per);
     const uint32_t *p = codes + ch.code_off;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const uint32_t v = p[i];
-        const uint32_t dist = v & 0xFFFFu, val = v >> 16;
-        if (dist == 0) {
-            atomicAdd(&h[val], 1u);
-        } else {
-            uint32_t eb, ex;
-            atomicAdd(&h[len_symbol(val, eb, ex)], 1u);
-            atomicAdd(&h[288 + dist_symbol(dist, eb, ex)], 1u);
+    // four loads in flight per lane (one load per iteration left the kernel waiting on HBM latency)
+    for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) v[q] = i0 + 256 * q < hi ? p[i0 + 256 * q] : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; ++q) {
+            if (i0 + 256 * q >= hi) break;
+            const uint32_t dist = v[q] & 0xFFFFu, val = v[q] >> 16;
+            if (dist == 0) {
+                atomicAdd(&h[val], 1u);
+            } else {
+                uint32_t eb, ex;
+                atomicAdd(&h[len_symbol(val, eb, ex)], 1u);
+                atomicAdd(&h[288 + dist_symbol(dist, eb, ex)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -757,26 +772,16 @@ __device__ __forceinline__ uint32_t code_bits(uint32_t v, const uint32_t *lit, c
     return n;
 }
 
-__device__ __forceinline__ uint32_t find_chunk(const ChunkDesc *chunks, uint32_t nchunks,
-                                               uint64_t gtile) {
-    uint32_t lo = 0, hi = nchunks;  // last chunk with tile_base <= gtile
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (chunks[mid].tile_base <= gtile) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 constexpr int PACK_THREADS = 256;
 constexpr int PACK_PER_THREAD = PACK_TILE / PACK_THREADS;  // 8
 
 __global__ __launch_bounds__(PACK_THREADS) void tile_bits_kernel(
     const ChunkDesc *__restrict__ chunks, uint32_t nchunks, const BlockDesc *__restrict__ blocks,
     const uint32_t *__restrict__ codes, const uint32_t *__restrict__ ncodes,
-    const BlockCodes *__restrict__ bc, uint32_t *__restrict__ tile_bits) {
+    const BlockCodes *__restrict__ bc, uint32_t *__restrict__ tile_bits, const uint32_t *__restrict__ tile_map) {
     __shared__ uint32_t lit[288], dst[32], red[PACK_THREADS / 64];
     const uint64_t gt = blockIdx.x;
-    const uint32_t c = find_chunk(chunks, nchunks, gt);
+    const uint32_t c = tile_map[gt];
     const ChunkDesc ch = chunks[c];
     const uint32_t t = (uint32_t)(gt - ch.tile_base);
     const uint32_t n = ncodes[c];
@@ -847,13 +852,14 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     const ChunkDesc *__restrict__ chunks, uint32_t nchunks, const BlockDesc *__restrict__ blocks,
     const uint32_t *__restrict__ codes, const uint32_t *__restrict__ ncodes,
     const BlockCodes *__restrict__ bc, const uint64_t *__restrict__ tile_start,
-    const EncodeResult *__restrict__ res, uint64_t out_base_bit, uint32_t *__restrict__ out) {
+    const EncodeResult *__restrict__ res, uint64_t out_base_bit, uint32_t *__restrict__ out,
+    const uint32_t *__restrict__ tile_map) {
     __shared__ uint32_t lit[288], dst[32];
     __shared__ uint32_t wsum[PACK_THREADS / 64];
     __shared__ unsigned long long stage[STAGE_WORDS64];
     if (res->status != 0) return;
     const uint64_t gt = blockIdx.x;
-    const uint32_t c = find_chunk(chunks, nchunks, gt);
+    const uint32_t c = tile_map[gt];
     const ChunkDesc ch = chunks[c];
     const uint32_t t = (uint32_t)(gt - ch.tile_base);
     const uint32_t n = ncodes[c];
@@ -1315,7 +1321,7 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
 }
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                  uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
-                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage) {
+                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map) {
     if (nchunks == 0) return 0;
     // seg_tmp: six arrays of nsegs words
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
@@ -1323,12 +1329,12 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     uint32_t *seg_kspec = seg_tmp + 5 * (size_t)nsegs;
     if (nsegs) {
         hipLaunchKernelGGL(parse_spec_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis, seg_exit,
-                           seg_count, stage);
+                           seg_count, stage, seg_map);
         LFX_LAUNCH_CHECK();
     }
     if (nsegs) {
         hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, chunks, nchunks, md, vis, seg_exit, seg_count,
-                           seg_exit2, seg_mpos, seg_kspec);
+                           seg_exit2, seg_mpos, seg_kspec, seg_map);
         LFX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(64), 0, st, in, in_bytes, chunks, md, vis, seg_exit,
@@ -1336,9 +1342,19 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     LFX_LAUNCH_CHECK();
     if (nsegs) {
         hipLaunchKernelGGL(parse_emit_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis,
-                           seg_off, codes, stage, seg_count, seg_mpos, seg_kspec);
+                           seg_off, codes, stage, seg_count, seg_mpos, seg_kspec, seg_map);
         LFX_LAUNCH_CHECK();
     }
+    return 0;
+}
+int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
+                      uint32_t *tile_map, uint32_t *seg_map) {
+    if (nchunks == 0) return 0;
+    // (few chunks = long chunks: several workgroups share one)
+    uint32_t split = nchunks >= 256 ? 1 : 256 / nchunks + 1;
+    if (split > 64) split = 64;
+    hipLaunchKernelGGL(chunk_maps_kernel, dim3(nchunks, split), dim3(256), 0, st, chunks, nchunks, ntiles, nsegs, tile_map, seg_map);
+    LFX_LAUNCH_CHECK();
     return 0;
 }
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
@@ -1366,16 +1382,16 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
                 uint32_t nchunks, const BlockDesc *blocks, uint32_t nblocks, uint64_t ntiles,
                 const uint32_t *codes, const uint32_t *ncodes, const BlockCodes *bc,
                 const uint64_t *block_start, uint32_t *tile_bits, uint64_t *tile_start,
-                const EncodeResult *res, uint64_t out_base_bit, uint32_t *out) {
+                const EncodeResult *res, uint64_t out_base_bit, uint32_t *out, const uint32_t *tile_map) {
     if (ntiles) {
         hipLaunchKernelGGL(tile_bits_kernel, dim3((uint32_t)ntiles), dim3(PACK_THREADS), 0, st, chunks,
-                           nchunks, blocks, codes, ncodes, bc, tile_bits);
+                           nchunks, blocks, codes, ncodes, bc, tile_bits, tile_map);
         LFX_LAUNCH_CHECK();
         hipLaunchKernelGGL(tile_scan_kernel, dim3(nblocks), dim3(256), 0, st, chunks, blocks, bc,
                            block_start, tile_bits, ntiles, nchunks, tile_start);
         LFX_LAUNCH_CHECK();
         hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)ntiles), dim3(PACK_THREADS), 0, st, chunks,
-                           nchunks, blocks, codes, ncodes, bc, tile_start, res, out_base_bit, out);
+                           nchunks, blocks, codes, ncodes, bc, tile_start, res, out_base_bit, out, tile_map);
         LFX_LAUNCH_CHECK();
     }
     if (nblocks) {
