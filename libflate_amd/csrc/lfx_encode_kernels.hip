@@ -1079,14 +1079,17 @@ __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t 
     uint32_t s1 = 0, s1_before = 0;   // sum of bytes
     uint64_t s2 = 0;                  // sum of (offset in region) * byte
     const uint32_t first = 64 * lane;
-    for (uint32_t o = first; o < rlen; o += 4096) {
+    // the sixteen loads of piece k+1 are issued before the (serially dependent) table walk over piece k starts: a
+    // wavefront's 64 KiB are sixteen pieces, and without the look-ahead every piece waited for its own HBM round trip
+    auto load_piece = [&](uint32_t (&w)[16], uint32_t o) {
+        const uint32_t len = o < rlen ? min(64u, rlen - o) : 0u;
+#pragma unroll
+        for (uint32_t q = 0; q < 16; ++q) w[q] = 4 * q < len ? src.load4(o + 4 * q) : 0u;
+    };
+    auto walk_piece = [&](const uint32_t (&w)[16], uint32_t o) {
         if (CRC && o != first)                           // over the other lanes' 4032 bytes
             crc = advt[0][crc & 0xFF] ^ advt[1][(crc >> 8) & 0xFF] ^ advt[2][(crc >> 16) & 0xFF] ^ advt[3][crc >> 24];
         const uint32_t len = min(64u, rlen - o);         // only the last piece can be short
-        // all sixteen loads are issued before the (serially dependent) table walk starts
-        uint32_t w[16];
-#pragma unroll
-        for (uint32_t q = 0; q < 16; ++q) w[q] = 4 * q < len ? src.load4(o + 4 * q) : 0u;
         uint32_t wsum = 0;       // sum of (offset in piece) * byte, fits 32 bits
 #pragma unroll
         for (uint32_t q = 0; q < 16; ++q) {
@@ -1112,8 +1115,15 @@ __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t 
         s2 += (uint64_t)o * (s1 - s1_before) + wsum;
         s1_before = s1;
         stand = o + len;
+    };
+    uint32_t wa[16], wb[16];
+    load_piece(wa, first);
+    for (uint32_t o = first; o < rlen; o += 2 * 4096) {
+        load_piece(wb, o + 4096);
+        walk_piece(wa, o);
+        load_piece(wa, o + 2 * 4096);
+        if (o + 4096 < rlen) walk_piece(wb, o + 4096);
     }
-    // every lane's register is brought to the region end; then they simply XOR together
     CkPartial r;
     r.crc = 0; r.a = 0; r.b = 0;
     if (CRC) {
