@@ -285,7 +285,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
             const uint32_t w_res = wring_off(t_res), s_res = t_res % PRING;   // wave-uniform
             const uint32_t pos = t_res + (wave - 1) * 64 + lane;
             const bool act = pos >= q0 && pos < q1;
-            uint32_t dist = 0, l = 0, lim = 0, oa = 0, ob = 0;
+            uint32_t dist = 0, l = 0, lim = 0, oa = 0, ob = 0, lit_byte = 0;
             bool found = false;
             if (act) {
                 // resolve: walk the hash chain until the exact 3-byte prefix matches (the most recent
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                 // reuses them, comes later in this wavefront's program order)
                 const uint32_t key = st_k[((uint32_t)it % 3) * MTILE + (wave - 1) * 64 + lane] & 0xFFFFFFu;
                 const uint32_t known = cd[((uint32_t)it & 1) * MTILE + (wave - 1) * 64 + lane];
+                lit_byte = key & 0xFFu;
                 uint32_t d = prevd[s_pos];
                 if (known) { dist = known; found = dist <= window; d = 0; }
                 while (d != 0) {
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
                 if (lane == sl) l = res;
             }
             if (act) {
-                uint32_t out = 0;
+                uint32_t out = lit_byte << 16;      // (no match: the literal's code word)
                 if (found) {
                     if (l > lim) l = lim;
                     out = ((3 + l) << 16) | dist;
@@ -410,29 +411,21 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const uint8_t *__restric
     uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
     if (ch.flags & CH_LITERALS) return;   // no walk: every byte is a literal
     uint32_t pos = s0, cnt = 0;
-    const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
     uint32_t *st = stage + ch.in_off + s0;
     const uint64_t lt = lanemask_lt();
-    // answers (and the bytes, for the literals) are prefetched four groups ahead (a group's walk is much shorter
-    // than an HBM round trip)
+    // answers are prefetched four groups ahead (a group's walk is much shorter than an HBM round trip); an answer IS
+    // the position's code word (a match, or the literal with its byte)
     auto fetch = [&](uint32_t g) -> uint32_t {
         const uint32_t i = s0 + g * 64 + lane;
         return (g < PARSE_SEG / 64 && i < end) ? md[ch.in_off + i] : 0;
     };
-    auto fetch_b = [&](uint32_t g) -> uint32_t {
-        const uint32_t i = s0 + g * 64 + lane;
-        return (g < PARSE_SEG / 64 && i < end) ? src.load1(i) : 0;
-    };
     uint32_t v0 = fetch(0), v1 = fetch(1), v2 = fetch(2), v3 = fetch(3);
-    uint32_t b0 = fetch_b(0), b1 = fetch_b(1), b2 = fetch_b(2), b3 = fetch_b(3);
     for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
         const uint32_t base = s0 + g * 64;
         uint64_t m = 0;
-        const uint32_t v = v0, byte = b0;
+        const uint32_t v = v0;
         v0 = v1; v1 = v2; v2 = v3;
-        b0 = b1; b1 = b2; b2 = b3;
         v3 = fetch(g + 4);
-        b3 = fetch_b(g + 4);
         if (base < end) {
             // The scalar unit is shared by the whole CU and the walk is a chain of dependent steps: the
             // vector side precomputes, for every position, where 2^SPEC_ROUNDS steps lead and the bits they
@@ -462,7 +455,7 @@ __global__ __launch_bounds__(64) void parse_spec_kernel(const uint8_t *__restric
             pos = base + r;
         }
         if (lane == 0) vw[g] = m;
-        if ((m >> lane) & 1) st[cnt + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (byte << 16);
+        if ((m >> lane) & 1) st[cnt + __popcll(m & lt)] = v;
         cnt += __popcll(m);
     }
     if (lane == 0) { seg_exit[seg] = pos; seg_count[seg] = cnt; }
@@ -644,8 +637,7 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
         if (m == 0) continue;
         if ((m >> lane) & 1) {
             const uint32_t i = base + lane;
-            const uint32_t v = md[ch.in_off + i];
-            out[nout + __popcll(m & lt)] = (v & 0xFFFFu) ? v : (src.load1(i) << 16);
+            out[nout + __popcll(m & lt)] = md[ch.in_off + i];
         }
         nout += __popcll(m);
     }

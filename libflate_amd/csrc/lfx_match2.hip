@@ -1,5 +1,6 @@
 // lfx_match2.hip — second-generation LZ77 match stage for gfx950: per position, the most recent earlier occurrence
-// of its 3-byte prefix inside the chunk and the match length, written to md[] for the parse kernels.
+// of its 3-byte prefix inside the chunk and the match length, written to md[] for the parse kernels — as the position's
+// LZ77 code word: (length << 16) | distance, or (byte << 16) when there is no match.
 //
 // Replaces, bit for bit, the table probe and longest_common_prefix of DefaultLz77Encoder::flush
 // (libflate_lz77/src/default.rs:76-87,122-129,146-182).  Parse independence (tests/test_host_pipeline.py): the
@@ -447,7 +448,9 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
                 if (lane == sl) l = res;
             }
             l = l > lim ? lim : l;
-            const uint32_t word = found ? ((3 + l) << 16) | dist : 0u;
+            // (no match: the literal's code word — the byte is the low byte of the prefix — so that the parse never has
+            //  to read the input)
+            const uint32_t word = found ? ((3 + l) << 16) | dist : (key_r & 0xFFu) << 16;
             if (act_r) md_c[p_r] = word;
         }
         const uint64_t c2 = DBG ? clock64() : 0;
