@@ -529,22 +529,25 @@ __global__ __launch_bounds__(64) void parse_fixseg_kernel(const ChunkDesc *__res
 // P2b: one wavefront per chunk: checks the assumption of P2a for 64 segments at a time (segment s was
 // entered correctly iff the exit of s-1 did not change), repairs the rare segment that was not, and turns
 // the counts into offsets; then the chunk's tail and the EndOfBlock marker.
-__global__ __launch_bounds__(64) void parse_fix_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                       const ChunkDesc *__restrict__ chunks,
-                                                       const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
-                                                       const uint32_t *__restrict__ seg_exit,
-                                                       uint32_t *__restrict__ seg_count,
-                                                       uint32_t *__restrict__ seg_exit2,
-                                                       uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
-                                                       uint32_t *__restrict__ ncodes, uint32_t *__restrict__ seg_mpos) {
+// One workgroup per chunk: 64 lanes when a chunk has a few dozen segments (the reference's 256 KiB chunks), 1024 when one
+// chunk is the whole input (schedule S1: 65536 segments per 256 MiB — a single wavefront walked them 64 at a time, 2 ms).
+__global__ __launch_bounds__(1024) void parse_fix_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                         const ChunkDesc *__restrict__ chunks,
+                                                         const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
+                                                         const uint32_t *__restrict__ seg_exit,
+                                                         uint32_t *__restrict__ seg_count,
+                                                         uint32_t *__restrict__ seg_exit2,
+                                                         uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
+                                                         uint32_t *__restrict__ ncodes, uint32_t *__restrict__ seg_mpos) {
+    __shared__ uint32_t s_first_bad, s_wsum[16], s_redo[2];
     const ChunkDesc ch = chunks[blockIdx.x];
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
     const uint32_t n = (uint32_t)ch.len;
     const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
     uint32_t *out = codes + ch.code_off;
     uint32_t total = 0;
     if (ch.flags & CH_LITERALS) {
-        for (uint32_t s = lane; s < ch.n_seg; s += 64) seg_off[ch.seg_base + s] = s * PARSE_SEG;
+        for (uint32_t s = tid; s < ch.n_seg; s += T) seg_off[ch.seg_base + s] = s * PARSE_SEG;
         total = n;
     } else {
         const uint32_t end = (n > 3 ? n : 3) - 3;
@@ -552,48 +555,64 @@ __global__ __launch_bounds__(64) void parse_fix_kernel(const uint8_t *__restrict
         uint32_t *sx2 = seg_exit2 + ch.seg_base, *sc = seg_count + ch.seg_base;
         uint32_t e_last = 0;   // true exit of the segment before the current batch
         for (uint32_t b0 = 0; b0 < ch.n_seg; ) {
-            const uint32_t s = b0 + lane;
+            if (tid == 0) s_first_bad = 0xFFFFFFFFu;
+            __syncthreads();
+            const uint32_t s = b0 + tid;
             const bool have = s < ch.n_seg;
             // entry assumed by P2a vs the true exit of the predecessor
             const uint32_t assumed = have ? (s ? sx[s - 1] : 0) : 0;
             const uint32_t actual = have ? (s == b0 ? e_last : sx2[s - 1]) : 0;
             const uint64_t bad = __ballot(have && assumed != actual);
-            const uint32_t nok = bad ? (uint32_t)__builtin_ctzll(bad) : min(64u, ch.n_seg - b0);   // leading good segments
+            if (bad && lane == 0) atomicMin(&s_first_bad, wave * 64 + (uint32_t)__builtin_ctzll(bad));
+            __syncthreads();
+            const uint32_t fb = s_first_bad;
+            const uint32_t nok = fb != 0xFFFFFFFFu ? fb : min(T, ch.n_seg - b0);   // leading good segments
             // offsets of the good prefix
-            const uint32_t c = (have && lane < nok) ? sc[s] : 0;
+            const uint32_t c = (have && tid < nok) ? sc[s] : 0;
             uint32_t x = c;
             for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
-            if (have && lane < nok) seg_off[ch.seg_base + s] = total + x - c;
+            if (lane == 63) s_wsum[wave] = x;
+            __syncthreads();
+            uint32_t pre = 0, all = 0;
+            for (uint32_t w = 0; w < nw; ++w) { const uint32_t v = s_wsum[w]; pre += w < wave ? v : 0u; all += v; }
+            if (have && tid < nok) seg_off[ch.seg_base + s] = total + pre + x - c;
             if (nok) {
-                total += __shfl(x, nok - 1);
-                e_last = __shfl(have ? sx2[s] : 0, nok - 1);
+                total += all;
+                e_last = sx2[b0 + nok - 1];
             }
             b0 += nok;
-            if (bad) {
-                // segment b0 was entered at the wrong position: redo it from the true entry
+            if (fb != 0xFFFFFFFFu) {
+                // segment b0 was entered at the wrong position: redo it from the true entry (one wavefront)
                 const uint32_t sb = b0;
-                const uint32_t s0 = sb * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
-                SegFix f{sc[sb], sx2[sb], 0u, 0u};
-                if (s0 >= end) { f.cnt = 0; f.ex = e_last; }
-                else f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)sb * (PARSE_SEG / 64), s0, s1, end, e_last, f.cnt, f.ex, lane);
-                // (walked a second time: the staged codes no longer line up with the visit bits — emit all of this
-                //  segment from the bits)
-                if (lane == 0) { sc[sb] = f.cnt; sx2[sb] = f.ex; seg_off[ch.seg_base + sb] = total; seg_mpos[ch.seg_base + sb] = 0xFFFFFFFFu; }
-                total += f.cnt;
-                e_last = f.ex;
+                if (wave == 0) {
+                    const uint32_t s0 = sb * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
+                    SegFix f{sc[sb], sx2[sb], 0u, 0u};
+                    if (s0 >= end) { f.cnt = 0; f.ex = e_last; }
+                    else f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)sb * (PARSE_SEG / 64), s0, s1, end, e_last, f.cnt, f.ex, lane);
+                    // (walked a second time: the staged codes no longer line up with the visit bits — emit all of this
+                    //  segment from the bits)
+                    if (lane == 0) {
+                        sc[sb] = f.cnt; sx2[sb] = f.ex; seg_off[ch.seg_base + sb] = total; seg_mpos[ch.seg_base + sb] = 0xFFFFFFFFu;
+                        s_redo[0] = f.cnt; s_redo[1] = f.ex;
+                    }
+                }
+                __syncthreads();
+                total += s_redo[0];
+                e_last = s_redo[1];
                 b0 += 1;
             }
+            __syncthreads();
         }
         // default.rs:105-107: the rest are literals (at most 3 bytes)
         const uint32_t pos = ch.n_seg ? e_last : 0;
-        for (uint32_t i = pos + lane; i < n; i += 64) out[total + (i - pos)] = src.load1(i) << 16;
+        for (uint32_t i = pos + tid; i < n; i += T) out[total + (i - pos)] = src.load1(i) << 16;
         if (n > pos) total += n - pos;
     }
     if (ch.flags & CH_LAST_IN_BLOCK) {
-        if (lane == 0) out[total] = CODE_EOB;  // encode.rs:417
+        if (tid == 0) out[total] = CODE_EOB;  // encode.rs:417
         total += 1;
     }
-    if (lane == 0) ncodes[blockIdx.x] = total;
+    if (tid == 0) ncodes[blockIdx.x] = total;
 }
 
 // P3: every segment emits the codes of its visited positions
@@ -800,7 +819,7 @@ __global__ __launch_bounds__(PACK_THREADS) void tile_bits_kernel(
 }
 
 // per block: exclusive scan of its tiles' bit counts → absolute start bit of every tile
-__global__ __launch_bounds__(256) void tile_scan_kernel(const ChunkDesc *__restrict__ chunks,
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const ChunkDesc *__restrict__ chunks,
                                                         const BlockDesc *__restrict__ blocks,
                                                         const BlockCodes *__restrict__ bc,
                                                         const uint64_t *__restrict__ block_start,
@@ -808,7 +827,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const ChunkDesc *__restr
                                                         uint64_t total_tiles,
                                                         uint32_t nchunks,
                                                         uint64_t *__restrict__ tile_start) {
-    __shared__ uint64_t wsum[4];
+    __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry;
     const uint32_t b = blockIdx.x;
     const BlockDesc bd = blocks[b];
@@ -819,7 +838,8 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const ChunkDesc *__restr
     if (threadIdx.x == 0) carry = block_start[b] + 3 + bc[b].hdr_bits;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint64_t base = t0; base < t1; base += 256) {
+    const uint32_t T = blockDim.x;   // (256, or 1024 when a block has many tiles: the scan is serial in batches of T)
+    for (uint64_t base = t0; base < t1; base += T) {
         const uint64_t i = base + threadIdx.x;
         const uint64_t v = i < t1 ? tile_bits[i] : 0;
         uint64_t x = v;  // inclusive wave scan
@@ -833,7 +853,7 @@ __global__ __launch_bounds__(256) void tile_scan_kernel(const ChunkDesc *__restr
         for (uint32_t w = 0; w < wave; ++w) pre += wsum[w];
         if (i < t1) tile_start[i] = pre + x - v;
         __syncthreads();
-        if (threadIdx.x == 255) carry = pre + x;
+        if (threadIdx.x == T - 1) carry = pre + x;
         __syncthreads();
     }
 }
@@ -1339,7 +1359,9 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                            seg_exit2, seg_mpos, seg_kspec, seg_map);
         LFX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(64), 0, st, in, in_bytes, chunks, md, vis, seg_exit,
+    // (workgroup size by the segments per chunk: the fold over a chunk's segments is serial in batches of that size)
+    const uint32_t fix_threads = nsegs / nchunks > 128 ? 1024u : 64u;
+    hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(fix_threads), 0, st, in, in_bytes, chunks, md, vis, seg_exit,
                        seg_count, seg_exit2, seg_off, codes, ncodes, seg_mpos);
     LFX_LAUNCH_CHECK();
     if (nsegs) {
@@ -1389,7 +1411,7 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
         hipLaunchKernelGGL(tile_bits_kernel, dim3((uint32_t)ntiles), dim3(PACK_THREADS), 0, st, chunks,
                            nchunks, blocks, codes, ncodes, bc, tile_bits, tile_map);
         LFX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(nblocks), dim3(256), 0, st, chunks, blocks, bc,
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(nblocks), dim3(ntiles / (nblocks ? nblocks : 1) > 2048 ? 1024 : 256), 0, st, chunks, blocks, bc,
                            block_start, tile_bits, ntiles, nchunks, tile_start);
         LFX_LAUNCH_CHECK();
         hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)ntiles), dim3(PACK_THREADS), 0, st, chunks,
