@@ -117,6 +117,49 @@ def measure_traffic(kernel, n, schedule):
 _WORKER_BUF = {}
 
 
+def measure_issue(kernel, n, schedule, waves_per_simd):
+    """Instruction-issue occupancy of `kernel`, measured now (one more rocprofv3 --pmc child pass; SQ counters only, no
+    trace domain): the share of the SIMDs' quad-cycles in which the kernel's wavefronts issue an instruction.  The match
+    kernel is bound by this, not by HBM: SQ_WAVE_CYCLES counts quad-cycles per resident wavefront, so a SIMD that hosts
+    `waves_per_simd` of them for the whole kernel has SQ_WAVE_CYCLES / waves_per_simd quad-cycles to issue in.
+    → dict (with "error" on failure)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {"error": "rocprofv3 not found"}
+    names = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"]
+    tmp = tempfile.mkdtemp(prefix="lfx_pmc_", dir="/tmp")
+    try:
+        cmd = [rocprof, "--pmc"] + names + ["--output-format", "csv", "-d", tmp, "--", sys.executable,
+                                            os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "0",
+                                            "--bytes", str(n), "--schedule", schedule]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+        if r.returncode != 0:
+            return {"error": "rocprofv3 SQ pass failed: %s" % (r.stderr or r.stdout)[-300:]}
+        acc, disp = {}, set()
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if kernel not in (row.get("Kernel_Name") or ""):
+                        continue
+                    disp.add(row.get("Dispatch_Id"))
+                    c = row.get("Counter_Name") or ""
+                    acc[c] = acc.get(c, 0.0) + float(row.get("Counter_Value") or 0)
+        if not disp or not acc.get("SQ_WAVE_CYCLES"):
+            return {"error": "kernel %s not in the counter output" % kernel}
+        k = float(len(disp))
+        per = {c: acc.get(c, 0.0) / k for c in names}
+        simd_quads = per["SQ_WAVE_CYCLES"] / waves_per_simd
+        return {"bound": "instruction issue", "busy_frac": round(per["SQ_ACTIVE_INST_ANY"] / simd_quads, 4),
+                "simd_quad_cycles": int(simd_quads), "issue_quad_cycles": int(per["SQ_ACTIVE_INST_ANY"]),
+                "wavefront_instructions": {c[9:].lower(): int(per[c]) for c in names[2:]},
+                "waves_per_simd": waves_per_simd,
+                "source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_*, one child pass of this run"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": "issue measurement failed: %r" % (e,)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def under_profiler():
     """True when this process runs under rocprofv3 (its tool library rides along into every child process)."""
     return any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ) or \
@@ -382,6 +425,9 @@ def main():
                 roof["traffic"] = t["hbm_bytes"]
                 roof["traffic_detail"] = t
                 step_traffic = t.get("step_hbm_bytes_all_kernels")
+            # what the dominant kernel is actually bound by: the HBM figures above are the contract's
+            if dom == "enc:lz77_match":
+                roof["issue"] = measure_issue(PHASE_KERNEL[dom], n, args.schedule, waves_per_simd=4)   # 16-wave workgroup, one per CU
             else:
                 roof["traffic_error"] = (t or {}).get("error", "unknown")
     whole_ach = 2.0 * algo_bytes * world / (elapsed / args.steps) / 1e9
