@@ -251,7 +251,8 @@ extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) {
     (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device);
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_zero, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         if (status) *status = LFX_E_DEVICE;
@@ -276,6 +277,7 @@ extern "C" void lfx_ctx_free(lfx_ctx *cc) {
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_zero) (void)hipEventDestroy(c->ev_zero);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -453,7 +455,12 @@ int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, b
     if (cap < prefix_len + trailer + 8) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
     const uint64_t cap_words = cap / 4;  // whole dwords only (kernels write dwords)
     const uint64_t cap_bits = (cap_words * 4 - trailer) * 8;
-    HIP_TRY(hipMemsetAsync(d_out, 0, cap_words * 4, st));
+    if (c->prezero_ptr == d_out && c->prezero_bytes == cap_words * 4) {
+        HIP_TRY(hipStreamWaitEvent(st, c->ev_zero, 0));      // zero-filled on the side stream, under the match kernel
+    } else {
+        HIP_TRY(hipMemsetAsync(d_out, 0, cap_words * 4, st));
+    }
+    c->prezero_ptr = nullptr;
     c->phase("memset_out");
     EncodeResult *dres = (EncodeResult *)c->d_res.p;
     LAUNCH_TRY(launch_offsets(st, (const BlockDesc *)c->d_blocks.p, c->cur_nblocks, (const BlockCodes *)c->d_bc.p,
@@ -511,13 +518,25 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
     apply_schedule(pl, s, n);
     Plan &plan = pl.finish();
     EncodeResult res{};
+    // the pack kernels OR into a zero-filled output: fill it now, on the side stream, instead of between the Huffman
+    // and the pack kernels (every entry point is synchronous, so nothing else is using the buffer)
+    c->prezero_ptr = nullptr;
+    if (((uintptr_t)d_out & 3) == 0 && cap >= 16) {
+        (void)hipSetDevice(c->device);
+        const uint64_t bytes = cap / 4 * 4;
+        if (hipMemsetAsync(d_out, 0, bytes, c->side_stream) == hipSuccess && hipEventRecord(c->ev_zero, c->side_stream) == hipSuccess) {
+            c->prezero_ptr = d_out;
+            c->prezero_bytes = bytes;
+        }
+    }
     for (;;) {
-        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) return rc;
+        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) { c->prezero_ptr = nullptr; return rc; }
         rc = encode_emit(c, format, true, 0, true, n, hdr.data(), (uint32_t)hdr.size(), 8 * (uint64_t)hdr.size(),
                          (uint8_t *)d_out, cap, &res);
         if (match_violation(c, res)) continue;   // (never observed: see lfx_match2.hip) redo with the first-generation kernel
         break;
     }
+    c->prezero_ptr = nullptr;
     if (rc) return rc;
     if (out_len) *out_len = res.out_bytes;
     return LFX_OK;

@@ -25,7 +25,10 @@ struct Ctx {
     // work that only depends on the input (the container checksum) runs beside the thin kernels of the
     // main stream: fork / join through these two events
     hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_zero = nullptr;
+    // one-shot encode: the output buffer is zero-filled on the side stream while the match kernel runs
+    const void *prezero_ptr = nullptr;
+    uint64_t prezero_bytes = 0;
     // Every entry point that touches the context's scratch holds this lock: handles (encoders, decoders, LZ77 plug-ins)
     // of one context may live on different threads, they simply take turns on the GPU (SURVEY §8b threading row).
     std::recursive_mutex mu;
