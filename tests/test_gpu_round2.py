@@ -97,6 +97,25 @@ def test_length_limit_clamp_runs_on_device(env, oracle):
             assert pyzlib.decompress(got, -15 if fmt == ffi.DEFLATE else 15) == data
 
 
+# ------------------------------------------------------------------ a-2: single-chunk inputs whose walks do not merge
+def test_single_chunk_parse_on_non_merging_data(env, oracle):
+    """One write_all of several MiB = ONE LZ77 chunk with thousands of parse segments (the 1024-lane segment fold).  Runs of
+    one byte and short periods make maximal-length matches whose greedy walks started at different phases never merge,
+    so segments are re-walked from their true entry, some of them twice (the serial repair path inside the fold)."""
+    lfx, ctx, ffi, synth = env
+    rng = np.random.default_rng(12)
+    text = synth.text(2 << 20, seed=0x5EED0031).tobytes()
+    unit = rng.integers(0, 256, 257, dtype=np.uint8).tobytes()
+    data = (b"\0" * (3 << 20) + text[:1 << 20] + unit * 6000 + bytes([7]) * 700001 + text[1 << 20:] +
+            (b"ab" * 300000) + rng.integers(0, 3, 1 << 20, dtype=np.uint8).tobytes())
+    for fmt, kw in ((ffi.GZIP, dict(mtime=0)), (ffi.DEFLATE, dict(max_length=100)), (ffi.ZLIB, dict(window_size=4096))):
+        got = ctx.encode_host(fmt, data, ffi.make_opts(**kw), ffi.make_schedule(0))
+        want = oracle.encode(fmt, data, write_size=0, **kw)
+        assert got == want, (fmt, kw, len(got), len(want))
+        rc, out = ctx.decode_host(fmt, got)[:2]
+        assert rc == 0 and out == data
+
+
 # ------------------------------------------------------------------ b-3: stream decoder
 class ChunkReader:
     """hands out at most `step` bytes per read() — and counts what it was asked for"""
