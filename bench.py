@@ -283,7 +283,8 @@ def main():
             self.member_len = 0
             if sharded_path and rank == 0:
                 self.d_member = torch.empty(self.bound * world, dtype=torch.uint8, device=dev)
-                self.staging = torch.empty(self.bound, dtype=torch.uint8, device=dev)
+                # (the shards of the other ranks side by side: they are received concurrently)
+                self.staging = torch.empty((self.bound + 256) * max(world - 1, 1), dtype=torch.uint8, device=dev)
             else:
                 self.d_member = self.staging = None
 

@@ -49,8 +49,10 @@ def member_bytes(start_bits, part_lens):
 
 def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
     """Concatenate the shards on rank 0 (the writer).  d_part / d_member / staging are torch uint8 tensors on the
-    rank's device; `dist` is torch.distributed (None for world == 1).  Point-to-point transfers, in rank order; each
-    shard is placed as soon as it has arrived.  Returns the member's length on rank 0, 0 elsewhere."""
+    rank's device; `dist` is torch.distributed (None for world == 1).  Point-to-point transfers, ALL posted at once
+    (one batch_isend_irecv: on RCCL the shards arrive over different xGMI links concurrently — the links are
+    point-to-point, a rank-by-rank receive would use one of seven at a time); `staging` must hold the shards of ranks
+    1..world-1 side by side (256-byte aligned).  Returns the member's length on rank 0, 0 elsewhere."""
     L = _ffi.lib()
 
     def place(src_tensor, r):
@@ -59,20 +61,42 @@ def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_m
         if rc:
             raise _ffi.LfxError(rc, ctx.last_error())
 
+    if world == 1 or dist is None:
+        place(d_part, 0)
+        return member_bytes(start_bits, part_lens)
+    import torch
+    host_hop = dist.get_backend() == "gloo"          # (CPU test rigs: gloo moves host tensors)
     if rank == 0:
         place(d_part, 0)
+        bufs, hosts, ops, off = [], [], [], 0
         for r in range(1, world):
-            buf = staging[:part_lens[r]]
-            if buf.device.type == "cpu" or dist.get_backend() == "gloo":
-                host = buf.cpu() if buf.device.type != "cpu" else buf
-                dist.recv(host, src=r)
-                buf.copy_(host)
+            need = (part_lens[r] + 255) & ~255
+            if off + need > staging.numel():
+                raise ValueError("staging holds %d bytes, the shards of ranks 1..%d need more" % (staging.numel(), world - 1))
+            buf = staging[off:off + part_lens[r]]
+            off += need
+            bufs.append(buf)
+            if host_hop and buf.device.type != "cpu":
+                host = torch.empty(part_lens[r], dtype=torch.uint8)
+                hosts.append(host)
+                ops.append(dist.P2POp(dist.irecv, host, r))
             else:
-                dist.recv(buf, src=r)
-            place(buf, r)
+                hosts.append(None)
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if not host_hop and torch.cuda.is_available():
+            # (wait() orders the RCCL stream before torch's current stream, not before the context's own stream on
+            #  which the placement kernels run: block the host until the shards have landed)
+            torch.cuda.synchronize()
+        for k, r in enumerate(range(1, world)):
+            if hosts[k] is not None:
+                bufs[k].copy_(hosts[k])
+            place(bufs[k], r)
         return member_bytes(start_bits, part_lens)
     send = d_part[:part_len]
-    if dist.get_backend() == "gloo":
+    if host_hop and send.device.type != "cpu":
         send = send.cpu()
-    dist.send(send, dst=0)
+    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, 0)]):
+        w.wait()
     return 0
