@@ -47,12 +47,13 @@ def member_bytes(start_bits, part_lens):
     return (start_bits[last] // 8 if last else 0) + part_lens[last]
 
 
-def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
-    """Concatenate the shards on rank 0 (the writer).  d_part / d_member / staging are torch uint8 tensors on the
-    rank's device; `dist` is torch.distributed (None for world == 1).  Point-to-point transfers, ALL posted at once
-    (one batch_isend_irecv: on RCCL the shards arrive over different xGMI links concurrently — the links are
-    point-to-point, a rank-by-rank receive would use one of seven at a time); `staging` must hold the shards of ranks
-    1..world-1 side by side (256-byte aligned).  Returns the member's length on rank 0, 0 elsewhere."""
+def gather_begin(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
+    """Start concatenating the shards on rank 0 (the writer) and return a handle for gather_finish().  d_part / d_member /
+    staging are torch uint8 tensors on the rank's device; `dist` is torch.distributed (None for world == 1).
+    Point-to-point transfers, ALL posted at once (one batch_isend_irecv: on RCCL the shards arrive over different xGMI
+    links concurrently — the links are point-to-point, a rank-by-rank receive would use one of seven at a time);
+    `staging` must hold the shards of ranks 1..world-1 side by side (256-byte aligned).  Between begin and finish the
+    caller is free to do other work on its own shard (the transfers run on RCCL's stream)."""
     L = _ffi.lib()
 
     def place(src_tensor, r):
@@ -61,42 +62,54 @@ def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_m
         if rc:
             raise _ffi.LfxError(rc, ctx.last_error())
 
+    h = {"rank": rank, "world": world, "works": [], "pending": [], "place": place, "host_hop": False,
+         "len": member_bytes(start_bits, part_lens) if rank == 0 else 0}
     if world == 1 or dist is None:
         place(d_part, 0)
-        return member_bytes(start_bits, part_lens)
+        return h
     import torch
-    host_hop = dist.get_backend() == "gloo"          # (CPU test rigs: gloo moves host tensors)
+    host_hop = h["host_hop"] = dist.get_backend() == "gloo"          # (CPU test rigs: gloo moves host tensors)
     if rank == 0:
         place(d_part, 0)
-        bufs, hosts, ops, off = [], [], [], 0
+        ops, off = [], 0
         for r in range(1, world):
             need = (part_lens[r] + 255) & ~255
             if off + need > staging.numel():
                 raise ValueError("staging holds %d bytes, the shards of ranks 1..%d need more" % (staging.numel(), world - 1))
             buf = staging[off:off + part_lens[r]]
             off += need
-            bufs.append(buf)
+            host = None
             if host_hop and buf.device.type != "cpu":
                 host = torch.empty(part_lens[r], dtype=torch.uint8)
-                hosts.append(host)
-                ops.append(dist.P2POp(dist.irecv, host, r))
-            else:
-                hosts.append(None)
-                ops.append(dist.P2POp(dist.irecv, buf, r))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        if not host_hop and torch.cuda.is_available():
-            # (wait() orders the RCCL stream before torch's current stream, not before the context's own stream on
-            #  which the placement kernels run: block the host until the shards have landed)
-            torch.cuda.synchronize()
-        for k, r in enumerate(range(1, world)):
-            if hosts[k] is not None:
-                bufs[k].copy_(hosts[k])
-            place(bufs[k], r)
-        return member_bytes(start_bits, part_lens)
+            ops.append(dist.P2POp(dist.irecv, host if host is not None else buf, r))
+            h["pending"].append((r, buf, host))
+        h["works"] = dist.batch_isend_irecv(ops)
+        return h
     send = d_part[:part_len]
     if host_hop and send.device.type != "cpu":
         send = send.cpu()
-    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, 0)]):
+    h["keep"] = send
+    h["works"] = dist.batch_isend_irecv([dist.P2POp(dist.isend, send, 0)])
+    return h
+
+
+def gather_finish(h):
+    """Wait for the transfers of gather_begin(); rank 0 places the received shards.  → member length on rank 0, else 0."""
+    for w in h["works"]:
         w.wait()
-    return 0
+    if h["pending"]:
+        import torch
+        if not h["host_hop"] and torch.cuda.is_available():
+            # (wait() orders the RCCL stream before torch's current stream, not before the context's own stream on
+            #  which the placement kernels run: block the host until the shards have landed)
+            torch.cuda.synchronize()
+        for r, buf, host in h["pending"]:
+            if host is not None:
+                buf.copy_(host)
+            h["place"](buf, r)
+    return h["len"]
+
+
+def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
+    """gather_begin() + gather_finish()."""
+    return gather_finish(gather_begin(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist, staging))
