@@ -14,7 +14,8 @@
 //                        F1(k+1) what the head pass returned → raw predecessor → same prefix? (answer known) :
 //                                plain link ; first link state lk[]
 //                        P(k+2)  3-byte prefix, hash, request word of the head pass
-//             wave 0:    window loads (global → registers), incremental sweep of stale head fields
+//             wave 0:    window bytes: stores of the previous iteration's loads, then this iteration's loads;
+//                        incremental sweep of stale head fields
 //   phase B   wave 0:    H(k+2)  ordered head pass.  head[] holds 2^14 16-bit fields (low 16 bits of the most recent
 //                                position per hash) packed two per dword; ONE ds_mskor_rtn_b32 per 64 positions
 //                                exchanges the field and returns the old dword.  The LDS serves the lanes of one
@@ -24,7 +25,6 @@
 //                                ph(p) = most recent earlier position with the same hash.  A lane that observes a
 //                                value "from the future" (distance >= 65536-64) proves a violation: the kernel
 //                                raises a flag and the host re-runs the first-generation kernel.
-//                        ... then the window stores
 //             resolvers: F2(k+1) duplicate-collapsed link by pointer jumping → prevd[]
 //                        R2(k)   match length → md[]
 //
@@ -58,9 +58,9 @@ constexpr uint32_t TILE = RW * 64;            // 960 positions
 constexpr uint32_t NSUB = RW;                 // 64-position sub-tiles per tile (= exchanges of the head pass)
 constexpr int HASH_BITS = 14;
 // ONE ring modulus for the window bytes and the link distances: a position's ring offset indexes both.  A multiple
-// of the tile size, so that a tile never straddles the end of the ring; >= window + 4 tiles + 4 (the fill of tile k+4
-// must not touch what R(k) reads).
-constexpr uint32_t RING = 39 * TILE;          // 37440
+// of the tile size, so that a tile never straddles the end of the ring; >= window + 5 tiles + 4 (the fill runs five
+// tiles ahead of R and must not touch what R(k) reads).
+constexpr uint32_t RING = 40 * TILE;          // 38400
 constexpr uint32_t HEAD_FAR = 33000;          // distance marker of an empty / swept head field
 constexpr uint32_t SWEEP_SLICES = 32;         // the whole table is swept every 32 tiles (30720 positions)
 constexpr uint32_t HB = 5;                    // exchanges per batch of the head pass (one wait per batch)
@@ -84,7 +84,7 @@ constexpr uint32_t LDS_BYTES = OFF_HEAD + (2u << HASH_BITS);
 static_assert(OFF_PREVD < 65536 && OFF_LK < 65536, "offset field");
 static_assert(NSUB % HB == 0, "the head pass issues whole batches");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(RING % 4 == 0 && 4 * TILE + 4 <= RING - 32768, "ring slack");
+static_assert(RING % 4 == 0 && 5 * TILE + 4 + 258 <= RING - 32768, "ring slack");
 static_assert(SWEEP_SLICES * TILE + 32768 + TILE + 64 < FUTURE, "head ages must stay below the violation zone");
 static_assert(HEAD_FAR + SWEEP_SLICES * TILE + TILE < FUTURE && HEAD_FAR > 32768, "far marker range");
 static_assert(LK_PTR + TILE <= 65536 && NONE < LK_PTR, "link states are 16 bits; every stored non-pointer is clamped to NONE");
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     }
     uint32_t loaded_to = base;                                    // window holds [.., loaded_to) (wave 0 keeps it)
     {
-        const uint32_t need = min(base + TILE + 4, n_pad);
+        const uint32_t need = min(base + 2 * TILE + 4, n_pad);    // (P(0) and P(1) read it before the first fill lands)
         for (uint32_t p = loaded_to + 4 * tid; p < need; p += 4 * THREADS) {
             const uint32_t v = src.load4(p), o = p - base;        // (first pass: no wrap)
             win32[o >> 2] = v;
@@ -226,6 +226,11 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     // (tile 0 = position `base` sits at ring offset 0; the loop starts two tiles early)
     uint32_t ok = RING - 2 * TILE;                 // ring offset of tile `it`
     uint32_t fill_off = loaded_to - base;          // wave 0: ring offset of position loaded_to
+    // wave 0: window bytes in flight — loaded (global → registers) in phase A of one iteration, stored to the LDS ring in
+    // phase A of the NEXT one, so that phase B of wave 0 is the head pass and nothing else (it is the longest phase B of
+    // the workgroup: the resolvers used to wait for it at the barrier)
+    uint32_t fill_w0[FILL_LOADS] = {}, fill_w1[FILL_LOADS] = {};
+    uint32_t pend_lo = loaded_to, pend_hi = loaded_to, pend_off = fill_off;
     uint64_t cy_a = 0, cy_b = 0, cy_w = 0;
 
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
@@ -240,20 +245,35 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
         const uint32_t t_r = base + (uint32_t)it * TILE;            // only used when do_r
         const uint32_t t_f = t_r + TILE;                            // only used when do_f
         const uint32_t t_p = t_f + TILE;                            // only used when do_p
-        uint32_t fill_w0[FILL_LOADS], fill_w1[FILL_LOADS];
-        uint32_t fill_need = loaded_to;
 
         // =================================================== phase A
         if (wave == 0) {
-            // ---- window bytes: global loads now, LDS stores in phase B behind the head pass.  Always four tiles ahead of R:
-            //      the last tiles' match lengths read up to 258 bytes past the segment.
-            fill_need = max(loaded_to, min(t_r + 4 * TILE + 4, n_pad));
+            // ---- window bytes of the previous iteration's loads → LDS ring
+            {
+                const uint32_t sh = (uint32_t)src.shift;
+#pragma unroll
+                for (uint32_t q = 0; q < FILL_LOADS; ++q) {
+                    const uint32_t p = pend_lo + 4 * lane + 256 * q;
+                    if (p < pend_hi) {
+                        const uint32_t v = __builtin_amdgcn_alignbyte(fill_w1[q], fill_w0[q], sh);
+                        const uint32_t o = ring_wrap(pend_off + 4 * lane + 256 * q);
+                        win32[o >> 2] = v;
+                        if (o < 8) win32[(RING + o) >> 2] = v;
+                    }
+                }
+            }
+            // ---- ... and this iteration's loads (global → registers).  Five tiles ahead of R: the stores land one
+            //      iteration later, and the last tiles' match lengths read up to 258 bytes past the segment.
+            const uint32_t fill_need = max(loaded_to, min(t_r + 5 * TILE + 4, n_pad));
+            pend_lo = loaded_to; pend_hi = fill_need; pend_off = fill_off;
 #pragma unroll
             for (uint32_t q = 0; q < FILL_LOADS; ++q) {
                 const uint32_t p = loaded_to + 4 * lane + 256 * q;
                 fill_w0[q] = fill_w1[q] = 0;
                 if (p < fill_need) src.load_raw(p, fill_w0[q], fill_w1[q]);
             }
+            fill_off = ring_wrap(fill_off + (fill_need - loaded_to));
+            loaded_to = fill_need;
             if (do_p) {
                 // ---- incremental sweep: stale fields (older than the window) → "far"
                 const uint32_t slice = (uint32_t)(it + 2) % SWEEP_SLICES;
@@ -365,20 +385,6 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
                     for (uint32_t s = 0; s < HB; ++s) oldb[(h * HB + s) * 64 + lane] = old[s];
                 }
             }
-            // ---- window stores (their loads were issued in phase A)
-            const uint32_t sh = (uint32_t)src.shift;
-#pragma unroll
-            for (uint32_t q = 0; q < FILL_LOADS; ++q) {
-                const uint32_t p = loaded_to + 4 * lane + 256 * q;
-                if (p < fill_need) {
-                    const uint32_t v = __builtin_amdgcn_alignbyte(fill_w1[q], fill_w0[q], sh);
-                    const uint32_t o = ring_wrap(fill_off + 4 * lane + 256 * q);
-                    win32[o >> 2] = v;
-                    if (o < 8) win32[(RING + o) >> 2] = v;
-                }
-            }
-            fill_off = ring_wrap(fill_off + (fill_need - loaded_to));
-            loaded_to = fill_need;
         } else if (wave <= RW) {
             const uint32_t p_r = t_r + idx;
             const uint32_t o_r = ok + idx, o_f = o1 + idx;
