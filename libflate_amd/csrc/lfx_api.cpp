@@ -216,6 +216,18 @@ void DevBuf::release() {
     cap = 0;
 }
 
+void Diag::read() {
+    auto on = [](const char *k) { return getenv(k) != nullptr; };
+    debug = on("LFX_DEBUG");
+    match_v1 = on("LFX_MATCH_V1");
+    no_serial = on("LFX_NO_SERIAL");
+    batch_serial = on("LFX_BATCH_SERIAL");
+    no_markers = on("LFX_NO_MARKERS");
+    no_pieces = on("LFX_NO_PIECES");
+    window_chain = on("LFX_WINDOW_CHAIN");
+    if (const char *fs = getenv("LFX_FREE_SHIFT")) free_shift = atoi(fs);
+}
+
 void Ctx::phase(const char *name) {
     if (!timing_on) return;
     if (n_ev >= 17) return;
@@ -248,6 +260,7 @@ extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) {
         return nullptr;
     }
     c->stream = c->own_stream;
+    c->diag.read();     // diagnostic environment switches are read once, here
     (void)hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device);
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -323,8 +336,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             return LFX_E_ARG;
         }
     const uint32_t nchunks = (uint32_t)plan.chunks.size(), nblocks = (uint32_t)plan.blocks.size();
-    // ---- which match stage: lfx_match2.hip unless it once reported a lane-order violation (or LFX_MATCH_V1 is set)
-    const bool match_v1 = c->force_match_v1 || getenv("LFX_MATCH_V1") != nullptr;
+    // ---- which candidate stage: lfx_match3.hip unless it once reported a lane-order violation (or LFX_MATCH_V1 is set)
+    const bool match_v1 = c->force_match_v1 || c->diag.match_v1;
     // A segment is one workgroup's serial walk (plus a 32 KiB warm-up when it does not start a chunk).  Small
     // inputs are cut finer so that the GPU still fills: halve the segment length until there are >= 512 of them
     // (never below 32 Ki positions: the warm-up would dominate).
@@ -345,6 +358,13 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                 segs.push_back(SegDesc{ci, (uint32_t)s, (uint32_t)std::min<uint64_t>(seg_len, ch.len - s), 0});
         }
     }
+    // workgroups of the parse walk: PARSE_WG_SEGS consecutive segments of one chunk each
+    std::vector<ParseWg> pwgs;
+    for (uint32_t ci = 0; ci < nchunks; ci++) {
+        const ChunkDesc &ch = plan.chunks[ci];
+        if (ch.flags & CH_LITERALS) continue;
+        for (uint32_t s = 0; s < ch.n_seg; s += PARSE_WG_SEGS) pwgs.push_back(ParseWg{ci, s});
+    }
     c->cur_nchunks = nchunks;
     c->cur_nblocks = nblocks;
     c->cur_ntiles = plan.n_tiles;
@@ -354,7 +374,9 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_chunks.reserve(sizeof(ChunkDesc) * std::max<size_t>(nchunks, 1)))) return rc;
     if ((rc = c->d_blocks.reserve(sizeof(BlockDesc) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
-    if ((rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;
+    if ((rc = c->d_pwgs.reserve(sizeof(ParseWg) * std::max<size_t>(pwgs.size(), 1)))) return rc;
+    if ((rc = c->d_cd.reserve(2 * n + 64))) return rc;                          // candidate distances, 16 bits per position
+    if (match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
     if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
@@ -374,6 +396,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if (nchunks) HIP_TRY(hipMemcpyAsync(c->d_chunks.p, plan.chunks.data(), sizeof(ChunkDesc) * nchunks, hipMemcpyHostToDevice, st));
     if (nblocks) HIP_TRY(hipMemcpyAsync(c->d_blocks.p, plan.blocks.data(), sizeof(BlockDesc) * nblocks, hipMemcpyHostToDevice, st));
     if (!segs.empty()) HIP_TRY(hipMemcpyAsync(c->d_segs.p, segs.data(), sizeof(SegDesc) * segs.size(), hipMemcpyHostToDevice, st));
+    if (!pwgs.empty()) HIP_TRY(hipMemcpyAsync(c->d_pwgs.p, pwgs.data(), sizeof(ParseWg) * pwgs.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(c->d_hist.p, 0, 4ull * 320 * std::max<size_t>(nblocks, 1), st));
     HIP_TRY(hipMemsetAsync(c->d_res.p, 0, 256, st));
     // the host vectors must outlive the async copies: synchronise the (tiny) uploads now
@@ -396,26 +419,29 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     } while (0)
 
     uint64_t *mdbg = nullptr;
-    if (getenv("LFX_DEBUG")) mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768);   // per-wavefront cycle counters of workgroup 0
+    if (c->diag.debug) mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768);   // per-wavefront cycle counters of workgroup 0
     uint32_t *d_match_flags = (uint32_t *)((uint8_t *)c->d_res.p + offsetof(EncodeResult, match_flags));
-    if (match_v1)
+    uint16_t *d_cd = (uint16_t *)c->d_cd.p;
+    if (match_v1) {
         LAUNCH_TRY(launch_match(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
-    else
-        LAUNCH_TRY(launch_match2(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, d_match_flags, mdbg));
+        LAUNCH_TRY(launch_md_to_cd(st, (const uint32_t *)c->d_md.p, n, d_cd));
+    } else {
+        LAUNCH_TRY(launch_match3(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                 (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
+    }
     if (mdbg) {
         uint64_t hv[128];
         (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
         for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "2", w,
+            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "3", w,
                     match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
     }
     c->phase("lz77_match");
-    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const uint32_t *)c->d_md.p,
-                            (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p, (uint32_t *)c->d_codes.p,
-                            (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map));
+    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const ParseWg *)c->d_pwgs.p,
+                            (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
+                            (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map));
     c->phase("lz77_parse");
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the histogram
@@ -524,18 +550,27 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
     if (((uintptr_t)d_out & 3) == 0 && cap >= 16) {
         (void)hipSetDevice(c->device);
         const uint64_t bytes = cap / 4 * 4;
-        if (hipMemsetAsync(d_out, 0, bytes, c->side_stream) == hipSuccess && hipEventRecord(c->ev_zero, c->side_stream) == hipSuccess) {
+        // ordered behind whatever the caller's stream still has queued on d_out (a consumer of the previous encode, an
+        // allocator-reused block): fork from c->stream exactly as the checksum does
+        if (hipEventRecord(c->ev_fork, c->stream) == hipSuccess && hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) == hipSuccess &&
+            hipMemsetAsync(d_out, 0, bytes, c->side_stream) == hipSuccess && hipEventRecord(c->ev_zero, c->side_stream) == hipSuccess) {
             c->prezero_ptr = d_out;
             c->prezero_bytes = bytes;
         }
     }
     for (;;) {
-        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) { c->prezero_ptr = nullptr; return rc; }
+        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) {
+            // the fill may still be running on the caller's buffer: do not return before it has finished
+            if (c->prezero_ptr) (void)hipEventSynchronize(c->ev_zero);
+            c->prezero_ptr = nullptr;
+            return rc;
+        }
         rc = encode_emit(c, format, true, 0, true, n, hdr.data(), (uint32_t)hdr.size(), 8 * (uint64_t)hdr.size(),
                          (uint8_t *)d_out, cap, &res);
         if (match_violation(c, res)) continue;   // (never observed: see lfx_match2.hip) redo with the first-generation kernel
         break;
     }
+    if (c->prezero_ptr) (void)hipEventSynchronize(c->ev_zero);   // (emit failed before it waited for the fill)
     c->prezero_ptr = nullptr;
     if (rc) return rc;
     if (out_len) *out_len = res.out_bytes;
@@ -847,7 +882,7 @@ extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
     ch.len = n;
     ch.n_seg = (uint32_t)div_up(n, PARSE_SEG);
     plan.n_segs = ch.n_seg;
-    plan.n_vis = (uint64_t)ch.n_seg * (PARSE_SEG / 64);
+    plan.n_vis = (uint64_t)ch.n_seg * 64;
     plan.chunks.push_back(ch);
     BlockDesc bd{};
     bd.type = BT_DYNAMIC;

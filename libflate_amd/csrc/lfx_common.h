@@ -55,7 +55,12 @@ struct BlockCodes {
 };
 
 constexpr uint32_t PACK_TILE = 2048;  // codes per pack tile
-constexpr uint32_t PARSE_SEG = 4096;  // positions per speculative parse segment (64 groups of 64)
+// Speculative parse segments: one wavefront per segment, 64 lanes ("groups") of PARSE_GROUP positions each; a group's
+// visited mask is one 64-bit word of vis[].  52 positions = 13 dwords per lane: an odd dword stride, so that 32 lanes
+// reading at the same offset inside their groups hit 32 different LDS banks (lfx_parse2.hip).
+constexpr uint32_t PARSE_GROUP = 52;
+constexpr uint32_t PARSE_SEG = 64 * PARSE_GROUP;   // 3328 positions
+constexpr uint32_t PARSE_WG_SEGS = 4;              // segments (wavefronts) per workgroup of the walk kernel
 
 #ifdef __HIPCC__
 // pointers that are known to address global memory (HBM): keeps loads on the global_load path —

@@ -18,8 +18,23 @@ struct DevBuf {
     void release();
 };
 
+// Diagnostic switches, read from the environment ONCE when the context is created — never on the
+// encode / decode paths.
+struct Diag {
+    bool debug = false;          // LFX_DEBUG: per-stage counters and cycle stamps on stderr
+    bool match_v1 = false;       // LFX_MATCH_V1: first-generation match kernel (+ md → cd) instead of lfx_match3.hip
+    bool no_serial = false;      // LFX_NO_SERIAL: the serial fallback of the single-stream decoder is an error
+    bool batch_serial = false;   // LFX_BATCH_SERIAL: every stream of a batch through the serial kernel
+    bool no_markers = false;     // LFX_NO_MARKERS
+    bool no_pieces = false;      // LFX_NO_PIECES
+    bool window_chain = false;   // LFX_WINDOW_CHAIN
+    int free_shift = -1;         // LFX_FREE_SHIFT
+    void read();
+};
+
 struct Ctx {
     int device = 0;
+    Diag diag;
     int n_cu = 0;   // compute units of the device
     hipStream_t own_stream = nullptr, stream = nullptr;
     // work that only depends on the input (the container checksum) runs beside the thin kernels of the
@@ -36,12 +51,12 @@ struct Ctx {
     void set_error(const std::string &e) { err = e; }
 
     // encode scratch
-    DevBuf d_chunks, d_blocks, d_segs, d_md, d_codes, d_ncodes, d_hist, d_bc, d_block_start, d_tile_bits,
+    DevBuf d_chunks, d_blocks, d_segs, d_pwgs, d_cd, d_md, d_codes, d_ncodes, d_hist, d_bc, d_block_start, d_tile_bits,
         d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage, d_chunkmap;
     // decode scratch
     DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks, d_dec_tabs, d_dec_sym, d_dec_win, d_dec_maps;
     std::vector<DevBuf *> all_bufs() {
-        return {&d_chunks, &d_blocks, &d_segs, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
+        return {&d_chunks, &d_blocks, &d_segs, &d_pwgs, &d_cd, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
                 &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage, &d_chunkmap,
                 &d_dec_streams, &d_dec_state, &d_dec_tmp, &d_dec_cand, &d_dec_blocks, &d_dec_tabs, &d_dec_sym, &d_dec_win, &d_dec_maps};
     }

@@ -169,7 +169,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // decode that starts a few Kbit early; it is accepted iff that boundary equals the exit of the piece in
             // front of it (piece 0 starts exactly behind the header), so the chain of pieces is proven, not assumed.
             // Pieces behave like blocks from here on (their back-references cross pieces: marker path).
-            if (nc <= 8 && comp >= (8u << 20) && stop_bit == ~0ull && !getenv("LFX_NO_PIECES")) {
+            if (nc <= 8 && comp >= (8u << 20) && stop_bit == ~0ull && !c->diag.no_pieces) {
                 constexpr uint64_t PIECE_BITS = 4ull << 20, OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
                 const uint32_t cap_slots = (uint32_t)std::min<uint64_t>((end_bits - first_bit) / PIECE_BITS * 2 + 64, 1u << 20);
@@ -199,7 +199,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     uint64_t prev_end = 0;
                     for (uint32_t q = 0; q < np && !closed; q++) {
                         const BlkInfo &r = pi[q];
-                        if (getenv("LFX_DEBUG") && (q < 3 || r.status != BLK_NO_EOB))
+                        if (c->diag.debug && (q < 3 || r.status != BLK_NO_EOB))
                             fprintf(stderr, "[lfx]   piece %u/%u: status=%u btype=%u data=%llu end=%llu prev_end=%llu lanes=%u codes=%u out=%llu\n", q, np,
                                     r.status, r.btype, (unsigned long long)r.data_bit, (unsigned long long)r.end_bit,
                                     (unsigned long long)prev_end, r.nlanes, r.n_codes, (unsigned long long)r.n_out);
@@ -224,7 +224,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     if (!closed) fail = true;
                     base += used;
                 }
-                if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  pieces: ok=%d fail=%d pieces=%zu total=%llu\n", (int)ok_chain, (int)fail, emit.size(), (unsigned long long)total);
+                if (c->diag.debug) fprintf(stderr, "[lfx]  pieces: ok=%d fail=%d pieces=%zu total=%llu\n", (int)ok_chain, (int)fail, emit.size(), (unsigned long long)total);
                 if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; last_end = 0; }
                 else pieces_mode = true;
                 c->phase("pieces");
@@ -278,7 +278,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             std::vector<uint32_t> slot(nc);
             for (uint32_t i = 0; i < nc; i++)
                 slot[i] = (bi[i].status == BLK_NO_EOB && alt[i] >= 0 && bi[alt[i]].status == BLK_OK) ? (uint32_t)alt[i] : i;
-            if (getenv("LFX_DEBUG")) {
+            if (c->diag.debug) {
                 fprintf(stderr, "[lfx] finder: stage1=%u candidates=%u\n", n1, nc);
                 for (uint32_t i = 0; i < nc && i < 12; i++)
                     fprintf(stderr, "[lfx]  cand %u start=%llu status=%u btype=%u final=%u end=%llu n_out=%llu n_codes=%u lanes=%u rounds=%u cyc_hdr=%u cyc_total=%u\n",
@@ -346,7 +346,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 pos = r.end_bit;
             }
             }   // !pieces_mode
-            if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  chain ok=%d blocks=%zu pos=%llu total=%llu\n", (int)ok_chain, emit.size(), (unsigned long long)pos, (unsigned long long)total);
+            if (c->diag.debug) fprintf(stderr, "[lfx]  chain ok=%d blocks=%zu pos=%llu total=%llu\n", (int)ok_chain, emit.size(), (unsigned long long)pos, (unsigned long long)total);
             if (ok_chain && total <= cap) {
                 // ---- K2 + K3: validated lanes emit codes, one wavefront per block materialises them
                 const uint32_t ne = (uint32_t)emit.size();
@@ -357,7 +357,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 uint32_t *d_flags = (uint32_t *)c->d_dec_tmp.p;
                 BlkEmit *d_emit = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64);
                 uint64_t *dbgbuf = nullptr;
-                if (getenv("LFX_DEBUG")) {
+                if (c->diag.debug) {
                     if ((rc = c->d_ck.reserve(64ull * 8 * ne + 64))) return rc;
                     dbgbuf = (uint64_t *)c->d_ck.p;
                     HIP_TRY(hipMemsetAsync(dbgbuf, 0, 64ull * 8 * ne, st));
@@ -373,7 +373,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 // 0.59 + 0.64 ms for window resolution + substitution)
                 uint32_t free_shift = 17;
                 while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
-                if (const char *fs = getenv("LFX_FREE_SHIFT")) free_shift = (uint32_t)atoi(fs);
+                if (c->diag.free_shift >= 0) free_shift = (uint32_t)c->diag.free_shift;
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                            (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
                                            c->d_dec_tabs.p, free_shift));
@@ -391,19 +391,19 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
                 }
-                if (!giant && !(probe && fl == 2 && !getenv("LFX_NO_MARKERS")))
+                if (!giant && !(probe && fl == 2 && !c->diag.no_markers))
                     LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                       (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
                 HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                if (giant && !(fl & 1) && !getenv("LFX_NO_MARKERS")) fl = 2;
+                if (giant && !(fl & 1) && !c->diag.no_markers) fl = 2;
                 else if (giant) {   // (markers switched off, or an invalid reference: materialise normally / fall back)
                     LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                       (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
                     HIP_TRY(hipStreamSynchronize(st));
                 }
                 c->phase("lz77_copy");
-                if (getenv("LFX_DEBUG")) {
+                if (c->diag.debug) {
                     fprintf(stderr, "[lfx]  emit flags=%u\n", fl);
                     std::vector<BlkUnits> uv(ne);
                     (void)hipMemcpy(uv.data(), c->d_hist.p, sizeof(BlkUnits) * ne, hipMemcpyDeviceToHost);
@@ -427,7 +427,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                                 (unsigned long long)dv[u * 8], (unsigned long long)dv[u * 8 + 1], (unsigned long long)dv[u * 8 + 2],
                                 (unsigned long long)dv[u * 8 + 3], (unsigned long long)dv[u * 8 + 4], (unsigned long long)dv[u * 8 + 5]);
                 }
-                if (fl == 2 && !getenv("LFX_NO_MARKERS")) {
+                if (fl == 2 && !c->diag.no_markers) {
                     // Blocks read the output of earlier blocks (streams of other encoders; the reference's own
                     // blocks never do).  Marker-based materialisation: every block, cut into units at slice
                     // boundaries, is materialised at once into 16-bit symbols (a byte, or a reference into the
@@ -454,7 +454,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     LAUNCH_TRY(launch_blk_materialize_sym(st, d_in, d_emit, ne, (const BlkUnits *)c->d_hist.p,
                                                           (const uint32_t *)c->d_codes.p, (uint16_t *)c->d_dec_sym.p));
                     c->phase("lz77_sym");
-                    if (nsu >= 128 && !getenv("LFX_WINDOW_CHAIN")) {   // long stream: blocked parallel prefix over the units
+                    if (nsu >= 128 && !c->diag.window_chain) {   // long stream: blocked parallel prefix over the units
                         if ((rc = c->d_dec_maps.reserve(window_prefix_scratch_bytes(nsu)))) return rc;
                         LAUNCH_TRY(launch_window_prefix(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, d_win));
                     } else LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win));
@@ -462,7 +462,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     LAUNCH_TRY(launch_sym_substitute(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, d_out, max_len));
                     HIP_TRY(hipStreamSynchronize(st));
                     c->phase("substitute");
-                    if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  cross-block references: %u blocks, %u units through markers\n", ne, nsu);
+                    if (c->diag.debug) fprintf(stderr, "[lfx]  cross-block references: %u blocks, %u units through markers\n", ne, nsu);
                     fl = 0;
                 }
                 if (fl == 2) {
@@ -503,7 +503,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                                                           (const uint32_t *)c->d_codes.p, d_out, nullptr));
                     HIP_TRY(hipStreamSynchronize(st));
                     c->phase("lz77_chain");
-                    if (getenv("LFX_DEBUG")) fprintf(stderr, "[lfx]  cross-block references: %u blocks re-materialised in %u ordered runs\n", ne, nr);
+                    if (c->diag.debug) fprintf(stderr, "[lfx]  cross-block references: %u blocks re-materialised in %u ordered runs\n", ne, nr);
                     fl = 0;
                 }
                 if (fl == 0) {   // no back-reference reached before its block's first byte
@@ -517,7 +517,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
         }
     }
-    if (!parallel_done && getenv("LFX_NO_SERIAL")) { c->set_error("serial fallback disabled (LFX_NO_SERIAL)"); return LFX_E_UNSUPPORTED; }
+    if (!parallel_done && c->diag.no_serial) { c->set_error("serial fallback disabled (LFX_NO_SERIAL)"); return LFX_E_UNSUPPORTED; }
     if (!parallel_done) {
         // ---- serial walk of the whole stream by one wavefront (exact error / partial-output semantics)
         jobs.clear();
@@ -788,7 +788,7 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
                 fast[l.stream] = 1;
             } else { l.bit = r.end_bit; next.push_back(l); }
         }
-        if (getenv("LFX_DEBUG")) {
+        if (c->diag.debug) {
             uint32_t bad = 0, nfl = 0;
             for (uint32_t k = 0; k < nj; k++) bad += bi[k].status != BLK_OK;
             for (uint32_t q = 0; q < ne; q++) nfl += jf[q];
@@ -850,7 +850,7 @@ extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, 
     for (uint32_t i = 0; i < count; i++) n_in = std::max(n_in, in_off[i] + in_len[i]);
     std::vector<uint8_t> fast;
     std::vector<InflateResult> fres;
-    if (getenv("LFX_BATCH_SERIAL")) { fast.assign(count, 0); fres.assign(count, InflateResult{}); }
+    if (c->diag.batch_serial) { fast.assign(count, 0); fres.assign(count, InflateResult{}); }
     else if ((rc = batch_fast(c, (const uint8_t *)d_in, n_in, (uint8_t *)d_out, count, jobs, fast, fres))) return rc;
     c->phase("fast");
     std::vector<InflateJob> slow_jobs;

@@ -26,15 +26,26 @@ struct EncodeResult {
     uint32_t match_flags;  // bit 0: the second-generation match kernel saw an LDS lane-order violation (results void)
 };
 
+// one workgroup of the parse walk: PARSE_WG_SEGS consecutive parse segments of one chunk, from segment seg0 on
+struct ParseWg {
+    uint32_t chunk;
+    uint32_t seg0;
+};
+
 int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                  const SegDesc *segs, uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md,
                  uint64_t *dbg = nullptr);
-// second-generation match stage (lfx_match2.hip): per-position answers → md.  flags[0] |= 1 on a lane-order violation.
-int launch_match2(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint32_t *flags, uint64_t *dbg = nullptr);
-int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
-                 uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
-                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage /* 4 bytes per input byte */, const uint32_t *seg_map);
+// candidate stage (lfx_match3.hip): per position the distance to the most recent earlier occurrence of its 3-byte prefix
+// (0 = none) → cd.  flags[0] |= 1 on a lane-order violation.
+int launch_match3(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg = nullptr);
+// the first-generation kernel's answers (length << 16 | distance) → cd
+int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd);
+// the greedy walk with lazy match lengths (lfx_parse2.hip) → code words per chunk
+int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
+                 uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
+                 uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage /* 4 bytes per input byte */,
+                 const uint32_t *seg_map);
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
                       uint32_t *tile_map, uint32_t *seg_map);
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,

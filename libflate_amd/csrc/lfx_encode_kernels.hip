@@ -368,13 +368,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// lz77_parse: the greedy walk i += length / i += 1 (default.rs:76-107) is a serial chain per chunk.
-// It is run speculatively in parallel: every PARSE_SEG-position segment is walked from its FIRST
-// position (P1); greedy parses that start at different positions merge after a few steps, so almost all
-// of each speculative walk is the true walk.  One wavefront per chunk (P2) then chains the true entry
-// points through the segments, re-walking only from a segment's true entry to the merge point, and
-// turns the per-segment counts into offsets; every segment finally emits its codes (P3).
-// The walk itself keeps 64 per-position answers in a VGPR and steps through them with v_readlane.
+// lz77_parse: lfx_parse2.hip.
 // tile → chunk and segment → chunk tables (one workgroup per chunk): the tile / segment kernels start with one load
 // instead of a binary search over the chunk list (ten dependent L2 round trips per workgroup, also in the many
 // workgroups of tiles that hold no code)
@@ -387,283 +381,6 @@ __global__ __launch_bounds__(256) void chunk_maps_kernel(const ChunkDesc *__rest
     const uint32_t s1 = c + 1 < nchunks ? chunks[c + 1].seg_base : nsegs;
     for (uint64_t t = ch.tile_base + blockIdx.y * 256 + threadIdx.x; t < t1; t += 256ull * gridDim.y) tile_map[t] = c;
     for (uint32_t q = ch.seg_base + blockIdx.y * 256 + threadIdx.x; q < s1; q += 256u * gridDim.y) seg_map[q] = c;
-}
-
-constexpr int SPEC_ROUNDS = 3;
-// The walk also STAGES its code words (stage[], indexed like md: a segment's codes, compacted, from its first
-// position on): the answers are in registers here, and everything behind the point where the true walk merges into
-// the speculative one is final — parse_emit then copies it instead of reading md (4 B per position) a second time.
-__global__ __launch_bounds__(64) void parse_spec_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                        const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
-                                                        const uint32_t *__restrict__ md,
-                                                        uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit,
-                                                        uint32_t *__restrict__ seg_count,
-                                                        uint32_t *__restrict__ stage,
-                                                        const uint32_t *__restrict__ seg_map) {
-    const uint32_t seg = blockIdx.x;
-    const uint32_t c = seg_map[seg];   // (a table, not a binary search over the chunk list: ten dependent loads less)
-    const ChunkDesc ch = chunks[c];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t s = seg - ch.seg_base;
-    const uint32_t n = (uint32_t)ch.len;
-    const uint32_t end = (n > 3 ? n : 3) - 3;
-    const uint32_t s0 = s * PARSE_SEG;
-    uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
-    if (ch.flags & CH_LITERALS) return;   // no walk: every byte is a literal
-    uint32_t pos = s0, cnt = 0;
-    uint32_t *st = stage + ch.in_off + s0;
-    const uint64_t lt = lanemask_lt();
-    // answers are prefetched four groups ahead (a group's walk is much shorter than an HBM round trip); an answer IS
-    // the position's code word (a match, or the literal with its byte)
-    auto fetch = [&](uint32_t g) -> uint32_t {
-        const uint32_t i = s0 + g * 64 + lane;
-        return (g < PARSE_SEG / 64 && i < end) ? md[ch.in_off + i] : 0;
-    };
-    uint32_t v0 = fetch(0), v1 = fetch(1), v2 = fetch(2), v3 = fetch(3);
-    for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
-        const uint32_t base = s0 + g * 64;
-        uint64_t m = 0;
-        const uint32_t v = v0;
-        v0 = v1; v1 = v2; v2 = v3;
-        v3 = fetch(g + 4);
-        if (base < end) {
-            // The scalar unit is shared by the whole CU and the walk is a chain of dependent steps: the
-            // vector side precomputes, for every position, where 2^SPEC_ROUNDS steps lead and the bits they
-            // visit (pointer doubling, three ds_bpermute per round), so that the serial loop is three readlanes
-            // per eight steps.
-            const uint32_t stepv = (v & 0xFFFFu) ? (v >> 16) : 1u;
-            const uint32_t stop_r = min(base + 64, end) - base;
-            uint32_t j = lane + stepv;                              // group-relative position after 2^k steps
-            uint32_t klo = lane < 32 ? 1u << lane : 0u, khi = lane >= 32 ? 1u << (lane - 32) : 0u;   // positions visited on the way
-#pragma unroll
-            for (int rd = 0; rd < SPEC_ROUNDS; ++rd) {
-                const bool inside = j < stop_r;                     // ... still inside the group
-                const int from = (int)((inside ? j : lane) << 2);
-                const uint32_t jn = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)j);
-                const uint32_t ln = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)klo);
-                const uint32_t hn = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)khi);
-                klo |= inside ? ln : 0u;
-                khi |= inside ? hn : 0u;
-                j = inside ? jn : j;
-            }
-            uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
-            while (r < stop_r) {
-                m |= (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)klo, r) |
-                     (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)khi, r) << 32;
-                r = (uint32_t)__builtin_amdgcn_readlane((int)j, r);
-            }
-            pos = base + r;
-        }
-        if (lane == 0) vw[g] = m;
-        if ((m >> lane) & 1) st[cnt + __popcll(m & lt)] = v;
-        cnt += __popcll(m);
-    }
-    if (lane == 0) { seg_exit[seg] = pos; seg_count[seg] = cnt; }
-}
-
-// P2a: one wavefront per segment.  The true walk enters segment s where the walk of segment s-1 left it;
-// that is the speculative exit of s-1 unless s-1 itself never merged (rare: P2b repairs those).  Re-walk
-// from the entry until the walk lands on a position the speculative walk visited — from there on both
-// coincide — and rewrite the visited mask, the count and the exit of the segment accordingly.
-struct SegFix { uint32_t cnt, ex, mpos, kspec; };   // codes, exit; merge position, staged codes in front of it
-__device__ __forceinline__ SegFix parse_rewalk(const ChunkDesc &ch, const uint32_t *__restrict__ md,
-                                               uint64_t *__restrict__ vw, uint32_t s0, uint32_t s1, uint32_t end,
-                                               uint32_t e, uint32_t cnt, uint32_t ex, uint32_t lane) {
-    uint32_t pos = e, walked = 0, spec_below = 0, merge_pos = s1;
-    bool merged = false;
-    for (uint32_t g = 0; g < PARSE_SEG / 64 && !merged; ++g) {
-        const uint32_t base = s0 + g * 64;
-        if (base >= s1) break;
-        const uint64_t V = vw[g];
-        if (pos >= base + 64) {          // wholly before the true entry: nothing visited here
-            spec_below += __popcll(V);
-            if (lane == 0 && V) vw[g] = 0;
-            continue;
-        }
-        const uint32_t i = base + lane;
-        const uint32_t v = i < end ? md[ch.in_off + i] : 0;
-        const uint32_t stop = min(base + 64, s1);
-        uint64_t T = 0;
-        uint32_t mr = 64;
-        while (pos < stop) {
-            const uint32_t r = __builtin_amdgcn_readfirstlane(pos - base);
-            if ((V >> r) & 1) { merged = true; mr = r; merge_pos = base + r; break; }
-            const uint32_t mv = __builtin_amdgcn_readlane(v, r);
-            T |= 1ull << r;
-            walked++;
-            pos += (mv & 0xFFFFu) ? (mv >> 16) : 1u;
-        }
-        const uint64_t keep = mr < 64 ? (V & ~((1ull << mr) - 1)) : 0;   // speculative bits from the merge on
-        spec_below += __popcll(V & ~keep);
-        if (lane == 0) vw[g] = T | keep;
-    }
-    SegFix f;
-    if (merged) { f.cnt = cnt - spec_below + walked; f.ex = ex; f.mpos = merge_pos; f.kspec = spec_below; }   // the exit stays the one already known
-    else { f.cnt = walked; f.ex = pos; f.mpos = s1; f.kspec = cnt; }     // never merged inside this segment: nothing staged survives
-    return f;
-}
-
-__global__ __launch_bounds__(64) void parse_fixseg_kernel(const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
-                                                          const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
-                                                          const uint32_t *__restrict__ seg_exit,
-                                                          uint32_t *__restrict__ seg_count,
-                                                          uint32_t *__restrict__ seg_exit2,
-                                                          uint32_t *__restrict__ seg_mpos,
-                                                          uint32_t *__restrict__ seg_kspec,
-                                                          const uint32_t *__restrict__ seg_map) {
-    const uint32_t seg = blockIdx.x;
-    const ChunkDesc ch = chunks[seg_map[seg]];
-    if (ch.flags & CH_LITERALS) return;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t s = seg - ch.seg_base;
-    const uint32_t n = (uint32_t)ch.len;
-    const uint32_t end = (n > 3 ? n : 3) - 3;
-    const uint32_t s0 = s * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
-    const uint32_t e = s ? seg_exit[seg - 1] : 0;                   // assumed entry
-    SegFix f{seg_count[seg], seg_exit[seg], s0, 0u};                 // (entered where assumed: every staged code is final)
-    if (s0 >= end) { f.cnt = 0; f.ex = e; }                          // behind the last walked position: pass through
-    else if (e != s0) f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64), s0, s1, end, e, f.cnt, f.ex, lane);
-    if (lane == 0) { seg_count[seg] = f.cnt; seg_exit2[seg] = f.ex; seg_mpos[seg] = f.mpos; seg_kspec[seg] = f.kspec; }
-}
-
-// P2b: one wavefront per chunk: checks the assumption of P2a for 64 segments at a time (segment s was
-// entered correctly iff the exit of s-1 did not change), repairs the rare segment that was not, and turns
-// the counts into offsets; then the chunk's tail and the EndOfBlock marker.
-// One workgroup per chunk: 64 lanes when a chunk has a few dozen segments (the reference's 256 KiB chunks), 1024 when one
-// chunk is the whole input (schedule S1: 65536 segments per 256 MiB — a single wavefront walked them 64 at a time, 2 ms).
-__global__ __launch_bounds__(1024) void parse_fix_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                         const ChunkDesc *__restrict__ chunks,
-                                                         const uint32_t *__restrict__ md, uint64_t *__restrict__ vis,
-                                                         const uint32_t *__restrict__ seg_exit,
-                                                         uint32_t *__restrict__ seg_count,
-                                                         uint32_t *__restrict__ seg_exit2,
-                                                         uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
-                                                         uint32_t *__restrict__ ncodes, uint32_t *__restrict__ seg_mpos) {
-    __shared__ uint32_t s_first_bad, s_wsum[16], s_redo[2];
-    const ChunkDesc ch = chunks[blockIdx.x];
-    const uint32_t tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
-    const uint32_t n = (uint32_t)ch.len;
-    const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
-    uint32_t *out = codes + ch.code_off;
-    uint32_t total = 0;
-    if (ch.flags & CH_LITERALS) {
-        for (uint32_t s = tid; s < ch.n_seg; s += T) seg_off[ch.seg_base + s] = s * PARSE_SEG;
-        total = n;
-    } else {
-        const uint32_t end = (n > 3 ? n : 3) - 3;
-        const uint32_t *sx = seg_exit + ch.seg_base;
-        uint32_t *sx2 = seg_exit2 + ch.seg_base, *sc = seg_count + ch.seg_base;
-        uint32_t e_last = 0;   // true exit of the segment before the current batch
-        for (uint32_t b0 = 0; b0 < ch.n_seg; ) {
-            if (tid == 0) s_first_bad = 0xFFFFFFFFu;
-            __syncthreads();
-            const uint32_t s = b0 + tid;
-            const bool have = s < ch.n_seg;
-            // entry assumed by P2a vs the true exit of the predecessor
-            const uint32_t assumed = have ? (s ? sx[s - 1] : 0) : 0;
-            const uint32_t actual = have ? (s == b0 ? e_last : sx2[s - 1]) : 0;
-            const uint64_t bad = __ballot(have && assumed != actual);
-            if (bad && lane == 0) atomicMin(&s_first_bad, wave * 64 + (uint32_t)__builtin_ctzll(bad));
-            __syncthreads();
-            const uint32_t fb = s_first_bad;
-            const uint32_t nok = fb != 0xFFFFFFFFu ? fb : min(T, ch.n_seg - b0);   // leading good segments
-            // offsets of the good prefix
-            const uint32_t c = (have && tid < nok) ? sc[s] : 0;
-            uint32_t x = c;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
-            if (lane == 63) s_wsum[wave] = x;
-            __syncthreads();
-            uint32_t pre = 0, all = 0;
-            for (uint32_t w = 0; w < nw; ++w) { const uint32_t v = s_wsum[w]; pre += w < wave ? v : 0u; all += v; }
-            if (have && tid < nok) seg_off[ch.seg_base + s] = total + pre + x - c;
-            if (nok) {
-                total += all;
-                e_last = sx2[b0 + nok - 1];
-            }
-            b0 += nok;
-            if (fb != 0xFFFFFFFFu) {
-                // segment b0 was entered at the wrong position: redo it from the true entry (one wavefront)
-                const uint32_t sb = b0;
-                if (wave == 0) {
-                    const uint32_t s0 = sb * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
-                    SegFix f{sc[sb], sx2[sb], 0u, 0u};
-                    if (s0 >= end) { f.cnt = 0; f.ex = e_last; }
-                    else f = parse_rewalk(ch, md, vis + ch.vis_base + (uint64_t)sb * (PARSE_SEG / 64), s0, s1, end, e_last, f.cnt, f.ex, lane);
-                    // (walked a second time: the staged codes no longer line up with the visit bits — emit all of this
-                    //  segment from the bits)
-                    if (lane == 0) {
-                        sc[sb] = f.cnt; sx2[sb] = f.ex; seg_off[ch.seg_base + sb] = total; seg_mpos[ch.seg_base + sb] = 0xFFFFFFFFu;
-                        s_redo[0] = f.cnt; s_redo[1] = f.ex;
-                    }
-                }
-                __syncthreads();
-                total += s_redo[0];
-                e_last = s_redo[1];
-                b0 += 1;
-            }
-            __syncthreads();
-        }
-        // default.rs:105-107: the rest are literals (at most 3 bytes)
-        const uint32_t pos = ch.n_seg ? e_last : 0;
-        for (uint32_t i = pos + tid; i < n; i += T) out[total + (i - pos)] = src.load1(i) << 16;
-        if (n > pos) total += n - pos;
-    }
-    if (ch.flags & CH_LAST_IN_BLOCK) {
-        if (tid == 0) out[total] = CODE_EOB;  // encode.rs:417
-        total += 1;
-    }
-    if (tid == 0) ncodes[blockIdx.x] = total;
-}
-
-// P3: every segment emits the codes of its visited positions
-__global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                        const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
-                                                        const uint32_t *__restrict__ md,
-                                                        const uint64_t *__restrict__ vis,
-                                                        const uint32_t *__restrict__ seg_off,
-                                                        uint32_t *__restrict__ codes,
-                                                        const uint32_t *__restrict__ stage,
-                                                        const uint32_t *__restrict__ seg_count,
-                                                        const uint32_t *__restrict__ seg_mpos,
-                                                        const uint32_t *__restrict__ seg_kspec,
-                                                        const uint32_t *__restrict__ seg_map) {
-    const uint32_t seg = blockIdx.x;
-    const uint32_t c = seg_map[seg];
-    const ChunkDesc ch = chunks[c];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t s = seg - ch.seg_base;
-    const uint32_t n = (uint32_t)ch.len;
-    const uint32_t s0 = s * PARSE_SEG;
-    const ByteSrc src = make_src(in + ch.in_off, in_bytes - ch.in_off);
-    uint32_t *out = codes + ch.code_off + seg_off[seg];
-    if (ch.flags & CH_LITERALS) {
-        const uint32_t s1 = min(s0 + PARSE_SEG, n);
-        for (uint32_t i = s0 + lane; i < s1; i += 64) out[i - s0] = src.load1(i) << 16;
-        return;
-    }
-    const uint32_t end = (n > 3 ? n : 3) - 3;
-    const uint64_t *vw = vis + ch.vis_base + (uint64_t)s * (PARSE_SEG / 64);
-    const uint64_t lt = lanemask_lt();
-    uint32_t nout = 0;
-    // positions in front of the merge point: from the (repaired) visit bits and md, as far as they go — usually less
-    // than one 64-position group, none at all when the segment was entered where the speculative walk assumed
-    const uint32_t mpos = min(seg_mpos[seg], min(s0 + PARSE_SEG, end));
-    for (uint32_t g = 0; g < PARSE_SEG / 64; ++g) {
-        const uint32_t base = s0 + g * 64;
-        if (base >= mpos) break;
-        uint64_t m = vw[g];
-        if (mpos - base < 64) m &= (1ull << (mpos - base)) - 1;
-        if (m == 0) continue;
-        if ((m >> lane) & 1) {
-            const uint32_t i = base + lane;
-            out[nout + __popcll(m & lt)] = md[ch.in_off + i];
-        }
-        nout += __popcll(m);
-    }
-    // everything behind it: the codes the speculative walk staged, behind the kspec it visited in front of the merge
-    const uint32_t n2 = seg_count[seg] - nout;
-    const uint32_t *st = stage + ch.in_off + s0 + seg_kspec[seg];
-    for (uint32_t j = lane; j < n2; j += 64) out[nout + j] = st[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1339,36 +1056,6 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     hipLaunchKernelGGL(lz77_match_kernel, dim3(nsegs), dim3(MATCH_THREADS), lds, st, in, in_bytes,
                        chunks, segs, window, max_len, md, dbg);
     LFX_LAUNCH_CHECK();
-    return 0;
-}
-int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
-                 uint32_t nchunks, uint32_t nsegs, const uint32_t *md, uint64_t *vis, uint32_t *seg_tmp,
-                 uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map) {
-    if (nchunks == 0) return 0;
-    // seg_tmp: six arrays of nsegs words
-    uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
-    uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs, *seg_mpos = seg_tmp + 4 * (size_t)nsegs;
-    uint32_t *seg_kspec = seg_tmp + 5 * (size_t)nsegs;
-    if (nsegs) {
-        hipLaunchKernelGGL(parse_spec_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis, seg_exit,
-                           seg_count, stage, seg_map);
-        LFX_LAUNCH_CHECK();
-    }
-    if (nsegs) {
-        hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, chunks, nchunks, md, vis, seg_exit, seg_count,
-                           seg_exit2, seg_mpos, seg_kspec, seg_map);
-        LFX_LAUNCH_CHECK();
-    }
-    // (workgroup size by the segments per chunk: the fold over a chunk's segments is serial in batches of that size)
-    const uint32_t fix_threads = nsegs / nchunks > 128 ? 1024u : 64u;
-    hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(fix_threads), 0, st, in, in_bytes, chunks, md, vis, seg_exit,
-                       seg_count, seg_exit2, seg_off, codes, ncodes, seg_mpos);
-    LFX_LAUNCH_CHECK();
-    if (nsegs) {
-        hipLaunchKernelGGL(parse_emit_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, nchunks, md, vis,
-                           seg_off, codes, stage, seg_count, seg_mpos, seg_kspec, seg_map);
-        LFX_LAUNCH_CHECK();
-    }
     return 0;
 }
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,

@@ -844,28 +844,6 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: one wavefront per unit turns codes into bytes through a 36 KiB LDS ring: the last 32 KiB of
-// output (the DEFLATE window) plus at most 4 KiB in flight, so that four units are resident per CU
-// (four 40 KiB rings are exactly the CU's 160 KiB and do NOT fit next to each other).
-// The ring size is 9 * 4096, its index is pos mod 36864.
-constexpr uint32_t MWIN = 36864;
-constexpr uint32_t MBATCH_MAX = 4096;   // bytes one batch may produce (a code produces <= 258)
-constexpr uint32_t PAR_LEN = 16;        // matches up to this length that read only pre-batch bytes go in parallel
-
-__device__ __forceinline__ uint32_t ring_idx(uint32_t pos) {
-    const uint32_t x = pos >> 12;
-    const uint32_t q = (uint32_t)(((uint64_t)x * 954437177ull) >> 33);   // x / 9
-    return ((x - 9 * q) << 12) | (pos & 4095);
-}
-__device__ __forceinline__ uint32_t ring_add(uint32_t idx, uint32_t k) {   // k < MWIN
-    const uint32_t r = idx + k;
-    return r >= MWIN ? r - MWIN : r;
-}
-
-// gfx950's LDS takes dword accesses at any byte address
-__device__ __forceinline__ uint32_t lds_ld32(const unsigned char *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-__device__ __forceinline__ void lds_st32(unsigned char *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
-
 // inclusive prefix sum over the wavefront: four row shifts and two row broadcasts, no LDS traffic
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
@@ -877,144 +855,13 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
     return x;
 }
 
-__global__ __launch_bounds__(64) void blk_materialize_kernel(const uint8_t *__restrict__ in,
-                                                             const BlkEmit *__restrict__ jobs,
-                                                             const BlkLanes *__restrict__ lanes,
-                                                             const BlkUnits *__restrict__ units,
-                                                             const uint32_t *__restrict__ codes,
-                                                             uint8_t *__restrict__ out, uint32_t njobs,
-                                                             uint64_t *__restrict__ dbg) {
-    __shared__ __attribute__((aligned(16))) unsigned char ring[MWIN];
-    // unit-major: workgroups go round-robin to the 8 XCDs, so consecutive indices must all carry work (with
-    // a block-major order the real units sit at indices = 0..3 mod 8 and half of the XCDs stay idle)
-    const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;
-    const BlkEmit job = jobs[bidx];
-    const uint32_t lane = threadIdx.x;
-    if (job.btype == 0) {
-        if (u != 0) return;
-        uint8_t *o = out + job.out_off;
-        const uint8_t *src = in + (job.data_bit >> 3);
-        for (uint64_t k = lane; k < job.n_out; k += 64) o[k] = src[k];
-        return;
-    }
-    const BlkUnits *U = &units[bidx];
-    if (u >= U->n) return;
-    const uint32_t c0 = U->code0[u], c1 = U->code0[u + 1];
-    const uint64_t ob = U->out0[u];                      // unit's first byte inside the block
-    const uint64_t gbase = job.out_off + ob;             // ... inside the output buffer
-    uint8_t *o = out + gbase;
-    const uint32_t *cp = codes + job.code_off + c0;
-    const uint32_t n = c1 - c0;
-    // byte `pos` of the unit lives at ring_idx(pos + shift): ring and output share their 4-byte alignment,
-    // so the flush moves aligned dwords
-    // history in front of the block (batch rounds: earlier blocks of the stream are already in `out`): the first
-    // unit preloads up to 32 KiB of it, so that back-references may reach across the block start
-    const uint32_t hist = (u == 0 && job.preload) ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
-    const uint32_t shift = (uint32_t)((gbase - hist) & 3) + hist;
-    for (uint32_t k = lane; k < hist; k += 64) ring[ring_idx(shift - hist + k)] = o[(int64_t)k - (int64_t)hist];
-    __builtin_amdgcn_wave_barrier();
-    uint64_t produced = 0, flushed = 0;
-    uint32_t base = 0;
-    uint32_t c_cur = lane < n ? cp[lane] : 0;
-    const uint64_t t0 = dbg ? clock64() : 0;
-    uint32_t nbatch = 0;
-    while (base < n) {
-        nbatch++;
-        const uint32_t i = base + lane;
-        const uint32_t c_pref = i + 64 < n ? cp[i + 64] : 0;   // next batch's code words, assuming 64 are taken
-        const uint32_t c = c_cur;
-        const uint32_t dist = c & 0xFFFFu, val = c >> 16;
-        bool valid = i < n;
-        uint32_t mylen = valid ? (dist ? val : 1u) : 0u;
-        uint32_t x = wave_inclusive_sum(mylen);
-        uint32_t take = 64;
-        if (__builtin_amdgcn_readlane(x, 63) > MBATCH_MAX) {
-            // rare (long runs): only the codes whose output fits are taken in this round
-            take = (uint32_t)__popcll(__ballot(x <= MBATCH_MAX));
-            if (lane >= take) { valid = false; mylen = 0; x = 0; }
-        }
-        const uint32_t total = __builtin_amdgcn_readlane(x, take - 1);
-        const bool is_match = valid && dist != 0;
-        const uint32_t rel = x - mylen;                  // my first byte relative to the batch start
-        const uint32_t at = (uint32_t)produced + shift + rel;
-        const uint32_t at_i = ring_idx(at);
-        if (valid && !is_match) ring[at_i] = (unsigned char)val;
-        // a match is "far" when every byte it reads was produced before this batch
-        const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
-        const uint32_t src_i = is_match ? ring_idx(at - dist) : 0;
-        const bool par = far && mylen <= PAR_LEN && dist >= mylen && src_i + PAR_LEN <= MWIN && at_i + PAR_LEN <= MWIN;
-        if (par) {
-            // dwords at [0,4) [4,8) [8,12) as far as they fit, then the last four bytes (overlapping the
-            // previous store); all loads come before the stores, the source is older than this batch
-            const unsigned char *sp = ring + src_i;
-            unsigned char *dp = ring + at_i;
-            if (mylen >= 4) {
-                const uint32_t a0 = lds_ld32(sp), at4 = lds_ld32(sp + mylen - 4);
-                uint32_t a1 = 0, a2 = 0;
-                if (mylen >= 8) a1 = lds_ld32(sp + 4);
-                if (mylen >= 12) a2 = lds_ld32(sp + 8);
-                lds_st32(dp, a0);
-                if (mylen >= 8) lds_st32(dp + 4, a1);
-                if (mylen >= 12) lds_st32(dp + 8, a2);
-                lds_st32(dp + mylen - 4, at4);
-            } else {
-                const unsigned char b0 = sp[0], b1 = sp[1], b2 = sp[2];
-                dp[0] = b0; dp[1] = b1; dp[2] = b2;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        uint64_t mm = __ballot(is_match && !par);
-        while (mm) {
-            const uint32_t sl = (uint32_t)__builtin_ctzll(mm);
-            mm &= mm - 1;
-            const uint32_t mc = __builtin_amdgcn_readlane(c, sl);
-            const uint32_t mat_i = __builtin_amdgcn_readlane(at_i, sl);
-            const uint32_t len = mc >> 16, d = mc & 0xFFFFu;
-            const uint32_t src_i = mat_i >= d ? mat_i - d : mat_i + MWIN - d;   // d <= 32768 < MWIN
-            // out[k] = src[k mod d] reproduces the overlapping forward copy (rle_decode, lib.rs:186-190);
-            // LDS operations of one wavefront execute in order, so later matches see these bytes
-            if (d >= len) {
-                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k)];
-            } else {
-                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k % d)];
-            }
-        }
-        produced += total;
-        base += take;
-        __builtin_amdgcn_wave_barrier();
-        // flush early and often: the ring holds the 32 KiB history in front of the batch plus the batch itself (<= 4 KiB)
-        const bool last = base >= n;
-        if (produced - flushed >= 512 || last) {
-            const uint64_t upto = produced;
-            while (flushed < upto && ((gbase + flushed) & 3)) {   // head: align the global address
-                if (lane == 0) o[flushed] = ring[ring_idx((uint32_t)flushed + shift)];
-                flushed++;
-            }
-            const uint64_t ndw = (upto - flushed) >> 2;
-            uint32_t *o32 = (uint32_t *)(o + flushed);
-            for (uint64_t k = lane; k < ndw; k += 64)
-                o32[k] = *(const uint32_t *)&ring[ring_idx((uint32_t)flushed + shift + 4 * (uint32_t)k)];
-            flushed += 4 * ndw;
-            if (last) {
-                for (uint64_t k = flushed + lane; k < upto; k += 64) o[k] = ring[ring_idx((uint32_t)k + shift)];
-                flushed = upto;
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        c_cur = take == 64 ? c_pref : (base + lane < n ? cp[base + lane] : 0);   // rare path: reload
-    }
-    if (dbg && lane == 0) {
-        uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
-        d[0] = clock64() - t0; d[1] = nbatch; d[2] = 0; d[3] = 0; d[4] = n; d[5] = produced; d[6] = wall_clock64();
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
-// K3, second generation: a 256-lane workgroup per unit, the copy itself data-parallel over BYTES.
+// K3: a 256-lane workgroup per unit, the copy itself data-parallel over BYTES.
 //
-// The first-generation kernel above gives a unit to ONE wavefront: lanes = codes, back-references that read bytes of
-// their own batch are executed one after the other, and with a single wavefront per SIMD every instruction's latency is
-// exposed (measured: 3360 cycles per batch of 64 codes = 234 bytes).  Here a tile of 256 codes (<= M2_TILE bytes) is
+// (The first-generation kernel — removed in round 3 — gave a unit to ONE wavefront: lanes = codes, back-references that
+// read bytes of their own batch executed one after the other, and with a single wavefront per SIMD every instruction's
+// latency was exposed: 3360 cycles per batch of 64 codes = 234 bytes.)  Here a tile of 256 codes (<= M2_TILE bytes) is
 // expanded to bytes: every lane owns four output bytes, finds the code that covers them (binary search in the codes'
 // end offsets), and
 //   * a literal, or a byte whose source lies in front of the tile (final, in the ring), is written at once;
@@ -1239,99 +1086,6 @@ __global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint
 // out holding the markers 256 + 0 .. 256 + 32767; back-references then copy symbols exactly as K3 copies
 // bytes, and the symbols go to `sym` (one per output byte).  Pass 2 (window_chain_kernel) walks the units in
 // order and resolves only each unit's LAST 32 KiB; pass 3 (sym_substitute_kernel) replaces every marker.
-constexpr uint32_t SWIN = 36864;        // ring entries: 32 Ki of history + 4 Ki in flight
-__global__ __launch_bounds__(64) void blk_materialize_sym_kernel(const uint8_t *__restrict__ in,
-                                                                 const BlkEmit *__restrict__ jobs,
-                                                                 const BlkUnits *__restrict__ units,
-                                                                 const uint32_t *__restrict__ codes,
-                                                                 uint16_t *__restrict__ sym, uint32_t njobs) {
-    extern __shared__ uint16_t ring[];   // SWIN entries (72 KiB: two units per CU)
-    const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;   // unit-major (XCD balance, see K3)
-    const BlkEmit job = jobs[bidx];
-    const uint32_t lane = threadIdx.x;
-    if (job.btype == 0) {
-        if (u != 0) return;
-        uint16_t *o = sym + job.out_off;
-        const uint8_t *src = in + (job.data_bit >> 3);
-        for (uint64_t k = lane; k < job.n_out; k += 64) o[k] = src[k];
-        return;
-    }
-    const BlkUnits *U = &units[bidx];
-    if (u >= U->fn) return;
-    const uint32_t c0 = U->fcode0[u], c1 = U->fcode0[u + 1];
-    uint16_t *o = sym + job.out_off + U->fout0[u];
-    const uint32_t *cp = codes + job.code_off + c0;
-    const uint32_t n = c1 - c0;
-    constexpr uint32_t H = 32768;       // unit byte `pos` lives at ring_idx(pos + H)
-    for (uint32_t k = lane; k < H; k += 64) ring[ring_idx(k)] = (uint16_t)(256 + k);
-    __builtin_amdgcn_wave_barrier();
-    uint32_t produced = 0, flushed = 0, base = 0;
-    uint32_t c_cur = lane < n ? cp[lane] : 0;
-    while (base < n) {
-        const uint32_t i = base + lane;
-        const uint32_t c_pref = i + 64 < n ? cp[i + 64] : 0;
-        const uint32_t c = c_cur;
-        const uint32_t dist = c & 0xFFFFu, val = c >> 16;
-        bool valid = i < n;
-        uint32_t mylen = valid ? (dist ? val : 1u) : 0u;
-        uint32_t x = wave_inclusive_sum(mylen);
-        uint32_t take = 64;
-        if (__builtin_amdgcn_readlane(x, 63) > MBATCH_MAX) {
-            take = (uint32_t)__popcll(__ballot(x <= MBATCH_MAX));
-            if (lane >= take) { valid = false; mylen = 0; x = 0; }
-        }
-        const uint32_t total = __builtin_amdgcn_readlane(x, take - 1);
-        const bool is_match = valid && dist != 0;
-        const uint32_t rel = x - mylen;
-        const uint32_t at_i = ring_idx(produced + H + rel);
-        if (valid && !is_match) ring[at_i] = (uint16_t)val;
-        // matches that read only symbols older than this batch: every lane copies its own (<= PAR_LEN symbols)
-        const bool far = is_match && dist >= rel + (mylen < dist ? mylen : dist);
-        const uint32_t src_i = is_match ? (at_i >= dist ? at_i - dist : at_i + SWIN - dist) : 0;
-        const bool par = far && mylen <= PAR_LEN && dist >= mylen && src_i + PAR_LEN <= SWIN && at_i + PAR_LEN <= SWIN;
-        if (par) {
-            // two symbols per dword (the LDS takes a dword at any 2-byte address): pairs [0,2) [2,4) ... as far
-            // as they fit, then the last two symbols (overlapping the previous store when the length is even);
-            // all loads come before the stores, the source is older than this batch
-            const unsigned char *sp = (const unsigned char *)(ring + src_i);
-            unsigned char *dp = (unsigned char *)(ring + at_i);
-            uint32_t t[PAR_LEN / 2];
-            const uint32_t tail = lds_ld32(sp + 2 * mylen - 4);
-#pragma unroll
-            for (uint32_t k = 0; k < PAR_LEN / 2; ++k) t[k] = 2 * k + 2 <= mylen ? lds_ld32(sp + 4 * k) : 0u;
-#pragma unroll
-            for (uint32_t k = 0; k < PAR_LEN / 2; ++k)
-                if (2 * k + 2 <= mylen) lds_st32(dp + 4 * k, t[k]);
-            lds_st32(dp + 2 * mylen - 4, tail);
-        }
-        __builtin_amdgcn_wave_barrier();
-        uint64_t mm = __ballot(is_match && !par);
-        while (mm) {                       // everything else cooperatively, in order (see K3)
-            const uint32_t sl = (uint32_t)__builtin_ctzll(mm);
-            mm &= mm - 1;
-            const uint32_t mc = __builtin_amdgcn_readlane(c, sl);
-            const uint32_t mat_i = __builtin_amdgcn_readlane(at_i, sl);
-            const uint32_t len = mc >> 16, d = mc & 0xFFFFu;
-            const uint32_t src_i = mat_i >= d ? mat_i - d : mat_i + SWIN - d;
-            if (d >= len) {
-                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k)];
-            } else {
-                for (uint32_t k = lane; k < len; k += 64) ring[ring_add(mat_i, k)] = ring[ring_add(src_i, k % d)];
-            }
-        }
-        produced += total;
-        base += take;
-        __builtin_amdgcn_wave_barrier();
-        const bool last = base >= n;
-        if (produced - flushed >= 512 || last) {
-            for (uint32_t k = flushed + lane; k < produced; k += 64) o[k] = ring[ring_idx(k + H)];
-            flushed = produced;
-            __builtin_amdgcn_wave_barrier();
-        }
-        c_cur = take == 64 ? c_pref : (base + lane < n ? cp[base + lane] : 0);
-    }
-}
-
 // Pass 2: one workgroup walks the units in stream order.  win[u] = the final 32 KiB of output that end where
 // unit u ends; byte i of it is a symbol of the unit's own tail resolved through win[u-1], or (for a unit
 // shorter than 32 KiB) byte i + len of win[u-1].  The two windows in flight live in LDS.
@@ -1669,31 +1423,14 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg) {
     if (!njobs) return 0;
-    static const bool first_gen = getenv("LFX_MAT_V1") != nullptr;   // (A/B measurements)
-    if (first_gen)
-        hipLaunchKernelGGL(blk_materialize_kernel, dim3(njobs * MAX_UNITS), dim3(64), 0, st, in, jobs, lanes, units, codes, out, njobs, dbg);
-    else
-        hipLaunchKernelGGL(blk_materialize2_kernel, dim3(njobs * MAX_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
+    hipLaunchKernelGGL(blk_materialize2_kernel, dim3(njobs * MAX_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
 int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                                const BlkUnits *units, const uint32_t *codes, uint16_t *sym) {
     if (!njobs) return 0;
-    static bool attr_set[64] = {};
-    int dev_ = 0;
-    (void)hipGetDevice(&dev_);
-    if (!attr_set[dev_ & 63]) {
-        (void)hipFuncSetAttribute((const void *)blk_materialize_sym_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SWIN * 2));
-        attr_set[dev_ & 63] = true;
-    }
-    static const bool first_gen = getenv("LFX_MAT_V1") != nullptr;   // (A/B measurements)
-    if (!first_gen) {
-        hipLaunchKernelGGL(blk_materialize2_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, sym, njobs);
-        LFX_LAUNCH_CHECK();
-        return 0;
-    }
-    hipLaunchKernelGGL(blk_materialize_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(64), SWIN * 2, st, in, jobs, units, codes, sym, njobs);
+    hipLaunchKernelGGL(blk_materialize2_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, sym, njobs);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -1,17 +1,18 @@
-// lfx_match2.hip — second-generation LZ77 match stage for gfx950: per position, the most recent earlier occurrence
-// of its 3-byte prefix inside the chunk and the match length, written to md[] for the parse kernels — as the position's
-// LZ77 code word: (length << 16) | distance, or (byte << 16) when there is no match.
+// lfx_match3.hip — LZ77 candidate stage for gfx950: per position, the DISTANCE to the most recent earlier occurrence of
+// its 3-byte prefix inside the chunk (0 = none inside the window), written to cd[] as 16 bits per position.
 //
-// Replaces, bit for bit, the table probe and longest_common_prefix of DefaultLz77Encoder::flush
-// (libflate_lz77/src/default.rs:76-87,122-129,146-182).  Parse independence (tests/test_host_pipeline.py): the
-// reference inserts EVERY position < end exactly once and in order (default.rs:78,92-97), so
-// cand(i) = max{ j < i : buf[j..j+3] == buf[i..i+3] } does not depend on which positions the walk visits.
+// Replaces, bit for bit, the table probe of DefaultLz77Encoder::flush (libflate_lz77/src/default.rs:76-87,146-182).
+// Parse independence (tests/test_host_pipeline.py): the reference inserts EVERY position < end exactly once and in
+// order (default.rs:78,92-97), so cand(i) = max{ j < i : buf[j..j+3] == buf[i..i+3] } does not depend on which
+// positions the walk visits.  The match LENGTH (longest_common_prefix, default.rs:122-129) is only ever needed at the
+// positions the greedy walk visits (about a quarter of them on text): it is computed by the walk itself
+// (lfx_parse2.hip), not here — the third generation of this kernel is the second one without its length stage (40 % of
+// its instructions, and 4 bytes of output per position instead of 2).
 //
 // One workgroup of 16 wavefronts per segment, a software pipeline over tiles of 960 positions (15 resolver
 // wavefronts x 64 lanes), two LDS-only barriers per tile:
 //
-//   phase A   resolvers: R1(k)   chain walk for the positions whose answer is not known yet
-//                        F1(k+1) what the head pass returned → raw predecessor → same prefix? (answer known) :
+//   phase A   resolvers: F1(k+1) what the head pass returned → raw predecessor → same prefix? (answer known) :
 //                                plain link ; first link state lk[]
 //                        P(k+2)  3-byte prefix, hash, request word of the head pass
 //             wave 0:    window bytes: stores of the previous iteration's loads, then this iteration's loads;
@@ -20,22 +21,14 @@
 //                                position per hash) packed two per dword; ONE ds_mskor_rtn_b32 per 64 positions
 //                                exchanges the field and returns the old dword.  The LDS serves the lanes of one
 //                                instruction that hit the same field in ascending lane order and a wavefront's
-//                                instructions in issue order (measured: tools/exp/mskor_test.hip, 0 violations in
-//                                1.3 M conflicting operations), so every lane receives exactly its raw predecessor
+//                                instructions in issue order (measured: tools/exp/mskor_test.hip,
+//                                profiles/r03_mskor_order.txt), so every lane receives exactly its raw predecessor
 //                                ph(p) = most recent earlier position with the same hash.  A lane that observes a
 //                                value "from the future" (distance >= 65536-64) proves a violation: the kernel
 //                                raises a flag and the host re-runs the first-generation kernel.
 //             resolvers: F2(k+1) duplicate-collapsed link by pointer jumping → prevd[]
-//                        R2(k)   match length → md[]
-//
-// What bounds it (rocprofv3, 256 MiB of text): the four SIMDs of a CU issue an instruction in EVERY quad-cycle
-// (SQ_ACTIVE_INST_ANY == SQ_WAVE_CYCLES / 4) — the kernel is bound by its total instruction count, scalar ones
-// included (VALU 4.7, SALU 3.4, branch 0.7, LDS 0.45 wavefront instructions per position), not by LDS bandwidth
-// (20 % busy) and not by latency: carrying two positions per lane, or handing the deep chain walks to helper
-// wavefronts, changed nothing (both measured).  Hence: one ring modulus for the window and the link ring
-// (one offset computation serves both), tiles that never straddle the ring end, branch-free selects, and the stages
-// of a phase interleaved — all loads of a step first (dummy addresses for lanes that do not need them), then their
-// uses.
+//                        R1(k)   chain walk for the positions whose answer is not known yet → cd[]
+//                                (reads link-ring entries of tiles <= k only, final since the previous iteration)
 //
 // Duplicate collapsing (exactness argument as in the first-generation kernel): link(p) = ph(p) if the
 // prefixes differ, else link(ph(p)); the chain from p therefore visits the most recent member of every run of equal
@@ -50,7 +43,7 @@
 
 namespace lfx {
 
-namespace m2 {
+namespace m3 {
 
 constexpr int THREADS = 1024;
 constexpr uint32_t RW = 15;                   // resolver wavefronts (waves 1..15; wave 0: head pass + window)
@@ -127,11 +120,6 @@ __device__ __forceinline__ uint32_t win4(const uint32_t *win32, uint32_t off) { 
     const uint32_t w0 = win32[off >> 2], w1 = win32[(off >> 2) + 1];
     return __builtin_amdgcn_alignbyte(w1, w0, off & 3);
 }
-__device__ __forceinline__ uint64_t win8(const uint32_t *win32, uint32_t off) {             // 8 bytes at ring offset
-    const uint32_t i = off >> 2;
-    const uint32_t w0 = win32[i], w1 = win32[i + 1], w2 = win32[i + 2];
-    return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, off & 3) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, off & 3) << 32;
-}
 
 // HB 16-bit exchanges, in order, one wait.  old[i] = the dword that held the field before.
 // A lane with mask 0 / value 0 leaves its dword untouched.
@@ -152,16 +140,16 @@ __device__ __forceinline__ void mskor_batch(uint32_t (&old)[HB], const uint32_t 
         : "memory");
 }
 
-}  // namespace m2
+}  // namespace m3
 
 // flags[0] |= 1 when the head pass observed a lane-order violation (results are then discarded by the host).
 // DBG: per-wavefront cycle stamps of workgroup 0 (LFX_DEBUG); the production instance carries none of it.
 template <bool DBG>
-__global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
+__global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
-    const SegDesc *__restrict__ segs, uint32_t window, uint32_t max_len, uint32_t *__restrict__ md,
+    const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd,
     uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg) {
-    using namespace m2;
+    using namespace m3;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     uint32_t *head32 = (uint32_t *)(smem + OFF_HEAD);
     uint16_t *prevd = (uint16_t *)(smem + OFF_PREVD);
@@ -183,7 +171,7 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
         src.shift = a & 3;
         src.nbytes = in_bytes - ch.in_off;
     }
-    uint32_t *md_c = md + ch.in_off;              // this chunk's answers
+    uint16_t *cd_c = cd + ch.in_off;              // this chunk's answers
     if (ch.flags & CH_LITERALS) return;           // NoCompressionLz77Encoder chunks never come here
     const uint32_t end = (n > 3 ? n : 3) - 3;     // default.rs:75
     const uint32_t q0 = sg.start;                 // first position answered by this segment
@@ -220,8 +208,6 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     uint32_t cd_f = 0, cd_r = 0;                   // known answer distance (0 = walk)
     uint32_t e_f = NONE, e_r = NONE;               // own final link distance
     uint32_t lk_f = NONE;                          // F1 → F2: first link state
-    uint32_t r_dist = 0;                           // R1 → R2
-    bool r_found = false;
     bool viol = false;                             // a lane-order violation seen by this lane (reported once, at the end)
     // (tile 0 = position `base` sits at ring offset 0; the loop starts two tiles early)
     uint32_t ok = RING - 2 * TILE;                 // ring offset of tile `it`
@@ -263,7 +249,7 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
                 }
             }
             // ---- ... and this iteration's loads (global → registers).  Five tiles ahead of R: the stores land one
-            //      iteration later, and the last tiles' match lengths read up to 258 bytes past the segment.
+            //      iteration later, and P reads the prefixes of tile it+2 (three bytes past its last position).
             const uint32_t fill_need = max(loaded_to, min(t_r + 5 * TILE + 4, n_pad));
             pend_lo = loaded_to; pend_hi = fill_need; pend_off = fill_off;
 #pragma unroll
@@ -292,43 +278,29 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
                 }
             }
         } else if (wave <= RW) {
-            const uint32_t p_r = t_r + idx;
-            const uint32_t o_r = ok + idx, o_f = o1 + idx, o_p = o2 + idx;   // ring offsets of the three positions (no wrap)
-            const bool act_r = do_r && val_r && p_r >= q0;       // (val_r implies p_r < q1)
+            const uint32_t o_f = o1 + idx, o_p = o2 + idx;       // ring offsets of the F and P positions (no wrap)
             const bool act_f = do_f && val_f;
-            // ---- R1(it): chain walk, only where the answer is not already known (cd) — and then starting at the LINK of
-            //      the raw predecessor, which is known to carry another prefix.  (A link never reaches in front of the
-            //      first inserted position, so the distance needs no check against the position itself.)
-            const bool known = act_r && cd_r != 0;
-            const bool walk = act_r && cd_r == 0 && e_r <= window;          // (NONE > every window)
-            uint32_t dist = known ? cd_r : (walk ? e_r : 0u);
-            uint32_t found = (known && dist <= window) ? 1u : 0u;
             // -- step 0: loads
-            const uint32_t d0 = prevd[walk ? ring_back(o_r, dist) : o_r];
             const uint32_t ow = oldb[idx];
             const uint32_t kp_raw = win4(win32, o_p);
             // -- step 0: uses
-            uint32_t d = walk ? d0 : 0u;
             const uint32_t of = (hh_f & 1) ? ow >> 16 : ow & 0xFFFFu;   // what the exchange returned for this field
             uint32_t d_f = act_f ? (t_f + idx - of) & 0xFFFFu : NONE;   // (never 0: the sweep retires a field long before)
             viol |= d_f >= FUTURE;
             d_f = min(d_f, NONE);
             const bool has_f = d_f < NONE;
-            // -- step 1: loads (R1 hop 1, F1 predecessor)
-            dist += d;
-            d = dist > window ? 0u : d;                          // default.rs:81 (inclusive window)
-            const uint32_t a1 = d ? ring_back(o_r, dist) : o_r;
-            const uint32_t kq1 = win4(win32, a1) & 0xFFFFFFu;
-            const uint32_t dn1 = prevd[a1];
+            // -- step 1: loads (F1 predecessor)
             const uint32_t af = has_f ? ring_back(o_f, d_f) : o_f;
             const uint32_t kqf = win4(win32, af) & 0xFFFFFFu;
             uint32_t pqf = prevd[af];                            // (final when the predecessor lies in an older tile)
             pin(pqf);
-            // -- step 1: uses
+            // P(it+2): request word of the head pass: hash << 17 | valid << 16 | low 16 bits of the position
             {
-                const bool hit = d != 0 && kq1 == key_r;
-                found = hit ? 1u : found;
-                d = (d == 0 || hit) ? 0u : dn1;
+                const uint32_t p_p = t_p + idx;
+                val_p = do_p && p_p >= l0 && p_p < q1;
+                key_p = kp_raw & 0xFFFFFFu;
+                hh_p = hash3(key_p);
+                if (do_p) reqb[idx] = val_p ? (hh_p << 17) | 0x10000u | (p_p & 0xFFFFu) : 0u;
             }
             // F1(it+1): raw predecessor → known answer / first link state
             {
@@ -341,27 +313,6 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
                 lk_f = e;
                 lk[idx] = (uint16_t)e;       // (a slot of a position outside the chain structure is never read)
             }
-            // P(it+2): request word of the head pass: hash << 17 | valid << 16 | low 16 bits of the position
-            {
-                const uint32_t p_p = t_p + idx;
-                val_p = do_p && p_p >= l0 && p_p < q1;
-                key_p = kp_raw & 0xFFFFFFu;
-                hh_p = hash3(key_p);
-                if (do_p) reqb[idx] = val_p ? (hh_p << 17) | 0x10000u | (p_p & 0xFFFFu) : 0u;
-            }
-            // -- further hops (2 % of the positions, but nearly every wavefront holds one)
-            while (__ballot(d != 0)) {
-                dist += d;
-                d = dist > window ? 0u : d;
-                const uint32_t a = d ? ring_back(o_r, dist) : o_r;
-                const uint32_t kq = win4(win32, a) & 0xFFFFFFu;
-                const uint32_t dn = prevd[a];
-                const bool hit = d != 0 && kq == key_r;
-                found = hit ? 1u : found;
-                d = (d == 0 || hit) ? 0u : dn;
-            }
-            r_dist = dist;
-            r_found = found != 0;
         }
         const uint64_t c1 = DBG ? clock64() : 0;
         lds_barrier();
@@ -388,42 +339,51 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
         } else if (wave <= RW) {
             const uint32_t p_r = t_r + idx;
             const uint32_t o_r = ok + idx, o_f = o1 + idx;
-            const bool act_r = do_r && val_r && p_r >= q0;
+            const bool act_r = do_r && val_r && p_r >= q0;       // (val_r implies p_r < q1)
             // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed: every
             //      state a reader can observe is valid and the oldest member of a run is final from the start)
-            // ---- R2(it): longest_common_prefix (default.rs:122-129): 8 bytes per step for the first 16
+            // ---- R1(it): chain walk, only where the answer is not already known (cd) — and then starting at the LINK of
+            //      the raw predecessor, which is known to carry another prefix.  (A link never reaches in front of the
+            //      first inserted position, so the distance needs no check against the position itself.)  It reads
+            //      link-ring entries of tiles <= it only: final since F2(it) of the previous iteration, and disjoint from
+            //      the slots F2(it+1) stores below.
             uint32_t e = lk_f;                                         // (NONE where the position takes no part)
-            const bool found = act_r && r_found;
-            const uint32_t dist = r_dist;
-            uint32_t l = 0;
-            uint32_t lim = n - (p_r + 3);                              // bounded by the end of the chunk
-            lim = lim > max_len - 3 ? max_len - 3 : lim;
-            lim = found ? lim : 0u;
-            uint32_t oa = ring_wrap(o_r + 3);
-            uint32_t ob = found ? ring_back(oa, dist) : oa;
-            bool cmp = lim != 0;                                       // still comparing
-#pragma unroll
-            for (int step = 0; step < 2; ++step) {
-                // loads
-                // (a lane whose state is final reads its own slot, which holds that state: the update is the identity)
-                const uint32_t j = min(e - LK_PTR, idx);
-                const uint32_t eq = lk[j];
-                const uint64_t xa = win8(win32, oa), xb = win8(win32, ob);
-                // uses
-                {
-                    const uint32_t en = min((idx - j) + eq, NONE);     // the predecessor's link is final: make it ours
-                    e = eq < LK_PTR ? en : eq;                         // ... or it still points on: jump
-                    lk[idx] = (uint16_t)e;
-                }
-                {
-                    const uint64_t x = xa ^ xb;
-                    const uint32_t adv = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
-                    l += cmp ? adv : 0u;
-                    cmp = cmp && x == 0 && l < lim;
-                    oa = ring_wrap(oa + 8);
-                    ob = ring_wrap(ob + 8);
-                }
+            const bool known = act_r && cd_r != 0;
+            const bool walk = act_r && cd_r == 0 && e_r <= window;          // (NONE > every window)
+            uint32_t dist = known ? cd_r : (walk ? e_r : 0u);
+            uint32_t found = (known && dist <= window) ? 1u : 0u;
+            // -- step 0: loads
+            // (a lane whose link state is final reads its own slot, which holds that state: the update is the identity)
+            const uint32_t j0 = min(e - LK_PTR, idx);
+            const uint32_t eq0 = lk[j0];
+            const uint32_t d0 = prevd[walk ? ring_back(o_r, dist) : o_r];
+            // -- step 0: uses
+            {
+                const uint32_t en = min((idx - j0) + eq0, NONE);       // the predecessor's link is final: make it ours
+                e = eq0 < LK_PTR ? en : eq0;                           // ... or it still points on: jump
+                lk[idx] = (uint16_t)e;
             }
+            uint32_t d = walk ? d0 : 0u;
+            dist += d;
+            d = dist > window ? 0u : d;                          // default.rs:81 (inclusive window)
+            // -- step 1: loads (R1 hop 1, F2 second jump)
+            const uint32_t a1 = d ? ring_back(o_r, dist) : o_r;
+            const uint32_t kq1 = win4(win32, a1) & 0xFFFFFFu;
+            const uint32_t dn1 = prevd[a1];
+            const uint32_t j1 = min(e - LK_PTR, idx);
+            const uint32_t eq1 = lk[j1];
+            // -- step 1: uses
+            {
+                const bool hit = d != 0 && kq1 == key_r;
+                found = hit ? 1u : found;
+                d = (d == 0 || hit) ? 0u : dn1;
+            }
+            {
+                const uint32_t en = min((idx - j1) + eq1, NONE);
+                e = eq1 < LK_PTR ? en : eq1;
+                lk[idx] = (uint16_t)e;
+            }
+            // -- further jumps / hops (a few percent of the positions, but nearly every wavefront holds one)
             while (__ballot(e >= LK_PTR)) {
                 const uint32_t j = min(e - LK_PTR, idx);
                 const uint32_t eq = lk[j];
@@ -433,31 +393,17 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
             }
             e_f = e;
             prevd[o_f] = (uint16_t)e;        // (positions outside the chain structure: their slot is never read)
-            // a lane still matching after 16 bytes gets the whole wavefront: lane j compares bytes
-            // [16+4j, 16+4j+4) — one step settles up to 256 more bytes
-            uint64_t lm = __ballot(cmp);                               // (cmp here ⇒ l == 16 < lim)
-            while (lm) {
-                const uint32_t sl = (uint32_t)__builtin_ctzll(lm);
-                lm &= lm - 1;
-                const uint32_t boa = __builtin_amdgcn_readlane(oa, sl), bob = __builtin_amdgcn_readlane(ob, sl);
-                const uint32_t blim = __builtin_amdgcn_readlane(lim, sl);
-                const uint32_t off = 4 * lane;
-                uint32_t x = 0;
-                if (16 + off < blim) x = win4(win32, ring_wrap(boa + off)) ^ win4(win32, ring_wrap(bob + off));
-                const uint64_t mis = __ballot(x != 0);
-                uint32_t res = blim;
-                if (mis) {
-                    const uint32_t fl = (uint32_t)__builtin_ctzll(mis);
-                    const uint32_t cand = 16 + off + ((uint32_t)__builtin_ctz(x | 0x80000000u) >> 3);
-                    res = __builtin_amdgcn_readlane(cand, fl);
-                }
-                if (lane == sl) l = res;
+            while (__ballot(d != 0)) {
+                dist += d;
+                d = dist > window ? 0u : d;
+                const uint32_t a = d ? ring_back(o_r, dist) : o_r;
+                const uint32_t kq = win4(win32, a) & 0xFFFFFFu;
+                const uint32_t dn = prevd[a];
+                const bool hit = d != 0 && kq == key_r;
+                found = hit ? 1u : found;
+                d = (d == 0 || hit) ? 0u : dn;
             }
-            l = l > lim ? lim : l;
-            // (no match: the literal's code word — the byte is the low byte of the prefix — so that the parse never has
-            //  to read the input)
-            const uint32_t word = found ? ((3 + l) << 16) | dist : (key_r & 0xFFu) << 16;
-            if (act_r) md_c[p_r] = word;
+            if (act_r) cd_c[p_r] = (uint16_t)(found ? dist : 0u);
         }
         const uint64_t c2 = DBG ? clock64() : 0;
         // ---- rotate the stage registers
@@ -476,15 +422,15 @@ __global__ __launch_bounds__(m2::THREADS) void lz77_match2_kernel(
     }
 }
 
-int launch_match2(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md, uint32_t *flags, uint64_t *dbg) {
+int launch_match3(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg) {
     if (nsegs == 0) return 0;
     if (dbg)
-        hipLaunchKernelGGL(lz77_match2_kernel<true>, dim3(nsegs), dim3(m2::THREADS), 0, st, in, in_bytes, chunks, segs, window,
-                           max_len, md, flags, dbg);
+        hipLaunchKernelGGL(lz77_match3_kernel<true>, dim3(nsegs), dim3(m3::THREADS), 0, st, in, in_bytes, chunks, segs, window,
+                           cd, flags, dbg);
     else
-        hipLaunchKernelGGL(lz77_match2_kernel<false>, dim3(nsegs), dim3(m2::THREADS), 0, st, in, in_bytes, chunks, segs, window,
-                           max_len, md, flags, dbg);
+        hipLaunchKernelGGL(lz77_match3_kernel<false>, dim3(nsegs), dim3(m3::THREADS), 0, st, in, in_bytes, chunks, segs, window,
+                           cd, flags, dbg);
     const hipError_t e_ = hipGetLastError();
     return e_ != hipSuccess ? (int)e_ : 0;
 }

@@ -1,0 +1,587 @@
+// lfx_parse2.hip — the greedy LZ77 walk i += length / i += 1 of DefaultLz77Encoder::flush
+// (libflate_lz77/src/default.rs:76-107) with LAZY match lengths, for gfx950.
+//
+// The candidate stage (lfx_match3.hip) leaves cd[p] = distance to the most recent earlier occurrence of p's 3-byte
+// prefix (0 = none).  longest_common_prefix (default.rs:122-129) is only ever needed at the positions the walk visits —
+// about a quarter of all positions on text — so it is computed HERE, by the walk, from the input bytes.
+//
+// The walk is a serial chain per chunk; it runs speculatively in parallel at two levels:
+//   * a LANE owns a group of PARSE_GROUP (52) consecutive positions and walks it from its first position; greedy
+//     parses that start at different positions merge after a few steps, so almost all of each group's speculative
+//     walk is the true walk;
+//   * a WAVEFRONT owns a segment of 64 groups (3328 positions).  Inside the wavefront the true entry of group L is the
+//     exit of group L-1: every lane re-walks from there until it lands on a position its speculative walk visited (from
+//     there on both coincide), then the chain of entries is verified lane by lane (one ballot when every lane merged —
+//     the common case on text) and repaired serially where it does not hold (long matches that jump over whole
+//     groups).  Segments are chained the same way by the three small kernels behind the walk (parse_fixseg / parse_fix
+//     / parse_emit): they re-walk from a segment's true entry to the merge point, through global memory.
+// A workgroup is PARSE_WG_SEGS (4) wavefronts = 13312 consecutive positions of one chunk; it stages the bytes
+// [first position - 32 KiB, last position + 258 + slack) and the cd[] values of its positions in LDS (72 KB: two
+// workgroups per CU), so that a walk step — cd[p], then 8 bytes at p+3 and at p+3-d per compare step — is three LDS
+// round trips and no HBM access.
+//
+// A code word is derivable from the visited set alone: the step at p is the distance to the next visited position, and
+// it is a match exactly when cd[p] != 0 (a match is at least 3 long, a literal step is 1).  The walk STAGES its code
+// words (stage[], a segment's codes compacted from its first position on); everything behind the point where the true
+// walk merges into a segment's speculative one is final, so parse_emit copies it and rebuilds only the few codes in
+// front of the merge point from the visit bits.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lfx_common.h"
+#include "lfx_device.h"
+
+namespace lfx {
+
+namespace p2 {
+
+constexpr uint32_t U = PARSE_GROUP;                 // positions per lane
+constexpr uint32_t WAVES = PARSE_WG_SEGS;           // segments per workgroup
+constexpr uint32_t THREADS = 64 * WAVES;
+constexpr uint32_t WG_POS = WAVES * PARSE_SEG;      // 13312 positions per workgroup
+constexpr uint32_t TAIL = 288;                      // bytes staged behind the last position: 3 + 255 + 8 + alignment
+constexpr uint32_t WIN_BYTES = MAX_WINDOW + WG_POS + TAIL + 8;   // (+ the dword alignment of the window start)
+constexpr uint32_t OFF_CD = (WIN_BYTES + 15) & ~15u;
+constexpr uint32_t CD_BYTES = 2 * WG_POS + 8;       // (+ one entry of alignment shift, + pad)
+constexpr uint32_t LDS_BYTES = OFF_CD + CD_BYTES;
+static_assert(U <= 64 && (U / 4) * 4 == U && ((U / 4) & 1) == 1, "a group is an odd number of dwords: bank-conflict-free lane stride");
+static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+
+struct ByteSrcG {
+    gptr_u32 w;
+    uint64_t shift, nbytes;
+    __device__ __forceinline__ uint32_t load4(uint64_t off) const {   // bytes [off, off+4), zeros past the buffer
+        const uint64_t a = off + shift, idx = a >> 2;
+        const uint32_t sh = (uint32_t)a & 3;
+        const uint64_t last = (nbytes + shift + 3) >> 2;
+        const uint32_t w0 = idx < last ? w[idx] : 0;
+        const uint32_t w1 = (sh != 0 && idx + 1 < last) ? w[idx + 1] : 0;
+        return __builtin_amdgcn_alignbyte(w1, w0, sh);
+    }
+    __device__ __forceinline__ uint32_t load1(uint64_t off) const {
+        const uint64_t a = off + shift;
+        return (w[a >> 2] >> (((uint32_t)a & 3) * 8)) & 0xFF;
+    }
+};
+__device__ __forceinline__ ByteSrcG make_src(const uint8_t *p, uint64_t n) {
+    ByteSrcG s;
+    const uint64_t a = (uint64_t)p;
+    s.w = (gptr_u32)(a & ~3ull);
+    s.shift = a & 3;
+    s.nbytes = n;
+    return s;
+}
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    const uint32_t lane = __lane_id();
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+__device__ __forceinline__ uint64_t bits_from(uint32_t r) { return ~0ull << r; }          // r < 64
+
+// 8 bytes at LDS byte offset off (aligned dword reads: an unaligned ds_read costs 21-26 cycles, tools/exp/lds_tput)
+__device__ __forceinline__ uint64_t lds8(const uint32_t *win32, uint32_t off) {
+    const uint32_t i = off >> 2;
+    const uint32_t w0 = win32[i], w1 = win32[i + 1], w2 = win32[i + 2];
+    return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, off & 3) | (uint64_t)__builtin_amdgcn_alignbyte(w2, w1, off & 3) << 32;
+}
+
+// what one wavefront needs to take walk steps out of LDS
+struct WalkCtx {
+    const uint32_t *win32;     // staged bytes; byte offset of chunk position p is p - w0
+    const uint16_t *cd16;      // staged candidates; index of chunk position p is p - c0
+    uint32_t w0, c0;
+    uint32_t n;                // chunk length
+    uint32_t max_len;
+};
+
+// One walk step at position pos (default.rs:79-103): 1 for a literal, the match length otherwise.  `act` lanes take
+// part; the others return 0 and read harmless addresses.  The compare runs 8 bytes per iteration and the wavefront
+// iterates until its longest match is settled.
+__device__ __forceinline__ uint32_t walk_step(const WalkCtx &w, uint32_t pos, bool act) {
+    const uint32_t d = act ? w.cd16[pos - w.c0] : 0u;
+    uint32_t lim = w.n - (pos + 3);                                 // default.rs:125 (bounded by the end of the chunk)
+    lim = lim > w.max_len - 3 ? w.max_len - 3 : lim;
+    lim = d ? lim : 0u;
+    uint32_t oa = act ? pos + 3 - w.w0 : 0u;                        // (idle lanes read offset 0)
+    uint32_t ob = oa - d;
+    uint32_t l = 0;
+    bool cmp = lim != 0;
+    for (int round = 0; round < 33 && __ballot(cmp); ++round) {      // (255 bytes at most: the bound is never reached)
+        const uint64_t x = lds8(w.win32, oa) ^ lds8(w.win32, ob);
+        const uint32_t adv = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+        l += cmp ? adv : 0u;
+        cmp = cmp && x == 0 && l < lim;
+        oa += cmp ? 8u : 0u;
+        ob += cmp ? 8u : 0u;
+    }
+    l = l > lim ? lim : l;
+    return act ? (d ? 3u + l : 1u) : 0u;
+}
+
+// The true walk enters this lane's group at `in`.  Re-walk from there until it lands on a position the speculative walk
+// visited (mask, exit) — from there on both coincide — or leaves the group.  → the visited mask and the exit for THAT
+// entry.  `act` lanes take part (wave-uniform loops inside).
+__device__ __forceinline__ void resolve(const WalkCtx &w, bool act, uint32_t in, uint32_t a, uint32_t stop, uint64_t mask,
+                                        uint32_t exit_spec, uint64_t &m_out, uint32_t &x_out) {
+    uint64_t walked = 0;
+    uint32_t pos = in;
+    bool run = act;
+    uint64_t m = 0;
+    uint32_t x = in;                                   // (passed over: nothing visited, the walk goes on where it was)
+    for (uint32_t guard = 0; guard <= U + 1; ++guard) {               // (a group holds U positions: U + 1 rounds settle it)
+        if (run) {
+            if (pos >= stop) { m = walked; x = pos; run = false; }
+            else if ((mask >> (pos - a)) & 1) { m = walked | (mask & bits_from(pos - a)); x = exit_spec; run = false; }
+        }
+        if (!__ballot(run)) break;
+        const uint32_t st = walk_step(w, run ? pos : a, run);
+        walked |= run ? 1ull << (pos - a) : 0ull;
+        pos += st;
+    }
+    if (act) { m_out = m; x_out = x; }
+}
+
+}  // namespace p2
+
+// workgroup → (chunk, first segment of the chunk it walks)
+// K1: speculative walk, in-wavefront chaining, staging.  seg_exit / seg_count / vis / stage describe the segment as
+// walked from its FIRST position.
+__global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
+    const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
+    const ParseWg *__restrict__ wgs, const uint16_t *__restrict__ cd, uint32_t max_len,
+    uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit, uint32_t *__restrict__ seg_count,
+    uint32_t *__restrict__ stage) {
+    using namespace p2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    uint32_t *win32 = (uint32_t *)smem;
+    uint32_t *cd32 = (uint32_t *)(smem + OFF_CD);
+
+    const ParseWg wg = wgs[blockIdx.x];
+    const ChunkDesc ch = chunks[wg.chunk];
+    if (ch.flags & CH_LITERALS) return;               // no walk: every byte is a literal
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n = (uint32_t)ch.len;
+    const uint32_t end = (n > 3 ? n : 3) - 3;         // default.rs:75
+    const uint32_t g0 = wg.seg0 * PARSE_SEG;          // first position of the workgroup
+    if (g0 >= end) {
+        // nothing to walk (the chunk's last three bytes, or an empty chunk): the segments pass the walk through
+        const uint32_t sidx = wg.seg0 + wave;
+        if (sidx < ch.n_seg) {
+            vis[ch.vis_base + (uint64_t)sidx * 64 + lane] = 0;
+            if (lane == 0) { seg_exit[ch.seg_base + sidx] = sidx * PARSE_SEG; seg_count[ch.seg_base + sidx] = 0; }
+        }
+        return;
+    }
+    // ---- stage the bytes [w0, w0 + WIN_BYTES) and the candidates of [g0, g0 + WG_POS)
+    const uint32_t w0 = (g0 > MAX_WINDOW ? g0 - MAX_WINDOW : 0u) & ~3u;
+    {
+        const ByteSrcG src = make_src(in + ch.in_off, in_bytes - ch.in_off);
+        const uint32_t hi = min(g0 + WG_POS + TAIL, (n + 3) & ~3u);          // (the compare never reads past the chunk)
+        for (uint32_t p = w0 + 4 * tid; p < hi; p += 4 * THREADS) win32[(p - w0) >> 2] = src.load4(p);
+    }
+    const uint64_t e0 = ch.in_off + g0;               // cd[] index of position g0
+    const uint32_t csh = (uint32_t)e0 & 1;            // cd is staged on its own dword grid: position p sits at p - g0 + csh
+    {
+        const uint32_t *g32 = (const uint32_t *)(cd + (e0 - csh));
+        const uint32_t cnt = min(WG_POS, end - g0) + csh;                     // entries needed
+        for (uint32_t k = tid; 2 * k < cnt; k += THREADS) cd32[k] = g32[k];
+    }
+    __syncthreads();
+
+    const uint32_t sidx = wg.seg0 + wave;
+    if (sidx >= ch.n_seg) return;
+    const uint32_t s0 = sidx * PARSE_SEG;
+    const uint32_t seg = ch.seg_base + sidx;
+    uint64_t *vw = vis + ch.vis_base + (uint64_t)sidx * 64;
+    if (s0 >= end) {
+        vw[lane] = 0;
+        if (lane == 0) { seg_exit[seg] = s0; seg_count[seg] = 0; }
+        return;
+    }
+    const uint32_t s1 = min(s0 + PARSE_SEG, end);
+    WalkCtx w;
+    w.win32 = win32;
+    w.cd16 = (const uint16_t *)cd32;
+    w.w0 = w0;
+    w.c0 = g0 - csh;
+    w.n = n;
+    w.max_len = max_len;
+
+    const uint32_t a = s0 + lane * U;                 // first position of this lane's group
+    const uint32_t stop = min(a + U, s1);
+    const bool have = a < s1;                         // the group holds positions (lanes behind the end stay idle)
+    const uint32_t nact = (s1 - s0 + U - 1) / U;      // groups with positions: lanes [0, nact)
+    // ---- speculative walk of every group from its first position
+    uint64_t mask = 0;
+    uint32_t pos = a;
+    for (uint32_t guard = 0; guard <= U; ++guard) {
+        const bool run = have && pos < stop;
+        if (!__ballot(run)) break;
+        const uint32_t st = walk_step(w, run ? pos : a, run);
+        mask |= run ? 1ull << (pos - a) : 0ull;
+        pos += st;
+    }
+    const uint32_t exit_spec = pos;
+    // ---- the walk enters group L where it left group L-1: assume that is the speculative exit (it is when the walk
+    //      through L-1 merged), resolve every group for that entry ...
+    uint32_t used_in = __shfl_up(exit_spec, 1);
+    if (lane == 0) used_in = a;
+    uint64_t m_fin = mask;
+    uint32_t x_fin = exit_spec;
+    resolve(w, have && lane != 0, used_in, a, stop, mask, exit_spec, m_fin, x_fin);
+    // ---- ... and verify the chain: lane 0's entry is the segment's first position by definition, so every lane in front
+    //      of the first one whose assumed entry is not its predecessor's exit is exact.  Repair that lane with its true
+    //      entry and look again (strictly increasing: at most nact rounds; none on text, one per jumped-over group on
+    //      runs).
+    for (uint32_t guard = 0; guard < 64; ++guard) {
+        const uint32_t prev_x = __shfl_up(x_fin, 1);
+        const uint64_t bad = __ballot(lane != 0 && lane < nact && used_in != prev_x);
+        if (!bad) break;
+        const uint32_t j = (uint32_t)__builtin_ctzll(bad);
+        const uint32_t tin = __builtin_amdgcn_readlane(x_fin, j - 1);
+        const bool me = lane == j;
+        used_in = me ? tin : used_in;
+        resolve(w, me, tin, a, stop, mask, exit_spec, m_fin, x_fin);
+        // the groups this lane's walk jumps over entirely are settled with it (a 258-byte match passes four of them)
+        const uint32_t xj = __builtin_amdgcn_readlane(x_fin, j);
+        if (lane > j && lane < nact && stop <= xj) { used_in = xj; m_fin = 0; x_fin = xj; }
+    }
+    if (!have) m_fin = 0;
+    // ---- results of the segment as walked from s0
+    const uint32_t cnt = (uint32_t)__popcll(m_fin);
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((int)lane >= o) incl += y; }
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    const uint32_t seg_x = __builtin_amdgcn_readlane(x_fin, nact - 1);
+    vw[lane] = m_fin;
+    if (lane == 0) { seg_exit[seg] = seg_x; seg_count[seg] = total; }
+    // ---- stage the code words, in position order: a visited position's step is the distance to the next visited one
+    uint32_t *st = stage + ch.in_off + s0 + (incl - cnt);
+    const uint8_t *win8 = (const uint8_t *)win32;
+    uint64_t m = m_fin;
+    uint32_t k = 0;
+    for (uint32_t guard = 0; guard < 64 && __ballot(m != 0); ++guard) {
+        if (m) {
+            const uint32_t b = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t p = a + b;
+            const uint32_t nxt = m ? a + (uint32_t)__builtin_ctzll(m) : x_fin;
+            const uint32_t d = w.cd16[p - w.c0];
+            const uint32_t byte = win8[p - w0];
+            st[k++] = d ? ((nxt - p) << 16) | d : byte << 16;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Walk steps out of global memory, one at a time, by a whole wavefront (the chaining kernels: a handful of steps per
+// segment).  Lane k compares bytes [4k, 4k+4) behind the prefix: one round settles a whole match.
+struct GWalk {
+    p2::ByteSrcG src;
+    const uint16_t *cd;      // this chunk's candidates
+    uint32_t n, max_len;
+};
+__device__ __forceinline__ uint32_t gwalk_step(const GWalk &g, uint32_t pos, uint32_t lane) {
+    const uint32_t d = g.cd[pos];                                    // (uniform address)
+    if (d == 0) return 1;
+    uint32_t lim = g.n - (pos + 3);
+    lim = lim > g.max_len - 3 ? g.max_len - 3 : lim;
+    const uint32_t off = 4 * lane;
+    uint32_t x = 0;
+    if (off < lim) x = g.src.load4((uint64_t)pos + 3 + off) ^ g.src.load4((uint64_t)pos + 3 - d + off);
+    const uint64_t mis = __ballot(x != 0);
+    uint32_t l = lim;
+    if (mis) {
+        const uint32_t fl = (uint32_t)__builtin_ctzll(mis);
+        const uint32_t cand = off + ((uint32_t)__builtin_ctz(x | 0x80000000u) >> 3);
+        l = __builtin_amdgcn_readlane(cand, fl);
+        l = l > lim ? lim : l;
+    }
+    return 3 + l;
+}
+
+// P2a: one wavefront per segment.  The true walk enters segment s where the walk of segment s-1 left it;
+// that is the speculative exit of s-1 unless s-1 itself never merged (rare: P2b repairs those).  Re-walk
+// from the entry until the walk lands on a position the speculative walk visited — from there on both
+// coincide — and rewrite the visited masks, the count and the exit of the segment accordingly.
+struct SegFix { uint32_t cnt, ex, mpos, kspec; };   // codes, exit; merge position, staged codes in front of it
+__device__ __forceinline__ SegFix parse_rewalk(const GWalk &gw, uint64_t *__restrict__ vw, uint32_t s0, uint32_t s1,
+                                               uint32_t e, uint32_t cnt, uint32_t ex, uint32_t lane) {
+    using p2::U;
+    uint32_t pos = e, walked = 0, spec_below = 0, merge_pos = s1;
+    bool merged = false;
+    for (uint32_t g = 0; g < 64 && !merged; ++g) {
+        const uint32_t base = s0 + g * U;
+        if (base >= s1) break;
+        const uint32_t stop = min(base + U, s1);
+        const uint64_t V = vw[g];
+        if (pos >= stop) {               // wholly before the true entry: nothing visited here
+            spec_below += __popcll(V);
+            if (lane == 0 && V) vw[g] = 0;
+            continue;
+        }
+        uint64_t T = 0;
+        uint32_t mr = 64;
+        while (pos < stop) {
+            const uint32_t r = pos - base;
+            if ((V >> r) & 1) { merged = true; mr = r; merge_pos = pos; break; }
+            T |= 1ull << r;
+            walked++;
+            pos += gwalk_step(gw, pos, lane);
+        }
+        const uint64_t keep = mr < 64 ? (V & ~((1ull << mr) - 1)) : 0;   // speculative bits from the merge on
+        spec_below += __popcll(V & ~keep);
+        if (lane == 0) vw[g] = T | keep;
+    }
+    SegFix f;
+    if (merged) { f.cnt = cnt - spec_below + walked; f.ex = ex; f.mpos = merge_pos; f.kspec = spec_below; }   // the exit stays the one already known
+    else { f.cnt = walked; f.ex = pos; f.mpos = s1; f.kspec = cnt; }     // never merged inside this segment: nothing staged survives
+    return f;
+}
+
+__global__ __launch_bounds__(64) void parse_fixseg_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                          const ChunkDesc *__restrict__ chunks,
+                                                          const uint16_t *__restrict__ cd, uint32_t max_len,
+                                                          uint64_t *__restrict__ vis,
+                                                          const uint32_t *__restrict__ seg_exit,
+                                                          uint32_t *__restrict__ seg_count,
+                                                          uint32_t *__restrict__ seg_exit2,
+                                                          uint32_t *__restrict__ seg_mpos,
+                                                          uint32_t *__restrict__ seg_kspec,
+                                                          const uint32_t *__restrict__ seg_map) {
+    const uint32_t seg = blockIdx.x;
+    const ChunkDesc ch = chunks[seg_map[seg]];
+    if (ch.flags & CH_LITERALS) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s = seg - ch.seg_base;
+    const uint32_t n = (uint32_t)ch.len;
+    const uint32_t end = (n > 3 ? n : 3) - 3;
+    const uint32_t s0 = s * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
+    const uint32_t e = s ? seg_exit[seg - 1] : 0;                   // assumed entry
+    SegFix f{seg_count[seg], seg_exit[seg], s0, 0u};                 // (entered where assumed: every staged code is final)
+    if (s0 >= end) { f.cnt = 0; f.ex = e; }                          // behind the last walked position: pass through
+    else if (e != s0) {
+        GWalk gw{p2::make_src(in + ch.in_off, in_bytes - ch.in_off), cd + ch.in_off, n, max_len};
+        f = parse_rewalk(gw, vis + ch.vis_base + (uint64_t)s * 64, s0, s1, e, f.cnt, f.ex, lane);
+    }
+    if (lane == 0) { seg_count[seg] = f.cnt; seg_exit2[seg] = f.ex; seg_mpos[seg] = f.mpos; seg_kspec[seg] = f.kspec; }
+}
+
+// P2b: one workgroup per chunk: checks the assumption of P2a for a batch of segments at a time (segment s was
+// entered correctly iff the exit of s-1 did not change), repairs the rare segment that was not, and turns
+// the counts into offsets; then the chunk's tail and the EndOfBlock marker.
+// 64 lanes when a chunk has a few dozen segments (the reference's 256 KiB chunks), 1024 when one chunk is the whole input
+// (schedule S1: 80 K segments per 256 MiB).
+__global__ __launch_bounds__(1024) void parse_fix_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                         const ChunkDesc *__restrict__ chunks,
+                                                         const uint16_t *__restrict__ cd, uint32_t max_len,
+                                                         uint64_t *__restrict__ vis,
+                                                         const uint32_t *__restrict__ seg_exit,
+                                                         uint32_t *__restrict__ seg_count,
+                                                         uint32_t *__restrict__ seg_exit2,
+                                                         uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
+                                                         uint32_t *__restrict__ ncodes, uint32_t *__restrict__ seg_mpos) {
+    __shared__ uint32_t s_first_bad, s_wsum[16], s_redo[2];
+    const ChunkDesc ch = chunks[blockIdx.x];
+    const uint32_t tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+    const uint32_t n = (uint32_t)ch.len;
+    const p2::ByteSrcG src = p2::make_src(in + ch.in_off, in_bytes - ch.in_off);
+    uint32_t *out = codes + ch.code_off;
+    uint32_t total = 0;
+    if (ch.flags & CH_LITERALS) {
+        for (uint32_t s = tid; s < ch.n_seg; s += T) seg_off[ch.seg_base + s] = s * PARSE_SEG;
+        total = n;
+    } else {
+        const uint32_t end = (n > 3 ? n : 3) - 3;
+        const uint32_t *sx = seg_exit + ch.seg_base;
+        uint32_t *sx2 = seg_exit2 + ch.seg_base, *sc = seg_count + ch.seg_base;
+        uint32_t e_last = 0;   // true exit of the segment before the current batch
+        for (uint32_t b0 = 0; b0 < ch.n_seg; ) {
+            if (tid == 0) s_first_bad = 0xFFFFFFFFu;
+            __syncthreads();
+            const uint32_t s = b0 + tid;
+            const bool have = s < ch.n_seg;
+            // entry assumed by P2a vs the true exit of the predecessor
+            const uint32_t assumed = have ? (s ? sx[s - 1] : 0) : 0;
+            const uint32_t actual = have ? (s == b0 ? e_last : sx2[s - 1]) : 0;
+            const uint64_t bad = __ballot(have && assumed != actual);
+            if (bad && lane == 0) atomicMin(&s_first_bad, wave * 64 + (uint32_t)__builtin_ctzll(bad));
+            __syncthreads();
+            const uint32_t fb = s_first_bad;
+            const uint32_t nok = fb != 0xFFFFFFFFu ? fb : min(T, ch.n_seg - b0);   // leading good segments
+            // offsets of the good prefix
+            const uint32_t c = (have && tid < nok) ? sc[s] : 0;
+            uint32_t x = c;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if ((int)lane >= o) x += y; }
+            if (lane == 63) s_wsum[wave] = x;
+            __syncthreads();
+            uint32_t pre = 0, all = 0;
+            for (uint32_t w = 0; w < nw; ++w) { const uint32_t v = s_wsum[w]; pre += w < wave ? v : 0u; all += v; }
+            if (have && tid < nok) seg_off[ch.seg_base + s] = total + pre + x - c;
+            if (nok) {
+                total += all;
+                e_last = sx2[b0 + nok - 1];
+            }
+            b0 += nok;
+            if (fb != 0xFFFFFFFFu) {
+                // segment b0 was entered at the wrong position: redo it from the true entry (one wavefront)
+                const uint32_t sb = b0;
+                if (wave == 0) {
+                    const uint32_t s0 = sb * PARSE_SEG, s1 = min(s0 + PARSE_SEG, end);
+                    SegFix f{sc[sb], sx2[sb], 0u, 0u};
+                    if (s0 >= end) { f.cnt = 0; f.ex = e_last; }
+                    else {
+                        GWalk gw{src, cd + ch.in_off, n, max_len};
+                        f = parse_rewalk(gw, vis + ch.vis_base + (uint64_t)sb * 64, s0, s1, e_last, f.cnt, f.ex, lane);
+                    }
+                    // (walked a second time: the staged codes no longer line up with the visit bits — emit all of this
+                    //  segment from the bits)
+                    if (lane == 0) {
+                        sc[sb] = f.cnt; sx2[sb] = f.ex; seg_off[ch.seg_base + sb] = total; seg_mpos[ch.seg_base + sb] = 0xFFFFFFFFu;
+                        s_redo[0] = f.cnt; s_redo[1] = f.ex;
+                    }
+                }
+                __syncthreads();
+                total += s_redo[0];
+                e_last = s_redo[1];
+                b0 += 1;
+            }
+            __syncthreads();
+        }
+        // default.rs:105-107: the rest are literals (at most 3 bytes)
+        const uint32_t pos = ch.n_seg ? e_last : 0;
+        for (uint32_t i = pos + tid; i < n; i += T) out[total + (i - pos)] = src.load1(i) << 16;
+        if (n > pos) total += n - pos;
+    }
+    if (ch.flags & CH_LAST_IN_BLOCK) {
+        if (tid == 0) out[total] = CODE_EOB;  // encode.rs:417
+        total += 1;
+    }
+    if (tid == 0) ncodes[blockIdx.x] = total;
+}
+
+// P3: every segment emits the codes of its visited positions
+__global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                        const ChunkDesc *__restrict__ chunks,
+                                                        const uint16_t *__restrict__ cd,
+                                                        const uint64_t *__restrict__ vis,
+                                                        const uint32_t *__restrict__ seg_off,
+                                                        uint32_t *__restrict__ codes,
+                                                        const uint32_t *__restrict__ stage,
+                                                        const uint32_t *__restrict__ seg_count,
+                                                        const uint32_t *__restrict__ seg_exit2,
+                                                        const uint32_t *__restrict__ seg_mpos,
+                                                        const uint32_t *__restrict__ seg_kspec,
+                                                        const uint32_t *__restrict__ seg_map) {
+    using p2::U;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t c = seg_map[seg];
+    const ChunkDesc ch = chunks[c];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t s = seg - ch.seg_base;
+    const uint32_t n = (uint32_t)ch.len;
+    const uint32_t s0 = s * PARSE_SEG;
+    const p2::ByteSrcG src = p2::make_src(in + ch.in_off, in_bytes - ch.in_off);
+    uint32_t *out = codes + ch.code_off + seg_off[seg];
+    if (ch.flags & CH_LITERALS) {
+        const uint32_t s1 = min(s0 + PARSE_SEG, n);
+        for (uint32_t i = s0 + lane; i < s1; i += 64) out[i - s0] = src.load1(i) << 16;
+        return;
+    }
+    const uint32_t end = (n > 3 ? n : 3) - 3;
+    const uint32_t s1 = min(s0 + PARSE_SEG, end);
+    const uint32_t total = seg_count[seg];
+    uint32_t nout = 0;
+    // positions in front of the merge point: rebuilt from the (repaired) visit bits — usually less than one group, none
+    // at all when the segment was entered where the speculative walk assumed.  A visited position's step is the
+    // distance to the next visited position (the segment's exit behind the last one); a match iff cd != 0.
+    const uint32_t mpos = s0 < s1 ? min(seg_mpos[seg], s1) : s0;
+    if (mpos > s0) {
+        const uint64_t *vw = vis + ch.vis_base + (uint64_t)s * 64;
+        const uint16_t *cdc = cd + ch.in_off;
+        const uint64_t W = vw[lane];                                           // lane g: the mask of group g
+        const uint32_t first = W ? s0 + lane * U + (uint32_t)__builtin_ctzll(W) : 0xFFFFFFFFu;
+        // next visited position behind group g: the first one of the groups behind it, else the segment's true exit
+        uint32_t sfx = first;                                                  // inclusive suffix minimum
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_down(sfx, o); if ((int)lane + o < 64) sfx = min(sfx, y); }
+        uint32_t nxt_g = __shfl_down(sfx, 1);
+        if (lane == 63) nxt_g = 0xFFFFFFFFu;
+        nxt_g = min(nxt_g, seg_exit2[seg]);
+        const uint64_t lt = p2::lanemask_lt();
+        for (uint32_t g = 0; g < 64; ++g) {
+            const uint32_t base = s0 + g * U;
+            if (base >= mpos) break;
+            const uint64_t V = __builtin_amdgcn_readlane((uint32_t)W, g) | (uint64_t)__builtin_amdgcn_readlane((uint32_t)(W >> 32), g) << 32;
+            uint64_t m = V;
+            if (mpos - base < 64) m &= (1ull << (mpos - base)) - 1;
+            if (m == 0) continue;
+            const uint32_t ng = __builtin_amdgcn_readlane(nxt_g, g);
+            if ((m >> lane) & 1) {
+                const uint32_t i = base + lane;
+                const uint64_t above = lane < 63 ? V >> (lane + 1) : 0ull;
+                const uint32_t nxt = above ? i + 1 + (uint32_t)__builtin_ctzll(above) : ng;
+                const uint32_t d = cdc[i];
+                out[nout + __popcll(m & lt)] = d ? ((nxt - i) << 16) | d : src.load1(i) << 16;
+            }
+            nout += __popcll(m);
+        }
+    }
+    // everything behind it: the codes the speculative walk staged, behind the kspec it visited in front of the merge
+    const uint32_t n2 = total - nout;
+    const uint32_t *st = stage + ch.in_off + s0 + seg_kspec[seg];
+    for (uint32_t j = lane; j < n2; j += 64) out[nout + j] = st[j];
+}
+
+// first-generation match kernel (the fallback behind a lane-order violation of lfx_match3.hip, LFX_MATCH_V1=1): its
+// md[] words (length << 16 | distance, or byte << 16) → cd[]
+__global__ __launch_bounds__(256) void md_to_cd_kernel(const uint32_t *__restrict__ md, uint64_t n, uint16_t *__restrict__ cd) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) cd[i] = (uint16_t)(md[i] & 0xFFFFu);
+}
+
+#define LFX_LAUNCH_CHECK()                          \
+    do {                                            \
+        hipError_t e_ = hipGetLastError();          \
+        if (e_ != hipSuccess) return (int)e_;       \
+    } while (0)
+
+int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(md_to_cd_kernel, dim3((uint32_t)(div_up(n, 256) < 16384 ? div_up(n, 256) : 16384)), dim3(256), 0, st, md, n, cd);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
+                 uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
+                 uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map) {
+    if (nchunks == 0) return 0;
+    // seg_tmp: six arrays of nsegs words
+    uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
+    uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs, *seg_mpos = seg_tmp + 4 * (size_t)nsegs;
+    uint32_t *seg_kspec = seg_tmp + 5 * (size_t)nsegs;
+    if (nwgs) {
+        hipLaunchKernelGGL(parse_walk_kernel, dim3(nwgs), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, cd, max_len, vis,
+                           seg_exit, seg_count, stage);
+        LFX_LAUNCH_CHECK();
+    }
+    if (nsegs) {
+        hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, cd, max_len, vis, seg_exit,
+                           seg_count, seg_exit2, seg_mpos, seg_kspec, seg_map);
+        LFX_LAUNCH_CHECK();
+    }
+    // (workgroup size by the segments per chunk: the fold over a chunk's segments is serial in batches of that size)
+    const uint32_t fix_threads = nsegs / nchunks > 128 ? 1024u : 64u;
+    hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(fix_threads), 0, st, in, in_bytes, chunks, cd, max_len, vis,
+                       seg_exit, seg_count, seg_exit2, seg_off, codes, ncodes, seg_mpos);
+    LFX_LAUNCH_CHECK();
+    if (nsegs) {
+        hipLaunchKernelGGL(parse_emit_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, cd, vis, seg_off, codes,
+                           stage, seg_count, seg_exit2, seg_mpos, seg_kspec, seg_map);
+        LFX_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace lfx

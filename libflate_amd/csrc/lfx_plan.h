@@ -125,7 +125,7 @@ class Planner {
         c.vis_base = plan_.n_vis;
         c.seg_base = plan_.n_segs;
         c.n_seg = (uint32_t)div_up(len, PARSE_SEG);
-        plan_.n_vis += (uint64_t)c.n_seg * (PARSE_SEG / 64);
+        plan_.n_vis += (uint64_t)c.n_seg * 64;   // one mask word per group of PARSE_GROUP positions
         plan_.n_segs += c.n_seg;
         code_cursor_ += len + 1;  // worst case all literals + a possible EndOfBlock
         tile_cursor_ += div_up(len + 1, PACK_TILE);

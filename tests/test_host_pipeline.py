@@ -2,6 +2,7 @@
 the SAME source the HIP kernels compile) reproduce the oracle bit for bit when the GPU-only stages
 (match, parse, pack) are stood in for by straightforward Python."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -233,6 +234,37 @@ def test_structural_insight_parse_independent_candidates(oracle):
                     codes.append(data[i] << 16); i += 1
             codes.extend(b << 16 for b in data[i:])
             assert codes == [int(x) for x in oracle.lz77_chunk(data, window, maxlen)], (window, maxlen, n)
+
+
+def test_lazy_parse_model_matches_oracle(oracle):
+    """The round-3 parse (lfx_parse2.hip) computes match lengths only at visited positions and rebuilds code words from
+    visit bits.  tools/parse2_model.py restates its four kernels statement for statement (lane loops instead of
+    wavefronts): speculative group walks, the in-wavefront entry chain with serial repair and jumped-over groups, the
+    segment chain, the rebuild in front of a merge point.  On the CPU it must reproduce DefaultLz77Encoder::flush
+    (default.rs:69-109) — on text (no repairs), on runs / periodic data (a repair per jumped-over stretch, segments that
+    never merge) and at every group / segment boundary size."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parse2_model as pm
+    import synth
+    rng = np.random.default_rng(3)
+    cases = [(synth.text(30000).tobytes(), {}), (synth.lowent(40000).tobytes(), {}), (bytes(15000), {}),
+             (rng.integers(0, 256, 9000, dtype=np.uint8).tobytes(), {}), (b"abc" * 5000, {}), (b"abcdefg" * 2500, {}),
+             (rng.integers(0, 4, 20000, dtype=np.uint8).tobytes(), {}),
+             (synth.text(20000).tobytes(), {"window": 1024, "max_len": 20}),
+             (synth.lowent(15000).tobytes(), {"max_len": 3}), (kat.ISSUE52, {})]
+    text = synth.text(7000).tobytes()
+    for n in (0, 1, 2, 3, 4, 5, 51, 52, 53, 55, 56, 3327, 3328, 3329, 3330, 3331, 3332, 6655, 6656, 6659):
+        cases.append((text[:n], {}))
+    saw_repairs = saw_redo = False
+    for data, kw in cases:
+        st = {}
+        got = pm.parse_chunk(data, stats=st, **kw)
+        want = oracle.lz77_chunk(data, kw.get("window", 32768), kw.get("max_len", 258))
+        assert len(got) == len(want) and (got == want).all(), (len(data), kw)
+        saw_repairs |= st.get("repairs", 0) > 0
+        saw_redo |= st.get("redo", 0) > 0
+    assert saw_repairs and saw_redo       # the corpus reaches the serial repair and the never-merged segment paths
 
 
 def test_incremental_planner_equals_one_shot(ffi):
