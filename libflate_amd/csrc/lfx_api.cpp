@@ -439,6 +439,26 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
     }
     c->phase("lz77_match");
+    if (c->diag.debug && getenv("LFX_DUMP_SEG")) {
+        // diagnostics: the parse state of one segment behind the walk, behind fixseg and at the end
+        const uint32_t sg = (uint32_t)atoi(getenv("LFX_DUMP_SEG"));
+        for (int stage_no = 1; stage_no <= 3 && sg < plan.n_segs; stage_no++) {
+            LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const ParseWg *)c->d_pwgs.p,
+                                    (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
+                                    (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map, stage_no % 3));
+            (void)hipStreamSynchronize(st);
+            uint64_t v[4];
+            uint32_t t[6];
+            uint16_t cdv[64];
+            (void)hipMemcpy(v, (uint64_t *)c->d_vis.p + (uint64_t)sg * 64, sizeof v, hipMemcpyDeviceToHost);
+            for (int q = 0; q < 6; q++) (void)hipMemcpy(&t[q], (uint32_t *)c->d_segtmp.p + (size_t)q * plan.n_segs + sg, 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(cdv, d_cd + (uint64_t)sg * PARSE_SEG, sizeof cdv, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[lfx] seg %u stage %d: vis %016llx %016llx %016llx %016llx exit=%u count=%u off=%u exit2=%u mpos=%u kspec=%u\n", sg,
+                    stage_no, (unsigned long long)v[0], (unsigned long long)v[1], (unsigned long long)v[2], (unsigned long long)v[3], t[0],
+                    t[1], t[2], t[3], t[4], t[5]);
+            if (stage_no == 1) { fprintf(stderr, "[lfx]  cd:"); for (int q = 0; q < 64; q++) fprintf(stderr, " %u", cdv[q]); fprintf(stderr, "\n"); }
+        }
+    }
     LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const ParseWg *)c->d_pwgs.p,
                             (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
                             (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map));

@@ -58,7 +58,6 @@ constexpr uint32_t HEAD_FAR = 33000;          // distance marker of an empty / s
 constexpr uint32_t SWEEP_SLICES = 32;         // the whole table is swept every 32 tiles (30720 positions)
 constexpr uint32_t HB = 5;                    // exchanges per batch of the head pass (one wait per batch)
 constexpr uint32_t FUTURE = 65536 - 64;       // a distance this large can only come from a lane-order violation
-constexpr uint32_t FILL_LOADS = (TILE + 255) / 256;   // dword loads per lane of wave 0 and tile
 // link values (16 bits, in lk[] and prevd[]): 1..32768 a distance; NONE..LK_PTR-1 no link (every sum of a distance and a
 // link is clamped to NONE with one v_min — no compare, no select); >= LK_PTR (lk[] only) inherit the link of in-tile
 // index (v - LK_PTR)
@@ -212,12 +211,16 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
     // (tile 0 = position `base` sits at ring offset 0; the loop starts two tiles early)
     uint32_t ok = RING - 2 * TILE;                 // ring offset of tile `it`
     uint32_t fill_off = loaded_to - base;          // wave 0: ring offset of position loaded_to
-    // wave 0: window bytes in flight — loaded (global → registers) in phase A of one iteration, stored to the LDS ring in
-    // phase A of the NEXT one, so that phase B of wave 0 is the head pass and nothing else (it is the longest phase B of
-    // the workgroup: the resolvers used to wait for it at the barrier)
-    uint32_t fill_w0[FILL_LOADS] = {}, fill_w1[FILL_LOADS] = {};
+    // window bytes in flight — loaded (global → registers) in phase A of one iteration, stored to the LDS ring in phase A
+    // of the NEXT one, by 240 resolver lanes (one dword each): wave 0 takes no part in phase A, so that phase A is as
+    // long as the resolvers' own two LDS round trips
+    uint32_t fill_w0 = 0, fill_w1 = 0;
     uint32_t pend_lo = loaded_to, pend_hi = loaded_to, pend_off = fill_off;
+    uint32_t r_dist = 0, r_d = 0, r_found = 0;     // R1: phase A (first hop) → phase B (further hops)
     uint64_t cy_a = 0, cy_b = 0, cy_w = 0;
+    constexpr uint32_t FILL_LANE0 = 4 * 64;        // resolver lanes [256, 496) move the window bytes
+    constexpr uint32_t SWEEP_DW = (1u << (HASH_BITS - 1)) / SWEEP_SLICES;   // 256 head dwords per tile: resolver lanes [0, 256)
+    static_assert(FILL_LANE0 + TILE / 4 <= TILE && SWEEP_DW <= FILL_LANE0, "lane assignment of the fill and the sweep");
 
     if (wave == 0) __builtin_amdgcn_s_setprio(3);
 
@@ -231,77 +234,64 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
         const uint32_t t_r = base + (uint32_t)it * TILE;            // only used when do_r
         const uint32_t t_f = t_r + TILE;                            // only used when do_f
         const uint32_t t_p = t_f + TILE;                            // only used when do_p
+        // window fill bookkeeping (uniform): five tiles ahead of R — the stores land one iteration later, and P reads the
+        // prefixes of tile it+2 (three bytes past its last position).  At most one tile (240 dwords) per iteration.
+        const uint32_t fill_need = max(loaded_to, min(t_r + 5 * TILE + 4, n_pad));
 
         // =================================================== phase A
-        if (wave == 0) {
-            // ---- window bytes of the previous iteration's loads → LDS ring
-            {
-                const uint32_t sh = (uint32_t)src.shift;
-#pragma unroll
-                for (uint32_t q = 0; q < FILL_LOADS; ++q) {
-                    const uint32_t p = pend_lo + 4 * lane + 256 * q;
-                    if (p < pend_hi) {
-                        const uint32_t v = __builtin_amdgcn_alignbyte(fill_w1[q], fill_w0[q], sh);
-                        const uint32_t o = ring_wrap(pend_off + 4 * lane + 256 * q);
-                        win32[o >> 2] = v;
-                        if (o < 8) win32[(RING + o) >> 2] = v;
-                    }
-                }
-            }
-            // ---- ... and this iteration's loads (global → registers).  Five tiles ahead of R: the stores land one
-            //      iteration later, and P reads the prefixes of tile it+2 (three bytes past its last position).
-            const uint32_t fill_need = max(loaded_to, min(t_r + 5 * TILE + 4, n_pad));
-            pend_lo = loaded_to; pend_hi = fill_need; pend_off = fill_off;
-#pragma unroll
-            for (uint32_t q = 0; q < FILL_LOADS; ++q) {
-                const uint32_t p = loaded_to + 4 * lane + 256 * q;
-                fill_w0[q] = fill_w1[q] = 0;
-                if (p < fill_need) src.load_raw(p, fill_w0[q], fill_w1[q]);
-            }
-            fill_off = ring_wrap(fill_off + (fill_need - loaded_to));
-            loaded_to = fill_need;
-            if (do_p) {
-                // ---- incremental sweep: stale fields (older than the window) → "far"
-                const uint32_t slice = (uint32_t)(it + 2) % SWEEP_SLICES;
-                const uint32_t far = (t_p - HEAD_FAR) & 0xFFFFu;
-                constexpr uint32_t PER = (1u << (HASH_BITS - 1)) / SWEEP_SLICES / 64;
-                uint32_t hw[PER];
-#pragma unroll
-                for (uint32_t q = 0; q < PER; ++q) hw[q] = head32[slice * (PER * 64) + q * 64 + lane];
-#pragma unroll
-                for (uint32_t q = 0; q < PER; ++q) {
-                    uint32_t lo = hw[q] & 0xFFFFu, hi = hw[q] >> 16;
-                    const uint32_t dlo = (t_p - lo) & 0xFFFFu, dhi = (t_p - hi) & 0xFFFFu;
-                    if (dlo == 0 || dlo > MAX_WINDOW) lo = far;
-                    if (dhi == 0 || dhi > MAX_WINDOW) hi = far;
-                    head32[slice * (PER * 64) + q * 64 + lane] = lo | hi << 16;
-                }
-            }
-        } else if (wave <= RW) {
-            const uint32_t o_f = o1 + idx, o_p = o2 + idx;       // ring offsets of the F and P positions (no wrap)
+        if (wave != 0 && wave <= RW) {
+            const uint32_t p_r = t_r + idx;
+            const uint32_t o_r = ok + idx, o_f = o1 + idx, o_p = o2 + idx;   // ring offsets of the three positions (no wrap)
+            const bool act_r = do_r && val_r && p_r >= q0;       // (val_r implies p_r < q1)
             const bool act_f = do_f && val_f;
+            // ---- R1(it), first hop: chain walk, only where the answer is not already known (cd) — and then starting at
+            //      the LINK of the raw predecessor, which is known to carry another prefix.  (A link never reaches in front
+            //      of the first inserted position, so the distance needs no check against the position itself.)
+            const bool known = act_r && cd_r != 0;
+            const bool walk = act_r && cd_r == 0 && e_r <= window;          // (NONE > every window)
+            uint32_t dist = known ? cd_r : (walk ? e_r : 0u);
+            uint32_t found = (known && dist <= window) ? 1u : 0u;
             // -- step 0: loads
+            const uint32_t d0 = prevd[walk ? ring_back(o_r, dist) : o_r];
             const uint32_t ow = oldb[idx];
             const uint32_t kp_raw = win4(win32, o_p);
+            // (the incremental sweep of stale head fields — older than the window → "far" — rides along: lanes [0, 256))
+            const uint32_t slice = (uint32_t)(it + 2) % SWEEP_SLICES;
+            const bool sweeper = do_p && idx < SWEEP_DW;
+            uint32_t hw = 0;
+            if (sweeper) hw = head32[slice * SWEEP_DW + idx];
             // -- step 0: uses
+            uint32_t d = walk ? d0 : 0u;
             const uint32_t of = (hh_f & 1) ? ow >> 16 : ow & 0xFFFFu;   // what the exchange returned for this field
             uint32_t d_f = act_f ? (t_f + idx - of) & 0xFFFFu : NONE;   // (never 0: the sweep retires a field long before)
             viol |= d_f >= FUTURE;
             d_f = min(d_f, NONE);
             const bool has_f = d_f < NONE;
-            // -- step 1: loads (F1 predecessor)
+            // -- step 1: loads (R1 hop 1, F1 predecessor)
+            dist += d;
+            d = dist > window ? 0u : d;                          // default.rs:81 (inclusive window)
+            const uint32_t a1 = d ? ring_back(o_r, dist) : o_r;
+            const uint32_t kq1 = win4(win32, a1) & 0xFFFFFFu;
+            const uint32_t dn1 = prevd[a1];
             const uint32_t af = has_f ? ring_back(o_f, d_f) : o_f;
             const uint32_t kqf = win4(win32, af) & 0xFFFFFFu;
             uint32_t pqf = prevd[af];                            // (final when the predecessor lies in an older tile)
             pin(pqf);
-            // P(it+2): request word of the head pass: hash << 17 | valid << 16 | low 16 bits of the position
-            {
-                const uint32_t p_p = t_p + idx;
-                val_p = do_p && p_p >= l0 && p_p < q1;
-                key_p = kp_raw & 0xFFFFFFu;
-                hh_p = hash3(key_p);
-                if (do_p) reqb[idx] = val_p ? (hh_p << 17) | 0x10000u | (p_p & 0xFFFFu) : 0u;
+            if (sweeper) {
+                const uint32_t far = (t_p - HEAD_FAR) & 0xFFFFu;
+                uint32_t lo = hw & 0xFFFFu, hi = hw >> 16;
+                const uint32_t dlo = (t_p - lo) & 0xFFFFu, dhi = (t_p - hi) & 0xFFFFu;
+                if (dlo == 0 || dlo > MAX_WINDOW) lo = far;
+                if (dhi == 0 || dhi > MAX_WINDOW) hi = far;
+                head32[slice * SWEEP_DW + idx] = lo | hi << 16;
             }
+            // -- step 1: uses
+            {
+                const bool hit = d != 0 && kq1 == key_r;
+                found = hit ? 1u : found;
+                d = (d == 0 || hit) ? 0u : dn1;
+            }
+            r_dist = dist; r_d = d; r_found = found;
             // F1(it+1): raw predecessor → known answer / first link state
             {
                 const bool same = has_f && kqf == key_f;
@@ -313,7 +303,30 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
                 lk_f = e;
                 lk[idx] = (uint16_t)e;       // (a slot of a position outside the chain structure is never read)
             }
+            // P(it+2): request word of the head pass: hash << 17 | valid << 16 | low 16 bits of the position
+            {
+                const uint32_t p_p = t_p + idx;
+                val_p = do_p && p_p >= l0 && p_p < q1;
+                key_p = kp_raw & 0xFFFFFFu;
+                hh_p = hash3(key_p);
+                if (do_p) reqb[idx] = val_p ? (hh_p << 17) | 0x10000u | (p_p & 0xFFFFu) : 0u;
+            }
+            // ---- window bytes: the previous iteration's dword → LDS ring, then this iteration's load (lanes [256, 496))
+            if (idx >= FILL_LANE0 && idx < FILL_LANE0 + TILE / 4) {
+                const uint32_t f4 = 4 * (idx - FILL_LANE0);
+                if (pend_lo + f4 < pend_hi) {
+                    const uint32_t v = __builtin_amdgcn_alignbyte(fill_w1, fill_w0, (uint32_t)src.shift);
+                    const uint32_t o = ring_wrap(pend_off + f4);
+                    win32[o >> 2] = v;
+                    if (o < 8) win32[(RING + o) >> 2] = v;
+                }
+                fill_w0 = fill_w1 = 0;
+                if (loaded_to + f4 < fill_need) src.load_raw(loaded_to + f4, fill_w0, fill_w1);
+            }
         }
+        pend_lo = loaded_to; pend_hi = fill_need; pend_off = fill_off;
+        fill_off = ring_wrap(fill_off + (fill_need - loaded_to));
+        loaded_to = fill_need;
         const uint64_t c1 = DBG ? clock64() : 0;
         lds_barrier();
         // =================================================== phase B
@@ -339,70 +352,41 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
         } else if (wave <= RW) {
             const uint32_t p_r = t_r + idx;
             const uint32_t o_r = ok + idx, o_f = o1 + idx;
-            const bool act_r = do_r && val_r && p_r >= q0;       // (val_r implies p_r < q1)
+            const bool act_r = do_r && val_r && p_r >= q0;
             // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed: every
             //      state a reader can observe is valid and the oldest member of a run is final from the start)
-            // ---- R1(it): chain walk, only where the answer is not already known (cd) — and then starting at the LINK of
-            //      the raw predecessor, which is known to carry another prefix.  (A link never reaches in front of the
-            //      first inserted position, so the distance needs no check against the position itself.)  It reads
-            //      link-ring entries of tiles <= it only: final since F2(it) of the previous iteration, and disjoint from
-            //      the slots F2(it+1) stores below.
+            // ---- R1(it), further hops (a few percent of the positions, but nearly every wavefront holds one).  They read
+            //      link-ring entries of tiles <= it only: final since F2(it) of the previous iteration, and disjoint from the
+            //      slots F2(it+1) stores at the end.
+            //      ONE loop advances both chains: its trip count is the longer of the two, not their sum — every trip is an
+            //      LDS round trip on the workgroup's critical path.
             uint32_t e = lk_f;                                         // (NONE where the position takes no part)
-            const bool known = act_r && cd_r != 0;
-            const bool walk = act_r && cd_r == 0 && e_r <= window;          // (NONE > every window)
-            uint32_t dist = known ? cd_r : (walk ? e_r : 0u);
-            uint32_t found = (known && dist <= window) ? 1u : 0u;
-            // -- step 0: loads
-            // (a lane whose link state is final reads its own slot, which holds that state: the update is the identity)
-            const uint32_t j0 = min(e - LK_PTR, idx);
-            const uint32_t eq0 = lk[j0];
-            const uint32_t d0 = prevd[walk ? ring_back(o_r, dist) : o_r];
-            // -- step 0: uses
-            {
-                const uint32_t en = min((idx - j0) + eq0, NONE);       // the predecessor's link is final: make it ours
-                e = eq0 < LK_PTR ? en : eq0;                           // ... or it still points on: jump
-                lk[idx] = (uint16_t)e;
-            }
-            uint32_t d = walk ? d0 : 0u;
-            dist += d;
-            d = dist > window ? 0u : d;                          // default.rs:81 (inclusive window)
-            // -- step 1: loads (R1 hop 1, F2 second jump)
-            const uint32_t a1 = d ? ring_back(o_r, dist) : o_r;
-            const uint32_t kq1 = win4(win32, a1) & 0xFFFFFFu;
-            const uint32_t dn1 = prevd[a1];
-            const uint32_t j1 = min(e - LK_PTR, idx);
-            const uint32_t eq1 = lk[j1];
-            // -- step 1: uses
-            {
-                const bool hit = d != 0 && kq1 == key_r;
-                found = hit ? 1u : found;
-                d = (d == 0 || hit) ? 0u : dn1;
-            }
-            {
-                const uint32_t en = min((idx - j1) + eq1, NONE);
-                e = eq1 < LK_PTR ? en : eq1;
-                lk[idx] = (uint16_t)e;
-            }
-            // -- further jumps / hops (a few percent of the positions, but nearly every wavefront holds one)
-            while (__ballot(e >= LK_PTR)) {
+            uint32_t dist = r_dist, d = r_d, found = r_found;
+            for (;;) {
+                // loads (a lane whose link state is final reads its own slot, which holds that state: the update is the
+                // identity; a lane whose walk has ended reads its own position)
                 const uint32_t j = min(e - LK_PTR, idx);
                 const uint32_t eq = lk[j];
-                const uint32_t en = min((idx - j) + eq, NONE);
-                e = eq < LK_PTR ? en : eq;
-                lk[idx] = (uint16_t)e;
-            }
-            e_f = e;
-            prevd[o_f] = (uint16_t)e;        // (positions outside the chain structure: their slot is never read)
-            while (__ballot(d != 0)) {
                 dist += d;
                 d = dist > window ? 0u : d;
                 const uint32_t a = d ? ring_back(o_r, dist) : o_r;
                 const uint32_t kq = win4(win32, a) & 0xFFFFFFu;
                 const uint32_t dn = prevd[a];
-                const bool hit = d != 0 && kq == key_r;
-                found = hit ? 1u : found;
-                d = (d == 0 || hit) ? 0u : dn;
+                // uses
+                {
+                    const uint32_t en = min((idx - j) + eq, NONE);     // the predecessor's link is final: make it ours
+                    e = eq < LK_PTR ? en : eq;                         // ... or it still points on: jump
+                    lk[idx] = (uint16_t)e;
+                }
+                {
+                    const bool hit = d != 0 && kq == key_r;
+                    found = hit ? 1u : found;
+                    d = (d == 0 || hit) ? 0u : dn;
+                }
+                if (!__ballot(e >= LK_PTR || d != 0)) break;
             }
+            e_f = e;
+            prevd[o_f] = (uint16_t)e;        // (positions outside the chain structure: their slot is never read)
             if (act_r) cd_c[p_r] = (uint16_t)(found ? dist : 0u);
         }
         const uint64_t c2 = DBG ? clock64() : 0;

@@ -40,7 +40,7 @@ constexpr uint32_t WAVES = PARSE_WG_SEGS;           // segments per workgroup
 constexpr uint32_t THREADS = 64 * WAVES;
 constexpr uint32_t WG_POS = WAVES * PARSE_SEG;      // 13312 positions per workgroup
 constexpr uint32_t TAIL = 288;                      // bytes staged behind the last position: 3 + 255 + 8 + alignment
-constexpr uint32_t WIN_BYTES = MAX_WINDOW + WG_POS + TAIL + 8;   // (+ the dword alignment of the window start)
+constexpr uint32_t WIN_BYTES = MAX_WINDOW + WG_POS + TAIL + 8;   // (+ the byte phase of the window start on the dword grid)
 constexpr uint32_t OFF_CD = (WIN_BYTES + 15) & ~15u;
 constexpr uint32_t CD_BYTES = 2 * WG_POS + 8;       // (+ one entry of alignment shift, + pad)
 constexpr uint32_t LDS_BYTES = OFF_CD + CD_BYTES;
@@ -172,19 +172,38 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
         }
         return;
     }
-    // ---- stage the bytes [w0, w0 + WIN_BYTES) and the candidates of [g0, g0 + WG_POS)
-    const uint32_t w0 = (g0 > MAX_WINDOW ? g0 - MAX_WINDOW : 0u) & ~3u;
-    {
-        const ByteSrcG src = make_src(in + ch.in_off, in_bytes - ch.in_off);
-        const uint32_t hi = min(g0 + WG_POS + TAIL, (n + 3) & ~3u);          // (the compare never reads past the chunk)
-        for (uint32_t p = w0 + 4 * tid; p < hi; p += 4 * THREADS) win32[(p - w0) >> 2] = src.load4(p);
-    }
+    // ---- stage the bytes [w0, w0 + WIN_BYTES) and the candidates of [g0, g0 + WG_POS).  Both are copied on their own
+    //      dword grid (position p sits at LDS byte p - w0 + sh, its candidate at entry p - g0 + csh): plain aligned
+    //      dword loads, all of a batch in flight before the first LDS store — a loop of load / store pairs waits one
+    //      memory round trip per iteration (46 of them: 85 K cycles per workgroup, measured).
+    const uint32_t w0 = g0 > MAX_WINDOW ? g0 - MAX_WINDOW : 0u;
+    const uint64_t abs0 = (uint64_t)(in + ch.in_off) + w0;
+    const uint32_t sh = (uint32_t)abs0 & 3;
     const uint64_t e0 = ch.in_off + g0;               // cd[] index of position g0
-    const uint32_t csh = (uint32_t)e0 & 1;            // cd is staged on its own dword grid: position p sits at p - g0 + csh
+    const uint32_t csh = (uint32_t)e0 & 1;
     {
-        const uint32_t *g32 = (const uint32_t *)(cd + (e0 - csh));
-        const uint32_t cnt = min(WG_POS, end - g0) + csh;                     // entries needed
-        for (uint32_t k = tid; 2 * k < cnt; k += THREADS) cd32[k] = g32[k];
+        const gptr_u32 gw = (gptr_u32)(abs0 & ~3ull);
+        const uint64_t left = (uint64_t)in + in_bytes - (abs0 & ~3ull);                   // bytes up to the end of the input
+        const uint32_t hi = min(g0 + WG_POS + TAIL, n);                                    // (the compare never reads past the chunk)
+        const uint64_t want_dw = ((uint64_t)(hi - w0) + sh + 3) >> 2, have_dw = (left + 3) >> 2;
+        const uint32_t ndw = (uint32_t)(want_dw < have_dw ? want_dw : have_dw);
+        const gptr_u32 gc = (gptr_u32)(cd + (e0 - csh));
+        const uint32_t ncd = (min(WG_POS, end - g0) + csh + 1) >> 1;                       // dwords of candidates
+        constexpr uint32_t CB = (CD_BYTES / 4 + THREADS - 1) / THREADS;                    // 26 + 1
+        constexpr uint32_t WB = ((WIN_BYTES / 4 + THREADS - 1) / THREADS + 1) / 2;         // two batches of window dwords
+        uint32_t cv[CB], wv[WB];
+#pragma unroll
+        for (uint32_t q = 0; q < CB; ++q) { const uint32_t i = q * THREADS + tid; cv[q] = i < ncd ? gc[i] : 0u; }
+#pragma unroll
+        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = q * THREADS + tid; wv[q] = i < ndw ? gw[i] : 0u; }
+#pragma unroll
+        for (uint32_t q = 0; q < CB; ++q) { const uint32_t i = q * THREADS + tid; if (i < ncd) cd32[i] = cv[q]; }
+#pragma unroll
+        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = q * THREADS + tid; if (i < ndw) win32[i] = wv[q]; }
+#pragma unroll
+        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = (WB + q) * THREADS + tid; wv[q] = i < ndw ? gw[i] : 0u; }
+#pragma unroll
+        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = (WB + q) * THREADS + tid; if (i < ndw) win32[i] = wv[q]; }
     }
     __syncthreads();
 
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
     WalkCtx w;
     w.win32 = win32;
     w.cd16 = (const uint16_t *)cd32;
-    w.w0 = w0;
+    w.w0 = w0 - sh;          // (LDS byte offset of position p: p - w.w0)
     w.c0 = g0 - csh;
     w.n = n;
     w.max_len = max_len;
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
             const uint32_t p = a + b;
             const uint32_t nxt = m ? a + (uint32_t)__builtin_ctzll(m) : x_fin;
             const uint32_t d = w.cd16[p - w.c0];
-            const uint32_t byte = win8[p - w0];
+            const uint32_t byte = win8[p - w.w0];
             st[k++] = d ? ((nxt - p) << 16) | d : byte << 16;
         }
     }
@@ -513,7 +532,9 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
         for (uint32_t g = 0; g < 64; ++g) {
             const uint32_t base = s0 + g * U;
             if (base >= mpos) break;
-            const uint64_t V = __builtin_amdgcn_readlane((uint32_t)W, g) | (uint64_t)__builtin_amdgcn_readlane((uint32_t)(W >> 32), g) << 32;
+            // (readlane returns int: through uint32_t, or a mask whose bit 31 is set is sign-extended into all of bits 32-63)
+            const uint64_t V = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)W, (int)g) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(W >> 32), (int)g) << 32;
             uint64_t m = V;
             if (mpos - base < 64) m &= (1ull << (mpos - base)) - 1;
             if (m == 0) continue;
@@ -555,7 +576,7 @@ int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd
 
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
-                 uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map) {
+                 uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map, int stop_after) {
     if (nchunks == 0) return 0;
     // seg_tmp: six arrays of nsegs words
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
@@ -566,11 +587,13 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                            seg_exit, seg_count, stage);
         LFX_LAUNCH_CHECK();
     }
+    if (stop_after == 1) return 0;      // (LFX_DEBUG dumps)
     if (nsegs) {
         hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, cd, max_len, vis, seg_exit,
                            seg_count, seg_exit2, seg_mpos, seg_kspec, seg_map);
         LFX_LAUNCH_CHECK();
     }
+    if (stop_after == 2) return 0;
     // (workgroup size by the segments per chunk: the fold over a chunk's segments is serial in batches of that size)
     const uint32_t fix_threads = nsegs / nchunks > 128 ? 1024u : 64u;
     hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(fix_threads), 0, st, in, in_bytes, chunks, cd, max_len, vis,
