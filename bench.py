@@ -117,47 +117,66 @@ def measure_traffic(kernel, n, schedule):
 _WORKER_BUF = {}
 
 
-def measure_issue(kernel, n, schedule, waves_per_simd):
-    """Instruction-issue occupancy of `kernel`, measured now (one more rocprofv3 --pmc child pass; SQ counters only, no
-    trace domain): the share of the SIMDs' quad-cycles in which the kernel's wavefronts issue an instruction.  The match
-    kernel is bound by this, not by HBM: SQ_WAVE_CYCLES counts quad-cycles per resident wavefront, so a SIMD that hosts
-    `waves_per_simd` of them for the whole kernel has SQ_WAVE_CYCLES / waves_per_simd quad-cycles to issue in.
-    → dict (with "error" on failure)."""
+def measure_bound(kernel, n, schedule, waves_per_simd):
+    """What `kernel` is bound by, measured now: two more rocprofv3 --pmc child passes (SQ counters only, no trace domain).
+    SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over wavefronts (MI355X_MICROARCH.md §PMC slots:
+    WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ≈ WAVE_CYCLES); a SIMD that hosts `waves_per_simd` wavefronts for the whole
+    kernel has SQ_WAVE_CYCLES / waves_per_simd quad-cycles.  Reported: the share of a wavefront's life it is parked at a
+    wait (s_waitcnt / barrier), stalled at issue, or executing; the VALU / scalar / LDS pipes' busy share of the SIMD
+    time; LDS array cycles and the bank-conflict share of them; instruction counts.  → dict ("error" on failure)."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return {"error": "rocprofv3 not found"}
-    names = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"]
-    tmp = tempfile.mkdtemp(prefix="lfx_pmc_", dir="/tmp")
+    passes = [["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+               "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS"],
+              ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_BRANCH", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+               "SQ_BUSY_CU_CYCLES"]]
+    per = {}
     try:
-        cmd = [rocprof, "--pmc"] + names + ["--output-format", "csv", "-d", tmp, "--", sys.executable,
-                                            os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "0",
-                                            "--bytes", str(n), "--schedule", schedule]
-        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
-        if r.returncode != 0:
-            return {"error": "rocprofv3 SQ pass failed: %s" % (r.stderr or r.stdout)[-300:]}
-        acc, disp = {}, set()
-        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
-            with open(f, newline="") as fh:
-                for row in csv.DictReader(fh):
-                    if kernel not in (row.get("Kernel_Name") or ""):
-                        continue
-                    disp.add(row.get("Dispatch_Id"))
-                    c = row.get("Counter_Name") or ""
-                    acc[c] = acc.get(c, 0.0) + float(row.get("Counter_Value") or 0)
-        if not disp or not acc.get("SQ_WAVE_CYCLES"):
-            return {"error": "kernel %s not in the counter output" % kernel}
-        k = float(len(disp))
-        per = {c: acc.get(c, 0.0) / k for c in names}
-        simd_quads = per["SQ_WAVE_CYCLES"] / waves_per_simd
-        return {"bound": "instruction issue", "busy_frac": round(per["SQ_ACTIVE_INST_ANY"] / simd_quads, 4),
-                "simd_quad_cycles": int(simd_quads), "issue_quad_cycles": int(per["SQ_ACTIVE_INST_ANY"]),
-                "wavefront_instructions": {c[9:].lower(): int(per[c]) for c in names[2:]},
-                "waves_per_simd": waves_per_simd,
-                "source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_*, one child pass of this run"}
+        for names in passes:
+            tmp = tempfile.mkdtemp(prefix="lfx_pmc_", dir="/tmp")
+            try:
+                cmd = [rocprof, "--pmc"] + names + ["--output-format", "csv", "-d", tmp, "--", sys.executable,
+                                                    os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "0",
+                                                    "--bytes", str(n), "--schedule", schedule]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+                if r.returncode != 0:
+                    return {"error": "rocprofv3 SQ pass failed: %s" % (r.stderr or r.stdout)[-300:]}
+                acc, disp = {}, set()
+                for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                    with open(f, newline="") as fh:
+                        for row in csv.DictReader(fh):
+                            if kernel not in (row.get("Kernel_Name") or ""):
+                                continue
+                            disp.add(row.get("Dispatch_Id"))
+                            c = row.get("Counter_Name") or ""
+                            acc[c] = acc.get(c, 0.0) + float(row.get("Counter_Value") or 0)
+                if not disp:
+                    return {"error": "kernel %s not in the counter output" % kernel}
+                for c in names:
+                    per[c] = acc.get(c, 0.0) / float(len(disp))
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        wc = per["SQ_WAVE_CYCLES"]
+        if not wc:
+            return {"error": "SQ_WAVE_CYCLES is zero"}
+        simd_quads = wc / waves_per_simd
+        out = {"bound": "latency / dependency (waves parked at s_waitcnt and barriers), then VALU issue",
+               "wave_parked_frac": round(per["SQ_WAIT_ANY"] / wc, 4),
+               "wave_issue_stall_frac": round(per["SQ_WAIT_INST_ANY"] / wc, 4),
+               "wave_executing_frac": round(per["SQ_ACTIVE_INST_ANY"] / wc, 4),
+               "valu_busy_frac": round(per["SQ_ACTIVE_INST_VALU"] / simd_quads, 4),
+               "scalar_busy_frac": round(per["SQ_ACTIVE_INST_SCA"] / simd_quads, 4),
+               "lds_inst_busy_frac": round(per["SQ_ACTIVE_INST_LDS"] / simd_quads, 4),
+               "lds_issue_stall_frac": round(per["SQ_WAIT_INST_LDS"] / wc, 4),
+               "lds_array_cycles": int(per["SQ_LDS_IDX_ACTIVE"]),
+               "lds_bank_conflict_frac": round(per["SQ_LDS_BANK_CONFLICT"] / per["SQ_LDS_IDX_ACTIVE"], 4) if per["SQ_LDS_IDX_ACTIVE"] else None,
+               "simd_quad_cycles": int(simd_quads), "waves_per_simd": waves_per_simd,
+               "wavefront_instructions": {c[9:].lower(): int(per[c]) for c in passes[1][:4]},
+               "source": "rocprofv3 --pmc, two child passes of this run: " + " ".join(passes[0] + passes[1])}
+        return out
     except Exception as e:  # noqa: BLE001
-        return {"error": "issue measurement failed: %r" % (e,)}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        return {"error": "bound measurement failed: %r" % (e,)}
 
 
 def under_profiler():
@@ -213,6 +232,73 @@ def oracle_worker(args):
     return t1 - t0, t2 - t1
 
 
+def sub_cfg3(ctx, torch, synth, _ffi, C, dev, reps=3):
+    """BASELINE cfg3 as a sub-record: 4096 independent 64 KiB zlib streams (made here by the GPU encoder, one write_all
+    each, as the reference's zlib::Encoder would emit them) decoded by ONE lfx_decode_batch_device call; wall clock
+    around the blocking call, streams and outputs resident in HBM.  GB/s of output bytes."""
+    import numpy as np
+    L = _ffi.lib()
+    count, size = 4096, 65536
+    big = synth.text(count * size, seed=synth.SEED_BASE + 3)
+    d_plain = torch.from_numpy(big).to(dev)
+    opts, sched = _ffi.make_opts(), _ffi.make_schedule(0)
+    bound = L.lfx_encode_bound(size, C.byref(opts), C.byref(sched)) & ~3
+    d_streams = torch.zeros(count * bound, dtype=torch.uint8, device=dev)
+    in_len = np.zeros(count, dtype=np.uint64)
+    for i in range(count):
+        in_len[i] = ctx.encode_device(_ffi.ZLIB, d_plain.data_ptr() + i * size, size, d_streams.data_ptr() + i * bound, bound, opts, sched)
+    in_off = (np.arange(count, dtype=np.uint64) * np.uint64(bound))
+    out_off = (np.arange(count, dtype=np.uint64) * np.uint64(size))
+    out_cap = np.full(count, size, dtype=np.uint64)
+    out_len = np.zeros(count, dtype=np.uint64)
+    status = np.zeros(count, dtype=np.int32)
+    d_out = torch.zeros(count * size, dtype=torch.uint8, device=dev)
+    best = None
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rc = L.lfx_decode_batch_device(ctx.handle, _ffi.ZLIB, count, d_streams.data_ptr(), in_off.ctypes.data, in_len.ctypes.data,
+                                       d_out.data_ptr(), out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
+                                       status.ctypes.data)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    ok = rc == 0 and not status.any() and bool((out_len == size).all()) and torch.equal(d_out, d_plain)
+    comp = int(in_len.sum())
+    return {"workload": "cfg3: %d independent %d KiB zlib streams, one lfx_decode_batch_device call" % (count, size >> 10),
+            "value": round(count * size / best / 1e9, 3), "unit": "GB/s of output", "ms": round(best * 1e3, 3),
+            "compressed_bytes": comp, "round_trip_ok": ok,
+            "hbm_frac_algorithmic": round((comp + count * size) / best / 1e9 / HBM_PEAK_GBPS, 5)}
+
+
+def sub_cfg5(ctx, torch, synth, _ffi, C, dev, reps=2):
+    """BASELINE cfg5 as a sub-record: zlib encode of 1 GiB of low-entropy binary (runs and fixed records: every other
+    match is 258 long), 8192-byte writes; then one decode of the result.  GB/s of input bytes."""
+    L = _ffi.lib()
+    n = 1 << 30
+    data = synth.lowent(n, seed=synth.SEED_BASE + 5)
+    d_in = torch.from_numpy(data).to(dev)
+    opts, sched = _ffi.make_opts(), _ffi.make_schedule(WRITE)
+    bound = L.lfx_encode_bound(n, C.byref(opts), C.byref(sched)) & ~3
+    d_out = torch.empty(bound, dtype=torch.uint8, device=dev)
+    best = None
+    m = 0
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m = ctx.encode_device(_ffi.ZLIB, d_in.data_ptr(), n, d_out.data_ptr(), bound, opts, sched)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    d_dec = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rc, ol, used, msg = ctx.decode_device(_ffi.ZLIB, d_out.data_ptr(), m, d_dec.data_ptr(), n)
+    tdec = time.perf_counter() - t0
+    ok = rc == 0 and ol == n and used == m and torch.equal(d_dec, d_in)
+    return {"workload": "cfg5: zlib::Encoder on LOWENT(1 GiB), 8192-byte writes", "value": round(n / best / 1e9, 3),
+            "unit": "GB/s of input", "ms": round(best * 1e3, 3), "compressed_bytes": int(m), "decode_ms": round(tdec * 1e3, 3),
+            "round_trip_ok": ok, "hbm_frac_algorithmic": round((n + m) / best / 1e9 / HBM_PEAK_GBPS, 5)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +308,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes")
     ap.add_argument("--no-s1", action="store_true", help="skip the S1 sub-record")
+    ap.add_argument("--no-subs", action="store_true", help="skip the cfg3 / cfg5 sub-records")
     ap.add_argument("--child", action="store_true", help="(internal) bare timed loop for a profiler pass")
     ap.add_argument("--schedule", choices=["S8K", "S1"], default="S8K",
                     help="write schedule of the encoder: S8K = 8192-byte writes (the metric's configuration), "
@@ -430,11 +517,11 @@ def main():
                 roof["traffic"] = t["hbm_bytes"]
                 roof["traffic_detail"] = t
                 step_traffic = t.get("step_hbm_bytes_all_kernels")
-            # what the dominant kernel is actually bound by (DESIGN.md §3.1): the HBM figures above are the contract's
-            if dom == "enc:lz77_match":
-                roof["issue"] = measure_issue(PHASE_KERNEL[dom], n, args.schedule, waves_per_simd=4)   # 16-wave workgroup, one per CU
             else:
                 roof["traffic_error"] = (t or {}).get("error", "unknown")
+            # what the dominant kernel is actually bound by (DESIGN.md §3.1): the HBM figures above are the contract's
+            if dom == "enc:lz77_match":
+                roof["bound_detail"] = measure_bound(PHASE_KERNEL[dom], n, args.schedule, waves_per_simd=4)   # 16-wave workgroup, one per CU
     whole_ach = 2.0 * algo_bytes * world / (elapsed / args.steps) / 1e9
     whole = {"achieved": round(whole_ach, 2), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
              "frac": round(whole_ach / (HBM_PEAK_GBPS * world), 5), "algorithmic_bytes_per_step": 2 * algo_bytes * world,
@@ -451,6 +538,16 @@ def main():
               "encode_GBps": round(n * k2 / en2 / 1e9, 4), "decode_GBps": round(n * k2 / de2 / 1e9, 4), "compressed_bytes": m2,
               "steps": k2}
         del r2
+    # ---- the other single-GPU configurations of BASELINE.json, as sub-records of the same line
+    subs = None
+    if world == 1 and not sharded_path and not args.no_subs and n == N_BYTES:
+        subs = {}
+        for name, fn in (("cfg3_batch_decode", sub_cfg3), ("cfg5_lowent_encode", sub_cfg5)):
+            try:
+                subs[name] = fn(ctx, torch, synth, _ffi, C, dev)
+            except Exception as e:      # noqa: BLE001  (a sub-record must not take the metric down)
+                subs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
     cpu = None
     if not args.no_cpu_baseline and world == 1 and not sharded_path:
         import multiprocessing as mp
@@ -509,6 +606,7 @@ def main():
         "decode_GBps": round(total_bytes * args.steps / dec_t / 1e9, 4),
         "phases_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
         "roofline": roof, "whole_path": whole, "schedule_S1" if args.schedule == "S8K" else "schedule_S8K": s1,
+        "other_configs": subs,
         "cpu_baseline": cpu,
     }
     print(json.dumps(line))

@@ -191,19 +191,22 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
         const uint32_t ncd = (min(WG_POS, end - g0) + csh + 1) >> 1;                       // dwords of candidates
         constexpr uint32_t CB = (CD_BYTES / 4 + THREADS - 1) / THREADS;                    // 26 + 1
         constexpr uint32_t WB = ((WIN_BYTES / 4 + THREADS - 1) / THREADS + 1) / 2;         // two batches of window dwords
+        // (branch-free: indices past the end are clamped to the last dword — a few redundant loads and stores of the same
+        //  value instead of 73 exec-mask round trips)
+        const uint32_t lastw = ndw - 1, lastc = ncd - 1;                                   // (ndw, ncd >= 1 here)
         uint32_t cv[CB], wv[WB];
 #pragma unroll
-        for (uint32_t q = 0; q < CB; ++q) { const uint32_t i = q * THREADS + tid; cv[q] = i < ncd ? gc[i] : 0u; }
+        for (uint32_t q = 0; q < CB; ++q) cv[q] = gc[min(q * THREADS + tid, lastc)];
 #pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = q * THREADS + tid; wv[q] = i < ndw ? gw[i] : 0u; }
+        for (uint32_t q = 0; q < WB; ++q) wv[q] = gw[min(q * THREADS + tid, lastw)];
 #pragma unroll
-        for (uint32_t q = 0; q < CB; ++q) { const uint32_t i = q * THREADS + tid; if (i < ncd) cd32[i] = cv[q]; }
+        for (uint32_t q = 0; q < CB; ++q) cd32[min(q * THREADS + tid, lastc)] = cv[q];
 #pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = q * THREADS + tid; if (i < ndw) win32[i] = wv[q]; }
+        for (uint32_t q = 0; q < WB; ++q) win32[min(q * THREADS + tid, lastw)] = wv[q];
 #pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = (WB + q) * THREADS + tid; wv[q] = i < ndw ? gw[i] : 0u; }
+        for (uint32_t q = 0; q < WB; ++q) wv[q] = gw[min((WB + q) * THREADS + tid, lastw)];
 #pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) { const uint32_t i = (WB + q) * THREADS + tid; if (i < ndw) win32[i] = wv[q]; }
+        for (uint32_t q = 0; q < WB; ++q) win32[min((WB + q) * THREADS + tid, lastw)] = wv[q];
     }
     __syncthreads();
 
