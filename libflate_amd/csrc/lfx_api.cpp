@@ -220,7 +220,6 @@ void Diag::read() {
     auto on = [](const char *k) { return getenv(k) != nullptr; };
     debug = on("LFX_DEBUG");
     match_v1 = on("LFX_MATCH_V1");
-    match3 = on("LFX_MATCH3");
     no_serial = on("LFX_NO_SERIAL");
     batch_serial = on("LFX_BATCH_SERIAL");
     no_markers = on("LFX_NO_MARKERS");
@@ -428,18 +427,14 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
         LAUNCH_TRY(launch_md_to_cd(st, (const uint32_t *)c->d_md.p, n, d_cd));
     } else {
-        if (c->diag.match3)
-            LAUNCH_TRY(launch_match3(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                     (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
-        else
-            LAUNCH_TRY(launch_match4(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                     (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
+        LAUNCH_TRY(launch_match3(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                 (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
     }
     if (mdbg) {
         uint64_t hv[128];
         (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
         for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : c->diag.match3 ? "3" : "4", w,
+            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "3", w,
                     match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
     }

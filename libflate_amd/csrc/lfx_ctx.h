@@ -23,7 +23,6 @@ struct DevBuf {
 struct Diag {
     bool debug = false;          // LFX_DEBUG: per-stage counters and cycle stamps on stderr
     bool match_v1 = false;       // LFX_MATCH_V1: first-generation match kernel (+ md → cd)
-    bool match3 = false;         // LFX_MATCH3: the two-barrier candidate kernel (lfx_match3.hip) instead of lfx_match4.hip
     bool no_serial = false;      // LFX_NO_SERIAL: the serial fallback of the single-stream decoder is an error
     bool batch_serial = false;   // LFX_BATCH_SERIAL: every stream of a batch through the serial kernel
     bool no_markers = false;     // LFX_NO_MARKERS

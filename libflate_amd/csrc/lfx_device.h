@@ -39,9 +39,6 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
 // (0 = none) → cd.  flags[0] |= 1 on a lane-order violation.
 int launch_match3(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg = nullptr);
-// the same stage with ONE barrier per tile (lfx_match4.hip): the default; lfx_match3.hip stays selectable (LFX_MATCH3=1)
-int launch_match4(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg = nullptr);
 // the first-generation kernel's answers (length << 16 | distance) → cd
 int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd);
 // the greedy walk with lazy match lengths (lfx_parse2.hip) → code words per chunk
