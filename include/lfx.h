@@ -183,12 +183,15 @@ typedef struct lfx_decoder lfx_decoder;
  * -LFX_E_WOULD_BLOCK at any point; read() / header() then return LFX_E_WOULD_BLOCK and can be called again
  * (the header is read lazily, non_blocking/gzip.rs:64-113).
  *
- * Input is pulled in growing batches (the GPU inflates whole members); a decode is attempted when a batch is
- * complete, the reader ends, hands over a short read, or would block.  Bytes pulled beyond the member's trailer
- * are not decoded: lfx_decoder_surplus() hands them back (what into_inner() means for a reader that cannot be
- * rewound, gzip.rs:987,1216-1226); a MultiDecoder continues with them.  A blocking reader that never ends and
- * never returns short reads can make a blocking decoder ask for more than the member holds: use the
- * non-blocking mode for sockets. */
+ * The body is decoded a WINDOW at a time, as the reference decodes a block at a time (src/deflate/decode.rs:136-164,
+ * 32 KiB of history: libflate_lz77/src/lib.rs:219-231): up to 16 MiB of input are pulled, the blocks that are complete
+ * in them (and fit 96 MiB of output) are decoded and served, their input is dropped, the last 32 KiB of output stay as
+ * history — what the decoder buffers (lfx_decoder_buffered) is bounded by one window of input plus one of output,
+ * whatever the member's size, and the first byte is served as soon as the first window is decoded.  Only a block
+ * larger than a window (members written by ONE huge write) makes the window grow.  A window is attempted when it is
+ * full, the reader ends, hands over a short read, or would block.  Bytes pulled beyond the member's trailer are not
+ * decoded: lfx_decoder_surplus() hands them back (what into_inner() means for a reader that cannot be rewound,
+ * gzip.rs:987,1216-1226); a MultiDecoder continues with them. */
 #define LFX_DEC_NONBLOCKING 2u
 lfx_decoder *lfx_decoder_new(lfx_ctx *c, int format, uint32_t flags, lfx_read_cb r, void *user,
                              int *status);
@@ -200,6 +203,8 @@ int lfx_decoder_unread(lfx_decoder *d, const uint8_t **p, size_t *n);
 /* bytes of the inner reader that belong to the members decoded so far (Decoder::into_inner position;
  * gzip.rs:1216-1226) */
 uint64_t lfx_decoder_consumed(const lfx_decoder *d);
+/* bytes the decoder holds right now: pulled input not yet decoded + decoded output not yet read + 32 KiB of history */
+uint64_t lfx_decoder_buffered(const lfx_decoder *d);
 /* bytes pulled from the reader behind the last finished member (valid until the next read()) */
 int lfx_decoder_surplus(lfx_decoder *d, const uint8_t **p, size_t *n);
 /* gzip::Header (gzip.rs:292-341: modification_time, compression_level (XFL), os, is_text, is_verified, extra_field,

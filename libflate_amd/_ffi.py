@@ -26,7 +26,7 @@ EXPORTS = [
     "lfx_crc32_combine", "lfx_adler32_combine", "lfx_container_header_len", "lfx_encoder_new",
     "lfx_encoder_write", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
     "lfx_encoder_free", "lfx_decoder_new", "lfx_decoder_read", "lfx_decoder_unread",
-    "lfx_decoder_consumed", "lfx_decoder_surplus", "lfx_decoder_header", "lfx_decoder_last_error", "lfx_decoder_free", "lfx_lz77_new",
+    "lfx_decoder_consumed", "lfx_decoder_buffered", "lfx_decoder_surplus", "lfx_decoder_header", "lfx_decoder_last_error", "lfx_decoder_free", "lfx_lz77_new",
     "lfx_lz77_encode", "lfx_lz77_flush", "lfx_lz77_window_size", "lfx_lz77_compression_level",
     "lfx_lz77_free", "lfx_ctx_last_timing", "lfx_ctx_enable_timing", "lfx_version",
 ]
@@ -144,6 +144,8 @@ def lib():
     L.lfx_decoder_unread.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.lfx_decoder_consumed.restype = u64
     L.lfx_decoder_consumed.argtypes = [vp]
+    L.lfx_decoder_buffered.restype = u64
+    L.lfx_decoder_buffered.argtypes = [vp]
     L.lfx_decoder_surplus.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
     L.lfx_decoder_header.argtypes = [vp, C.POINTER(Header)]
     L.lfx_decoder_last_error.restype = C.c_char_p

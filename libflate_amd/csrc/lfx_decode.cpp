@@ -84,6 +84,10 @@ struct MemberResult {
     uint64_t blk_out_start = 0;  // bytes of completed blocks
     uint64_t end_byte = 0;       // input byte after the last DEFLATE byte (relative to member base)
     std::string msg;
+    // windowed (partial) decode: where the decoded part ends and whether the member's last block is behind it
+    uint64_t end_bit = 0;
+    bool final_seen = false;
+    bool need_cap = false;       // nothing decoded because the first block does not fit the output capacity
 };
 
 // run `njobs` inflate jobs and fetch their results
@@ -107,9 +111,14 @@ int run_jobs(Ctx *c, const uint8_t *d_in, uint8_t *d_out, const std::vector<Infl
 // hist0 = 0 (a member starts with an empty Lz77Decoder buffer, gzip.rs:1000-1005).
 // stop_bit != ~0: the walk ends cleanly when a block ends exactly at stop_bit (a shard of a member that
 // does not hold the BFINAL block); start_bit0 may be any bit of the first byte.
+// partial: a WINDOW of a member (the stream decoders): decode the blocks that are complete in d_in[0..n) and fit into
+// `cap`, stop cleanly in front of the first one that is not (mr.end_bit = its header bit, mr.final_seen = false); `hist`
+// = bytes of the member produced by earlier windows — the last 32 KiB of them lie right in front of d_out.
 int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8_t *d_out, uint64_t cap,
-                   MemberResult &mr, uint64_t start_bit0 = ~0ull, uint64_t stop_bit = ~0ull) {
+                   MemberResult &mr, uint64_t start_bit0 = ~0ull, uint64_t stop_bit = ~0ull, bool partial = false,
+                   uint64_t hist = 0) {
     const uint64_t first_bit = start_bit0 == ~0ull ? off0 * 8 : start_bit0;
+    mr.end_bit = first_bit;
     hipStream_t st = c->stream;
     std::vector<InflateJob> jobs;
     std::vector<InflateResult> res;
@@ -159,7 +168,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             auto start_at = [&](uint32_t i) { return i < nc ? starts[i] : n * 8; };
             std::vector<BlkEmit> emit;
             uint64_t pos = first_bit, total = 0, total_codes = 0;
-            bool ok_chain = false;
+            bool ok_chain = false, chain_final = false;
+            bool front_bad = false;      // the window's FIRST block does not scan: damaged rather than incomplete
             uint64_t last_end = 0;   // end bit of the last block of the chain
             bool pieces_mode = false;
             const size_t tab_bytes = blk_tabs_bytes();
@@ -169,7 +179,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // decode that starts a few Kbit early; it is accepted iff that boundary equals the exit of the piece in
             // front of it (piece 0 starts exactly behind the header), so the chain of pieces is proven, not assumed.
             // Pieces behave like blocks from here on (their back-references cross pieces: marker path).
-            if (nc <= 8 && comp >= (8u << 20) && stop_bit == ~0ull && !c->diag.no_pieces) {
+            if (nc <= 8 && comp >= (8u << 20) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
                 constexpr uint64_t PIECE_BITS = 4ull << 20, OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
                 const uint32_t cap_slots = (uint32_t)std::min<uint64_t>((end_bits - first_bit) / PIECE_BITS * 2 + 64, 1u << 20);
@@ -218,7 +228,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                         if (r.status == BLK_OK) {          // the piece that holds EndOfBlock (or a whole stored block)
                             closed = true;
                             last_end = r.end_bit;
-                            if (r.bfinal) ok_chain = true; else pos = r.end_bit;
+                            if (r.bfinal) { ok_chain = true; chain_final = true; } else pos = r.end_bit;
                         }
                     }
                     if (!closed) fail = true;
@@ -333,20 +343,32 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     HIP_TRY(hipStreamSynchronize(st));
                     if (r.status == BLK_OK && r.btype != 0) n_extra++;   // the slot stays in use
                 }
-                if (r.status != BLK_OK || r.end_bit <= pos) break;
+                if (r.status != BLK_OK || r.end_bit <= pos) { front_bad = emit.empty() && r.status == BLK_BAD; break; }
+                if (partial && total + r.n_out > cap) { mr.need_cap = emit.empty(); break; }   // (the next window takes it)
                 BlkEmit e{};
                 e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
                 e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
-                e.hist = total;      // (hist0 = 0: a member starts with an empty window)
+                e.hist = hist + total;      // (hist = 0: a member starts with an empty window)
                 emit.push_back(e);
                 total += r.n_out;
                 total_codes += r.n_codes;
                 last_end = r.end_bit;
-                if (r.bfinal) { ok_chain = true; break; }
+                if (r.bfinal) { ok_chain = true; chain_final = true; break; }
                 pos = r.end_bit;
             }
+            // a window: the blocks in front of the first incomplete one are what this call delivers
+            if (partial && !ok_chain && !emit.empty()) ok_chain = true;
             }   // !pieces_mode
             if (c->diag.debug) fprintf(stderr, "[lfx]  chain ok=%d blocks=%zu pos=%llu total=%llu\n", (int)ok_chain, emit.size(), (unsigned long long)pos, (unsigned long long)total);
+            if (partial && emit.empty() && !front_bad) {
+                // a window without one complete block (or whose first block does not fit `cap`): nothing to deliver — the
+                // caller widens the window (the exact serial walk of the whole window would only find out the same, slowly).
+                // A first block that does not even scan is different: the serial walk below says at once whether the
+                // stream is damaged there (a verdict) or merely cut (nothing to deliver).
+                mr.status = LFX_OK; mr.out_len = 0; mr.blk_out_start = 0; mr.final_seen = false;
+                mr.end_bit = first_bit; mr.end_byte = first_bit / 8;
+                return LFX_OK;
+            }
             if (ok_chain && total <= cap) {
                 // ---- K2 + K3: validated lanes emit codes, one wavefront per block materialises them
                 const uint32_t ne = (uint32_t)emit.size();
@@ -427,6 +449,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                                 (unsigned long long)dv[u * 8], (unsigned long long)dv[u * 8 + 1], (unsigned long long)dv[u * 8 + 2],
                                 (unsigned long long)dv[u * 8 + 3], (unsigned long long)dv[u * 8 + 4], (unsigned long long)dv[u * 8 + 5]);
                 }
+                // (a later window of a member: the 32 KiB in front of d_out hold the member's earlier output — the markers of
+                //  the first unit resolve through them; bytes in front of what `hist` covers are never looked up: a reference
+                //  that far back raised flag 1 above)
+                const uint8_t *init_win = hist ? d_out - MAX_WINDOW : nullptr;
                 if (fl == 2 && !c->diag.no_markers) {
                     // Blocks read the output of earlier blocks (streams of other encoders; the reference's own
                     // blocks never do).  Marker-based materialisation: every block, cut into units at slice
@@ -456,10 +482,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     c->phase("lz77_sym");
                     if (nsu >= 128 && !c->diag.window_chain) {   // long stream: blocked parallel prefix over the units
                         if ((rc = c->d_dec_maps.reserve(window_prefix_scratch_bytes(nsu)))) return rc;
-                        LAUNCH_TRY(launch_window_prefix(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, d_win));
-                    } else LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win));
+                        LAUNCH_TRY(launch_window_prefix(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, d_win, init_win));
+                    } else LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, init_win));
                     c->phase("win_chain");
-                    LAUNCH_TRY(launch_sym_substitute(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, d_out, max_len));
+                    LAUNCH_TRY(launch_sym_substitute(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, d_out, max_len, init_win));
                     HIP_TRY(hipStreamSynchronize(st));
                     c->phase("substitute");
                     if (c->diag.debug) fprintf(stderr, "[lfx]  cross-block references: %u blocks, %u units through markers\n", ne, nsu);
@@ -512,6 +538,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     mr.blk_out_start = total;
                     const uint64_t eb = pos == stop_bit ? pos : last_end;
                     mr.end_byte = eb / 8 + ((eb & 7) ? 1 : 0);
+                    mr.end_bit = eb;
+                    mr.final_seen = chain_final;
                     parallel_done = true;
                 }
             }
@@ -523,7 +551,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         jobs.clear();
         InflateJob j{};
         j.in_off = 0; j.in_len = n; j.start_bit = first_bit;
-        j.out_off = 0; j.out_cap = cap; j.hist_avail = 0; j.flags = 0;
+        j.out_off = 0; j.out_cap = cap; j.hist_avail = hist; j.flags = 0;
         j.stop_bit = stop_bit == ~0ull ? 0 : stop_bit;   // (small or irregular shards: the exact walk, ended at the shard's last bit)
         jobs.push_back(j);
         int rc;
@@ -538,7 +566,22 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         mr.out_len = r.out_len;
         mr.blk_out_start = r.status ? r.blk_out_start : r.out_len;
         mr.end_byte = std::min<uint64_t>((r.end_bit + 7) / 8, n);
+        mr.end_bit = r.end_bit;
+        mr.final_seen = r.status == 0 && r.final_seen;
         mr.msg = format_error(r.err, r.a0, r.a1);
+        // a window: running out of input (or of output capacity) inside a block is not a verdict — deliver the blocks in
+        // front of it and let the caller come back with more.  An error in the very last bits of the window may be an
+        // artefact of the cut (the reference's BitReader reads zeros past the end before it reports UnexpectedEof) and
+        // is treated the same way; the caller repeats it without `partial` once the reader has ended.
+        if (partial && r.status != 0 && (r.status == 2 || r.status == 3 || r.end_bit + 64 >= n * 8)) {
+            mr.status = LFX_OK;
+            mr.out_len = mr.blk_out_start = r.blk_out_start;
+            mr.end_bit = r.blk_start_bit;
+            mr.end_byte = r.blk_start_bit / 8;
+            mr.final_seen = false;
+            mr.need_cap = r.status == 3 && r.blk_out_start == 0;
+            mr.msg.clear();
+        }
     }
     return LFX_OK;
 }
@@ -909,7 +952,8 @@ struct lfx_decoder {
     uint32_t flags;
     lfx_read_cb r;
     void *user;
-    std::vector<uint8_t> in;        // pulled from the reader and not yet consumed by a finished member
+    std::vector<uint8_t> in;        // pulled from the reader and not yet consumed by a decoded window
+    std::vector<uint8_t> chunk;     // what one read callback fills
     bool reader_eof = false;
     enum State { ST_HEADER, ST_BODY, ST_SERVE, ST_DONE, ST_FAILED } state = ST_HEADER;
     bool first_member = true;
@@ -924,6 +968,15 @@ struct lfx_decoder {
     uint64_t target = 0;            // input size at which the next attempt is due
     uint64_t tried_at = 0;          // input size of the last attempt that ran out of input
     std::string err;
+    // windowed body decode: the member is decoded a window of complete blocks at a time
+    bool body_started = false;      // the header bytes have been dropped from `in`; in[0] holds the next block's first bit
+    uint32_t bit_off = 0;           // ... at this bit of in[0]
+    uint64_t member_out = 0;        // bytes of the member decoded by earlier windows
+    std::vector<uint8_t> hist;      // the last (at most 32 KiB) of them: the LZ77 window the next blocks may reach into
+    uint32_t run_crc = 0, run_adler = 1;   // container checksum over member_out bytes
+    bool member_final = false;      // the BFINAL block has been decoded: the trailer is next
+    bool more_windows = false;      // ST_SERVE: another window follows the bytes being served
+    uint64_t out_cap = 0;           // output capacity of one window
 };
 
 namespace {
@@ -933,10 +986,11 @@ enum { PULL_OK = 0, PULL_EOF = 1, PULL_BLOCK = 2, PULL_ERR = 3 };
 int dec_pull(lfx_decoder *d, size_t want, size_t *got) {
     *got = 0;
     if (d->reader_eof) return PULL_EOF;
-    const size_t at = d->in.size();
-    d->in.resize(at + want);
-    const int64_t k = d->r(d->user, d->in.data() + at, want);
-    d->in.resize(at + (k > 0 ? (size_t)k : 0));
+    // (into a reusable chunk, then appended: growing `in` by `want` zero-filled bytes per callback made a reader that
+    //  hands over a few bytes at a time pay for 4 MiB of memset each time)
+    if (d->chunk.size() < want) d->chunk.resize(want);
+    const int64_t k = d->r(d->user, d->chunk.data(), want);
+    if (k > 0) d->in.insert(d->in.end(), d->chunk.begin(), d->chunk.begin() + (std::ptrdiff_t)std::min<int64_t>(k, (int64_t)want));
     if (k == -(int64_t)LFX_E_WOULD_BLOCK) return PULL_BLOCK;
     if (k < 0) return PULL_ERR;
     if (k == 0) { d->reader_eof = true; return PULL_EOF; }
@@ -970,14 +1024,70 @@ int dec_header(lfx_decoder *d) {
     }
 }
 
-// decode the member at the front of d->in.  → LFX_OK when a verdict is in (state ST_SERVE), LFX_E_WOULD_BLOCK /
-// LFX_E_IO from the reader, or a device error
+// The body is decoded a WINDOW at a time (the reference decodes one block per read, src/deflate/decode.rs:136-164, and keeps
+// 32 KiB of history, libflate_lz77/src/lib.rs:219-231): pull up to WINDOW_IN compressed bytes, decode the blocks that are
+// complete in them and fit WINDOW_OUT (inflate_member, partial), serve those bytes, drop the input they used, keep the
+// last 32 KiB of output as history — what is buffered never exceeds one window of input plus one window of output,
+// whatever the member's size, and the first byte is served as soon as the first window is decoded.  The container
+// checksum is folded window by window (CRC-32 / Adler-32 combine).  A window without one complete block (a block larger
+// than the window: schedule-S1 members) doubles the window.
+constexpr uint64_t WINDOW_IN = 16ull << 20, WINDOW_OUT = 96ull << 20, WINDOW_IN_MAX = 1ull << 40;
+
+// → LFX_OK when bytes or a verdict are ready (state ST_SERVE), LFX_E_WOULD_BLOCK / LFX_E_IO from the reader, or a device error
 int dec_body(lfx_decoder *d) {
     Ctx *c = d->c;
-    const bool nonblock = (d->flags & LFX_DEC_NONBLOCKING) != 0;
-    if (d->target == 0) d->target = 1 << 16;
+    if (!d->body_started) {
+        // the header has been parsed on the host (dec_header): drop its bytes, the first block starts at bit 0
+        const size_t hl = d->hdr_bytes.size();
+        d->in.erase(d->in.begin(), d->in.begin() + (std::ptrdiff_t)std::min(hl, d->in.size()));
+        d->consumed_total += hl;
+        d->body_started = true;
+        d->bit_off = 0; d->member_out = 0; d->hist.clear(); d->run_crc = 0; d->run_adler = 1; d->member_final = false;
+        d->target = 0; d->tried_at = 0;
+        d->out_cap = WINDOW_OUT;
+    }
+    if (d->target == 0) d->target = 1 << 16;       // (small members: do not wait for a whole window)
+    const uint64_t trailer = d->format == LFX_GZIP ? 8 : d->format == LFX_ZLIB ? 4 : 0;
     for (;;) {
-        // ---- input: up to the next attempt size; a short read or the end of the reader also triggers an attempt
+        // ---- the member's blocks are done: the trailer (gzip.rs:1030-1042, zlib.rs:387-401)
+        if (d->member_final) {
+            const uint64_t tpos = d->bit_off ? 1 : 0;       // (the last block ends inside in[0]: the trailer is byte aligned)
+            while (d->in.size() < tpos + trailer && !d->reader_eof) {
+                size_t got;
+                const int pr = dec_pull(d, (size_t)(tpos + trailer - d->in.size()), &got);
+                if (pr == PULL_ERR) { d->err = "read callback failed"; return LFX_E_IO; }
+                if (pr == PULL_BLOCK) return LFX_E_WOULD_BLOCK;
+            }
+            d->out.clear(); d->cursor = 0; d->serve_limit = 0; d->more_windows = false;
+            d->pending_status = LFX_OK; d->err.clear();
+            if (d->in.size() < tpos + trailer) {
+                d->pending_status = LFX_E_UNEXPECTED_EOF;
+                d->err = "failed to fill whole buffer";
+                d->consumed_total += d->in.size();
+                d->in.clear();
+            } else {
+                const uint8_t *t = d->in.data() + tpos;
+                if (d->format == LFX_GZIP) {
+                    const uint32_t crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+                    if (crc != d->run_crc) {   // gzip.rs:1035-1040 (ISIZE is read but never verified)
+                        d->pending_status = LFX_E_INVALID_DATA;
+                        d->err = format_error(ERR_CRC32, d->run_crc, crc);
+                    }
+                } else if (d->format == LFX_ZLIB) {
+                    const uint32_t ad = (uint32_t)t[0] << 24 | (uint32_t)t[1] << 16 | (uint32_t)t[2] << 8 | t[3];
+                    if (ad != d->run_adler) {
+                        d->pending_status = LFX_E_INVALID_DATA;
+                        d->err = format_error(ERR_ADLER32, d->run_adler, ad);
+                    }
+                }
+                d->consumed_total += tpos + trailer;
+                d->in.erase(d->in.begin(), d->in.begin() + (std::ptrdiff_t)(tpos + trailer));   // what is left is the surplus
+            }
+            d->body_started = false;
+            d->state = lfx_decoder::ST_SERVE;
+            return LFX_OK;
+        }
+        // ---- input: up to the window size; a short read or the end of the reader also triggers an attempt
         bool attempt = d->reader_eof;
         while (!attempt) {
             if (d->in.size() >= d->target) { attempt = true; break; }
@@ -987,54 +1097,122 @@ int dec_body(lfx_decoder *d) {
             if (pr == PULL_ERR) { d->err = "read callback failed"; return LFX_E_IO; }
             if (pr == PULL_EOF) { attempt = true; break; }
             if (pr == PULL_BLOCK) {
-                // everything the peer has sent is here: decode it if anything new arrived, else report WouldBlock
-                if (d->in.size() > d->tried_at) { attempt = true; break; }
+                // everything the peer has sent is here: decode it if enough new bytes arrived since an attempt that found
+                // no complete block (an eighth more: the retries of one long block stay linear in its size), else WouldBlock
+                if (d->in.size() > d->tried_at + d->tried_at / 8) { attempt = true; break; }
                 return LFX_E_WOULD_BLOCK;
             }
             // a short read hints that the reader has no more right now (pipes, sockets): worth an attempt once the
             // input has grown by a quarter since the last one (keeps the total work linear)
             if (got < want && d->in.size() >= d->tried_at + d->tried_at / 4 + 1) { attempt = true; break; }
         }
-        // ---- attempt (the context's scratch is shared: one decode at a time per context)
+        // ---- one window (the context's scratch is shared: one decode at a time per context)
         const uint64_t n = d->in.size();
-        DecodeOutcome oc;
+        MemberResult mr;
+        uint32_t w_crc = 0, w_adler = 1;
+        bool verdict = false;                        // mr is the member's final word (an error, or a decode without `partial`)
         {
             std::lock_guard<std::recursive_mutex> lock(c->mu);
             (void)hipSetDevice(c->device);
+            c->n_ev = 0;
+            c->phase("start");
             int rc;
-            uint64_t cap = std::max<uint64_t>(n * 8, 1 << 20);
-            for (;;) {
-                if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
-                if ((rc = c->d_io_out.reserve(cap))) return rc;
-                if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
-                oc = DecodeOutcome{};       // (a fresh verdict per attempt: a retry must not inherit NOSPACE)
-                rc = decode_stream(c, d->format, 0, (const uint8_t *)c->d_io_in.p, n, (uint8_t *)c->d_io_out.p, cap, oc);
-                if (rc) return rc;
-                if (oc.status == LFX_E_NOSPACE && cap < n * 1040 + (1 << 20)) { cap *= 8; continue; }
-                break;
+            const uint64_t H = d->hist.size();
+            if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+            if ((rc = c->d_io_out.reserve(MAX_WINDOW + d->out_cap))) return rc;
+            if ((rc = c->d_res.reserve(256))) return rc;
+            uint8_t *d_out = (uint8_t *)c->d_io_out.p + MAX_WINDOW;          // the history lies right in front of it
+            if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
+            if (H && hipMemcpyAsync(d_out - H, d->hist.data(), H, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
+            // (once the reader has ended nothing more can arrive: the exact walk gives the member's verdict)
+            const bool partial = !d->reader_eof;
+            rc = inflate_member(c, (const uint8_t *)c->d_io_in.p, n, 0, d_out, d->out_cap, mr, d->bit_off, ~0ull, partial, d->member_out);
+            if (rc) return rc;
+            verdict = mr.status != LFX_OK || !partial;
+            if (mr.status == LFX_E_NOSPACE && !partial) {     // (the tail of the member does not fit one window: grow and retry)
+                d->out_cap *= 2;
+                continue;
             }
-            if (!(oc.status == LFX_E_UNEXPECTED_EOF && !d->reader_eof)) {
-                d->out.resize(oc.out_len);
-                if (oc.out_len && hipMemcpy(d->out.data(), c->d_io_out.p, oc.out_len, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
+            const uint64_t keep = mr.status == LFX_OK ? mr.out_len : mr.out_len;   // bytes produced (also on failure)
+            if (keep && mr.status == LFX_OK && trailer) {
+                const uint64_t nspans = div_up(keep, 65536);                       // CK_SPAN
+                if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
+                uint32_t *ck = (uint32_t *)c->d_ck.p;
+                if (int e_ = launch_checksum(c->stream, d_out, keep, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,
+                                             d->format == LFX_GZIP ? 1 : 2)) {
+                    c->set_error(hipGetErrorString((hipError_t)e_));
+                    return LFX_E_DEVICE;
+                }
+                if (hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return LFX_E_DEVICE;
+            }
+            d->out.resize(keep);
+            if (keep && hipMemcpyAsync(d->out.data(), d_out, keep, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return LFX_E_DEVICE;
+            if (hipStreamSynchronize(c->stream) != hipSuccess) return LFX_E_DEVICE;
+            if (keep && mr.status == LFX_OK && trailer) {
+                const EncodeResult er = *(EncodeResult *)c->h_res;
+                w_crc = er.crc32; w_adler = er.adler32;
             }
         }
-        if (oc.status == LFX_E_UNEXPECTED_EOF && !d->reader_eof) {
-            // ran out of input, not out of stream: wait for more
+        if (c->diag.debug)
+            fprintf(stderr, "[lfx] window: n=%llu bit_off=%u eof=%d hist=%llu → status=%d out=%llu blk_out=%llu end_bit=%llu final=%d need_cap=%d target=%llu\n",
+                    (unsigned long long)n, d->bit_off, (int)d->reader_eof, (unsigned long long)d->member_out, mr.status,
+                    (unsigned long long)mr.out_len, (unsigned long long)mr.blk_out_start, (unsigned long long)mr.end_bit,
+                    (int)mr.final_seen, (int)mr.need_cap, (unsigned long long)d->target);
+        if (mr.status == LFX_OK && mr.out_len == 0 && !mr.final_seen) {
+            // no complete block in this window: more input (or, for a block that does not fit, more room)
+            if (mr.need_cap) { d->out_cap *= 2; continue; }
+            if (d->reader_eof || n >= WINDOW_IN_MAX) {
+                // (cannot happen with !partial; kept as the way out of a reader that never ends on a broken stream)
+                d->pending_status = LFX_E_UNEXPECTED_EOF; d->err = "failed to fill whole buffer";
+                d->out.clear(); d->cursor = 0; d->serve_limit = 0; d->more_windows = false;
+                d->state = lfx_decoder::ST_SERVE;
+                return LFX_OK;
+            }
             d->tried_at = n;
-            d->target = std::max<uint64_t>(d->target, n) * 2;
-            if (nonblock) continue;      // (the pull loop reports WouldBlock unless new bytes arrive)
+            d->target = std::max<uint64_t>(d->target, std::max<uint64_t>(2 * n, 1 << 16));   // the next try: twice what did not suffice
             continue;
         }
+        // ---- bytes (and maybe a verdict) to serve
         d->cursor = 0;
-        d->serve_limit = oc.status == LFX_OK ? oc.out_len : oc.delivered_len;
-        d->pending_status = oc.status;
-        d->err = oc.msg;
-        const uint64_t used = std::min<uint64_t>(oc.consumed, n);
+        d->pending_status = LFX_OK;
+        d->err.clear();
+        if (mr.status != LFX_OK) {
+            // the reference hands out what completed blocks produced, then the error (decode.rs:136-164); everything
+            // produced stays available through unread_decoded_data (decode.rs:68-73)
+            d->serve_limit = mr.blk_out_start;
+            d->pending_status = mr.status;
+            d->err = mr.msg;
+            d->more_windows = false;
+            const uint64_t used = std::min<uint64_t>(mr.end_byte, n);
+            d->consumed_total += used;
+            d->in.erase(d->in.begin(), d->in.begin() + (std::ptrdiff_t)used);
+            d->body_started = false;
+            d->state = lfx_decoder::ST_SERVE;
+            (void)verdict;
+            return LFX_OK;
+        }
+        d->serve_limit = mr.out_len;
+        if (trailer && mr.out_len) {
+            d->run_crc = lfx_crc32_combine(d->run_crc, w_crc, mr.out_len);
+            d->run_adler = lfx_adler32_combine(d->run_adler, w_adler, mr.out_len);
+        }
+        d->member_out += mr.out_len;
+        // history: the last 32 KiB of (history ++ this window's output)
+        if (mr.out_len >= MAX_WINDOW) d->hist.assign(d->out.end() - MAX_WINDOW, d->out.end());
+        else {
+            d->hist.insert(d->hist.end(), d->out.begin(), d->out.end());
+            if (d->hist.size() > MAX_WINDOW) d->hist.erase(d->hist.begin(), d->hist.end() - MAX_WINDOW);
+        }
+        // input: everything in front of the byte that holds the next unread bit is done with
+        const uint64_t used = std::min<uint64_t>(mr.end_bit / 8, n);
         d->consumed_total += used;
-        d->in.erase(d->in.begin(), d->in.begin() + (size_t)used);   // what is left is the surplus
-        d->state = lfx_decoder::ST_SERVE;
-        d->target = 0;
+        d->in.erase(d->in.begin(), d->in.begin() + (std::ptrdiff_t)used);
+        d->bit_off = (uint32_t)(mr.end_bit & 7);
+        d->member_final = mr.final_seen;
+        d->more_windows = true;                        // (the trailer check, at least, follows)
+        d->target = std::max<uint64_t>(WINDOW_IN, d->target > (1 << 16) ? d->target : 0);
         d->tried_at = 0;
+        d->state = lfx_decoder::ST_SERVE;
         return LFX_OK;
     }
 }
@@ -1080,6 +1258,7 @@ extern "C" int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap) {
                     return (int64_t)k;
                 }
                 if (d->pending_status != LFX_OK) { d->state = lfx_decoder::ST_FAILED; return -(int64_t)d->pending_status; }
+                if (d->more_windows) { d->state = lfx_decoder::ST_BODY; continue; }      // the next window (or the trailer)
                 if (d->format == LFX_GZIP && (d->flags & LFX_DEC_MULTI)) {   // MultiDecoder::read gzip.rs:1142-1166
                     d->first_member = false;
                     d->state = lfx_decoder::ST_HEADER;
@@ -1126,7 +1305,8 @@ extern "C" int lfx_decoder_surplus(lfx_decoder *d, const uint8_t **p, size_t *n)
     if (!d) return LFX_E_ARG;
     // input pulled from the reader that lies behind the last finished member (only meaningful between members /
     // at the end: while a member is being collected `in` holds that member's bytes)
-    const bool settled = d->state == lfx_decoder::ST_SERVE || d->state == lfx_decoder::ST_DONE || d->state == lfx_decoder::ST_FAILED;
+    const bool settled = (d->state == lfx_decoder::ST_SERVE && !d->more_windows && !d->body_started) ||
+                         d->state == lfx_decoder::ST_DONE || d->state == lfx_decoder::ST_FAILED;
     *p = d->in.data();
     *n = settled ? d->in.size() : 0;
     return LFX_OK;
@@ -1159,5 +1339,8 @@ extern "C" int lfx_decoder_header(lfx_decoder *d, lfx_header *h) {
     return LFX_OK;
 }
 extern "C" uint64_t lfx_decoder_consumed(const lfx_decoder *d) { return d ? d->consumed_total : 0; }
+extern "C" uint64_t lfx_decoder_buffered(const lfx_decoder *d) {
+    return d ? (uint64_t)(d->in.size() + d->out.size() + d->hist.size() + d->chunk.size()) : 0;
+}
 extern "C" const char *lfx_decoder_last_error(const lfx_decoder *d) { return d ? d->err.c_str() : "null"; }
 extern "C" void lfx_decoder_free(lfx_decoder *d) { delete d; }

@@ -60,6 +60,7 @@ struct InflateResult {
     uint32_t nblocks;
     uint32_t _pad;
     uint64_t blk_out_start;  // output bytes before the block that was being decoded last
+    uint64_t blk_start_bit;  // ... and the bit its header started at (a windowed decode resumes there)
 };
 
 // ---- lane-parallel single-stream path (lfx_inflate_fast.hip)
@@ -135,14 +136,16 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
 int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                                const BlkUnits *units, const uint32_t *codes, uint16_t *sym);
 //  windows[u] = the final 32 KiB of output up to the end of unit u (units in stream order, one workgroup walks them)
-int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows);
+// init_win: the 32 KiB of output in front of the first unit (a later window of a member), or null (start of a member)
+int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows,
+                        const uint8_t *init_win = nullptr);
 //  the same windows by a blocked parallel prefix over the units' index maps (long streams)
 size_t window_prefix_scratch_bytes(uint32_t nunits);
 int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch,
-                         uint8_t *windows);
+                         uint8_t *windows, const uint8_t *init_win = nullptr);
 //  out = sym with every marker replaced through the window in front of its unit
 int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits,
-                          const uint8_t *windows, uint8_t *out, uint64_t max_len);   // max_len: longest unit
+                          const uint8_t *windows, uint8_t *out, uint64_t max_len, const uint8_t *init_win = nullptr);   // max_len: longest unit
 
 int launch_container(hipStream_t st, int format, uint32_t count, const uint8_t *in,
                      const DecStream *streams, DecHeader *hdrs);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
     const bool do_write = !(job.flags & JOB_COUNT_ONLY);
     uint64_t produced = 0;        // bytes produced by this job
     uint32_t status = 0, final_seen = 0, needs_hist = 0, nblocks = 0;
-    uint64_t blk_out_start = 0;
+    uint64_t blk_out_start = 0, blk_start_bit = job.start_bit;
     uint64_t hist_avail = job.hist_avail;  // bytes of the member already produced before this job
 
     if (lane == 0) {
@@ -258,6 +258,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
     for (;;) {
         // ---- block header: deflate::Decoder::read decode.rs:146-162
         blk_out_start = produced;
+        blk_start_bit = b.pos;
         win_ensure(b, 700, lane);
         if (lane == 0) {
             s_ctl[2] = 0;
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
         r.nblocks = nblocks;
         r._pad = 0;
         r.blk_out_start = blk_out_start;
+        r.blk_start_bit = blk_start_bit;
         results[blockIdx.x] = r;
     }
 }

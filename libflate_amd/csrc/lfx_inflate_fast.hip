@@ -1089,12 +1089,14 @@ __global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint
 // Pass 2: one workgroup walks the units in stream order.  win[u] = the final 32 KiB of output that end where
 // unit u ends; byte i of it is a symbol of the unit's own tail resolved through win[u-1], or (for a unit
 // shorter than 32 KiB) byte i + len of win[u-1].  The two windows in flight live in LDS.
+// init_win: the 32 KiB of output in front of unit 0 (a later window of a stream decoder: the member's earlier output), or
+// null at the start of a member (an empty Lz77Decoder buffer: no marker can survive to be looked up there).
 __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__restrict__ sym,
                                                             const SymUnit *__restrict__ units, uint32_t nunits,
-                                                            uint8_t *__restrict__ windows) {
+                                                            uint8_t *__restrict__ windows, const uint8_t *__restrict__ init_win) {
     extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
     uint8_t *prev = wbuf, *cur = wbuf + 32768;
-    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = init_win ? init_win[i] : (uint8_t)0;
     // Thread t owns the four window bytes 4 (t + 1024 k) .. +3 of row k = 0..7: one 8-byte symbol load, four LDS
     // gathers, one dword LDS store and one dword global store per row.  The symbols of unit u+1's tail do not
     // depend on the chain: they are loaded while unit u is being resolved, so the walk itself only touches LDS.
@@ -1177,10 +1179,10 @@ __global__ __launch_bounds__(1024) void window_compose_kernel(const uint16_t *__
     }
 }
 __global__ __launch_bounds__(1024) void window_groups_kernel(const uint16_t *__restrict__ maps, uint32_t nunits,
-                                                             uint8_t *__restrict__ gwin) {
+                                                             uint8_t *__restrict__ gwin, const uint8_t *__restrict__ init_win) {
     extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
     uint8_t *prev = wbuf, *cur = wbuf + 32768;
-    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = 0;
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = init_win ? init_win[i] : (uint8_t)0;
     __syncthreads();
     const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
     for (uint32_t g = 0; g < ngroups; ++g) {
@@ -1198,14 +1200,15 @@ __global__ __launch_bounds__(1024) void window_groups_kernel(const uint16_t *__r
     }
 }
 __global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__restrict__ maps, const uint8_t *__restrict__ gwin,
-                                                           uint8_t *__restrict__ windows) {
+                                                           uint8_t *__restrict__ windows, const uint8_t *__restrict__ init_win) {
     const uint32_t u = blockIdx.x, g = u / WC_GROUP;
     const uint16_t *m = maps + (uint64_t)u * 32768;
-    const uint8_t *w = g ? gwin + (uint64_t)(g - 1) * 32768 : gwin;   // (group 0: nothing in front, no markers left)
+    // (group 0: the member's earlier output, or nothing in front — then no markers are left)
+    const uint8_t *w = g ? gwin + (uint64_t)(g - 1) * 32768 : init_win;
     uint8_t *wout = windows + (uint64_t)u * 32768;
     for (uint32_t i = threadIdx.x; i < 32768; i += 256) {
         const uint32_t s = m[i];
-        wout[i] = s < 256 ? (uint8_t)s : (g ? w[s - 256] : (uint8_t)0);
+        wout[i] = s < 256 ? (uint8_t)s : (w ? w[s - 256] : (uint8_t)0);
     }
 }
 
@@ -1213,10 +1216,11 @@ __global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__res
 __global__ __launch_bounds__(256) void sym_substitute_kernel(const uint16_t *__restrict__ sym,
                                                              const SymUnit *__restrict__ units,
                                                              const uint8_t *__restrict__ windows,
-                                                             uint8_t *__restrict__ out) {
+                                                             uint8_t *__restrict__ out, const uint8_t *__restrict__ init_win) {
     const uint32_t u = blockIdx.x;
     const SymUnit su = units[u];
-    const uint8_t *w = u ? windows + (uint64_t)(u - 1) * 32768 : windows;   // (unit 0 holds no markers)
+    // (unit 0: the member's earlier output; at the start of a member it holds no markers)
+    const uint8_t *w = u ? windows + (uint64_t)(u - 1) * 32768 : (init_win ? init_win : windows);
     const uint64_t lo = (uint64_t)blockIdx.y * 16384, hi = lo + 16384 < su.len ? lo + 16384 : su.len;
     for (uint64_t k = lo + threadIdx.x; k < hi; k += 256) {
         const uint32_t s = sym[su.start + k];
@@ -1434,7 +1438,8 @@ int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit 
     LFX_LAUNCH_CHECK();
     return 0;
 }
-int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows) {
+int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows,
+                        const uint8_t *init_win) {
     if (!nunits) return 0;
     static bool attr_set[64] = {};
     int dev_ = 0;
@@ -1443,7 +1448,7 @@ int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *unit
         (void)hipFuncSetAttribute((const void *)window_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
         attr_set[dev_ & 63] = true;
     }
-    hipLaunchKernelGGL(window_chain_kernel, dim3(1), dim3(1024), 65536, st, sym, units, nunits, windows);
+    hipLaunchKernelGGL(window_chain_kernel, dim3(1), dim3(1024), 65536, st, sym, units, nunits, windows, init_win);
     LFX_LAUNCH_CHECK();
     return 0;
 }
@@ -1453,7 +1458,7 @@ size_t window_prefix_scratch_bytes(uint32_t nunits) {
     return (size_t)nunits * 65536 + (size_t)((nunits + WC_GROUP - 1) / WC_GROUP) * 32768;
 }
 int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch,
-                         uint8_t *windows) {
+                         uint8_t *windows, const uint8_t *init_win) {
     if (!nunits) return 0;
     static bool attr_set[64] = {};
     int dev_ = 0;
@@ -1468,17 +1473,17 @@ int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *uni
     const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
     hipLaunchKernelGGL(window_compose_kernel, dim3(ngroups), dim3(1024), 131072, st, sym, units, nunits, maps);
     LFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 65536, st, maps, nunits, gwin);
+    hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 65536, st, maps, nunits, gwin, init_win);
     LFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(256), 0, st, maps, gwin, windows);
+    hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(256), 0, st, maps, gwin, windows, init_win);
     LFX_LAUNCH_CHECK();
     return 0;
 }
 int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits,
-                          const uint8_t *windows, uint8_t *out, uint64_t max_len) {
+                          const uint8_t *windows, uint8_t *out, uint64_t max_len, const uint8_t *init_win) {
     if (!nunits) return 0;
     const uint32_t gy = (uint32_t)((max_len + 16383) / 16384);
-    hipLaunchKernelGGL(sym_substitute_kernel, dim3(nunits, gy ? gy : 1), dim3(256), 0, st, sym, units, windows, out);
+    hipLaunchKernelGGL(sym_substitute_kernel, dim3(nunits, gy ? gy : 1), dim3(256), 0, st, sym, units, windows, out, init_win);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -96,6 +96,7 @@ extern "C" {
     pub fn lfx_decoder_unread(d: *mut lfx_decoder, p: *mut *const u8, n: *mut usize) -> c_int;
     pub fn lfx_decoder_surplus(d: *mut lfx_decoder, p: *mut *const u8, n: *mut usize) -> c_int;
     pub fn lfx_decoder_consumed(d: *const lfx_decoder) -> u64;
+    pub fn lfx_decoder_buffered(d: *const lfx_decoder) -> u64;
     pub fn lfx_decoder_header(d: *mut lfx_decoder, h: *mut lfx_header) -> c_int;
     pub fn lfx_decoder_last_error(d: *const lfx_decoder) -> *const c_char;
     pub fn lfx_decoder_free(d: *mut lfx_decoder);

@@ -140,6 +140,7 @@ int main(void) {
         CHECK(lfx_decoder_read(d, out, 0) == 0);                /* a zero-capacity read never latches EOS (gzip.rs:1025) */
         CHECK(read_all(d, out, sizeof out, &got, NULL) == 0 && got == 6 && !memcmp(out, "Hello ", 6));
         CHECK(lfx_decoder_consumed(d) == sizeof MEMBER_A);
+        CHECK(lfx_decoder_buffered(d) >= sizeof MEMBER_B && lfx_decoder_buffered(d) < (1u << 20));   /* the surplus, a read chunk, history */
         const uint8_t *sp; size_t sn;
         CHECK(lfx_decoder_surplus(d, &sp, &sn) == LFX_OK && sn == sizeof MEMBER_B && !memcmp(sp, MEMBER_B, sn));
         CHECK(lfx_decoder_unread(d, &sp, &sn) == LFX_OK && sn == 0);

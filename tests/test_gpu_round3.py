@@ -126,3 +126,118 @@ def test_mskor_lane_order_property():
     with open(os.path.join(ROOT, "gpurun_out", "r3_mskor_order.txt"), "w") as f:
         f.write("# tools/exp/mskor_test (built and run by tests/test_gpu_round3.py::test_mskor_lane_order_property)\n")
         f.write(out.stdout)
+
+
+# ------------------------------------------------------------------ b-3: block-granular, bounded-memory stream decode
+class _TrackedReader:
+    """A reader over a bytes object that hands out at most `step` bytes per call and remembers how far it got."""
+
+    def __init__(self, data, step):
+        self.data, self.step, self.pos, self.calls = data, step, 0, 0
+
+    def __call__(self, _user, p, cap):
+        import ctypes as C
+        k = min(cap, self.step, len(self.data) - self.pos)
+        if k:
+            C.memmove(p, self.data[self.pos:self.pos + k], k)
+        self.pos += k
+        self.calls += 1
+        return k
+
+
+def _stream_decode(ctx, ffi, fmt, stream, step, out_chunk, flags=0):
+    """→ (crc32 of the output, output length, first-read reader position, peak lfx_decoder_buffered, status)"""
+    import ctypes as C
+    import zlib
+    rd = _TrackedReader(stream, step)
+    cb = ffi.READ_CB(rd)
+    st = C.c_int(0)
+    d = ffi.lib().lfx_decoder_new(ctx.handle, fmt, flags, cb, None, C.byref(st))
+    assert d, st.value
+    buf = (C.c_uint8 * out_chunk)()
+    crc, total, first_pos, peak, status = 0, 0, None, 0, 0
+    while True:
+        k = ffi.lib().lfx_decoder_read(d, buf, out_chunk)
+        if first_pos is None:
+            first_pos = rd.pos
+        peak = max(peak, ffi.lib().lfx_decoder_buffered(d))
+        if k <= 0:
+            status = -k
+            break
+        crc = zlib.crc32(memoryview(buf)[:k], crc)
+        total += k
+    consumed = ffi.lib().lfx_decoder_consumed(d)
+    ffi.lib().lfx_decoder_free(d)
+    return crc, total, first_pos, peak, status, consumed
+
+
+def test_stream_decoder_bounded_memory_2gib(env):
+    """A 2 GiB member (gzip::Encoder, 8192-byte writes: 2048 blocks) through the io::Read-shaped decoder: the decoder
+    works a window of blocks at a time (src/deflate/decode.rs:136-164 decodes a block per read and keeps 32 KiB,
+    libflate_lz77/src/lib.rs:219-231) — the first read returns long before the reader is drained, and what it buffers
+    never exceeds 256 MiB."""
+    import ctypes as C
+    import zlib
+    import torch
+    lfx, ctx, ffi, synth = env
+    n = 2 << 30
+    piece = synth.text(256 << 20)                      # 8 x the same 256 MiB: the encoder's chunks never reach across 256 KiB
+    d_in = torch.from_numpy(piece).cuda().repeat(8)
+    opts, sched = ffi.make_opts(mtime=0), ffi.make_schedule(8192)
+    bound = ffi.lib().lfx_encode_bound(n, C.byref(opts), C.byref(sched)) & ~3
+    d_out = torch.empty(bound, dtype=torch.uint8, device="cuda")
+    m = ctx.encode_device(ffi.GZIP, d_in.data_ptr(), n, d_out.data_ptr(), bound, opts, sched)
+    member = d_out[:m].cpu().numpy().tobytes()
+    del d_out
+    want_crc = 0
+    pb = piece.tobytes()
+    for _ in range(8):
+        want_crc = zlib.crc32(pb, want_crc)
+    assert int.from_bytes(member[-8:-4], "little") == want_crc
+    del d_in
+    torch.cuda.empty_cache()
+    crc, total, first_pos, peak, status, consumed = _stream_decode(ctx, ffi, ffi.GZIP, member, 4 << 20, 16 << 20)
+    assert status == 0 and total == n and crc == want_crc and consumed == len(member)
+    assert first_pos < len(member) // 8, (first_pos, len(member))          # the first bytes came out of the first windows
+    assert peak <= (256 << 20), peak
+    print("stream decode of a 2 GiB member: %d compressed bytes, first read after %d, peak buffered %d MiB" % (
+        len(member), first_pos, peak >> 20))
+
+
+def test_stream_decoder_windows_vs_oracle(env, oracle):
+    """Windows on everything the block-parallel path distinguishes: reference-made members (blocks never read earlier
+    blocks), a foreign encoder's (python zlib / gzip: every block reads the 32 KiB in front of it — the marker path, seeded
+    with the previous window's tail), a member written by ONE write (one block larger than a window: the window grows),
+    multi-member input, a truncated and a corrupted member (same verdict, same bytes in front of it as the one-shot
+    decode).  Readers that hand out 1 MiB and 100 000 bytes at a time."""
+    import gzip as pygzip
+    import zlib
+    lfx, ctx, ffi, synth = env
+    text = synth.text(120 << 20).tobytes()
+    low = synth.lowent(200 << 20).tobytes()
+    ref = ctx.encode_host(ffi.GZIP, text, ffi.make_opts(mtime=0), ffi.make_schedule(8192))          # ~58 MB: 4 windows
+    one = ctx.encode_host(ffi.ZLIB, text[:(40 << 20)], ffi.make_opts(), ffi.make_schedule(0))       # one ~19 MB block
+    foreign = pygzip.compress(text, 6, mtime=0)                                                      # ~45 MB
+    lows = ctx.encode_host(ffi.ZLIB, low, ffi.make_opts(), ffi.make_schedule(8192))                  # 6 MB → 200 MB out
+    cases = [("reference gzip", ffi.GZIP, ref, text), ("one block", ffi.ZLIB, one, text[:(40 << 20)]),
+             ("python gzip", ffi.GZIP, foreign, text), ("lowent zlib", ffi.ZLIB, lows, low)]
+    for name, fmt, stream, plain in cases:
+        for step in (1 << 20, 100000):
+            crc, total, first_pos, peak, status, consumed = _stream_decode(ctx, ffi, fmt, stream, step, 8 << 20)
+            assert status == 0 and total == len(plain) and crc == zlib.crc32(plain) and consumed == len(stream), (name, step, status, total)
+            assert peak <= (256 << 20), (name, peak)
+        if len(stream) > (40 << 20):
+            assert first_pos < len(stream) // 2, (name, first_pos)
+    # two members, MultiDecoder (gzip.rs:1142-1166)
+    two = ref + foreign
+    crc, total, _, _, status, consumed = _stream_decode(ctx, ffi, ffi.GZIP, two, 1 << 20, 8 << 20, flags=ffi.DEC_MULTI)
+    assert status == 0 and total == 2 * len(text) and consumed == len(two) and crc == zlib.crc32(text + text)
+    # a truncated member and a corrupted one: verdict and delivered bytes as the one-shot decode / the oracle give them
+    cut = ref[:len(ref) * 3 // 5]
+    bad = bytearray(ref); bad[len(ref) * 3 // 5] ^= 0x55; bad = bytes(bad)
+    for name, s in (("truncated", cut), ("corrupted", bad)):
+        want = oracle.decode(oracle.GZIP, s)
+        crc, total, _, _, status, _ = _stream_decode(ctx, ffi, ffi.GZIP, s, 1 << 20, 8 << 20)
+        assert status == {1: ffi.E_INVALID_DATA, 2: ffi.E_UNEXPECTED_EOF}[want[0]], (name, status, want[0], want[3])
+        # the reference hands out the bytes of complete blocks before the error (decode.rs:136-164)
+        assert total <= len(want[1]) and crc == zlib.crc32(want[1][:total]) and len(want[1]) - total < (2 << 20), (name, total, len(want[1]))
