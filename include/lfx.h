@@ -143,6 +143,41 @@ int lfx_encode_shard_emit(lfx_ctx *c, uint64_t start_bit, uint32_t combined_chec
 int lfx_decode_shard_device(lfx_ctx *c, const void *d_in, uint64_t n, uint64_t start_bit,
                             uint64_t total_bits, int is_last, void *d_out, uint64_t cap,
                             uint64_t *out_len);
+/* ---- N-GPU decode of ONE member WITHOUT the encoder's layout (north_star: "independent DEFLATE blocks
+ * partition across the GPUs").  The member is cut by compressed bytes; rank r holds the bytes [lo_byte, lo_byte + n_part)
+ * of it in d_part — its own range [lo_byte, hi_byte) plus a tail of a few MiB from its right neighbour, so that a block
+ * that starts inside the range can be scanned to its end.
+ *   1. lfx_decode_range_scan: block finder + speculative scan of every candidate that STARTS inside the range →
+ *      one tuple per candidate (bit offsets relative to the member).  first_bit: the known start of the member's first
+ *      block, on the rank whose range holds it (right behind the container header), ~0 elsewhere.
+ *   2. the ranks all-gather their tuples (the only collective: 56 bytes per candidate, a few hundred per rank);
+ *   3. lfx_decode_chain (host only, deterministic): the true block list from the known first block; candidates that
+ *      are not block starts are never reached.  LFX_E_UNSUPPORTED when the chain breaks (a stored / fixed block the
+ *      finder cannot see, damage): decode on one GPU then;
+ *   4. lfx_decode_range_emit: materialises the chain blocks owned by `rank` (those that start in its range) into
+ *      d_out — the rank's slice of the output, which starts *out_base bytes into the member's output — and returns
+ *      the slice's CRC-32 / Adler-32 (fold them with lfx_crc32_combine / lfx_adler32_combine and compare with the
+ *      trailer).  Must follow the same rank's range_scan on the same context (the scan's tables live in its scratch).
+ * Reference-made blocks never read earlier blocks (default.rs:73), which is what makes a slice decodable alone; a
+ * member whose blocks do (another encoder's) makes range_emit return LFX_E_UNSUPPORTED. */
+typedef struct lfx_blk_tuple {
+    uint64_t start_bit, end_bit;  /* header bit, bit behind EndOfBlock (relative to the member's first byte) */
+    uint64_t n_out;               /* bytes the block produces */
+    uint64_t data_bit;            /* first symbol bit */
+    uint32_t n_codes, nlanes;
+    uint8_t btype, bfinal, status /* 0 = scanned to its EndOfBlock */, _pad;
+    uint16_t rank;                /* owner: the rank whose range holds start_bit */
+    uint16_t _pad2;
+    uint32_t slot;                /* the owner's scan slot */
+    uint32_t _pad3;
+} lfx_blk_tuple;                  /* 56 bytes */
+int lfx_decode_range_scan(lfx_ctx *c, const void *d_part, uint64_t n_part, uint64_t lo_byte, uint64_t hi_byte,
+                          uint64_t first_bit, uint32_t rank, lfx_blk_tuple *tuples, uint32_t cap, uint32_t *count);
+int lfx_decode_chain(const lfx_blk_tuple *all, uint32_t n_all, uint64_t first_bit, uint32_t *chain, uint32_t cap,
+                     uint32_t *n_chain, uint64_t *total_out);
+int lfx_decode_range_emit(lfx_ctx *c, const void *d_part, uint64_t n_part, uint64_t lo_byte, const lfx_blk_tuple *all,
+                          const uint32_t *chain, uint32_t n_chain, uint32_t rank, void *d_out, uint64_t cap,
+                          uint64_t *out_len, uint64_t *out_base, uint32_t *crc32, uint32_t *adler32);
 /* stream concatenation on the writer rank: places one shard's bytes (as written by emit(), already
  * on this device — e.g. received over RCCL / xGMI) at byte start_bit/8 of the member buffer; when the shard starts
  * inside a byte (start_bit % 8 != 0) that byte is shared with the shard in front and is OR-ed.  Place the shards in

@@ -22,7 +22,7 @@ DEC_NONBLOCKING = 2
 EXPORTS = [
     "lfx_encode_opts_default", "lfx_ctx_new", "lfx_ctx_free", "lfx_ctx_last_error", "lfx_ctx_set_stream",
     "lfx_device_count", "lfx_encode_bound", "lfx_encode_device", "lfx_encode_host", "lfx_decode_device",
-    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device", "lfx_shard_place_device",
+    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device", "lfx_shard_place_device", "lfx_decode_range_scan", "lfx_decode_chain", "lfx_decode_range_emit",
     "lfx_crc32_combine", "lfx_adler32_combine", "lfx_container_header_len", "lfx_encoder_new",
     "lfx_encoder_write", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
     "lfx_encoder_free", "lfx_decoder_new", "lfx_decoder_read", "lfx_decoder_unread",
@@ -45,6 +45,14 @@ class EncodeOpts(C.Structure):
 class Schedule(C.Structure):
     _fields_ = [("kind", C.c_int32), ("fixed_write", C.c_uint64), ("writes", C.POINTER(C.c_uint64)),
                 ("n_writes", C.c_size_t)]
+
+
+class BlkTuple(C.Structure):
+    """lfx_blk_tuple: what the ranks of an N-GPU decode exchange about every candidate block (56 bytes)"""
+    _fields_ = [("start_bit", C.c_uint64), ("end_bit", C.c_uint64), ("n_out", C.c_uint64), ("data_bit", C.c_uint64),
+                ("n_codes", C.c_uint32), ("nlanes", C.c_uint32), ("btype", C.c_uint8), ("bfinal", C.c_uint8),
+                ("status", C.c_uint8), ("_pad", C.c_uint8), ("rank", C.c_uint16), ("_pad2", C.c_uint16),
+                ("slot", C.c_uint32), ("_pad3", C.c_uint32)]
 
 
 class ShardInfo(C.Structure):
@@ -122,6 +130,10 @@ def lib():
     L.lfx_encode_shard_emit.argtypes = [vp, u64, u32, u64, vp, u64, C.POINTER(u64)]
     L.lfx_decode_shard_device.argtypes = [vp, vp, u64, u64, u64, i32, vp, u64, C.POINTER(u64)]
     L.lfx_shard_place_device.argtypes = [vp, vp, u64, vp, u64, u64, i32]
+    L.lfx_decode_range_scan.argtypes = [vp, vp, u64, u64, u64, u64, u32, C.POINTER(BlkTuple), u32, C.POINTER(u32)]
+    L.lfx_decode_chain.argtypes = [C.POINTER(BlkTuple), u32, u64, C.POINTER(u32), u32, C.POINTER(u32), C.POINTER(u64)]
+    L.lfx_decode_range_emit.argtypes = [vp, vp, u64, u64, C.POINTER(BlkTuple), C.POINTER(u32), u32, u32, vp, u64,
+                                        C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
     L.lfx_crc32_combine.restype = u32
     L.lfx_crc32_combine.argtypes = [u32, u32, u64]
     L.lfx_adler32_combine.restype = u32

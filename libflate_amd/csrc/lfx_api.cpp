@@ -808,9 +808,11 @@ extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encod
     return e;
 }
 
-// closed blocks are encoded once this much input is waiting (a batch large enough to fill the GPU); the open
-// block's bytes — all the reference itself would be holding (encode.rs:386-426) — stay in `pending`
-static const uint64_t ENC_BATCH_BYTES = 64ull << 20;
+// closed blocks are encoded — and handed to the sink — once this much input is waiting; the open block's bytes — all the
+// reference itself would be holding (encode.rs:386-426) — stay in `pending`.  8 MiB keeps what the encoder buffers within
+// eight default blocks (the reference emits per block, encode.rs:277-286) at a third of the one-shot call's throughput:
+// a batch is one GPU pass with ~0.4 ms of fixed latency.
+static const uint64_t ENC_BATCH_BYTES = 8ull << 20;
 
 extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n) {
     if (!e || e->finished) return -(int64_t)LFX_E_ARG;

@@ -719,6 +719,222 @@ extern "C" int lfx_decode_shard_device(lfx_ctx *cc, const void *d_in, uint64_t n
     return mr.status;
 }
 
+// ------------------------------------------------------------------------------------------------
+// N-GPU decode of ONE member without the encoder's help: the member is cut by compressed BYTES;
+// every rank finds and scans the blocks that START in its byte range (lfx_decode_range_scan), the ranks exchange one
+// tuple per candidate (one all-gather), every rank walks the same chain over the gathered table (lfx_decode_chain) and
+// materialises the blocks it owns into its slice of the output (lfx_decode_range_emit).  The container checksum is
+// folded from the ranks' slice checksums (lfx_crc32_combine / lfx_adler32_combine).
+static_assert(sizeof(lfx_blk_tuple) == 56, "tuple layout (all-gathered as raw bytes)");
+
+extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t n_part, uint64_t lo_byte, uint64_t hi_byte,
+                                     uint64_t first_bit, uint32_t rank, lfx_blk_tuple *tuples, uint32_t cap, uint32_t *count) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    const uint8_t *d_in = (const uint8_t *)d_part_;
+    if (!count || hi_byte < lo_byte || n_part < hi_byte - lo_byte) return LFX_E_ARG;
+    *count = 0;
+    c->n_ev = 0;
+    c->phase("start");
+    const uint64_t n = n_part, range_bits = (hi_byte - lo_byte) * 8, base_bit = lo_byte * 8;
+    // ---- block-start candidates in the local bytes (the tail behind hi_byte is searched too: a false candidate there
+    //      still ends the range guess of the last real block early, exactly as on one GPU)
+    const uint32_t shard_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 17, n / 1000), 1u << 26);
+    const uint32_t final_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 16, n / 4096), 1u << 24);
+    int rc;
+    if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 512))) return rc;
+    uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;
+    uint32_t *d_final_count = d_count + 64;
+    uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 512);
+    uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
+    HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
+    std::vector<uint64_t> starts;
+    if (n >= 16) {
+        LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap));
+        uint32_t counts[FIND_SHARDS + 1];
+        HIP_TRY(hipMemcpyAsync(counts, d_count, sizeof counts, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        FindPrefix pre;
+        bool overflow = counts[FIND_SHARDS] != 0;
+        pre.off[0] = 0;
+        for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (counts[k] > shard_cap) overflow = true; pre.off[k + 1] = pre.off[k] + counts[k]; }
+        if (overflow) { c->set_error("block finder overflow"); return LFX_E_UNSUPPORTED; }
+        LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, pre, d_final_count, d_final, final_cap));
+        uint32_t nf = 0;
+        HIP_TRY(hipMemcpyAsync(&nf, d_final_count, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (nf > final_cap) nf = final_cap;
+        starts.resize(nf);
+        if (nf) HIP_TRY(hipMemcpy(starts.data(), d_final, 8ull * nf, hipMemcpyDeviceToHost));
+    }
+    c->phase("find");
+    if (first_bit != ~0ull) {            // the member's first block (its start is known: right behind the container header)
+        if (first_bit < base_bit || first_bit - base_bit >= n * 8) return LFX_E_ARG;
+        starts.push_back(first_bit - base_bit);
+    }
+    std::sort(starts.begin(), starts.end());
+    starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+    // jobs: the candidates that start inside the range; a job's range guess ends at the next candidate (inside or behind it)
+    uint32_t nc = 0;
+    while (nc < starts.size() && starts[nc] < range_bits) nc++;
+    if (nc > cap) { c->set_error("more candidates than the caller's tuple buffer holds"); return LFX_E_NOSPACE; }
+    const size_t tab_bytes = blk_tabs_bytes();
+    if (nc) {
+        auto start_at = [&](uint32_t i) { return i < starts.size() ? starts[i] : n * 8; };
+        std::vector<BlkJob> bj(nc);
+        for (uint32_t i = 0; i < nc; i++) bj[i] = BlkJob{starts[i], start_at(i + 1)};
+        if ((rc = c->d_dec_streams.reserve(sizeof(BlkJob) * (nc + 1)))) return rc;
+        if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * (nc + 1)))) return rc;
+        if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)(nc + 1)))) return rc;
+        if ((rc = c->d_dec_tabs.reserve(tab_bytes * (nc + 1)))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nc, hipMemcpyHostToDevice, st));
+        LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nc, (BlkInfo *)c->d_dec_state.p,
+                                   (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
+        std::vector<BlkInfo> bi(nc);
+        HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nc, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // a false candidate inside a block cuts that block's range guess short (no EndOfBlock): rescan with wider ranges
+        for (uint32_t widen = 2; widen <= 6; widen++) {
+            std::vector<uint32_t> redo;
+            for (uint32_t i = 0; i < nc; i++) if (bi[i].status == BLK_NO_EOB && i + widen <= starts.size()) redo.push_back(i);
+            if (redo.empty()) break;
+            std::vector<BlkJob> rj(redo.size());
+            for (size_t q = 0; q < redo.size(); q++) rj[q] = BlkJob{starts[redo[q]], start_at(redo[q] + widen)};
+            if ((rc = c->d_dec_tmp.reserve(sizeof(BlkJob) * redo.size()))) return rc;
+            BlkJob *d_rj = (BlkJob *)c->d_dec_tmp.p;
+            HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), sizeof(BlkJob) * redo.size(), hipMemcpyHostToDevice, st));
+            for (size_t q = 0; q < redo.size(); q++)
+                LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_rj + q, 1, (BlkInfo *)c->d_dec_state.p + redo[q],
+                                           (BlkLanes *)c->d_dec_blocks.p + redo[q], (uint8_t *)c->d_dec_tabs.p + tab_bytes * redo[q]));
+            for (size_t q = 0; q < redo.size(); q++)
+                HIP_TRY(hipMemcpyAsync(&bi[redo[q]], (BlkInfo *)c->d_dec_state.p + redo[q], sizeof(BlkInfo), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        for (uint32_t i = 0; i < nc; i++) {
+            lfx_blk_tuple &t = tuples[i];
+            t = lfx_blk_tuple{};
+            t.start_bit = base_bit + starts[i];
+            t.end_bit = base_bit + bi[i].end_bit;
+            t.n_out = bi[i].n_out;
+            t.n_codes = bi[i].n_codes;
+            t.btype = (uint8_t)bi[i].btype;
+            t.bfinal = (uint8_t)bi[i].bfinal;
+            t.status = (uint8_t)bi[i].status;
+            t._pad = 0;
+            t.slot = i;
+            t.rank = (uint16_t)rank;
+            t._pad2 = 0;
+            t.nlanes = bi[i].nlanes;
+            t.data_bit = base_bit + bi[i].data_bit;
+        }
+    }
+    c->phase("blk_scan");
+    *count = nc;
+    return LFX_OK;
+}
+
+extern "C" int lfx_decode_chain(const lfx_blk_tuple *all, uint32_t n_all, uint64_t first_bit, uint32_t *chain, uint32_t cap,
+                                uint32_t *n_chain, uint64_t *total_out) {
+    if (!all || !chain || !n_chain) return LFX_E_ARG;
+    // the true block list: from the known first block, every block starts where the one before it ended; false candidates
+    // (inside a block) are never reached.  Deterministic: every rank computes the same list from the same table.
+    std::vector<uint32_t> order(n_all);
+    for (uint32_t i = 0; i < n_all; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return all[a].start_bit != all[b].start_bit ? all[a].start_bit < all[b].start_bit : all[a].rank < all[b].rank;
+    });
+    uint64_t pos = first_bit, total = 0;
+    uint32_t k = 0;
+    for (;;) {
+        auto it = std::lower_bound(order.begin(), order.end(), pos, [&](uint32_t a, uint64_t v) { return all[a].start_bit < v; });
+        if (it == order.end() || all[*it].start_bit != pos) return LFX_E_UNSUPPORTED;     // a block the finder cannot see (stored / fixed), or damage
+        const lfx_blk_tuple &t = all[*it];
+        if (t.status != BLK_OK || t.end_bit <= pos) return LFX_E_UNSUPPORTED;
+        if (k >= cap) return LFX_E_NOSPACE;
+        chain[k++] = *it;
+        total += t.n_out;
+        if (t.bfinal) break;
+        pos = t.end_bit;
+    }
+    *n_chain = k;
+    if (total_out) *total_out = total;
+    return LFX_OK;
+}
+
+extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t n_part, uint64_t lo_byte, const lfx_blk_tuple *all,
+                                     const uint32_t *chain, uint32_t n_chain, uint32_t rank, void *d_out_, uint64_t cap,
+                                     uint64_t *out_len, uint64_t *out_base, uint32_t *crc32, uint32_t *adler32) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    const uint8_t *d_in = (const uint8_t *)d_part_;
+    uint8_t *d_out = (uint8_t *)d_out_;
+    const uint64_t base_bit = lo_byte * 8;
+    // the chain blocks this rank owns (consecutive in stream order: ownership goes by start position)
+    std::vector<BlkEmit> emit;
+    uint64_t before = 0, total = 0, total_codes = 0;
+    bool seen = false;
+    for (uint32_t q = 0; q < n_chain; q++) {
+        const lfx_blk_tuple &t = all[chain[q]];
+        if (t.rank != rank) { if (!seen) before += t.n_out; continue; }
+        seen = true;
+        BlkEmit e{};
+        e.start_bit = t.start_bit - base_bit; e.data_bit = t.data_bit - base_bit; e.code_off = total_codes; e.out_off = total;
+        e.n_out = t.n_out; e.n_codes = t.n_codes; e.nlanes = t.nlanes; e.btype = t.btype; e.cand = t.slot;
+        e.hist = before + total;             // bytes of the member in front of the block: bounds its back-references
+        emit.push_back(e);
+        total += t.n_out;
+        total_codes += t.n_codes;
+    }
+    if (out_base) *out_base = before;
+    if (out_len) *out_len = total;
+    if (crc32) *crc32 = 0;
+    if (adler32) *adler32 = 1;
+    if (total > cap) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
+    if (emit.empty()) return LFX_OK;
+    const uint32_t ne = (uint32_t)emit.size();
+    int rc;
+    if ((rc = c->d_dec_tmp.reserve(sizeof(BlkEmit) * (size_t)ne + 64))) return rc;
+    if ((rc = c->d_hist.reserve(sizeof(BlkUnits) * (size_t)ne + 64))) return rc;
+    if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(total_codes, 1)))) return rc;
+    if ((rc = c->d_res.reserve(256))) return rc;
+    uint32_t *d_flags = (uint32_t *)c->d_dec_tmp.p;
+    BlkEmit *d_emit = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64);
+    HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
+    HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
+    const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
+    const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
+    LAUNCH_TRY(launch_blk_emit(st, d_in, n_part, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (uint32_t *)c->d_codes.p, d_flags,
+                               (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, 17));
+    c->phase("blk_emit");
+    LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (const BlkUnits *)c->d_hist.p,
+                                      (const uint32_t *)c->d_codes.p, d_out, nullptr));
+    uint32_t fl = 0;
+    HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
+    const uint64_t nspans = div_up(std::max<uint64_t>(total, 1), 65536);
+    if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
+    uint32_t *ck = (uint32_t *)c->d_ck.p;
+    LAUNCH_TRY(launch_checksum(st, d_out, total, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, 3));
+    HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    c->phase("lz77_copy");
+    if (fl != 0) {
+        // blocks that read the output of earlier blocks (another encoder's member): the cross-rank window hand-over
+        //  is not built — the caller decodes such a member on one GPU
+        c->set_error("blocks of this member read earlier blocks' output: decode it with lfx_decode_device");
+        return LFX_E_UNSUPPORTED;
+    }
+    const EncodeResult er = *(EncodeResult *)c->h_res;
+    if (crc32) *crc32 = er.crc32;
+    if (adler32) *adler32 = er.adler32;
+    return LFX_OK;
+}
+
 extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const void *in, uint64_t n, void *out,
                                uint64_t cap, uint64_t *out_len, uint64_t *consumed) {
     if (!cc) return LFX_E_DEVICE;

@@ -113,3 +113,112 @@ def gather_finish(h):
 def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
     """gather_begin() + gather_finish()."""
     return gather_finish(gather_begin(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist, staging))
+
+
+# ------------------------------------------------------------------------------------------------
+# N-GPU decode of ONE member without the encoder's layout (include/lfx.h: lfx_decode_range_scan / lfx_decode_chain /
+# lfx_decode_range_emit).  The member is cut by compressed BYTES; the only collective is one all-gather of the ranks'
+# candidate tuples (56 bytes each) and one of their slice checksums.
+RANGE_TAIL = 4 << 20      # bytes of the right neighbour's range a rank also holds: a block that starts in a rank's range
+                          # is scanned to its end (reference-made blocks: <= ~1.1 MB of stream)
+
+
+def byte_ranges(first_byte, member_len, world):
+    """Equal byte ranges of the DEFLATE part [first_byte, member_len) (the trailer's few bytes ride along in the last
+    one) → list of (lo, hi); a rank holds [lo, min(hi + RANGE_TAIL, member_len))."""
+    span = member_len - first_byte
+    cuts = [first_byte + span * r // world for r in range(world)] + [member_len]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def range_scan(ctx, rank, d_part_ptr, n_part, lo, hi, first_bit=None, cap=1 << 16):
+    """step 1 on one rank → list of BlkTuple (ctypes array slice)"""
+    L = _ffi.lib()
+    tuples = (_ffi.BlkTuple * cap)()
+    cnt = C.c_uint32(0)
+    rc = L.lfx_decode_range_scan(ctx.handle, d_part_ptr, n_part, lo, hi, (1 << 64) - 1 if first_bit is None else first_bit,
+                                 rank, tuples, cap, C.byref(cnt))
+    if rc:
+        raise _ffi.LfxError(rc, ctx.last_error())
+    return tuples, cnt.value
+
+
+def chain_of(all_tuples, n_all, first_bit):
+    """step 3 (host, deterministic) → (chain indices as a ctypes array, length, total output bytes)"""
+    L = _ffi.lib()
+    chain = (C.c_uint32 * max(n_all, 1))()
+    nch, total = C.c_uint32(0), C.c_uint64(0)
+    rc = L.lfx_decode_chain(all_tuples, n_all, first_bit, chain, max(n_all, 1), C.byref(nch), C.byref(total))
+    if rc:
+        raise _ffi.LfxError(rc, "the block chain of the member breaks (a stored / fixed block, or damage): decode it on one GPU")
+    return chain, nch.value, total.value
+
+
+def range_emit(ctx, rank, d_part_ptr, n_part, lo, all_tuples, chain, n_chain, d_out_ptr, cap):
+    """step 4 on one rank → (bytes written, offset of the slice in the member's output, crc32, adler32)"""
+    L = _ffi.lib()
+    ol, base, crc, ad = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+    rc = L.lfx_decode_range_emit(ctx.handle, d_part_ptr, n_part, lo, all_tuples, chain, n_chain, rank, d_out_ptr, cap,
+                                 C.byref(ol), C.byref(base), C.byref(crc), C.byref(ad))
+    if rc:
+        raise _ffi.LfxError(rc, ctx.last_error())
+    return ol.value, base.value, crc.value, ad.value
+
+
+def fold_checks(parts):
+    """parts: (length, crc32, adler32) per rank, in rank order → (crc32, adler32) of the concatenation"""
+    L = _ffi.lib()
+    crc, ad = 0, 1
+    for n, c, a in parts:
+        crc = L.lfx_crc32_combine(crc, c, n)
+        ad = L.lfx_adler32_combine(ad, a, n)
+    return crc, ad
+
+
+def gather_tuples(tuples, cnt, world, dist, device="cpu"):
+    """step 2: all-gather of the ranks' candidate tuples (variable counts: the counts first, then rows padded to the
+    longest) → (ctypes array of all tuples in rank order, their number)"""
+    if dist is None or world == 1:
+        return tuples, cnt
+    import torch
+    tsz = C.sizeof(_ffi.BlkTuple)
+    dev = "cpu" if dist.get_backend() == "gloo" else device
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([cnt], dtype=torch.int64, device=dev))
+    counts = [int(x.item()) for x in counts]
+    width = max(max(counts), 1) * tsz
+    mine = torch.zeros(width, dtype=torch.uint8)
+    if cnt:
+        mine[:cnt * tsz] = torch.frombuffer(bytearray(C.string_at(tuples, cnt * tsz)), dtype=torch.uint8)
+    mine = mine.to(dev)
+    gathered = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(gathered, mine)                      # RCCL over xGMI: a few KB per rank
+    n_all = sum(counts)
+    all_t = (_ffi.BlkTuple * max(n_all, 1))()
+    at = 0
+    for r in range(world):
+        raw = gathered[r][:counts[r] * tsz].cpu().numpy().tobytes()
+        C.memmove(C.byref(all_t, at * tsz), raw, len(raw))
+        at += counts[r]
+    return all_t, n_all
+
+
+def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_out, cap, dist=None):
+    """One rank's side of the N-GPU decode over torch.distributed (RCCL on GPUs, gloo in CPU rigs): scan → all-gather of
+    the tuples → chain → emit → all-gather of (length, crc, adler).  d_part / d_out: torch uint8 tensors on the rank's
+    device.  → (bytes of this rank's slice, its offset in the member's output, total output bytes, crc32, adler32 of the
+    whole member's output)."""
+    import torch
+    tuples, cnt = range_scan(ctx, rank, d_part.data_ptr(), n_part, lo, hi, first_bit if rank == 0 else None)
+    all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device)
+    chain, nch, total = chain_of(all_t, n_all, first_bit)
+    ol, base, crc, ad = range_emit(ctx, rank, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_out.data_ptr(), cap)
+    if dist is None or world == 1:
+        return ol, base, total, crc, ad
+    host = dist.get_backend() == "gloo"
+    dev = "cpu" if host else d_part.device
+    mine = torch.tensor([ol, crc, ad], dtype=torch.int64, device=dev)
+    parts = [torch.empty(3, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    crc_all, ad_all = fold_checks([tuple(int(v) for v in p.cpu().tolist()) for p in parts])
+    return ol, base, total, crc_all, ad_all

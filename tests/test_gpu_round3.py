@@ -241,3 +241,66 @@ def test_stream_decoder_windows_vs_oracle(env, oracle):
         assert status == {1: ffi.E_INVALID_DATA, 2: ffi.E_UNEXPECTED_EOF}[want[0]], (name, status, want[0], want[3])
         # the reference hands out the bytes of complete blocks before the error (decode.rs:136-164)
         assert total <= len(want[1]) and crc == zlib.crc32(want[1][:total]) and len(want[1]) - total < (2 << 20), (name, total, len(want[1]))
+
+
+# ------------------------------------------------------------------ e: N-GPU decode of one member, no encoder layout
+def _virtual_rank_decode(lfx, ffi, member, hdr_len, world, plain_len):
+    """`world` virtual ranks on one device (a context each: a rank's scan tables live in its context): every rank sees only
+    its byte range plus the tail, the tuples are concatenated in rank order (what the all-gather yields)."""
+    import ctypes as C
+    import torch
+    from libflate_amd import sharded
+    d_member = torch.frombuffer(bytearray(member), dtype=torch.uint8).cuda()
+    ranges = sharded.byte_ranges(hdr_len, len(member), world)
+    ctxs = [lfx.Context(0) for _ in range(world)]
+    parts, rows, total_cnt = [], [], 0
+    for r, (lo, hi) in enumerate(ranges):
+        n_part = min(hi + sharded.RANGE_TAIL, len(member)) - lo
+        d_part = d_member[lo:lo + n_part].clone()                     # (its own buffer: nothing outside it can be read)
+        tuples, cnt = sharded.range_scan(ctxs[r], r, d_part.data_ptr(), n_part, lo, hi, hdr_len * 8 if r == 0 else None)
+        parts.append((d_part, n_part, lo))
+        rows.append((tuples, cnt))
+        total_cnt += cnt
+    tsz = C.sizeof(ffi.BlkTuple)
+    all_t = (ffi.BlkTuple * max(total_cnt, 1))()
+    at = 0
+    for tuples, cnt in rows:
+        C.memmove(C.byref(all_t, at * tsz), tuples, cnt * tsz)
+        at += cnt
+    chain, nch, total = sharded.chain_of(all_t, total_cnt, hdr_len * 8)
+    assert total == plain_len
+    out = torch.zeros(plain_len, dtype=torch.uint8, device="cuda")
+    checks, owned = [], []
+    for r, (d_part, n_part, lo) in enumerate(parts):
+        d_slice = torch.zeros(plain_len, dtype=torch.uint8, device="cuda")
+        ol, base, crc, ad = sharded.range_emit(ctxs[r], r, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_slice.data_ptr(), plain_len)
+        out[base:base + ol] = d_slice[:ol]
+        checks.append((ol, crc, ad))
+        owned.append(ol)
+    for c in ctxs:
+        c.close()
+    return out, sharded.fold_checks(checks), owned, nch, total_cnt
+
+
+def test_member_decode_on_virtual_ranks(env, oracle):
+    """north_star: "independent DEFLATE blocks … partition across the GPUs".  An oracle-made 64 MiB gzip member (64 blocks)
+    cut into 4 (and 3, 8) byte ranges: every rank finds and scans the blocks that start in its range, the chain is walked
+    over the gathered tuples, every rank materialises its blocks — no bit offset comes from the encoder.  Output ==
+    input, folded CRC-32 == the trailer's, every rank owns a share."""
+    import zlib
+    import torch
+    lfx, ctx, ffi, synth = env
+    data = synth.text(64 << 20)
+    plain = data.tobytes()
+    member = oracle.encode(oracle.GZIP, plain, write_size=8192, mtime=0)
+    for world in (4, 3, 8):
+        out, (crc, ad), owned, nch, ncand = _virtual_rank_decode(lfx, ffi, member, 10, world, len(plain))
+        assert torch.equal(out, torch.from_numpy(data).cuda()), world
+        assert crc == zlib.crc32(plain) == int.from_bytes(member[-8:-4], "little") and ad == zlib.adler32(plain)
+        assert nch == 65 and min(owned) > (len(plain) // world) // 2, (world, nch, owned)       # 64 blocks + the empty final one
+        assert ncand >= nch
+    # a member whose blocks read earlier blocks (python zlib) is refused, not decoded wrongly
+    import gzip as pygzip
+    foreign = pygzip.compress(plain[:(16 << 20)], 6, mtime=0)
+    with pytest.raises(ffi.LfxError):
+        _virtual_rank_decode(lfx, ffi, foreign, 10, 4, 16 << 20)

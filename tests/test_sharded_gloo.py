@@ -101,3 +101,72 @@ def test_layout_and_combine_single_process(oracle):
     assert ad == oracle.adler32(b"".join(shards))
     # shared boundary bytes are OR-ed
     assert sharded.assemble([b"\x01\x02\x03", b"\x30\x04"], [0, 20]) == b"\x01\x02\x33\x04"
+
+
+def _decode_worker(rank, world, port, q):
+    """N-GPU decode of one member, the exchange: every rank contributes the tuples of the blocks that START in its byte
+    range — produced here from the oracle's block scan standing in for lfx_decode_range_scan, which needs a GPU — plus
+    a false candidate; the PRODUCT code all-gathers them (sharded.gather_tuples), walks the chain (lfx_decode_chain,
+    host only) and folds the slice checksums (sharded.fold_checks)."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import lfo_oracle as oracle
+        import synth
+        from libflate_amd import _ffi, sharded
+        data = synth.text(5 << 20).tobytes()
+        member = oracle.encode(oracle.GZIP, data, write_size=8192, mtime=0)
+        hdr = 10
+        blocks = oracle.scan_blocks(member[hdr:-8])              # (start_bit, end_bit, btype, bfinal, out_len) relative to the DEFLATE data
+        lo, hi = sharded.byte_ranges(hdr, len(member), world)[rank]
+        mine = [b for b in blocks if lo * 8 <= hdr * 8 + b[0] < hi * 8]
+        tuples = (_ffi.BlkTuple * (len(mine) + 1))()
+        for i, b in enumerate(mine):
+            t = tuples[i]
+            t.start_bit, t.end_bit, t.n_out, t.btype, t.bfinal, t.status, t.rank, t.slot = hdr * 8 + b[0], hdr * 8 + b[1], b[4], b[2], b[3], 0, rank, i
+        f = tuples[len(mine)]                                    # a false candidate in the middle of my range: never on the chain
+        f.start_bit, f.end_bit, f.n_out, f.status, f.rank, f.slot = (lo + hi) * 4 + 3, (lo + hi) * 4 + 4000, 999, 0, rank, len(mine)
+        all_t, n_all = sharded.gather_tuples(tuples, len(mine) + 1, world, dist)
+        chain, nch, total = sharded.chain_of(all_t, n_all, hdr * 8)
+        got = [(all_t[chain[k]].start_bit, all_t[chain[k]].rank) for k in range(nch)]
+        want = [(hdr * 8 + b[0], next(r for r, (l, h) in enumerate(sharded.byte_ranges(hdr, len(member), world)) if l * 8 <= hdr * 8 + b[0] < h * 8))
+                for b in blocks]
+        # slice checksums: rank r "decoded" the output of its blocks
+        off = sum(b[4] for b in blocks if hdr * 8 + b[0] < lo * 8)
+        ln = sum(b[4] for b in mine)
+        sl = data[off:off + ln]
+        part = torch.tensor([ln, oracle.crc32(sl), oracle.adler32(sl)], dtype=torch.int64)
+        parts = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(parts, part)
+        crc, ad = sharded.fold_checks([tuple(int(v) for v in p.tolist()) for p in parts])
+        ok = got == want and total == len(data) and crc == oracle.crc32(data) and ad == oracle.adler32(data)
+        ok = ok and crc == int.from_bytes(member[-8:-4], "little")
+        if rank == 0:
+            q.put(("ok", ok, nch, len(blocks), n_all))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+def test_member_decode_exchange_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == "ok", res
+    assert res[1], ("chain / checksum fold of the gathered tuples is wrong", res)
+    assert res[2] == res[3] and res[4] == res[3] + 2          # every block on the chain; the two false candidates are not
