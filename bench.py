@@ -341,6 +341,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         dist.barrier()
     sharded_path = dist is not None
+    # the decode's two small all-gathers get a communicator of their own: on the default one they would queue behind the
+    # member's concatenation (7 x 130 MB into rank 0), which is still in flight when the decode starts
+    small_group = dist.new_group() if sharded_path and world > 1 else None
     import libflate_amd
     from libflate_amd import _ffi, sharded
     import synth
@@ -433,13 +436,17 @@ def main():
             gh = sharded.gather_begin(ctx, rank, world, self.d_out, m.value, start_bits, part_lens,
                                       self.d_member, self.bound * world if rank == 0 else 0, dist, self.staging)
             t1 = time.perf_counter()
-            ol = C.c_uint64(0)
-            sb = start_bits[rank]
-            first_byte_bits = sb if rank == 0 else sb & 7
-            self.check(L.lfx_decode_shard_device(ctx.handle, self.d_out.data_ptr(), m.value, first_byte_bits, infos[rank][0],
-                                                 int(rank == world - 1), self.d_dec.data_ptr(), n, C.byref(ol)), "shard_decode")
-            if ol.value != n:
-                raise RuntimeError("shard decode produced %d bytes" % ol.value)
+            # ---- N-GPU decode of the ONE member, no bit offset from the encoder: every rank holds a byte range of the member
+            #      (here: the bytes it emitted — [start_bit // 8, next start_bit // 8] — the cut a consumer reading the member
+            #      in parallel would also know), finds and scans the blocks that start in it, the ranks all-gather their
+            #      candidate tuples (56 bytes each over RCCL), walk the same chain and materialise their own blocks;
+            #      arbitrary byte cuts: tests/test_gpu_round3.py::test_member_decode_on_virtual_ranks
+            lo = start_bits[rank] // 8 if rank else 0
+            hi = start_bits[rank + 1] // 8 if rank + 1 < world else lo + m.value
+            ol, base, total_out, crc_all, _ad = sharded.decode_member_ranks(ctx, rank, world, self.d_out, m.value, lo, hi,
+                                                                            8 * self.hdr_len, self.d_dec, n, dist, small_group)
+            if ol != n or base != rank * n or total_out != total_n or crc_all != combined:
+                raise RuntimeError("member decode: slice %d bytes at %d of %d, crc %08x vs %08x" % (ol, base, total_out, crc_all, combined))
             t2 = time.perf_counter()
             if record:
                 self.acc_timing("dec:")
@@ -600,8 +607,9 @@ def main():
                    "bytes_per_gpu": n, "schedule": args.schedule, "compressed_bytes": m,
                    "parallelism": "1 rank" if not sharded_path else
                    "%d ranks, one gzip member: all-gather of shard infos + shards concatenated on rank 0 (RCCL point-to-point, "
-                   "all posted at once, in flight while each rank decodes its own shard); decode = shard decode with the "
-                   "encoder-provided bit offsets" % world},
+                   "all posted at once, in flight while the ranks decode); decode = N-GPU decode of the one member by byte ranges: "
+                   "block finder + scan per range, one all-gather of candidate tuples, chain walk on every rank, no bit "
+                   "offset from the encoder" % world},
         "encode_GBps": round(total_bytes * args.steps / enc_t / 1e9, 4),
         "decode_GBps": round(total_bytes * args.steps / dec_t / 1e9, 4),
         "phases_ms": {k: round(v, 4) for k, v in sorted(avg.items())},

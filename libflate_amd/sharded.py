@@ -175,7 +175,7 @@ def fold_checks(parts):
     return crc, ad
 
 
-def gather_tuples(tuples, cnt, world, dist, device="cpu"):
+def gather_tuples(tuples, cnt, world, dist, device="cpu", group=None):
     """step 2: all-gather of the ranks' candidate tuples (variable counts: the counts first, then rows padded to the
     longest) → (ctypes array of all tuples in rank order, their number)"""
     if dist is None or world == 1:
@@ -184,7 +184,7 @@ def gather_tuples(tuples, cnt, world, dist, device="cpu"):
     tsz = C.sizeof(_ffi.BlkTuple)
     dev = "cpu" if dist.get_backend() == "gloo" else device
     counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([cnt], dtype=torch.int64, device=dev))
+    dist.all_gather(counts, torch.tensor([cnt], dtype=torch.int64, device=dev), group=group)
     counts = [int(x.item()) for x in counts]
     width = max(max(counts), 1) * tsz
     mine = torch.zeros(width, dtype=torch.uint8)
@@ -192,7 +192,7 @@ def gather_tuples(tuples, cnt, world, dist, device="cpu"):
         mine[:cnt * tsz] = torch.frombuffer(bytearray(C.string_at(tuples, cnt * tsz)), dtype=torch.uint8)
     mine = mine.to(dev)
     gathered = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, mine)                      # RCCL over xGMI: a few KB per rank
+    dist.all_gather(gathered, mine, group=group)         # RCCL over xGMI: a few KB per rank
     n_all = sum(counts)
     all_t = (_ffi.BlkTuple * max(n_all, 1))()
     at = 0
@@ -203,14 +203,15 @@ def gather_tuples(tuples, cnt, world, dist, device="cpu"):
     return all_t, n_all
 
 
-def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_out, cap, dist=None):
+def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_out, cap, dist=None, group=None):
     """One rank's side of the N-GPU decode over torch.distributed (RCCL on GPUs, gloo in CPU rigs): scan → all-gather of
     the tuples → chain → emit → all-gather of (length, crc, adler).  d_part / d_out: torch uint8 tensors on the rank's
-    device.  → (bytes of this rank's slice, its offset in the member's output, total output bytes, crc32, adler32 of the
+    device; `group`: a process group of its own for these two small collectives, so that they do not queue behind bulk
+    transfers posted on the default group (bench.py: the member's concatenation is in flight).  → (bytes of this rank's slice, its offset in the member's output, total output bytes, crc32, adler32 of the
     whole member's output)."""
     import torch
     tuples, cnt = range_scan(ctx, rank, d_part.data_ptr(), n_part, lo, hi, first_bit if rank == 0 else None)
-    all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device)
+    all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device, group)
     chain, nch, total = chain_of(all_t, n_all, first_bit)
     ol, base, crc, ad = range_emit(ctx, rank, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_out.data_ptr(), cap)
     if dist is None or world == 1:
@@ -219,6 +220,6 @@ def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_o
     dev = "cpu" if host else d_part.device
     mine = torch.tensor([ol, crc, ad], dtype=torch.int64, device=dev)
     parts = [torch.empty(3, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(parts, mine)
+    dist.all_gather(parts, mine, group=group)
     crc_all, ad_all = fold_checks([tuple(int(v) for v in p.cpu().tolist()) for p in parts])
     return ol, base, total, crc_all, ad_all

@@ -1,36 +1,42 @@
 //! `libflate::deflate` (reference `src/deflate/{mod,encode,decode}.rs`).
+use crate::lz77::{DefaultLz77Encoder, GpuLz77};
 use crate::{ffi, Finish, RawDecoder, RawEncoder};
 use std::io;
+use std::marker::PhantomData;
 
 pub const DEFAULT_BLOCK_SIZE: usize = 1024 * 1024; // encode.rs:11
 
-/// Which LZ77 stage runs on the GPU (`EncodeOptions::with_lz77`, encode.rs:59-65): the default encoder with a
-/// window / maximum length, or `NoCompressionLz77Encoder` (libflate_lz77/src/lib.rs:111-145).
-#[derive(Debug, Clone, Copy)]
-pub enum Lz77 {
-    Default { window_size: u16, max_length: u16 },
-    NoCompression,
-}
-
-/// `deflate::EncodeOptions` (encode.rs:17-128)
-#[derive(Debug, Clone)]
-pub struct EncodeOptions {
+/// `deflate::EncodeOptions<E>` (encode.rs:17-128).  `E` is the LZ77 stage — the reference's own parameter; here it must
+/// be one the GPU pipeline implements (`lz77::GpuLz77`: `DefaultLz77Encoder`, `NoCompressionLz77Encoder`), see lz77.rs.
+#[derive(Debug)]
+pub struct EncodeOptions<E = DefaultLz77Encoder>
+where
+    E: GpuLz77,
+{
     pub(crate) block_size: usize,
     pub(crate) dynamic_huffman: bool,
-    pub(crate) no_compression: bool,
-    pub(crate) lz77: Lz77,
+    pub(crate) lz77: Option<E>,        // None = stored blocks (encode.rs:77-80)
 }
-impl Default for EncodeOptions {
-    fn default() -> Self {
-        EncodeOptions { block_size: DEFAULT_BLOCK_SIZE, dynamic_huffman: true, no_compression: false,
-                        lz77: Lz77::Default { window_size: 32768, max_length: 258 } }
+impl Default for EncodeOptions<DefaultLz77Encoder> {
+    fn default() -> Self { Self::new() }
+}
+impl EncodeOptions<DefaultLz77Encoder> {
+    /// encode.rs:45-51
+    pub fn new() -> Self {
+        EncodeOptions { block_size: DEFAULT_BLOCK_SIZE, dynamic_huffman: true, lz77: Some(DefaultLz77Encoder::new()) }
     }
 }
-impl EncodeOptions {
-    pub fn new() -> Self { Self::default() }
-    pub fn with_lz77(lz77: Lz77) -> Self { EncodeOptions { lz77, ..Self::default() } }
-    pub fn no_compression(mut self) -> Self { self.no_compression = true; self }
+impl<E> EncodeOptions<E>
+where
+    E: GpuLz77,
+{
+    /// encode.rs:59-65
+    pub fn with_lz77(lz77: E) -> Self { EncodeOptions { block_size: DEFAULT_BLOCK_SIZE, dynamic_huffman: true, lz77: Some(lz77) } }
+    /// encode.rs:77-80
+    pub fn no_compression(mut self) -> Self { self.lz77 = None; self }
+    /// encode.rs:92-95
     pub fn block_size(mut self, size: usize) -> Self { self.block_size = size; self }
+    /// encode.rs:107-110
     pub fn fixed_huffman_codes(mut self) -> Self { self.dynamic_huffman = false; self }
 
     pub(crate) fn to_ffi(&self) -> ffi::lfx_encode_opts {
@@ -38,33 +44,33 @@ impl EncodeOptions {
         unsafe { ffi::lfx_encode_opts_default(&mut o) };
         o.block_size = self.block_size as u64;
         o.dynamic_huffman = self.dynamic_huffman as i32;
-        o.no_compression = self.no_compression as i32;
         match self.lz77 {
-            Lz77::Default { window_size, max_length } => {
-                o.lz77_kind = ffi::LFX_LZ77_DEFAULT;
-                o.window_size = if window_size == 0 { 32768 } else { window_size as u32 };
-                o.max_length = max_length as u32;
-            }
-            Lz77::NoCompression => o.lz77_kind = ffi::LFX_LZ77_NOCOMPRESSION,
+            Some(ref e) => e.configure(&mut o),
+            None => o.no_compression = 1,
         }
         o
     }
 }
 
-/// `deflate::Encoder` (encode.rs:136-249)
-pub struct Encoder<W: io::Write> {
+/// `deflate::Encoder<W, E>` (encode.rs:132-249)
+pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> {
     raw: RawEncoder<W>,
+    _lz77: PhantomData<E>,
 }
-impl<W: io::Write> Encoder<W> {
+impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
+    /// encode.rs:156-158
     pub fn new(inner: W) -> Self {
         Self::with_options(inner, EncodeOptions::default())
     }
-    /// Panics when no GPU is usable (the reference constructor is infallible; there is no CPU fallback here).
-    pub fn with_options(inner: W, options: EncodeOptions) -> Self {
+}
+impl<W: io::Write, E: GpuLz77> Encoder<W, E> {
+    /// encode.rs:182-189.  Panics when no GPU is usable (the reference constructor is infallible; there is no CPU
+    /// fallback here) — `try_with_options` reports it instead.
+    pub fn with_options(inner: W, options: EncodeOptions<E>) -> Self {
         Self::try_with_options(inner, options).expect("libflate-amd: no usable MI355X device")
     }
-    pub fn try_with_options(inner: W, options: EncodeOptions) -> io::Result<Self> {
-        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_DEFLATE, &options.to_ffi(), inner)? })
+    pub fn try_with_options(inner: W, options: EncodeOptions<E>) -> io::Result<Self> {
+        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_DEFLATE, &options.to_ffi(), inner)?, _lz77: PhantomData })
     }
     pub fn finish(self) -> Finish<W, io::Error> {
         let (w, e) = self.raw.finish();
@@ -74,7 +80,7 @@ impl<W: io::Write> Encoder<W> {
     pub fn as_inner_mut(&mut self) -> &mut W { self.raw.inner_mut() }
     pub fn into_inner(self) -> W { self.raw.into_inner() }
 }
-impl<W: io::Write> io::Write for Encoder<W> {
+impl<W: io::Write, E> io::Write for Encoder<W, E> {
     fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.raw.write(buf) }
     fn flush(&mut self) -> io::Result<()> { self.raw.flush() }
 }

@@ -1,8 +1,9 @@
 //! `libflate::gzip` (reference `src/gzip.rs`).
-use crate::deflate::Lz77;
+use crate::lz77::{DefaultLz77Encoder, GpuLz77};
 use crate::{ffi, Finish, RawDecoder, RawEncoder};
 use std::ffi::{CStr, CString};
 use std::io;
+use std::marker::PhantomData;
 
 /// gzip.rs:58-92 (XFL)
 #[derive(Debug, Clone, PartialEq, Eq)]
@@ -72,6 +73,8 @@ impl Header {
             extra_field: if h.has_extra != 0 {
                 Some(ExtraField::from_bytes(unsafe { std::slice::from_raw_parts(h.extra, h.extra_len as usize) }))
             } else { None },
+            // (a present-but-empty FNAME / FCOMMENT is Some("") in the reference, gzip.rs:415-431: lfx_header hands out a
+            //  pointer to the NUL in that case and NULL only when the flag bit is clear)
             filename: cs(h.filename),
             comment: cs(h.comment),
         }
@@ -99,27 +102,39 @@ impl HeaderBuilder {
     pub fn finish(&self) -> Header { self.header.clone() }
 }
 
-/// `gzip::EncodeOptions` (gzip.rs:639-751)
-#[derive(Debug, Clone)]
-pub struct EncodeOptions { inner: crate::deflate::EncodeOptions, header: Header }
-impl Default for EncodeOptions {
-    fn default() -> Self { EncodeOptions { inner: Default::default(), header: HeaderBuilder::new().finish() } }
+/// `gzip::EncodeOptions<E>` (gzip.rs:639-751)
+#[derive(Debug)]
+pub struct EncodeOptions<E = DefaultLz77Encoder>
+where
+    E: GpuLz77,
+{
+    inner: crate::deflate::EncodeOptions<E>,
+    header: Header,
 }
-impl EncodeOptions {
-    pub fn new() -> Self { Self::default() }
-    pub fn with_lz77(lz77: Lz77) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), ..Self::default() } }
+impl Default for EncodeOptions<DefaultLz77Encoder> {
+    fn default() -> Self { Self::new() }
+}
+impl EncodeOptions<DefaultLz77Encoder> {
+    pub fn new() -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::new(), header: HeaderBuilder::new().finish() } }
+}
+impl<E: GpuLz77> EncodeOptions<E> {
+    /// gzip.rs:667-672
+    pub fn with_lz77(lz77: E) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), header: HeaderBuilder::new().finish() } }
     pub fn no_compression(mut self) -> Self { self.inner = self.inner.no_compression(); self }
     pub fn header(mut self, header: Header) -> Self { self.header = header; self }
     pub fn block_size(mut self, size: usize) -> Self { self.inner = self.inner.block_size(size); self }
     pub fn fixed_huffman_codes(mut self) -> Self { self.inner = self.inner.fixed_huffman_codes(); self }
 }
 
-/// `gzip::Encoder` (gzip.rs:754-908)
-pub struct Encoder<W: io::Write> { raw: RawEncoder<W>, header: Header }
-impl<W: io::Write> Encoder<W> {
+/// `gzip::Encoder<W, E>` (gzip.rs:754-908)
+pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> { raw: RawEncoder<W>, header: Header, _lz77: PhantomData<E> }
+impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
     /// writes the header immediately and can fail (gzip.rs:804-812)
     pub fn new(inner: W) -> io::Result<Self> { Self::with_options(inner, EncodeOptions::default()) }
-    pub fn with_options(inner: W, options: EncodeOptions) -> io::Result<Self> {
+}
+impl<W: io::Write, E: GpuLz77> Encoder<W, E> {
+    /// gzip.rs:830-838
+    pub fn with_options(inner: W, options: EncodeOptions<E>) -> io::Result<Self> {
         let mut o = options.inner.to_ffi();
         let h = &options.header;
         let extra = h.extra_field.as_ref().map(|e| e.to_bytes());
@@ -132,7 +147,7 @@ impl<W: io::Write> Encoder<W> {
         if let Some(ref c) = h.comment { o.comment = c.as_ptr(); }
         // (lfx_encoder_new copies the strings and the extra field before it returns)
         let raw = RawEncoder::new(ffi::LFX_GZIP, &o, inner)?;
-        Ok(Encoder { raw, header: options.header.clone() })
+        Ok(Encoder { raw, header: options.header.clone(), _lz77: PhantomData })
     }
     pub fn header(&self) -> &Header { &self.header }
     pub fn finish(self) -> Finish<W, io::Error> { let (w, e) = self.raw.finish(); Finish::new(w, e) }
@@ -140,7 +155,7 @@ impl<W: io::Write> Encoder<W> {
     pub fn as_inner_mut(&mut self) -> &mut W { self.raw.inner_mut() }
     pub fn into_inner(self) -> W { self.raw.into_inner() }
 }
-impl<W: io::Write> io::Write for Encoder<W> {
+impl<W: io::Write, E> io::Write for Encoder<W, E> {
     fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.raw.write(buf) }
     fn flush(&mut self) -> io::Result<()> { self.raw.flush() }
 }
@@ -171,15 +186,26 @@ impl<R: io::Read> io::Read for Decoder<R> {
 }
 
 /// `gzip::MultiDecoder` (gzip.rs:1052-1167): all members of a concatenated stream
-pub struct MultiDecoder<R: io::Read> { raw: RawDecoder<R> }
+pub struct MultiDecoder<R: io::Read> { raw: RawDecoder<R>, header: Header }
 impl<R: io::Read> MultiDecoder<R> {
-    pub fn new(inner: R) -> io::Result<Self> { Ok(MultiDecoder { raw: RawDecoder::new(ffi::LFX_GZIP, ffi::LFX_DEC_MULTI, inner)? }) }
-    /// header of the member being read (gzip.rs:1106)
-    pub fn header(&mut self) -> io::Result<Header> { Ok(Header::from_ffi(&self.raw.header()?)) }
+    /// reads the first member's header and can fail (gzip.rs:1089-1095)
+    pub fn new(inner: R) -> io::Result<Self> {
+        let mut raw = RawDecoder::new(ffi::LFX_GZIP, ffi::LFX_DEC_MULTI, inner)?;
+        let header = Header::from_ffi(&raw.header()?);
+        Ok(MultiDecoder { raw, header })
+    }
+    /// header of the member being read (gzip.rs:1106: `&Header`; refreshed by `read` when it crosses into a member)
+    pub fn header(&self) -> &Header { &self.header }
     pub fn as_inner_ref(&self) -> &R { self.raw.inner_ref() }
     pub fn as_inner_mut(&mut self) -> &mut R { self.raw.inner_mut() }
     pub fn into_inner(self) -> R { self.raw.into_inner() }
 }
 impl<R: io::Read> io::Read for MultiDecoder<R> {
-    fn read(&mut self, buf: &mut [u8]) -> io::Result<usize> { self.raw.read(buf) }
+    fn read(&mut self, buf: &mut [u8]) -> io::Result<usize> {
+        let n = self.raw.read(buf)?;
+        if n != 0 {
+            if let Ok(h) = self.raw.header() { self.header = Header::from_ffi(&h); }     // (the member these bytes came from)
+        }
+        Ok(n)
+    }
 }

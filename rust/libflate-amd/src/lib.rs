@@ -99,6 +99,11 @@ pub(crate) struct RawEncoder<W: io::Write> {
     pub(crate) inner: Option<Box<W>>,    // boxed: the callbacks hold its address
     pub(crate) _ctx: Arc<Context>,
 }
+// (the handles are plain heap objects behind the C ABI and the context serialises every call: moving an encoder /
+//  decoder to another thread is sound whenever the inner stream may move — the reference's types are Send when W / R are)
+unsafe impl<W: io::Write + Send> Send for RawEncoder<W> {}
+unsafe impl<R: io::Read + Send> Send for RawDecoder<R> {}
+
 impl<W: io::Write> RawEncoder<W> {
     pub(crate) fn new(format: c_int, opts: &ffi::lfx_encode_opts, inner: W) -> io::Result<Self> {
         let ctx = default_context()?;

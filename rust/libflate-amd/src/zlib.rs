@@ -1,7 +1,8 @@
 //! `libflate::zlib` (reference `src/zlib.rs`).
-use crate::deflate::Lz77;
+use crate::lz77::{DefaultLz77Encoder, GpuLz77};
 use crate::{ffi, Finish, RawDecoder, RawEncoder};
 use std::io;
+use std::marker::PhantomData;
 
 /// zlib.rs:28-58
 #[derive(Debug, Clone, Copy, PartialEq, Eq)]
@@ -23,15 +24,24 @@ impl Header {
     }
 }
 
-/// `zlib::EncodeOptions` (zlib.rs:414-518)
-#[derive(Debug, Clone)]
-pub struct EncodeOptions { inner: crate::deflate::EncodeOptions, flush_mode: FlushMode }
-impl Default for EncodeOptions {
-    fn default() -> Self { EncodeOptions { inner: Default::default(), flush_mode: FlushMode::None } }
+/// `zlib::EncodeOptions<E>` (zlib.rs:414-518)
+#[derive(Debug)]
+pub struct EncodeOptions<E = DefaultLz77Encoder>
+where
+    E: GpuLz77,
+{
+    inner: crate::deflate::EncodeOptions<E>,
+    flush_mode: FlushMode,
 }
-impl EncodeOptions {
-    pub fn new() -> Self { Self::default() }
-    pub fn with_lz77(lz77: Lz77) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), flush_mode: FlushMode::None } }
+impl Default for EncodeOptions<DefaultLz77Encoder> {
+    fn default() -> Self { Self::new() }
+}
+impl EncodeOptions<DefaultLz77Encoder> {
+    pub fn new() -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::new(), flush_mode: FlushMode::None } }
+}
+impl<E: GpuLz77> EncodeOptions<E> {
+    /// zlib.rs:441-449
+    pub fn with_lz77(lz77: E) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), flush_mode: FlushMode::None } }
     pub fn no_compression(mut self) -> Self { self.inner = self.inner.no_compression(); self }
     pub fn block_size(mut self, size: usize) -> Self { self.inner = self.inner.block_size(size); self }
     pub fn fixed_huffman_codes(mut self) -> Self { self.inner = self.inner.fixed_huffman_codes(); self }
@@ -43,20 +53,23 @@ impl EncodeOptions {
     }
 }
 
-/// `zlib::Encoder` (zlib.rs:522-681)
-pub struct Encoder<W: io::Write> { raw: RawEncoder<W> }
-impl<W: io::Write> Encoder<W> {
+/// `zlib::Encoder<W, E>` (zlib.rs:522-681)
+pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> { raw: RawEncoder<W>, _lz77: PhantomData<E> }
+impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
     /// writes the 2-byte header immediately and can fail (zlib.rs:577-585)
     pub fn new(inner: W) -> io::Result<Self> { Self::with_options(inner, EncodeOptions::default()) }
-    pub fn with_options(inner: W, options: EncodeOptions) -> io::Result<Self> {
-        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_ZLIB, &options.to_ffi(), inner)? })
+}
+impl<W: io::Write, E: GpuLz77> Encoder<W, E> {
+    /// zlib.rs:603-611
+    pub fn with_options(inner: W, options: EncodeOptions<E>) -> io::Result<Self> {
+        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_ZLIB, &options.to_ffi(), inner)?, _lz77: PhantomData })
     }
     pub fn finish(self) -> Finish<W, io::Error> { let (w, e) = self.raw.finish(); Finish::new(w, e) }
     pub fn as_inner_ref(&self) -> &W { self.raw.inner_ref() }
     pub fn as_inner_mut(&mut self) -> &mut W { self.raw.inner_mut() }
     pub fn into_inner(self) -> W { self.raw.into_inner() }
 }
-impl<W: io::Write> io::Write for Encoder<W> {
+impl<W: io::Write, E> io::Write for Encoder<W, E> {
     fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.raw.write(buf) }
     /// `FlushMode::Sync` appends the empty stored block `00 00 FF FF` (zlib.rs:666-671)
     fn flush(&mut self) -> io::Result<()> { self.raw.flush() }

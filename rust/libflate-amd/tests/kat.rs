@@ -34,19 +34,68 @@ fn zlib_encode_hello() {
 }
 
 #[test]
-fn zlib_sync_flush_issue_27() {
-    // src/zlib.rs:862-902: three writes + flush, twice, FlushMode::Sync
-    let writes: [&[u8]; 3] = [b"a", b"b", b"c"];
+fn zlib_issue_27_both_flush_modes() {
+    // src/zlib.rs:838-902, byte for byte: three writes + flush, twice — FlushMode::None, then FlushMode::Sync
+    let writes = ["fooooooooooooooooo", "bar", "baz"];
+    let mut encoder = zlib::Encoder::new(Vec::new()).unwrap();
+    for _ in 0..2 {
+        for string in &writes { encoder.write(string.as_bytes()).expect("Write failed"); }
+        encoder.flush().expect("Flush failed");
+    }
+    let finished = encoder.finish().unwrap();
+    let expected = vec![
+        120, 156, // header
+        92, 192, 161, 17, 0, 0, 0, 1, 192, 89, 9, 170, 59, 209, 244, 186, 151, 31, 17, 162,
+        227, 2, 14, 141, 0, 0, 0, 8, 0, 206, 74, 80, 221, 137, 166, 215, 189, 252, 136, 16, 93,
+        1, 112, 32, 0, 0, 0, 0, 0, 228, 255, 26, 246, 95, 20, 111,
+    ];
+    assert_eq!(finished.0, expected);
+    let mut output = Vec::new();
+    zlib::Decoder::new(&finished.0[..]).unwrap().read_to_end(&mut output).unwrap();
+    assert_eq!(output, "fooooooooooooooooobarbazfooooooooooooooooobarbaz".as_bytes());
+
     let mut encoder = zlib::Encoder::with_options(Vec::new(), zlib::EncodeOptions::new().flush_mode(zlib::FlushMode::Sync)).unwrap();
     for _ in 0..2 {
-        for w in writes.iter() { encoder.write_all(w).unwrap(); }
-        encoder.flush().unwrap();
+        for string in &writes { encoder.write(string.as_bytes()).expect("Write failed"); }
+        encoder.flush().expect("Flush failed");
     }
+    let finished = encoder.finish().unwrap();
+    let expected = vec![
+        120, 156, // header
+        92, 192, 161, 17, 0, 0, 0, 1, 192, 89, 9, 170, 59, 209, 244, 186, 151, 31, 17, 162, 3,
+        0, 0, 255, 255, // sync bytes
+        92, 192, 161, 17, 0, 0, 0, 1, 192, 89, 9, 170, 59, 209, 244, 186, 151, 31, 17, 162, 3,
+        0, 0, 255, 255, // sync bytes
+        5, 192, 129, 0, 0, 0, 0, 0, 144, 255, 107, 0, 246, 95, 20, 111,
+    ];
+    assert_eq!(finished.0, expected);
+    let mut output = Vec::new();
+    zlib::Decoder::new(&finished.0[..]).unwrap().read_to_end(&mut output).unwrap();
+    assert_eq!(output, "fooooooooooooooooobarbazfooooooooooooooooobarbaz".as_bytes());
+}
+
+#[test]
+fn encode_options_carry_the_lz77_type_parameter() {
+    // src/deflate/encode.rs:17,59-65,132; src/gzip.rs:639,754; src/zlib.rs:414,522: EncodeOptions<E> / Encoder<W, E>
+    use libflate_amd::lz77::{DefaultLz77Encoder, DefaultLz77EncoderBuilder, NoCompressionLz77Encoder};
+    let options: deflate::EncodeOptions<DefaultLz77Encoder> =
+        deflate::EncodeOptions::with_lz77(DefaultLz77EncoderBuilder::new().window_size(1024).max_length(20).build());
+    let mut encoder: deflate::Encoder<Vec<u8>, DefaultLz77Encoder> = deflate::Encoder::with_options(Vec::new(), options);
+    encoder.write_all(b"abcabcabcabcabcabcabcabc").unwrap();
     let out = encoder.finish().into_result().unwrap();
-    let mut decoder = zlib::Decoder::new(&out[..]).unwrap();
-    let mut buf = Vec::new();
-    decoder.read_to_end(&mut buf).unwrap();
-    assert_eq!(buf, b"abcabc");
+    let mut back = Vec::new();
+    deflate::Decoder::new(&out[..]).read_to_end(&mut back).unwrap();
+    assert_eq!(back, b"abcabcabcabcabcabcabcabc");
+    // every byte a literal (libflate_lz77/src/lib.rs:111-145), still Huffman coded
+    let options = gzip::EncodeOptions::with_lz77(NoCompressionLz77Encoder::new());
+    let mut encoder: gzip::Encoder<Vec<u8>, NoCompressionLz77Encoder> = gzip::Encoder::with_options(Vec::new(), options).unwrap();
+    encoder.write_all(b"aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa").unwrap();
+    let out = encoder.finish().into_result().unwrap();
+    let mut back = Vec::new();
+    gzip::Decoder::new(&out[..]).unwrap().read_to_end(&mut back).unwrap();
+    assert_eq!(back.len(), 32);
+    // the default parameter: `Encoder<W>` is `Encoder<W, DefaultLz77Encoder>`
+    let _e: zlib::Encoder<Vec<u8>> = zlib::Encoder::new(Vec::new()).unwrap();
 }
 
 #[test]
@@ -80,6 +129,7 @@ fn gzip_multi_member() {
              222, 157, 40, 118, 6, 0, 0, 0];
     let both: Vec<u8> = a.iter().chain(b.iter()).cloned().collect();
     let mut decoder = gzip::MultiDecoder::new(&both[..]).unwrap();
+    assert_eq!(decoder.header().modification_time(), 0x5A4BCE33);          // `&Header` of the member being read (gzip.rs:1106)
     let mut buf = Vec::new();
     decoder.read_to_end(&mut buf).unwrap();
     assert_eq!(buf, b"Hello World!");

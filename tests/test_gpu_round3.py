@@ -304,3 +304,17 @@ def test_member_decode_on_virtual_ranks(env, oracle):
     foreign = pygzip.compress(plain[:(16 << 20)], 6, mtime=0)
     with pytest.raises(ffi.LfxError):
         _virtual_rank_decode(lfx, ffi, foreign, 10, 4, 16 << 20)
+
+
+def test_gzip_header_empty_name_and_comment(env, oracle):
+    """A present-but-empty FNAME / FCOMMENT is Some("") in the reference (gzip.rs:415-431), not None."""
+    lfx, ctx, ffi, synth = env
+    data = kat.test_i()[:5000]
+    s = oracle.encode(oracle.GZIP, data, 0, filename=b"", comment=b"", mtime=9)
+    assert s[3] & 0x18 == 0x18                                   # FNAME and FCOMMENT present
+    d = lfx.gzip.Decoder.new(s)
+    h = d.header()
+    assert h["filename"] == b"" and h["comment"] == b"" and h["modification_time"] == 9
+    assert d.read_to_end() == data
+    s2 = oracle.encode(oracle.GZIP, data, 0, mtime=9)
+    assert lfx.gzip.Decoder.new(s2).header()["filename"] is None
