@@ -461,7 +461,15 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     }
     LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const ParseWg *)c->d_pwgs.p,
                             (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
-                            (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map));
+                            (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map, 0,
+                            mdbg ? mdbg + 256 : nullptr));
+    if (mdbg) {
+        uint64_t hv[32];
+        (void)hipMemcpy(hv, mdbg + 256, sizeof hv, hipMemcpyDeviceToHost);
+        for (int w = 0; w < 4; w++)
+            fprintf(stderr, "[lfx] walk wave%d: fill=%llu spec=%llu resolve+chain=%llu emit=%llu cycles\n", w, (unsigned long long)hv[w * 8],
+                    (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 3]);
+    }
     c->phase("lz77_parse");
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the histogram

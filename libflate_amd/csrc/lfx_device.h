@@ -45,7 +45,8 @@ int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
                  uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage /* 4 bytes per input byte */,
-                 const uint32_t *seg_map, int stop_after = 0 /* diagnostics: 1 = behind the walk, 2 = behind fixseg */);
+                 const uint32_t *seg_map, int stop_after = 0 /* diagnostics: 1 = behind the walk, 2 = behind fixseg */,
+                 uint64_t *dbg = nullptr /* LFX_DEBUG: cycle stamps of one walk workgroup */);
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
                       uint32_t *tile_map, uint32_t *seg_map);
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,

@@ -39,7 +39,7 @@ constexpr uint32_t U = PARSE_GROUP;                 // positions per lane
 constexpr uint32_t WAVES = PARSE_WG_SEGS;           // segments per workgroup
 constexpr uint32_t THREADS = 64 * WAVES;
 constexpr uint32_t WG_POS = WAVES * PARSE_SEG;      // 13312 positions per workgroup
-constexpr uint32_t TAIL = 288;                      // bytes staged behind the last position: 3 + 255 + 8 + alignment
+constexpr uint32_t TAIL = 288;                      // bytes staged behind the last position: 3 + 240 + 16 + 4 (dword reads) + alignment
 constexpr uint32_t WIN_BYTES = MAX_WINDOW + WG_POS + TAIL + 8;   // (+ the byte phase of the window start on the dword grid)
 constexpr uint32_t OFF_CD = (WIN_BYTES + 15) & ~15u;
 constexpr uint32_t CD_BYTES = 2 * WG_POS + 8;       // (+ one entry of alignment shift, + pad)
@@ -94,25 +94,52 @@ struct WalkCtx {
     uint32_t max_len;
 };
 
+// 16 bytes at LDS byte offset off as four dwords (five aligned dword reads)
+struct B16 { uint32_t v[4]; };
+__device__ __forceinline__ B16 lds16(const uint32_t *win32, uint32_t off) {
+    const uint32_t i = off >> 2, sh = off & 3;
+    const uint32_t w0 = win32[i], w1 = win32[i + 1], w2 = win32[i + 2], w3 = win32[i + 3], w4 = win32[i + 4];
+    B16 r;
+    r.v[0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    r.v[1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    r.v[2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
+    r.v[3] = __builtin_amdgcn_alignbyte(w4, w3, sh);
+    return r;
+}
+// number of equal leading bytes of two 16-byte strings (16 when all are equal)
+__device__ __forceinline__ uint32_t eq_bytes16(const B16 &a, const B16 &b) {
+    const uint32_t x0 = a.v[0] ^ b.v[0], x1 = a.v[1] ^ b.v[1], x2 = a.v[2] ^ b.v[2], x3 = a.v[3] ^ b.v[3];
+    const uint64_t lo = (uint64_t)x0 | (uint64_t)x1 << 32, hi = (uint64_t)x2 | (uint64_t)x3 << 32;
+    const uint32_t nlo = lo ? (uint32_t)__builtin_ctzll(lo) >> 3 : 8u;
+    const uint32_t nhi = hi ? (uint32_t)__builtin_ctzll(hi) >> 3 : 8u;
+    return lo ? nlo : 8u + nhi;
+}
+
 // One walk step at position pos (default.rs:79-103): 1 for a literal, the match length otherwise.  `act` lanes take
-// part; the others return 0 and read harmless addresses.  The compare runs 8 bytes per iteration and the wavefront
-// iterates until its longest match is settled.
+// part; the others return 0 and read harmless addresses.  The compare runs 16 bytes per iteration and the wavefront
+// iterates until its longest match is settled: with 8 bytes per iteration nearly every step of a wavefront held some
+// lane with a match of 12 or more, and every lane paid its extra iterations (1400 cycles per step, measured; the LDS
+// round trips of one iteration are the same for 8 and for 16 bytes).  The position's own bytes do not depend on the
+// candidate: they are loaded together with it.
 __device__ __forceinline__ uint32_t walk_step(const WalkCtx &w, uint32_t pos, bool act) {
+    uint32_t oa = act ? pos + 3 - w.w0 : 0u;                        // (idle lanes read offset 0)
+    // loads that do not depend on the candidate
     const uint32_t d = act ? w.cd16[pos - w.c0] : 0u;
+    B16 a = lds16(w.win32, oa);
     uint32_t lim = w.n - (pos + 3);                                 // default.rs:125 (bounded by the end of the chunk)
     lim = lim > w.max_len - 3 ? w.max_len - 3 : lim;
     lim = d ? lim : 0u;
-    uint32_t oa = act ? pos + 3 - w.w0 : 0u;                        // (idle lanes read offset 0)
     uint32_t ob = oa - d;
     uint32_t l = 0;
     bool cmp = lim != 0;
-    for (int round = 0; round < 33 && __ballot(cmp); ++round) {      // (255 bytes at most: the bound is never reached)
-        const uint64_t x = lds8(w.win32, oa) ^ lds8(w.win32, ob);
-        const uint32_t adv = x ? (uint32_t)__builtin_ctzll(x) >> 3 : 8u;
+    for (int round = 0; round < 17 && __ballot(cmp); ++round) {      // (255 bytes at most: the bound is never reached)
+        if (round) a = lds16(w.win32, oa);
+        const B16 b = lds16(w.win32, ob);
+        const uint32_t adv = eq_bytes16(a, b);
         l += cmp ? adv : 0u;
-        cmp = cmp && x == 0 && l < lim;
-        oa += cmp ? 8u : 0u;
-        ob += cmp ? 8u : 0u;
+        cmp = cmp && adv == 16 && l < lim;
+        oa += cmp ? 16u : 0u;
+        ob += cmp ? 16u : 0u;
     }
     l = l > lim ? lim : l;
     return act ? (d ? 3u + l : 1u) : 0u;
@@ -146,12 +173,14 @@ __device__ __forceinline__ void resolve(const WalkCtx &w, bool act, uint32_t in,
 // workgroup → (chunk, first segment of the chunk it walks)
 // K1: speculative walk, in-wavefront chaining, staging.  seg_exit / seg_count / vis / stage describe the segment as
 // walked from its FIRST position.
+template <bool DBG>
 __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
     const ParseWg *__restrict__ wgs, const uint16_t *__restrict__ cd, uint32_t max_len,
     uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit, uint32_t *__restrict__ seg_count,
-    uint32_t *__restrict__ stage) {
+    uint32_t *__restrict__ stage, uint64_t *__restrict__ dbg) {
     using namespace p2;
+    const uint64_t t0 = DBG ? clock64() : 0;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     uint32_t *win32 = (uint32_t *)smem;
     uint32_t *cd32 = (uint32_t *)(smem + OFF_CD);
@@ -209,6 +238,7 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
         for (uint32_t q = 0; q < WB; ++q) win32[min((WB + q) * THREADS + tid, lastw)] = wv[q];
     }
     __syncthreads();
+    const uint64_t t1 = DBG ? clock64() : 0;
 
     const uint32_t sidx = wg.seg0 + wave;
     if (sidx >= ch.n_seg) return;
@@ -244,6 +274,7 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
         pos += st;
     }
     const uint32_t exit_spec = pos;
+    const uint64_t t2 = DBG ? clock64() : 0;
     // ---- the walk enters group L where it left group L-1: assume that is the speculative exit (it is when the walk
     //      through L-1 merged), resolve every group for that entry ...
     uint32_t used_in = __shfl_up(exit_spec, 1);
@@ -269,6 +300,7 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
         if (lane > j && lane < nact && stop <= xj) { used_in = xj; m_fin = 0; x_fin = xj; }
     }
     if (!have) m_fin = 0;
+    const uint64_t t3 = DBG ? clock64() : 0;
     // ---- results of the segment as walked from s0
     const uint32_t cnt = (uint32_t)__popcll(m_fin);
     uint32_t incl = cnt;
@@ -281,18 +313,45 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
     // ---- stage the code words, in position order: a visited position's step is the distance to the next visited one
     uint32_t *st = stage + ch.in_off + s0 + (incl - cnt);
     const uint8_t *win8 = (const uint8_t *)win32;
+    // Four code words per store (a lane's run is contiguous): a wavefront's store touches 64 different lines whatever its
+    // width, so a quarter of the store instructions is a quarter of the line transactions.
     uint64_t m = m_fin;
     uint32_t k = 0;
-    for (uint32_t guard = 0; guard < 64 && __ballot(m != 0); ++guard) {
-        if (m) {
-            const uint32_t b = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1;
-            const uint32_t p = a + b;
-            const uint32_t nxt = m ? a + (uint32_t)__builtin_ctzll(m) : x_fin;
-            const uint32_t d = w.cd16[p - w.c0];
-            const uint32_t byte = win8[p - w.w0];
-            st[k++] = d ? ((nxt - p) << 16) | d : byte << 16;
+    for (uint32_t guard = 0; guard < 16 && __ballot(m != 0); ++guard) {
+        // the (up to) four positions and their successors come from the mask alone; all eight LDS loads are issued before
+        // the first use (one round trip per four code words: issued one by one they cost 2000-3500 cycles per round)
+        uint32_t pp[4], nx[4], dd[4], bb[4];
+        uint32_t nc4 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool on = m != 0;
+            const uint32_t b = on ? (uint32_t)__builtin_ctzll(m) : 0u;
+            m &= m - 1;                                    // (0 stays 0)
+            pp[q] = a + b;
+            nx[q] = m ? a + (uint32_t)__builtin_ctzll(m) : x_fin;
+            nc4 += on ? 1u : 0u;
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // (a slot without a position reads the group's first one)
+            dd[q] = w.cd16[pp[q] - w.c0];
+            bb[q] = win8[pp[q] - w.w0];
+        }
+        uint32_t c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[q] = dd[q] ? ((nx[q] - pp[q]) << 16) | dd[q] : bb[q] << 16;
+        if (nc4 == 4) {
+            struct __attribute__((packed, aligned(4))) Q { uint32_t v[4]; } qv{{c[0], c[1], c[2], c[3]}};   // 16-byte store at a dword address
+            *(Q *)(st + k) = qv;
+        } else {
+            if (nc4 > 0) st[k] = c[0];
+            if (nc4 > 1) st[k + 1] = c[1];
+            if (nc4 > 2) st[k + 2] = c[2];
+        }
+        k += nc4;
+    }
+    if (DBG && dbg && blockIdx.x == 1000 && lane == 0) {      // (a workgroup in the middle of the launch)
+        uint64_t *d = dbg + wave * 8;
+        d[0] = t1 - t0; d[1] = t2 - t1; d[2] = t3 - t2; d[3] = clock64() - t3;
     }
 }
 
@@ -579,15 +638,20 @@ int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd
 
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
-                 uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map, int stop_after) {
+                 uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map, int stop_after,
+                 uint64_t *dbg) {
     if (nchunks == 0) return 0;
     // seg_tmp: six arrays of nsegs words
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
     uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs, *seg_mpos = seg_tmp + 4 * (size_t)nsegs;
     uint32_t *seg_kspec = seg_tmp + 5 * (size_t)nsegs;
     if (nwgs) {
-        hipLaunchKernelGGL(parse_walk_kernel, dim3(nwgs), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, cd, max_len, vis,
-                           seg_exit, seg_count, stage);
+        if (dbg)
+            hipLaunchKernelGGL(parse_walk_kernel<true>, dim3(nwgs), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, cd, max_len,
+                               vis, seg_exit, seg_count, stage, dbg);
+        else
+            hipLaunchKernelGGL(parse_walk_kernel<false>, dim3(nwgs), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, cd, max_len,
+                               vis, seg_exit, seg_count, stage, dbg);
         LFX_LAUNCH_CHECK();
     }
     if (stop_after == 1) return 0;      // (LFX_DEBUG dumps)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# round-end artifacts: full GPU suite, bench line (default run), kernel stats of the same loop, SQ counters per kernel, small sizes
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 1800 python -m pytest tests -q -m gpu > $O/r3_suite.log 2>&1; tail -4 $O/r3_suite.log
+timeout 900 python bench.py > $O/r3_bench_default.json 2> $O/r3_bench_default.err; echo "bench rc=$?"; cut -c1-400 $O/r3_bench_default.json
+cd /tmp
+rm -rf $O/kt_r3
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_r3 -- python $R/bench.py --child --steps 5 --warmup 2 > $O/kt_r3.log 2>&1
+f=$(find $O/kt_r3 -name "*kernel_stats.csv" | head -1); cp $f $O/r3_kernel_stats.csv; rm -rf $O/kt_r3; head -4 $O/r3_kernel_stats.csv | cut -c1-200
+for pass in 1 2; do
+  if [ $pass = 1 ]; then C="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS";
+  else C="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_VMEM"; fi
+  rm -rf $O/pmc_r3_$pass
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $O/pmc_r3_$pass -- python $R/bench.py --child --steps 1 --warmup 0 > $O/pmc_r3_$pass.log 2>&1
+  python $R/tools/pmc_summary.py $O/pmc_r3_$pass > $O/r3_pmc_$pass.csv 2>/dev/null
+  rm -rf $O/pmc_r3_$pass
+done
+cat $O/r3_pmc_1.csv $O/r3_pmc_2.csv | grep -v "at::native" > $O/r3_pmc_counters.csv; wc -l $O/r3_pmc_counters.csv
+cd $R
+timeout 300 python tools/bench_small.py > $O/r3_small.json 2>/dev/null; cut -c1-300 $O/r3_small.json
