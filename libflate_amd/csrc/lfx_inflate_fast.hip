@@ -871,37 +871,49 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
 // In-place jumping is safe without a second buffer: every value a reader can observe in P[j] is either "resolved" —
 // and then the byte is already in the ring, because the LDS executes a wavefront's instructions in order — or an
 // earlier byte with the same content.
-// Four units per CU (39.5 KB of LDS each), 16 wavefronts per CU instead of 4.
-constexpr uint32_t M2_THREADS = 256;
-constexpr uint32_t M2_TILE = 1536;                        // bytes one tile may produce
-constexpr uint32_t M2_RING = 32768 + M2_TILE;             // the DEFLATE window + the tile in flight
-constexpr uint32_t M2_PASSES = (M2_TILE + 4 * M2_THREADS - 1) / (4 * M2_THREADS);
+// Four units per CU (39.7 KB of LDS each), 16 wavefronts per CU instead of 4.
+// Geometry by workgroup size.  Measured on the 256 MiB corpus (round 3, units = the 1024 LZ77 chunks): 256 lanes, four
+// units per CU: 1.03 ms; 512 lanes (tiles of 512 codes, three units per CU): 1.11 ms; 1024 lanes (two units): 1.47 ms.
+// Larger tiles amortise the per-tile latencies (barriers, the owner search, the pointer rounds) and still lose: the
+// kernel is bound by its VALU instruction count — about 250 per wavefront and tile of 256 codes = 640 bytes, four
+// cycles each on a SIMD — not by those latencies, and the wider search and the second pass add instructions.
+template <uint32_t THREADS>
+struct M2 {
+    static constexpr uint32_t WAVES = THREADS / 64;
+    static constexpr uint32_t TILE = 6 * THREADS;                           // bytes one tile may produce
+    static constexpr uint32_t RING = 32768 + TILE;                          // the DEFLATE window + the tile in flight
+    static constexpr uint32_t PASSES = (TILE + 4 * THREADS - 1) / (4 * THREADS);
+    static_assert(RING % 4 == 0 && TILE >= 258 && TILE < 0xFFFFu && RING + 64 < 65536, "tile");
+};
+constexpr uint32_t M2_THREADS = 256;                      // direct path
+constexpr uint32_t M2_SYM_THREADS = 256;                  // marker path
 constexpr uint32_t M2_DONE = 0xFFFFu;
-static_assert(M2_RING % 4 == 0 && M2_TILE >= 258 && M2_TILE < M2_DONE, "tile");
 
-__device__ __forceinline__ uint32_t m2_wrap(uint32_t x) { return min(x, x - M2_RING); }          // x in [0, 2 RING)
-__device__ __forceinline__ uint32_t m2_back(uint32_t idx, uint32_t d) {                           // idx, d < RING
+template <uint32_t RING> __device__ __forceinline__ uint32_t m2_wrap(uint32_t x) { return min(x, x - RING); }   // x in [0, 2 RING)
+template <uint32_t RING> __device__ __forceinline__ uint32_t m2_back(uint32_t idx, uint32_t d) {                 // idx, d < RING
     const uint32_t a = idx - d;
-    return min(a, a + M2_RING);
+    return min(a, a + RING);
 }
 
 // One body for both materialisations: SYM = false writes BYTES (direct path: the unit's history is known or empty),
 // SYM = true writes 16-bit SYMBOLS for the marker path (below): the 32 Ki entries in front of the unit start out as the
 // markers 256 + j, and the units are the ones cut without regard to back-references (fcode0 / fout0).
-template <bool SYM>
+template <bool SYM, uint32_t THREADS>
 __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in, const BlkEmit *__restrict__ jobs,
                                                   const BlkUnits *__restrict__ units,
                                                   const uint32_t *__restrict__ codes,
                                                   typename std::conditional<SYM, uint16_t, uint8_t>::type *__restrict__ out,
                                                   uint32_t njobs, uint64_t *__restrict__ dbg) {
     using elem_t = typename std::conditional<SYM, uint16_t, uint8_t>::type;
+    using G = M2<THREADS>;
+    constexpr uint32_t WAVES = G::WAVES, TILE = G::TILE, RING = G::RING, PASSES = G::PASSES;
     constexpr uint32_t EPD = 4 / sizeof(elem_t);                                // elements per dword (flush granule)
-    __shared__ __attribute__((aligned(16))) elem_t ring[M2_RING + 64];   // (+ a dump for the stores of idle bytes)
-    __shared__ __attribute__((aligned(8))) uint16_t P[M2_PASSES * 4 * M2_THREADS];
+    __shared__ __attribute__((aligned(16))) elem_t ring[RING + 64];   // (+ a dump for the stores of idle bytes)
+    __shared__ __attribute__((aligned(8))) uint16_t P[PASSES * 4 * THREADS];
     // per code of the tile: x = inclusive end offset, y = code word; four sentinels behind the last (never passed)
-    __shared__ __attribute__((aligned(8))) uint2 XC[M2_THREADS + 4];
-    __shared__ uint32_t s_w[8];
-    __shared__ uint32_t s_any[2][4];
+    __shared__ __attribute__((aligned(8))) uint2 XC[THREADS + 4];
+    __shared__ uint32_t s_w[2 * WAVES];
+    __shared__ uint32_t s_any[2][WAVES];
     const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;   // unit-major (XCD balance, see K3)
     const BlkEmit job = jobs[bidx];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -909,7 +921,7 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
         if (u != 0) return;
         elem_t *o = out + job.out_off;
         const uint8_t *src = in + (job.data_bit >> 3);
-        for (uint64_t k = tid; k < job.n_out; k += M2_THREADS) o[k] = src[k];
+        for (uint64_t k = tid; k < job.n_out; k += THREADS) o[k] = src[k];
         return;
     }
     const BlkUnits *U = &units[bidx];
@@ -920,14 +932,14 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     elem_t *o = out + gbase;
     const uint32_t *cp = codes + job.code_off + c0;
     const uint32_t n = c1 - c0;
-    // unit element p lives at ring index (p + shift) mod M2_RING; ring and output share their dword alignment.
+    // unit element p lives at ring index (p + shift) mod RING; ring and output share their dword alignment.
     // History in front of the block (batch rounds / ordered runs: already final in `out`): up to 32 KiB preloaded;
     // SYM: the 32 Ki markers "entry j of the window in front of this unit".
     const uint32_t hist = SYM ? 32768u : (u == 0 && job.preload) ? (uint32_t)(job.hist < 32768 ? job.hist : 32768) : 0;
-    const uint32_t shift = (uint32_t)((gbase - hist) & (EPD - 1)) + hist;       // < M2_RING
-    for (uint32_t k = tid; k < hist; k += M2_THREADS)
+    const uint32_t shift = (uint32_t)((gbase - hist) & (EPD - 1)) + hist;       // < RING
+    for (uint32_t k = tid; k < hist; k += THREADS)
         ring[shift - hist + k] = SYM ? (elem_t)(256 + k) : (elem_t)o[(int64_t)k - (int64_t)hist];
-    if (tid < 4) XC[M2_THREADS + tid] = make_uint2(0xFFFFFFFFu, 0u);
+    if (tid < 4) XC[THREADS + tid] = make_uint2(0xFFFFFFFFu, 0u);
     uint64_t produced = 0, flushed = 0;
     uint32_t tr = shift;                       // ring index of the tile's first byte
     uint32_t fr = shift;                       // ring index of byte `flushed`
@@ -938,39 +950,45 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     while (base < n) {
         ntiles++;
         const uint32_t i = base + tid;
-        const uint32_t c_pref = (uint64_t)i + M2_THREADS < n ? cp[i + M2_THREADS] : 0;   // assuming the whole tile is taken
+        const uint32_t c_pref = (uint64_t)i + THREADS < n ? cp[i + THREADS] : 0;   // assuming the whole tile is taken
         const uint32_t c = c_cur;
         const uint32_t mylen = i < n ? ((c & 0xFFFFu) ? c >> 16 : 1u) : 0u;
         uint32_t x = wave_inclusive_sum(mylen);
         if (lane == 63) s_w[wave] = x;
         __syncthreads();       // (also: the previous tile's flush has read the ring before this tile writes it)
-        const uint32_t w0 = s_w[0], w1 = s_w[1], w2 = s_w[2], w3 = s_w[3];
-        x += (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-        const uint32_t tot = w0 + w1 + w2 + w3;
+        uint32_t tot = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < WAVES; ++j) {
+            const uint32_t wj = s_w[j];
+            x += j < wave ? wj : 0u;
+            tot += wj;
+        }
         XC[tid] = make_uint2(x, c);
-        if (tot > M2_TILE) {   // (uniform) only the codes whose output fits are taken; a code is at most 258 bytes
-            const uint32_t cnt = (uint32_t)__popcll(__ballot(x <= M2_TILE));
-            if (lane == 0) s_w[4 + wave] = cnt;
+        if (tot > TILE) {   // (uniform) only the codes whose output fits are taken; a code is at most 258 bytes
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(x <= TILE));
+            if (lane == 0) s_w[WAVES + wave] = cnt;
         }
         __syncthreads();
-        uint32_t take = M2_THREADS, total = tot;
-        if (tot > M2_TILE) {
-            take = s_w[4] + s_w[5] + s_w[6] + s_w[7];
+        uint32_t take = THREADS, total = tot;
+        if (tot > TILE) {
+            take = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < WAVES; ++j) take += s_w[WAVES + j];
             total = XC[take - 1].x;
         }
         // ---- round 0: bytes -> owner code -> literal / final source / pointer.  Branch-free: every byte loads from the
         //      ring (its own slot when there is nothing to fetch) and stores (to the dump when it lies behind the tile).
-        uint32_t pp[M2_PASSES][4];
+        uint32_t pp[PASSES][4];
         bool pend = false;
 #pragma unroll
-        for (uint32_t ps = 0; ps < M2_PASSES; ++ps) {
-            const uint32_t b = ps * 4 * M2_THREADS + 4 * tid;
+        for (uint32_t ps = 0; ps < PASSES; ++ps) {
+            const uint32_t b = ps * 4 * THREADS + 4 * tid;
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) pp[ps][q] = M2_DONE;
             if (ps == 0 || __ballot(b < total)) {   // (pass 1 and later: whole wavefronts skip)
                 uint32_t k = 0;   // smallest k with X[k] > b  (zero-length slots behind the last code are never chosen)
 #pragma unroll
-                for (uint32_t step = M2_THREADS / 2; step; step >>= 1) k += XC[k + step - 1].x <= b ? step : 0u;
+                for (uint32_t step = THREADS / 2; step; step >>= 1) k += XC[k + step - 1].x <= b ? step : 0u;
                 uint32_t src[4], dst[4], cwq[4];
                 bool lit[4], fin[4];
 #pragma unroll
@@ -979,12 +997,12 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
                     if (q) k += bi >= cwq[q - 1] ? 1u : 0u;        // (cwq[q-1] still holds the previous owner's end offset)
                     const uint2 xc = XC[k];
                     const uint32_t d = xc.y & 0xFFFFu;
-                    const uint32_t t = m2_wrap(tr + bi);
+                    const uint32_t t = m2_wrap<RING>(tr + bi);
                     const bool in = bi < total;
                     lit[q] = d == 0;
                     fin[q] = lit[q] || d > bi;
-                    src[q] = (d > bi && in) ? m2_back(t, d) : t;
-                    dst[q] = in ? t : M2_RING + (tid & 63u);
+                    src[q] = (d > bi && in) ? m2_back<RING>(t, d) : t;
+                    dst[q] = in ? t : RING + (tid & 63u);
                     pp[ps][q] = (fin[q] || !in) ? M2_DONE : bi - d;
                     cwq[q] = xc.x;                                  // end offset now, code word's literal below
                     src[q] |= xc.y & 0xFFFF0000u;                   // (ring indices are below 2^16: the value rides along)
@@ -1005,14 +1023,16 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
             const uint64_t bal = __ballot(pend);
             if (lane == 0) s_any[par][wave] = bal != 0;
             __syncthreads();
-            const uint32_t any = s_any[par][0] | s_any[par][1] | s_any[par][2] | s_any[par][3];
+            uint32_t any = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < WAVES; ++j) any |= s_any[par][j];
             par ^= 1;
             if (!any) break;
             nrounds++;
             if (pend) {
 #pragma unroll
-                for (uint32_t ps = 0; ps < M2_PASSES; ++ps) {
-                    const uint32_t b = ps * 4 * M2_THREADS + 4 * tid;
+                for (uint32_t ps = 0; ps < PASSES; ++ps) {
+                    const uint32_t b = ps * 4 * THREADS + 4 * tid;
                     if (ps && (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) == M2_DONE) continue;
                     uint32_t nx[4], hv[4], jj[4];
 #pragma unroll
@@ -1022,12 +1042,12 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
                     }
                     asm volatile("" ::: "memory");   // the states are loaded BEFORE the bytes (the LDS keeps a wavefront's order)
 #pragma unroll
-                    for (uint32_t q = 0; q < 4; ++q) hv[q] = ring[m2_wrap(tr + jj[q])];
+                    for (uint32_t q = 0; q < 4; ++q) hv[q] = ring[m2_wrap<RING>(tr + jj[q])];
 #pragma unroll
                     for (uint32_t q = 0; q < 4; ++q) {
                         // (a byte that was final before reads itself — also one behind the tile — and writes the same
                         //  byte and the same state back)
-                        ring[m2_wrap(tr + b + q)] = (elem_t)hv[q];
+                        ring[m2_wrap<RING>(tr + b + q)] = (elem_t)hv[q];
                         pp[ps][q] = nx[q];
                     }
                     asm volatile("" ::: "memory");   // ... and the bytes are stored BEFORE the states
@@ -1035,7 +1055,7 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
                 }
                 pend = false;
 #pragma unroll
-                for (uint32_t ps = 0; ps < M2_PASSES; ++ps) pend |= (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) != M2_DONE;
+                for (uint32_t ps = 0; ps < PASSES; ++ps) pend |= (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) != M2_DONE;
             }
         }
         // ---- flush: whole dwords; what is left over waits for the next tile
@@ -1045,23 +1065,23 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
         if ((gbase + flushed) & (EPD - 1)) {   // (only in front of the first aligned dword)
             uint32_t hb = EPD - (uint32_t)((gbase + flushed) & (EPD - 1));
             if (hb > upto - flushed) hb = (uint32_t)(upto - flushed);
-            if (tid < hb) o[flushed + tid] = ring[m2_wrap(fr + tid)];
+            if (tid < hb) o[flushed + tid] = ring[m2_wrap<RING>(fr + tid)];
             flushed += hb;
-            fr = m2_wrap(fr + hb);
+            fr = m2_wrap<RING>(fr + hb);
         }
         const uint32_t ndw = (uint32_t)((upto - flushed) / EPD);
         uint32_t *o32 = (uint32_t *)(o + flushed);
-        for (uint32_t k = tid; k < ndw; k += M2_THREADS) o32[k] = *(const uint32_t *)&ring[m2_wrap(fr + EPD * k)];
+        for (uint32_t k = tid; k < ndw; k += THREADS) o32[k] = *(const uint32_t *)&ring[m2_wrap<RING>(fr + EPD * k)];
         flushed += (uint64_t)EPD * ndw;
-        fr = m2_wrap(fr + EPD * ndw);
+        fr = m2_wrap<RING>(fr + EPD * ndw);
         if (last) {
             const uint32_t rest = (uint32_t)(upto - flushed);
-            if (tid < rest) o[flushed + tid] = ring[m2_wrap(fr + tid)];
+            if (tid < rest) o[flushed + tid] = ring[m2_wrap<RING>(fr + tid)];
             flushed = upto;
         }
         produced = upto;
-        tr = m2_wrap(tr + total);
-        c_cur = take == M2_THREADS ? c_pref : ((uint64_t)base + tid < n ? cp[base + tid] : 0);   // rare path: reload
+        tr = m2_wrap<RING>(tr + total);
+        c_cur = take == THREADS ? c_pref : ((uint64_t)base + tid < n ? cp[base + tid] : 0);   // rare path: reload
     }
     if (!SYM && dbg && tid == 0) {
         uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
@@ -1070,13 +1090,14 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
 }
 
 
-__global__ __launch_bounds__(M2_THREADS) void blk_materialize2_kernel(const uint8_t *__restrict__ in,
-                                                                      const BlkEmit *__restrict__ jobs,
-                                                                      const BlkUnits *__restrict__ units,
-                                                                      const uint32_t *__restrict__ codes,
-                                                                      uint8_t *__restrict__ out, uint32_t njobs,
-                                                                      uint64_t *__restrict__ dbg) {
-    materialize2_body<false>(in, jobs, units, codes, out, njobs, dbg);
+template <uint32_t THREADS>
+__global__ __launch_bounds__(THREADS) void blk_materialize2_kernel(const uint8_t *__restrict__ in,
+                                                                   const BlkEmit *__restrict__ jobs,
+                                                                   const BlkUnits *__restrict__ units,
+                                                                   const uint32_t *__restrict__ codes,
+                                                                   uint8_t *__restrict__ out, uint32_t njobs,
+                                                                   uint64_t *__restrict__ dbg) {
+    materialize2_body<false, THREADS>(in, jobs, units, codes, out, njobs, dbg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1382,12 +1403,12 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
 
 // marker path, pass 1, second generation: the byte kernel's tiles on 16-bit symbols (75 KB of LDS: two units per CU,
 // eight wavefronts per CU where the first-generation kernel above runs two)
-__global__ __launch_bounds__(M2_THREADS) void blk_materialize2_sym_kernel(const uint8_t *__restrict__ in,
+__global__ __launch_bounds__(M2_SYM_THREADS) void blk_materialize2_sym_kernel(const uint8_t *__restrict__ in,
                                                                           const BlkEmit *__restrict__ jobs,
                                                                           const BlkUnits *__restrict__ units,
                                                                           const uint32_t *__restrict__ codes,
                                                                           uint16_t *__restrict__ sym, uint32_t njobs) {
-    materialize2_body<true>(in, jobs, units, codes, sym, njobs, nullptr);
+    materialize2_body<true, M2_SYM_THREADS>(in, jobs, units, codes, sym, njobs, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1427,14 +1448,14 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_materialize2_kernel, dim3(njobs * MAX_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
+    hipLaunchKernelGGL(blk_materialize2_kernel<M2_THREADS>, dim3(njobs * MAX_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
 int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                                const BlkUnits *units, const uint32_t *codes, uint16_t *sym) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_materialize2_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, sym, njobs);
+    hipLaunchKernelGGL(blk_materialize2_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_SYM_THREADS), 0, st, in, jobs, units, codes, sym, njobs);
     LFX_LAUNCH_CHECK();
     return 0;
 }
