@@ -224,6 +224,7 @@ void Diag::read() {
     batch_serial = on("LFX_BATCH_SERIAL");
     no_markers = on("LFX_NO_MARKERS");
     no_pieces = on("LFX_NO_PIECES");
+    no_final_cand = on("LFX_NO_FINAL_CAND");
     window_chain = on("LFX_WINDOW_CHAIN");
     if (const char *fs = getenv("LFX_FREE_SHIFT")) free_shift = atoi(fs);
 }

@@ -27,6 +27,7 @@ struct Diag {
     bool batch_serial = false;   // LFX_BATCH_SERIAL: every stream of a batch through the serial kernel
     bool no_markers = false;     // LFX_NO_MARKERS
     bool no_pieces = false;      // LFX_NO_PIECES
+    bool no_final_cand = false;  // LFX_NO_FINAL_CAND: the finder reports no BFINAL header at all (the chain walk scans the last block on demand)
     bool window_chain = false;   // LFX_WINDOW_CHAIN
     int free_shift = -1;         // LFX_FREE_SHIFT
     void read();

@@ -139,7 +139,11 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 512);
         uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
         HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
-        LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap));
+        // (the member's last block is looked for in the final eighth of the input, at least 8 MiB of it: one that starts
+        //  earlier — a last block of more than that — is scanned on demand by the chain walk below)
+        const uint64_t tail_bytes = std::max<uint64_t>(comp / 8, 8ull << 20);
+        const uint64_t final_from = c->diag.no_final_cand ? ~0ull >> 1 : comp > tail_bytes ? (n - tail_bytes) * 8 : 0;
+        LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap, final_from));
         uint32_t counts[FIND_SHARDS + 1];
         HIP_TRY(hipMemcpyAsync(counts, d_count, sizeof counts, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -753,7 +757,7 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
     HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
     std::vector<uint64_t> starts;
     if (n >= 16) {
-        LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap));
+        LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap, 0));   // (the chain is walked on tuples: every start is needed)
         uint32_t counts[FIND_SHARDS + 1];
         HIP_TRY(hipMemcpyAsync(counts, d_count, sizeof counts, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

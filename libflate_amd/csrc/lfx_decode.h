@@ -155,7 +155,7 @@ constexpr uint32_t FIND_SHARDS = 32;
 struct FindPrefix { uint32_t off[FIND_SHARDS + 1]; };   // prefix sums of the per-shard survivor counts
 // count: FIND_SHARDS + 1 words (the last one marks a workgroup overflow)
 int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint64_t first_byte,
-                       uint32_t *count, uint64_t *cand, uint32_t shard_cap);
+                       uint32_t *count, uint64_t *cand, uint32_t shard_cap, uint64_t final_from_bit);
 // survivors of the full header check are appended to final[] (final_count = number appended)
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
                        uint32_t shard_cap, FindPrefix pre, uint32_t *final_count, uint64_t *final_list,

@@ -502,7 +502,8 @@ constexpr uint32_t FIND_DWORDS = 1024;   // dwords (4 KiB of stream) per workgro
 constexpr uint32_t FIND_WL = 512;        // survivors a workgroup can hold (expected: ~30)
 __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                           uint64_t first_byte, uint32_t *__restrict__ count,
-                                                          uint64_t *__restrict__ cand, uint32_t shard_cap) {
+                                                          uint64_t *__restrict__ cand, uint32_t shard_cap,
+                                                          uint64_t final_from_bit) {
     __shared__ uint32_t sd[FIND_DWORDS + 4];
     __shared__ uint64_t wl[FIND_WL];
     __shared__ uint32_t wn, wbase;
@@ -527,8 +528,11 @@ __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restr
         const uint64_t dword_bit0 = (4 * (w0 + t) - shift) * 8;    // "negative" only for the first dword when shift > 0
         const uint32_t d0 = sd[t], d1 = sd[t + 1], d2 = sd[t + 2], d3 = sd[t + 3];
         const uint64_t lo = (uint64_t)d0 | (uint64_t)d1 << 32, hi = (uint64_t)d2 | (uint64_t)d3 << 32;
-        // offsets whose BTYPE field (bits 1..2) reads 2: bit 1 clear, bit 2 set — a quarter of them
-        uint32_t pm = (uint32_t)(~(lo >> 1) & (lo >> 2));
+        // offsets whose BTYPE field (bits 1..2) reads 2: bit 1 clear, bit 2 set — a quarter of them.  A header with
+        // BFINAL set is wanted only near the end of the stream (final_from_bit, see launch_find_stage1): elsewhere the
+        // offsets with bit 0 set are dropped too, which halves the candidates of both stages.
+        const uint32_t allow_final = dword_bit0 + 32 > final_from_bit ? ~0u : 0u;
+        uint32_t pm = (uint32_t)(~(lo >> 1) & (lo >> 2)) & (~d0 | allow_final);
         while (pm) {
             const uint32_t ph = (uint32_t)__builtin_ctz(pm);
             pm &= pm - 1;
@@ -624,12 +628,16 @@ int launch_inflate(hipStream_t st, const uint8_t *in, uint8_t *out, const Inflat
     LFX_LAUNCH_CHECK();
     return 0;
 }
+// final_from_bit: headers with BFINAL set are reported only from this stream bit on.  The last block of a member is the
+// only one that carries the flag, and the chain walk scans a block the finder did not report on demand — so a caller that
+// walks the chain itself may pass the start of the stream's tail (where a last block of ordinary size begins) instead
+// of 0 and save half of the finder's work; a caller that depends on every start being reported passes 0.
 int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint64_t first_byte,
-                       uint32_t *count, uint64_t *cand, uint32_t shard_cap) {
+                       uint32_t *count, uint64_t *cand, uint32_t shard_cap, uint64_t final_from_bit) {
     if (nbytes <= first_byte) return 0;
     const uint64_t n = nbytes - first_byte;
     hipLaunchKernelGGL(find_blocks_stage1, dim3((uint32_t)div_up(n + 4, 4 * FIND_DWORDS)), dim3(256), 0, st, in, nbytes,
-                       first_byte, count, cand, shard_cap);
+                       first_byte, count, cand, shard_cap, final_from_bit);
     LFX_LAUNCH_CHECK();
     return 0;
 }

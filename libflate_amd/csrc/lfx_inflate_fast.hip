@@ -243,9 +243,15 @@ struct FastBits {
         const uint32_t off = (uint32_t)abs & 31;
         const uint32_t f = ld(widx);
         q0 = ld(widx + 1); q1 = ld(widx + 2); q2 = ld(widx + 3); q3 = ld(widx + 4); q4 = 0; qn = 4;
+        // The FIFO dwords are pinned (an empty asm that reads them) before the in-flight ones are loaded: without it the
+        // compiler issues the q loads LAST, the first use of the FIFO inside the symbol loop then needs vmcnt(0), and —
+        // the wait being one instruction for both loop edges — every symbol waited for the four prefetch loads (and the
+        // code stores) just issued: the look-ahead was dead and every reload period paid a full memory round trip.
+        uint32_t f_ = f;
+        asm volatile("" : "+v"(f_), "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
         x0 = ld(widx + 5); x1 = ld(widx + 6); x2 = ld(widx + 7); x3 = ld(widx + 8);
         widx += 9;
-        buf = (uint64_t)(f >> off);
+        buf = (uint64_t)(f_ >> off);
         nb = 32 - off;
         used = 0;
     }
@@ -259,13 +265,19 @@ struct FastBits {
         qn -= need ? 1u : 0u;
     }
     __device__ __forceinline__ void skip(uint32_t k) { buf >>= k; nb -= k; used += k; }
-    __device__ __forceinline__ void reload() {   // qn is 0 or 1 here
+    // reload in two halves, so that the caller's code stores go between them: the wait for the in-flight dwords then
+    // sits in FRONT of the stores (vmcnt counts loads and stores alike, in order: behind them it waits for their
+    // acknowledgements too)
+    __device__ __forceinline__ void take() {     // qn is 0 or 1 here
         if (qn == 0) { q0 = x0; q1 = x1; q2 = x2; q3 = x3; qn = 4; }
         else { q1 = x0; q2 = x1; q3 = x2; q4 = x3; qn = 5; }
-        __builtin_amdgcn_sched_barrier(0);       // keep the loads below the moves above
+        __builtin_amdgcn_sched_barrier(0);       // keep the caller's stores and the loads of issue() below the moves above
+    }
+    __device__ __forceinline__ void issue() {
         x0 = ld(widx); x1 = ld(widx + 1); x2 = ld(widx + 2); x3 = ld(widx + 3);
         widx += 4;
     }
+    __device__ __forceinline__ void reload() { take(); issue(); }
 };
 
 constexpr uint32_t EMIT_STAGE = 8;             // code words staged per lane (two workgroups' staging must fit one CU)
@@ -293,43 +305,56 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
     const uint32_t lim = span > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)span;
     int ret = 0;
     uint32_t no = 0;   // bytes produced by this call (added to nout at the end)
+    int32_t reach_rel = INT32_MAX;   // EMIT: smallest (bytes produced by this call) - distance over the matches
     while (b.used < lim && ret == 0) {
-        // each symbol takes at most two dwords from the FIFO
-        while (b.qn >= 2 && b.used < lim && (!EMIT || staged < EMIT_STAGE)) {
+        // each symbol takes at most two dwords from the FIFO.
+        // ONE divergent region per symbol: the loop runs on the lanes that still take a symbol, and EndOfBlock or an
+        // undecodable code end a lane by predication (zero-length skips, nothing staged, nothing counted) instead of by
+        // breaks — every break cost the loop an exec-mask save / merge of its own, about 30 scalar instructions per
+        // symbol on top of 95 vector ones.
+        bool act = b.qn >= 2 && (!EMIT || staged < EMIT_STAGE);      // (b.used < lim holds here)
+        while (act) {
             b.append();
             uint32_t e = T.lit[(uint32_t)b.buf & ((1u << LIT_BITS) - 1)];
-            if (__builtin_expect((e & 15) == 0, 0)) {
+            if (__builtin_expect((e & 15) == 0, 0))
                 e = e == E_LONG ? long_lookup(T.lit_count, T.lit_sorted, T.lit_info, 286, b.buf) : 0;
-                if (e == 0) { ret = 2; break; }
-            }
+            const bool bad1 = e == 0;
             const uint32_t kind = (e >> 4) & 3;
-            if (__builtin_expect(kind == K_EOB, 0)) { b.skip(e & 15); ret = 1; break; }
+            const bool eob = kind == K_EOB;              // (an entry 0 has kind 0: never EndOfBlock)
             // Literals and matches share one straight-line path (a literal is a symbol without extra bits and
             // without a distance): nearly every wavefront iteration holds both kinds, and a divergent branch
             // costs exec-mask round trips and a register copy per live value.  A literal lane also tops up
             // its bit window and looks up a distance entry; both are harmless and ignored.
             const bool is_match = kind == K_LEN;
-            const uint32_t w = e & 15, eb = (e >> 6) & 31;
+            const uint32_t w = e & 15, eb = (e >> 6) & 31;      // (EndOfBlock carries no extra bits; entry 0: w = eb = 0)
             const uint32_t val = (e >> 16) + (((uint32_t)(b.buf >> w)) & ((1u << eb) - 1));   // byte, or length
             b.skip(w + eb);
             b.append();
             uint32_t d = T.dist[(uint32_t)b.buf & ((1u << DIST_BITS) - 1)];
-            if (__builtin_expect(is_match && (d & 15) == 0, 0)) {
+            if (__builtin_expect(is_match && (d & 15) == 0, 0))
                 d = d == E_LONG ? long_lookup(T.dist_count, T.dist_sorted, T.dist_info, 30, b.buf) : 0;
-                if (d == 0) { ret = 2; break; }
-            }
+            const bool bad2 = is_match && d == 0;
+            const bool ok = !(bad1 || eob || bad2);
+            const bool okm = ok && is_match;
             const uint32_t dw = d & 15, db = (d >> 6) & 31;
             const uint32_t distance = (d >> 16) + (((uint32_t)(b.buf >> dw)) & ((1u << db) - 1));
-            b.skip(is_match ? dw + db : 0u);
+            b.skip(okm ? dw + db : 0u);
+            ret = (bad1 || bad2) ? 2 : eob ? 1 : 0;
             if (EMIT) {
-                stage[staged++] = (val << 16) | (is_match ? distance : 0u);
-                const int64_t srcpos = (int64_t)(nout + no) - (int64_t)distance;   // first byte a match reads
-                if (is_match && srcpos < reach) reach = srcpos;
-                if (is_match && (int32_t)no - (int32_t)distance < (int32_t)cut_out) { cut_code = ncodes + 1; cut_out = no + val; }
+                stage[staged] = (val << 16) | (is_match ? distance : 0u);    // (a slot behind the last code is never flushed)
+                staged += ok ? 1u : 0u;
+                const int32_t rel = (int32_t)no - (int32_t)distance;          // first byte a match reads
+                reach_rel = okm && rel < reach_rel ? rel : reach_rel;
+                const bool cut = okm && rel < (int32_t)cut_out;
+                cut_code = cut ? ncodes + 1 : cut_code;
+                cut_out = cut ? no + val : cut_out;
             }
-            ncodes++;
-            no += is_match ? val : 1u;
+            ncodes += ok ? 1u : 0u;
+            no += ok ? (is_match ? val : 1u) : 0u;
+            act = ok && b.qn >= 2 && b.used < lim && (!EMIT || staged < EMIT_STAGE);
         }
+        const bool refill = ret == 0 && b.used < lim && b.qn < 2;
+        if (refill) b.take();
         if (EMIT) {
             uint32_t *dst = codes + (ncodes - staged);
             for (uint32_t j = 0; j < EMIT_STAGE; j += 4) {
@@ -349,7 +374,11 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
             }
             staged = 0;
         }
-        if (ret == 0 && b.used < lim && b.qn < 2) b.reload();
+        if (refill) b.issue();
+    }
+    if (EMIT && reach_rel != INT32_MAX) {
+        const int64_t r = (int64_t)nout + (int64_t)reach_rel;
+        reach = r < reach ? r : reach;
     }
     nout += no;
     endpos = start + b.used;

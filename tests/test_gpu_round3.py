@@ -318,3 +318,23 @@ def test_gzip_header_empty_name_and_comment(env, oracle):
     assert d.read_to_end() == data
     s2 = oracle.encode(oracle.GZIP, data, 0, mtime=9)
     assert lfx.gzip.Decoder.new(s2).header()["filename"] is None
+
+
+def test_final_block_outside_the_finder_tail(env, oracle, monkeypatch):
+    """The block finder reports headers with BFINAL set only near the end of the stream (lfx_decode.cpp, final_from);
+    a last block that starts earlier is scanned on demand by the chain walk.  LFX_NO_FINAL_CAND drops every BFINAL
+    candidate, so the last block of every multi-block member takes that path (decode.rs:112-164: same bytes)."""
+    lfx, ctx, ffi, synth = env
+    monkeypatch.setenv("LFX_NO_FINAL_CAND", "1")
+    c1 = lfx.Context(0)
+    monkeypatch.delenv("LFX_NO_FINAL_CAND")
+    try:
+        for n in (3 * (1 << 20) + 12345, (12 << 20) + 7):           # the last block: a remainder of ordinary size
+            data = synth.text(n).tobytes()
+            s = oracle.encode(oracle.GZIP, data, write_size=8192, mtime=0)
+            rc, out, used, msg = c1.decode_host(ffi.GZIP, s, n)
+            assert rc == 0 and used == len(s) and out == data, (n, rc, msg)
+            rc, out, used, msg = ctx.decode_host(ffi.GZIP, s, n)
+            assert rc == 0 and used == len(s) and out == data, (n, rc, msg)
+    finally:
+        c1.close()
