@@ -438,6 +438,11 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "3", w,
                     match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
+        if (!match_v1)
+            for (int w = 1; w < 16; w++)
+                fprintf(stderr, "[lfx] match3 wave%d loop trips: sum=%u max=%u tiles>4=%u tiles>8=%u trips-without-pointers=%u\n", w,
+                        (unsigned)hv[w * 8 + 3], (unsigned)(hv[w * 8 + 3] >> 32), (unsigned)hv[w * 8 + 4], (unsigned)(hv[w * 8 + 4] >> 32),
+                        (unsigned)hv[w * 8 + 6]);
     }
     c->phase("lz77_match");
     if (c->diag.debug && getenv("LFX_DUMP_SEG")) {

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
     uint32_t pend_lo = loaded_to, pend_hi = loaded_to, pend_off = fill_off;
     uint32_t r_dist = 0, r_d = 0, r_found = 0;     // R1: phase A (first hop) → phase B (further hops)
     uint64_t cy_a = 0, cy_b = 0, cy_w = 0;
+    uint32_t tr_sum = 0, tr_max = 0, tr_gt4 = 0, tr_gt8 = 0, tr_r1 = 0;   // DBG: trips of the phase-B loop
     constexpr uint32_t FILL_LANE0 = 4 * 64;        // resolver lanes [256, 496) move the window bytes
     constexpr uint32_t SWEEP_DW = (1u << (HASH_BITS - 1)) / SWEEP_SLICES;   // 256 head dwords per tile: resolver lanes [0, 256)
     static_assert(FILL_LANE0 + TILE / 4 <= TILE && SWEEP_DW <= FILL_LANE0, "lane assignment of the fill and the sweep");
@@ -360,9 +361,18 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
             //      slots F2(it+1) stores at the end.
             //      ONE loop advances both chains: its trip count is the longer of the two, not their sum — every trip is an
             //      LDS round trip on the workgroup's critical path.
+            //      (Measured, round 3: 3.2 trips per wavefront and tile on average, more than 4 in one of seven, more than
+            //      8 in one of 23 — a rare prefix in a bucket that two frequent ones alternate in walks dozens of links —
+            //      so most tiles see a wavefront with 8-9 trips.  Carrying unfinished walks over into the next two tiles
+            //      (nothing in the kernel consumes their answers) cut the tiles with more than 4 trips from 36 to 4 per
+            //      wavefront and made the kernel SLOWER, 3.04 ms against 2.65: the second walk's loads in every trip cost
+            //      more than the waiting they remove — the tile is bound by the sum of the LDS and vector work of its
+            //      fifteen wavefronts, not by the slowest of them.)
             uint32_t e = lk_f;                                         // (NONE where the position takes no part)
             uint32_t dist = r_dist, d = r_d, found = r_found;
+            uint32_t trips = 0;
             for (;;) {
+                if (DBG) { trips++; if (__ballot(e >= LK_PTR) == 0) tr_r1++; }
                 // loads (a lane whose link state is final reads its own slot, which holds that state: the update is the
                 // identity; a lane whose walk has ended reads its own position)
                 const uint32_t j = min(e - LK_PTR, idx);
@@ -385,6 +395,7 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
                 }
                 if (!__ballot(e >= LK_PTR || d != 0)) break;
             }
+            if (DBG) { tr_sum += trips; tr_max = max(tr_max, trips); tr_gt4 += trips > 4; tr_gt8 += trips > 8; }
             e_f = e;
             prevd[o_f] = (uint16_t)e;        // (positions outside the chain structure: their slot is never read)
             if (act_r) cd_c[p_r] = (uint16_t)(found ? dist : 0u);
@@ -402,7 +413,8 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
     if (__ballot(viol) && lane == 0) atomicOr(flags, 1u);             // lane-order violation (never observed)
     if (DBG && dbg && blockIdx.x == 0 && lane == 0) {
         uint64_t *d = dbg + wave * 8;
-        d[0] = cy_a; d[1] = cy_b; d[2] = cy_w; d[3] = 0; d[4] = 0; d[5] = (uint64_t)ntiles;
+        d[0] = cy_a; d[1] = cy_b; d[2] = cy_w; d[3] = (uint64_t)tr_sum | (uint64_t)tr_max << 32; d[4] = (uint64_t)tr_gt4 | (uint64_t)tr_gt8 << 32;
+        d[5] = (uint64_t)ntiles; d[6] = tr_r1;
     }
 }
 
