@@ -366,6 +366,19 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         if (ch.flags & CH_LITERALS) continue;
         for (uint32_t s = 0; s < ch.n_seg; s += PARSE_WG_SEGS) pwgs.push_back(ParseWg{ci, s});
     }
+    // XCD-aware launch order: workgroup i runs on XCD i mod 8, and every XCD has an L2 of its own.  A workgroup stages the
+    // 32 KiB window in front of its 13 KiB of positions — the positions of its two or three left neighbours — so each XCD
+    // takes one contiguous eighth of the list and finds those bytes (and its own `cd` lines) in ITS L2 instead of
+    // fetching them over the fabric again (slots behind the end of an eighth are marked empty).
+    if (pwgs.size() > 8) {
+        const size_t nl = pwgs.size(), per = (nl + 7) / 8;
+        std::vector<ParseWg> phys(per * 8);
+        for (size_t i = 0; i < phys.size(); i++) {
+            const size_t l = (i % 8) * per + i / 8;
+            phys[i] = (i / 8 < per && l < nl && l / per == i % 8) ? pwgs[l] : ParseWg{0xFFFFFFFFu, 0u};
+        }
+        pwgs.swap(phys);
+    }
     c->cur_nchunks = nchunks;
     c->cur_nblocks = nblocks;
     c->cur_ntiles = plan.n_tiles;

@@ -17,7 +17,7 @@
 //     / parse_emit): they re-walk from a segment's true entry to the merge point, through global memory.
 // A workgroup is PARSE_WG_SEGS (4) wavefronts = 13312 consecutive positions of one chunk; it stages the bytes
 // [first position - 32 KiB, last position + 258 + slack) and the cd[] values of its positions in LDS (72 KB: two
-// workgroups per CU), so that a walk step — cd[p], then 8 bytes at p+3 and at p+3-d per compare step — is three LDS
+// workgroups per CU), so that a walk step — cd[p] together with 16 bytes at p+3, then 16 bytes at p+3-d per compare step — is two LDS
 // round trips and no HBM access.
 //
 // A code word is derivable from the visited set alone: the step at p is the distance to the next visited position, and
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
     uint32_t *cd32 = (uint32_t *)(smem + OFF_CD);
 
     const ParseWg wg = wgs[blockIdx.x];
+    if (wg.chunk == 0xFFFFFFFFu) return;              // an empty slot of the XCD-aware order (lfx_api.cpp)
     const ChunkDesc ch = chunks[wg.chunk];
     if (ch.flags & CH_LITERALS) return;               // no walk: every byte is a literal
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
