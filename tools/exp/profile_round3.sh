@@ -19,5 +19,9 @@ for pass in 1 2; do
   rm -rf $O/pmc_r3_$pass
 done
 cat $O/r3_pmc_1.csv $O/r3_pmc_2.csv | grep -v "at::native" > $O/r3_pmc_counters.csv; wc -l $O/r3_pmc_counters.csv
+# in-flight levels: SQ_INST_LEVEL_{VMEM,LDS} / SQ_INSTS_{VMEM,LDS} = average latency of vector-memory / LDS instructions (in LDS-latency units)
+rm -rf $O/pmc_r3_lat
+timeout 300 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM SQ_INSTS_LDS SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_r3_lat -- python $R/bench.py --child --steps 1 --warmup 0 > $O/pmc_r3_lat.log 2>&1
+python $R/tools/pmc_summary.py $O/pmc_r3_lat 2>/dev/null | grep -v "at::native" > $O/r3_pmc_latency.csv; rm -rf $O/pmc_r3_lat; wc -l $O/r3_pmc_latency.csv
 cd $R
 timeout 300 python tools/bench_small.py > $O/r3_small.json 2>/dev/null; cut -c1-300 $O/r3_small.json
