@@ -617,9 +617,21 @@ def main():
         "other_configs": subs,
         "cpu_baseline": cpu,
     }
-    print(json.dumps(line))
+    # The JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, whose buffer (when stdout is
+    # a pipe or a file) would otherwise be flushed at process exit, behind this line.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if dist:
-        dist.destroy_process_group()
+        dist.destroy_process_group()       # (the other ranks left theirs right after the timed region)
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -326,7 +326,8 @@ namespace lfx {
 // Stage A: plan upload → match → parse → histogram → Huffman (+ checksum).  Leaves everything the
 // emit stage needs in the context.
 int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *d_in, uint64_t n,
-                   bool want_checksum) {
+                   int ck_mode) {
+    const bool want_checksum = ck_mode != 0;   // 1: CRC-32 (gzip), 2: Adler-32 (zlib), 3: both (a shard: the caller folds either)
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     c->n_ev = 0;
@@ -496,7 +497,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         uint32_t *ck = (uint32_t *)c->d_ck.p;
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        LAUNCH_TRY(launch_checksum(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p));
+        LAUNCH_TRY(launch_checksum(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, ck_mode));
         HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
     }
     // enough workgroups to fill the GPU even when there are few chunks (schedule S1: one)
@@ -606,7 +607,7 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
         }
     }
     for (;;) {
-        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format != LFX_DEFLATE))) {
+        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, n, format == LFX_GZIP ? 1 : format == LFX_ZLIB ? 2 : 0))) {
             // the fill may still be running on the caller's buffer: do not return before it has finished
             if (c->prezero_ptr) (void)hipEventSynchronize(c->ev_zero);
             c->prezero_ptr = nullptr;
@@ -683,7 +684,7 @@ extern "C" int lfx_encode_shard_prepare(lfx_ctx *cc, int format, const lfx_encod
     hipStream_t st = c->stream;
     EncodeResult r{};
     for (;;) {
-        if ((rc = encode_prepare(c, *plan, po, (const uint8_t *)d_in, n, true))) return rc;
+        if ((rc = encode_prepare(c, *plan, po, (const uint8_t *)d_in, n, 3))) return rc;
         // total bits at bit phase 0 (compressed blocks only → independent of the phase)
         LAUNCH_TRY(launch_offsets(st, (const BlockDesc *)c->d_blocks.p, c->cur_nblocks, (const BlockCodes *)c->d_bc.p,
                                   0, ~0ull, (uint64_t *)c->d_block_start.p, (EncodeResult *)c->d_res.p));
@@ -788,7 +789,7 @@ static int enc_run(lfx_encoder *e, bool final) {
     EncodeResult res{};
     uint8_t prefix[1] = {e->carry};
     for (;;) {
-        if ((rc = encode_prepare(c, plan, e->po, (const uint8_t *)e->d_in.p, n, e->format != LFX_DEFLATE))) { e->err = c->err; return rc; }
+        if ((rc = encode_prepare(c, plan, e->po, (const uint8_t *)e->d_in.p, n, e->format == LFX_GZIP ? 1 : e->format == LFX_ZLIB ? 2 : 0))) { e->err = c->err; return rc; }
         // the container trailer is written by the host here (the checksum spans batches)
         rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits,
                          (uint8_t *)e->d_out.p, bound & ~3ull, &res);
@@ -944,7 +945,7 @@ extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
     HIP_TRY(hipMemcpyAsync(z->d_in.p, z->buf.data(), n, hipMemcpyHostToDevice, c->stream));
     uint32_t nc = 0;
     for (;;) {
-        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)z->d_in.p, n, false))) return rc;
+        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)z->d_in.p, n, 0))) return rc;
         EncodeResult r{};
         HIP_TRY(hipMemcpy(&r, c->d_res.p, sizeof r, hipMemcpyDeviceToHost));
         if (match_violation(c, r)) continue;

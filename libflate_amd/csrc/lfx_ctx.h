@@ -82,6 +82,6 @@ struct Ctx {
 };
 
 int encode_prepare(Ctx *c, const struct Plan &plan, const struct PlanOpts &po, const uint8_t *d_in,
-                   uint64_t n, bool want_checksum);
+                   uint64_t n, int ck_mode);
 
 }  // namespace lfx

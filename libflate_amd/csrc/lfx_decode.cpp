@@ -144,23 +144,26 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         const uint64_t tail_bytes = std::max<uint64_t>(comp / 8, 8ull << 20);
         const uint64_t final_from = c->diag.no_final_cand ? ~0ull >> 1 : comp > tail_bytes ? (n - tail_bytes) * 8 : 0;
         LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap, final_from));
-        uint32_t counts[FIND_SHARDS + 1];
-        HIP_TRY(hipMemcpyAsync(counts, d_count, sizeof counts, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         c->phase("find1");
-        FindPrefix pre;
-        bool overflow = counts[FIND_SHARDS] != 0;
-        pre.off[0] = 0;
-        for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (counts[k] > shard_cap) overflow = true; pre.off[k + 1] = pre.off[k] + counts[k]; }
-        const uint32_t n1 = pre.off[FIND_SHARDS];
+        // stage 2 takes the survivor counts from the device (persistent grid): no host round trip between the stages; the
+        // counts, the overflow marker, the number of results and the first results come back in ONE round trip
+        LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
+                                      (uint32_t)std::max(c->n_cu, 1)));
+        uint32_t hc[66];
+        constexpr uint32_t HEAD_N = 1024;      // (results that come back with the counts; a stream has a few hundred)
+        const uint32_t head_n = std::min<uint32_t>(HEAD_N, final_cap);
+        std::vector<uint64_t> cand(head_n);
+        HIP_TRY(hipMemcpyAsync(hc, d_count, sizeof hc, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cand.data(), d_final, 8ull * head_n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool overflow = hc[FIND_SHARDS] != 0;
+        uint32_t n1 = 0;
+        for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (hc[k] > shard_cap) overflow = true; n1 += hc[k]; }
         if (!overflow) {
-            LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, pre, d_final_count, d_final, final_cap));
-            uint32_t nf = 0;
-            HIP_TRY(hipMemcpyAsync(&nf, d_final_count, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            uint32_t nf = hc[64];
             if (nf > final_cap) nf = final_cap;
-            std::vector<uint64_t> cand(nf);
-            if (nf) HIP_TRY(hipMemcpy(cand.data(), d_final, 8ull * nf, hipMemcpyDeviceToHost));
+            cand.resize(nf);
+            if (nf > head_n) HIP_TRY(hipMemcpy(cand.data() + head_n, d_final + head_n, 8ull * (nf - head_n), hipMemcpyDeviceToHost));
             c->phase("find2");
             std::vector<uint64_t> starts;
             starts.push_back(first_bit);  // the first block's start is known
@@ -758,18 +761,15 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
     std::vector<uint64_t> starts;
     if (n >= 16) {
         LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap, 0));   // (the chain is walked on tuples: every start is needed)
-        uint32_t counts[FIND_SHARDS + 1];
-        HIP_TRY(hipMemcpyAsync(counts, d_count, sizeof counts, hipMemcpyDeviceToHost, st));
+        LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
+                                      (uint32_t)std::max(c->n_cu, 1)));
+        uint32_t hc[66];
+        HIP_TRY(hipMemcpyAsync(hc, d_count, sizeof hc, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        FindPrefix pre;
-        bool overflow = counts[FIND_SHARDS] != 0;
-        pre.off[0] = 0;
-        for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (counts[k] > shard_cap) overflow = true; pre.off[k + 1] = pre.off[k] + counts[k]; }
+        bool overflow = hc[FIND_SHARDS] != 0;
+        for (uint32_t k = 0; k < FIND_SHARDS; k++) if (hc[k] > shard_cap) overflow = true;
         if (overflow) { c->set_error("block finder overflow"); return LFX_E_UNSUPPORTED; }
-        LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, pre, d_final_count, d_final, final_cap));
-        uint32_t nf = 0;
-        HIP_TRY(hipMemcpyAsync(&nf, d_final_count, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t nf = hc[64];
         if (nf > final_cap) nf = final_cap;
         starts.resize(nf);
         if (nf) HIP_TRY(hipMemcpy(starts.data(), d_final, 8ull * nf, hipMemcpyDeviceToHost));

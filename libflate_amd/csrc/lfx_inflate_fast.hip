@@ -1314,30 +1314,23 @@ __device__ __forceinline__ void clen_table_build(uint8_t *tab, uint32_t lane, ui
 // block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
 // decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length code must be
 // complete and the distance code complete, single or empty.
-__global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restrict__ in, uint64_t nbytes,
-                                                         const uint64_t *__restrict__ cand, uint32_t shard_cap,
-                                                         FindPrefix pre, uint32_t *__restrict__ final_count,
-                                                         uint64_t *__restrict__ final_list, uint32_t final_cap) {
-    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= pre.off[FIND_SHARDS]) return;
-    uint32_t shard = 0;
-    for (uint32_t k = 1; k < FIND_SHARDS; ++k) shard += gi >= pre.off[k];
-    const uint64_t i = (uint64_t)shard * shard_cap + (gi - pre.off[shard]);
+// One stage-1 survivor per lane (`valid` lanes; the others walk along frozen): true when the header at cand_bit checks out.
+__device__ __forceinline__ bool stage2_check(const uint8_t *__restrict__ in, uint64_t nbytes, uint64_t cand_bit, bool valid,
+                                             uint8_t *cl_tab) {
     HdrBits hb;
-    hb.init(in, nbytes, cand[i]);
+    hb.init(in, nbytes, cand_bit);
     auto bits = [&](uint32_t w) -> uint32_t { return hb.get(w); };
     bits(3);
     const uint32_t nl = bits(5) + 257, nd = bits(5) + 1, nc = bits(4) + 4;
     uint64_t clw = 0;
     for (uint32_t k = 0; k < nc; ++k) clw |= (uint64_t)bits(3) << (3 * clen_order(k));
-    __shared__ uint8_t cl_tab[128 * 64];
     clen_table_build(cl_tab, threadIdx.x, clw);
     uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
     const uint32_t total = nl + nd;
-    bool good = !hb.bad;
+    bool good = valid && !hb.bad;
     // a header is at most 17 + 19*3 + 320*(7+7) = 4554 bits long: when every candidate of the wavefront lies
     // further than that from the end of the stream, the walk needs no bounds checks at all
-    const bool lean = __ballot(cand[i] + 6000 > hb.nbits) == 0;
+    const bool lean = __ballot(cand_bit + 6000 > hb.nbits) == 0;
     if (lean) {
         // Branch-free walk, one uniform loop for the wavefront: nearly every false candidate runs until its literal /
         // length widths are complete (their Kraft sum only then shows), so the wavefront's time is its instruction
@@ -1345,7 +1338,7 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
         // Bit source: the position behind the fixed header fields is known arithmetically; a 64-bit window topped up
         // from a one-dword-ahead pointer, no bounds checks (lean).
         const uint64_t a = (uint64_t)in;
-        const uint64_t abs = cand[i] + 17 + 3ull * nc + (a & 3) * 8;
+        const uint64_t abs = cand_bit + 17 + 3ull * nc + (a & 3) * 8;
         gptr_u32 p = (gptr_u32)(a & ~3ull) + (abs >> 5);
         const uint32_t off = (uint32_t)abs & 31;
         uint64_t buf = ((uint64_t)p[1] << 32 | p[0]) >> off;
@@ -1424,9 +1417,44 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
         if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
         if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
     }
-    if (good) {
-        const uint32_t slot = atomicAdd(final_count, 1u);   // a few hundred per stream
-        if (slot < final_cap) final_list[slot] = cand[i];
+    return good;
+}
+
+// Persistent grid (round 3): the number of survivors is only known on the device, so a fixed number of one-wavefront
+// workgroups fetch batches of 64 survivors from a device counter until the lists are exhausted — stage 1 and stage 2 run
+// back to back without the host reading the counts in between (it reads them, the overflow marker and the result list
+// in ONE round trip afterwards).
+__global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restrict__ in, uint64_t nbytes,
+                                                         const uint64_t *__restrict__ cand, uint32_t shard_cap,
+                                                         const uint32_t *__restrict__ count, uint32_t *__restrict__ work,
+                                                         uint32_t *__restrict__ final_count,
+                                                         uint64_t *__restrict__ final_list, uint32_t final_cap) {
+    __shared__ uint8_t cl_tab[128 * 64];
+    __shared__ uint32_t s_pre[FIND_SHARDS + 1], s_base;
+    if (threadIdx.x == 0) {
+        uint32_t off = 0;
+        for (uint32_t k = 0; k < FIND_SHARDS; ++k) { s_pre[k] = off; off += min(count[k], shard_cap); }   // (an overflow is the host's to report)
+        s_pre[FIND_SHARDS] = off;
+    }
+    __syncthreads();
+    const uint32_t n1 = s_pre[FIND_SHARDS];
+    for (;;) {
+        if (threadIdx.x == 0) s_base = atomicAdd(work, 64u);
+        __syncthreads();
+        const uint32_t base = s_base;
+        if (base >= n1) break;
+        const uint32_t gi = base + threadIdx.x;
+        const bool valid = gi < n1;
+        uint32_t shard = 0;
+        for (uint32_t k = 1; k < FIND_SHARDS; ++k) shard += gi >= s_pre[k];
+        const uint64_t i = (uint64_t)shard * shard_cap + (gi - s_pre[shard]);
+        const uint64_t cand_bit = valid ? cand[i] : 0;
+        const bool good = stage2_check(in, nbytes, cand_bit, valid, cl_tab);
+        if (good) {
+            const uint32_t slot = atomicAdd(final_count, 1u);   // a few hundred per stream
+            if (slot < final_cap) final_list[slot] = cand_bit;
+        }
+        __syncthreads();      // (s_base and the per-lane tables are reused)
     }
 }
 
@@ -1538,11 +1566,10 @@ int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *un
     return 0;
 }
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
-                       uint32_t shard_cap, FindPrefix pre, uint32_t *final_count, uint64_t *final_list,
-                       uint32_t final_cap) {
-    const uint32_t ncand = pre.off[FIND_SHARDS];
-    if (!ncand) return 0;
-    hipLaunchKernelGGL(find_blocks_stage2, dim3((ncand + 63) / 64), dim3(64), 0, st, in, nbytes, cand, shard_cap, pre,
+                       uint32_t shard_cap, const uint32_t *count, uint32_t *work, uint32_t *final_count, uint64_t *final_list,
+                       uint32_t final_cap, uint32_t n_cu) {
+    // (sixteen one-wavefront workgroups per CU: 8 KB of LDS each)
+    hipLaunchKernelGGL(find_blocks_stage2, dim3(16u * (n_cu ? n_cu : 256u)), dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work,
                        final_count, final_list, final_cap);
     LFX_LAUNCH_CHECK();
     return 0;
