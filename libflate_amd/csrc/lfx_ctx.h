@@ -14,6 +14,7 @@ namespace lfx {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    uint32_t gen = 0;           // bumped by every (re)allocation: a cached "this table is already there" must not survive one
     int reserve(size_t bytes);  // grow-only; contents are NOT preserved
     void release();
 };
@@ -55,6 +56,11 @@ struct Ctx {
     DevBuf d_chunks, d_blocks, d_segs, d_pwgs, d_cd, d_md, d_codes, d_ncodes, d_hist, d_bc, d_block_start, d_tile_bits,
         d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage, d_chunkmap;
     // decode scratch
+    // host shadows of the plan tables last uploaded (chunks, blocks, segments, parse workgroups) and the device buffers they
+    // went to: an encode with the same plan (same size, schedule and options — every step of a loop) uploads nothing, and a
+    // different plan is copied from the shadow, which outlives the asynchronous copy (no synchronisation either way)
+    std::vector<uint8_t> up_shadow[4];
+    uint64_t up_dev[4] = {0, 0, 0, 0};      // (buffer address ^ allocation generation << 48)
     DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks, d_dec_tabs, d_dec_sym, d_dec_win, d_dec_maps;
     std::vector<DevBuf *> all_bufs() {
         return {&d_chunks, &d_blocks, &d_segs, &d_pwgs, &d_cd, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
