@@ -517,8 +517,17 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                                 (const uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_hist.p));
     c->phase("histogram");
     LAUNCH_TRY(launch_huffman(st, (const BlockDesc *)c->d_blocks.p, nblocks, (const uint32_t *)c->d_hist.p,
-                              (BlockCodes *)c->d_bc.p));
+                              (BlockCodes *)c->d_bc.p, mdbg ? mdbg + 512 : nullptr));
     c->phase("huffman");
+    if (mdbg) {
+        uint64_t hv[24];
+        (void)hipMemcpy(hv, mdbg + 512, sizeof hv, hipMemcpyDeviceToHost);
+        static const char *nm[10] = {"lit: rank sort", "lit: depth", "lit: package-merge", "lit: widths", "lit: codes", "dist tree", "run lengths",
+                                     "code-length tree", "header bits", "body size"};
+        fprintf(stderr, "[lfx] huffman block 0 (cycles):");
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %s=%llu", nm[k], (unsigned long long)(hv[k + 1] - hv[k]));
+        fprintf(stderr, "\n");
+    }
     if (want_checksum) {
         HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
         c->phase("checksum");

@@ -52,7 +52,7 @@ int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks,
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
                      const uint32_t *codes, const uint32_t *ncodes, uint32_t *hist);
 int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,
-                   BlockCodes *bc);
+                   BlockCodes *bc, uint64_t *dbg = nullptr);
 int launch_offsets(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const BlockCodes *bc,
                    uint64_t start_bit, uint64_t cap_bits, uint64_t *block_start, EncodeResult *res);
 int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,

@@ -428,12 +428,13 @@ __global__ __launch_bounds__(256) void histogram_kernel(const ChunkDesc *__restr
 constexpr int HUFF_THREADS = 256;   // four wavefronts per block: the rank / merge / code passes stride over the lanes
 __global__ __launch_bounds__(HUFF_THREADS) void huffman_kernel(const BlockDesc *__restrict__ blocks,
                                                                const uint32_t *__restrict__ hist,
-                                                               BlockCodes *__restrict__ bc) {
+                                                               BlockCodes *__restrict__ bc, uint64_t *__restrict__ dbg) {
     __shared__ HuffScratch S;
     const uint32_t b = blockIdx.x;
     const uint32_t type = blocks[b].type;
     if (type == BT_RAW) return;
     huff_block_build(hist + (uint64_t)b * HIST_STRIDE, type, &bc[b], S, (int)threadIdx.x, HUFF_THREADS);
+    if (dbg && b == 0 && threadIdx.x < 24) dbg[threadIdx.x] = S.stamp[threadIdx.x];   // (LFX_DEBUG)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1101,9 +1102,9 @@ int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, 
     return 0;
 }
 int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,
-                   BlockCodes *bc) {
+                   BlockCodes *bc, uint64_t *dbg) {
     if (nblocks == 0) return 0;
-    hipLaunchKernelGGL(huffman_kernel, dim3(nblocks), dim3(HUFF_THREADS), 0, st, blocks, hist, bc);
+    hipLaunchKernelGGL(huffman_kernel, dim3(nblocks), dim3(HUFF_THREADS), 0, st, blocks, hist, bc, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }

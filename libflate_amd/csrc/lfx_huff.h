@@ -71,28 +71,40 @@ struct HuffScratch {
     int32_t L;                   // max bitwidth in force
     // header builder
     uint8_t rl_code[HMAX + 32], rl_bits[HMAX + 32], rl_extra[HMAX + 32];
+    uint8_t rl_w[HMAX + 32];     // header assembly: bits of entry i (its code-length code + extra bits)
     int32_t rl_n;
     uint8_t clw[19];
     uint16_t clc[19];
-    uint8_t lw[HMAX];            // saved literal widths while the clen code is built
-    uint8_t dw[32];
+    alignas(4) uint8_t lw[HMAX]; // saved literal widths while the clen code is built (read as dwords by the run-length pass)
+    alignas(4) uint8_t dw[32];
     uint32_t hdrw[160];          // the header bits are assembled here (not by read-modify-write on global memory)
+    uint64_t stamp[24];          // device diagnostics (LFX_STAMP)
 };
 
 #ifdef __HIP_DEVICE_COMPILE__
 #define LFX_SYNC() __syncthreads()
+#define LFX_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define LFX_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define LFX_STAMP(S, k) do { if (lane == 0) (S).stamp[k] = clock64(); } while (0)   /* LFX_DEBUG: where the kernel's time goes */
+#define LFX_UNROLL8 _Pragma("unroll 8")   /* independent LDS reads of a counting loop: issue them in batches, not one round trip each */
 #else
+#define LFX_STAMP(S, k) ((void)0)
+#define LFX_UNROLL8
 #define LFX_SYNC() ((void)0)
+#define LFX_ATOMIC_ADD(p, v) (*(p) += (v))       /* (the host runs the shared code with one lane) */
+#define LFX_ATOMIC_OR(p, v) (*(p) |= (v))
 #endif
 
 // Code widths for S.freq[0..nsym) with limit `limit` → S.width[], S.code[] (bit-reversed).
 // All lanes of the (single-wave) workgroup must call it.
-LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int nlanes) {
+LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int nlanes, int stamp0 = -1) {
+    (void)stamp0;
     // 1. used symbols, stable order by weight (huffman.rs:309-315)
     for (int i = lane; i < HMAX; i += nlanes) { S.width[i] = 0; S.code[i] = 0; }
     LFX_SYNC();
     if (lane == 0) {
         int n = 0;
+        LFX_UNROLL8
         for (int s = 0; s < nsym; s++) n += S.freq[s] > 0;
         S.n = n;
     }
@@ -102,6 +114,7 @@ LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int
         uint32_t f = S.freq[s];
         if (f == 0) continue;
         int r = 0;  // rank = #{used t : f_t < f or (f_t == f and t < s)}
+        LFX_UNROLL8
         for (int t = 0; t < nsym; t++) {
             uint32_t g = S.freq[t];
             r += (g != 0) & ((g < f) | ((g == f) & (t < s)));
@@ -110,6 +123,7 @@ LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int
         S.ssym[r] = (uint16_t)s;
     }
     LFX_SYNC();
+    if (stamp0 >= 0) LFX_STAMP(S, stamp0 + 0);       // rank sort done
     if (n == 0) return;                       // every width 0
     if (n == 1) {                             // package() leaves a 1-element list untouched → width 1
         if (lane == 0) { S.width[S.ssym[0]] = 1; S.code[S.ssym[0]] = 0; }
@@ -120,30 +134,40 @@ LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int
     //    leaves have depth 0, so on equal weight an internal node goes first, and among internal
     //    nodes of equal weight (a contiguous run at the queue head, weights are created in
     //    non-decreasing order) the deepest goes first.
+    //    Serial on lane 0, one dependent LDS round trip after the other: the two queue heads (next leaf weight, weight
+    //    at the head of the internal-node queue) are kept in registers and reloaded only when consumed (round 3: 7n → 4n
+    //    dependent reads).
     if (lane == 0) {
         int li = 0, qh = 0, qt = 0, depth = 0;
+        uint64_t lw = S.sw[0];     // weight of the leaf at li (while li < n)
+        uint64_t qw0 = 0;          // weight at the queue head (while qh < qt)
         for (int m = 0; m < n - 1; m++) {
             uint64_t w2[2];
             int d2[2];
             for (int k = 0; k < 2; k++) {
-                bool takeq = qh < qt && (li >= n || S.qw[qh] <= S.sw[li]);
+                const bool takeq = qh < qt && (li >= n || qw0 <= lw);
                 if (takeq) {
-                    uint64_t w = S.qw[qh];
+                    const uint64_t w = qw0;
                     int best = qh;
                     for (int g = qh + 1; g < qt && S.qw[g] == w; g++)
                         if (S.qd[g] > S.qd[best]) best = g;
                     d2[k] = S.qd[best];
-                    S.qd[best] = S.qd[qh];  // weights in the run are equal: only depths move
+                    if (best != qh) S.qd[best] = S.qd[qh];  // weights in the run are equal: only depths move
                     w2[k] = w;
                     qh++;
+                    if (qh < qt) qw0 = S.qw[qh];
                 } else {
-                    w2[k] = S.sw[li++];
+                    w2[k] = lw;
                     d2[k] = 0;
+                    li++;
+                    if (li < n) lw = S.sw[li];
                 }
             }
             int d = 1 + (d2[0] > d2[1] ? d2[0] : d2[1]);
-            S.qw[qt] = w2[0] + w2[1];
+            const uint64_t ws = w2[0] + w2[1];
+            S.qw[qt] = ws;
             S.qd[qt] = (uint8_t)(d > 255 ? 255 : d);
+            if (qh == qt) qw0 = ws;   // the queue was empty: the new node is its head
             qt++;
             depth = d;  // the last node created is the root
         }
@@ -151,6 +175,7 @@ LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int
         S.L = limit < opt ? limit : opt;
     }
     LFX_SYNC();
+    if (stamp0 >= 0) LFX_STAMP(S, stamp0 + 1);       // depth done
     const int L = S.L;
     // 3. package-merge forward (huffman.rs:317-318): level 0 = source
     for (int i = lane; i < n; i += nlanes) { S.cur[i] = S.sw[i]; S.leafpos[0][i] = (uint16_t)i; }
@@ -186,6 +211,7 @@ LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int
         if (lane == 0) S.listlen[k] = (uint16_t)(np + n);
         LFX_SYNC();
     }
+    if (stamp0 >= 0) LFX_STAMP(S, stamp0 + 2);       // forward passes done
     // 4. backward: the final package() keeps the first 2*floor(len/2) items of the last list; a
     //    selected package at level k expands to two items of level k-1 (a prefix, merge is stable)
     if (lane == 0) {
@@ -203,16 +229,19 @@ LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int
     LFX_SYNC();
     for (int i = lane; i < n; i += nlanes) {
         int w = 0;
+        LFX_UNROLL8
         for (int k = 0; k < L; k++) w += i < S.acnt[k];
         S.width[S.ssym[i]] = (uint8_t)w;
     }
     LFX_SYNC();
+    if (stamp0 >= 0) LFX_STAMP(S, stamp0 + 3);       // widths done
     // 5. canonical codes (huffman.rs:35-55): symbols in (width, symbol) order
     for (int s = lane; s < nsym; s += nlanes) {
         int w = S.width[s];
         if (w == 0) continue;
         // code = (number of codes before me, each scaled to my width)
         uint32_t c = 0;
+        LFX_UNROLL8
         for (int t = 0; t < nsym; t++) {
             int wt = S.width[t];
             if (wt == 0) continue;
@@ -273,23 +302,28 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
         return;
     }
     // DynamicHuffmanCodec::build symbol.rs:321-342 — literal/length alphabet
+    LFX_STAMP(S, 0);
     for (int s = lane; s < HMAX; s += nlanes) S.freq[s] = s < 286 ? hist[s] : 0;
     LFX_SYNC();
-    huff_build(S, 286, 15, lane, nlanes);
+    huff_build(S, 286, 15, lane, nlanes, 1);
+    LFX_STAMP(S, 5);
     for (int s = lane; s < 288; s += nlanes) {
         out->lit[s] = (uint32_t)S.code[s] | ((uint32_t)S.width[s] << 16);
         S.lw[s] = S.width[s];
     }
     LFX_SYNC();
     // distance alphabet, with the dist[0] = 1 dummy when the block has no pointer (symbol.rs:332-337)
+    for (int d = lane; d < HMAX; d += nlanes) S.freq[d] = d < 30 ? hist[288 + d] : 0;   // (lanes in parallel: on lane 0 these were sixty dependent global loads)
+    LFX_SYNC();
     if (lane == 0) {
-        int any = 0;
-        for (int d = 0; d < 30; d++) any |= hist[288 + d] != 0;
-        for (int d = 0; d < HMAX; d++) S.freq[d] = d < 30 ? hist[288 + d] : 0;
+        uint32_t any = 0;
+        LFX_UNROLL8
+        for (int d = 0; d < 30; d++) any |= S.freq[d];
         if (!any) S.freq[0] = 1;
     }
     LFX_SYNC();
     huff_build(S, 30, 15, lane, nlanes);
+    LFX_STAMP(S, 6);
     for (int s = lane; s < 32; s += nlanes) {
         out->dist[s] = s < 30 ? ((uint32_t)S.code[s] | ((uint32_t)S.width[s] << 16)) : 0;
         S.dw[s] = s < 30 ? S.width[s] : 0;
@@ -305,13 +339,20 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
         // build_bitwidth_codes symbol.rs:486-540
         int rn = 0;
         for (int t = 0; t < 2; t++) {
-            const uint8_t *w = t ? S.dw : S.lw;
+            // (the widths are read a dword at a time: every read is a dependent LDS round trip on this one lane)
+            const uint32_t *w32 = (const uint32_t *)(t ? S.dw : S.lw);
             int size = t ? nd : nl;
             int i = 0;
+            int cidx = -1;
+            uint32_t cw = 0;
+            auto wat = [&](int q) -> uint8_t {
+                if ((q >> 2) != cidx) { cidx = q >> 2; cw = w32[cidx]; }
+                return (uint8_t)(cw >> (8 * (q & 3)));
+            };
             while (i < size) {
-                uint8_t v = w[i];
+                uint8_t v = wat(i);
                 int c = 1;
-                while (i + c < size && w[i + c] == v) c++;  // a run never crosses into the next table
+                while (i + c < size && wat(i + c) == v) c++;  // a run never crosses into the next table
                 i += c;
                 if (v == 0) {
                     while (c >= 11) {
@@ -334,17 +375,25 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
             }
         }
         S.rl_n = rn;
-        for (int s = 0; s < HMAX; s++) S.freq[s] = 0;
-        for (int i = 0; i < rn; i++) S.freq[S.rl_code[i]]++;
         // stash nl/nd for the emit step
         S.listlen[15] = (uint16_t)nl;
         S.acnt[15] = (uint16_t)nd;
     }
+    LFX_STAMP(S, 7);                                   // run-length pass done (lane 0)
+    for (int s = lane; s < HMAX; s += nlanes) S.freq[s] = 0;
+    LFX_SYNC();
+    // code-length-symbol counts and the header's bit assembly are spread over the lanes (round 3: on lane 0 they were
+    // ~500 dependent LDS read-modify-writes, a third of the kernel's time)
+    for (int i = lane; i < S.rl_n; i += nlanes) LFX_ATOMIC_ADD(&S.freq[S.rl_code[i]], 1u);
     LFX_SYNC();
     // keep the code-length counts: huff_build leaves S.freq intact
     huff_build(S, 19, 7, lane, nlanes);
+    LFX_STAMP(S, 8);
+    for (int i = lane; i < 19; i += nlanes) { S.clw[i] = S.width[i]; S.clc[i] = S.code[i]; }
+    for (int i = lane; i < 160; i += nlanes) S.hdrw[i] = 0;
+    LFX_SYNC();
+    for (int i = lane; i < S.rl_n; i += nlanes) S.rl_w[i] = (uint8_t)(S.clw[S.rl_code[i]] + S.rl_bits[i]);
     if (lane == 0) {
-        for (int i = 0; i < 19; i++) { S.clw[i] = S.width[i]; S.clc[i] = S.code[i]; }
         int nl = S.listlen[15], nd = S.acnt[15];
         int bcc = 0;  // symbol.rs:357-364
         for (int k = 18; k >= 0; k--) {
@@ -352,7 +401,6 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
             if (S.freq[i] != 0 && S.clw[i] > 0) { bcc = k + 1; break; }
         }
         if (bcc < 4) bcc = 4;
-        for (int i = 0; i < 160; i++) S.hdrw[i] = 0;
         HdrWriter hw{S.hdrw, 0};
         hw.put(5, (uint32_t)(nl - 257));
         hw.put(5, (uint32_t)(nd - 1));
@@ -361,14 +409,29 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
             int i = clen_order(k);
             hw.put(3, S.freq[i] == 0 ? 0u : (uint32_t)S.clw[i]);
         }
-        for (int i = 0; i < S.rl_n; i++) {
-            hw.put(S.clw[S.rl_code[i]], S.clc[S.rl_code[i]]);
-            if (S.rl_bits[i]) hw.put(S.rl_bits[i], S.rl_extra[i]);
-        }
-        out->hdr_bits = hw.nbits;
-        S.rl_n = (int32_t)hw.nbits;   // (for the sum below)
+        S.acnt[14] = (uint16_t)hw.nbits;   // first bit of the code-length sequence
     }
     LFX_SYNC();
+    {
+        // entry i = its code-length code, then its extra bits (LSB first, bit.rs:25-49): at most 7 + 7 bits at the
+        // offset Σ widths of the entries in front of it
+        const uint32_t base = S.acnt[14];
+        const int rn = S.rl_n;
+        for (int i = lane; i < rn; i += nlanes) {
+            uint32_t at = base;
+            for (int j = 0; j < i; j++) at += S.rl_w[j];
+            const uint32_t cw = S.clw[S.rl_code[i]];
+            const uint32_t v = (uint32_t)S.clc[S.rl_code[i]] | ((uint32_t)S.rl_extra[i] << cw);
+            const uint32_t word = at >> 5, sh = at & 31, wd = S.rl_w[i];
+            if (wd) {
+                LFX_ATOMIC_OR(&S.hdrw[word], v << sh);
+                if (sh + wd > 32) LFX_ATOMIC_OR(&S.hdrw[word + 1], v >> (32 - sh));
+            }
+            if (i == rn - 1) { out->hdr_bits = at + wd; S.L = (int32_t)(at + wd); }   // (S.L: free by now; read by the sum below.  rn is never 0: at least 258 widths)
+        }
+    }
+    LFX_SYNC();
+    LFX_STAMP(S, 9);                                   // header bits assembled
     // header words out; body size = 3 + header + Σ count · (width + extra bits), partial sums per lane
     for (int i = lane; i < 160; i += nlanes) out->hdr[i] = S.hdrw[i];
     {
@@ -381,10 +444,11 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
     }
     LFX_SYNC();
     if (lane == 0) {
-        uint64_t bits = 3 + (uint64_t)(uint32_t)S.rl_n;
+        uint64_t bits = 3 + (uint64_t)(uint32_t)S.L;
         for (int l = 0; l < nlanes; l++) bits += S.cur[l];
         out->body_bits = bits;
     }
+    LFX_STAMP(S, 10);
     LFX_SYNC();
 }
 
