@@ -520,7 +520,15 @@ __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restr
     const uint64_t wlast = (shift + nbytes + 3) / 4 - 1;
     const uint64_t wg_byte = first_byte + (uint64_t)blockIdx.x * (4 * FIND_DWORDS);   // first stream byte of this workgroup
     const uint64_t w0 = (wg_byte + shift) >> 2;
-    for (uint32_t i = threadIdx.x; i < FIND_DWORDS + 4; i += 256) { const uint64_t idx = w0 + i; sd[i] = w[idx < wlast ? idx : wlast]; }
+    {
+        // the staging loads are issued together (clamped addresses): a loop of dependent load → store pairs made every
+        // workgroup wait five HBM round trips before its first test
+        uint32_t v[5];
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) { const uint64_t idx = w0 + threadIdx.x + 256 * k; v[k] = w[idx < wlast ? idx : wlast]; }
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) { const uint32_t i = threadIdx.x + 256 * k; if (i < FIND_DWORDS + 4) sd[i] = v[k]; }
+    }
     __syncthreads();
     const uint64_t stream_bits = nbytes * 8, lo_bit = first_byte * 8;
     for (uint32_t t = threadIdx.x; t < FIND_DWORDS; t += 256) {

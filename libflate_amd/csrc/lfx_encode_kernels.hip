@@ -534,9 +534,17 @@ __global__ __launch_bounds__(PACK_THREADS) void tile_bits_kernel(
     const uint32_t hi = min(n, lo + PACK_TILE);
     const uint32_t *p = codes + ch.code_off;
     uint32_t sum = 0;
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += PACK_THREADS) {
+    // all of the lane's loads are issued before the first use (clamped addresses, no branch around a load): one after the
+    // other they were PACK_TILE / PACK_THREADS dependent HBM round trips per workgroup — the whole kernel (round 3)
+    constexpr uint32_t PER = PACK_TILE / PACK_THREADS;
+    uint32_t v[PER];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) v[k] = p[min(lo + threadIdx.x + k * PACK_THREADS, hi - 1)];
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
         uint64_t bits;
-        sum += code_bits(p[i], lit, dst, bits);
+        const uint32_t nb = code_bits(v[k], lit, dst, bits);
+        sum += lo + threadIdx.x + k * PACK_THREADS < hi ? nb : 0u;
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
@@ -615,12 +623,15 @@ __global__ __launch_bounds__(PACK_THREADS) void pack_kernel(
     uint32_t cn[PACK_PER_THREAD];
     uint32_t mine = 0;
     const uint32_t first = lo + threadIdx.x * PACK_PER_THREAD;
+    uint32_t cv[PACK_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < PACK_PER_THREAD; ++k) cv[k] = p[min(first + k, hi - 1)];    // (loads first, branch-free: see tile_bits_kernel)
 #pragma unroll
     for (int k = 0; k < PACK_PER_THREAD; ++k) {
         const uint32_t i = first + k;
-        cn[k] = 0;
-        cb[k] = 0;
-        if (i < hi) cn[k] = code_bits(p[i], lit, dst, cb[k]);
+        const uint32_t nb = code_bits(cv[k], lit, dst, cb[k]);
+        cn[k] = i < hi ? nb : 0u;
+        cb[k] = i < hi ? cb[k] : 0ull;
         mine += cn[k];
     }
     // exclusive scan of `mine` over the workgroup

@@ -615,7 +615,14 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
     // everything behind it: the codes the speculative walk staged, behind the kspec it visited in front of the merge
     const uint32_t n2 = total - nout;
     const uint32_t *st = stage + ch.in_off + s0 + seg_kspec[seg];
-    for (uint32_t j = lane; j < n2; j += 64) out[nout + j] = st[j];
+    // (eight loads in flight per lane: a load → store pair per trip made the copy ~20 dependent HBM round trips per segment)
+    for (uint32_t j0 = 0; j0 < n2; j0 += 8 * 64) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v[k] = st[min(j0 + 64 * k + lane, n2 - 1)];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) { const uint32_t j = j0 + 64 * k + lane; if (j < n2) out[nout + j] = v[k]; }
+    }
 }
 
 // first-generation match kernel (the fallback behind a lane-order violation of lfx_match3.hip, LFX_MATCH_V1=1): its
