@@ -1272,9 +1272,27 @@ __global__ __launch_bounds__(256) void sym_substitute_kernel(const uint16_t *__r
     // (unit 0: the member's earlier output; at the start of a member it holds no markers)
     const uint8_t *w = u ? windows + (uint64_t)(u - 1) * 32768 : (init_win ? init_win : windows);
     const uint64_t lo = (uint64_t)blockIdx.y * 16384, hi = lo + 16384 < su.len ? lo + 16384 : su.len;
-    for (uint64_t k = lo + threadIdx.x; k < hi; k += 256) {
-        const uint32_t s = sym[su.start + k];
-        out[su.start + k] = s < 256 ? (uint8_t)s : w[s - 256];
+    if (lo >= hi) return;
+    // Eight symbols per lane and trip (round 3): one 16-byte load, the (up to eight) window bytes gathered together, one
+    // 8-byte store.  One symbol per lane and trip was 64 dependent round trips per lane for 64 bytes of output.
+    // Octets are aligned on the ABSOLUTE symbol index (the arrays are 16-byte aligned); the elements of the first and last
+    // octet that belong to a neighbouring range are masked.
+    const uint64_t A = su.start + lo, B = su.start + hi;
+    const bool out_aligned = ((uint64_t)out & 7) == 0;        // (the caller's buffer: usually, not necessarily)
+    for (uint64_t p = (A & ~7ull) + 8ull * threadIdx.x; p < B; p += 8ull * 256) {
+        const uint4 q = *(const uint4 *)(sym + p);
+        const uint32_t s8[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
+        uint32_t b8[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) b8[j] = w[s8[j] >= 256 ? s8[j] - 256 : 0];     // (a plain byte reads window entry 0: ignored)
+        uint64_t v = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) v |= (uint64_t)((s8[j] < 256 ? s8[j] : b8[j]) & 0xFFu) << (8 * j);
+        if (p >= A && p + 8 <= B && out_aligned) *(uint64_t *)(out + p) = v;
+        else {
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) if (p + j >= A && p + j < B) out[p + j] = (uint8_t)(v >> (8 * j));
+        }
     }
 }
 
