@@ -404,13 +404,16 @@ __global__ __launch_bounds__(256) void histogram_kernel(const ChunkDesc *__restr
     const uint32_t per = (uint32_t)div_up(n, gridDim.y);
     const uint32_t lo = blockIdx.y * per, hi = min(n, lo + per);
     const uint32_t *p = codes + ch.code_off;
-    // four loads in flight per lane (one load per iteration left the kernel waiting on HBM latency)
-    for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += 4 * 256) {
-        uint32_t v[4];
+    // HLOADS loads in flight per lane: the kernel is one workgroup per chunk (more workgroups cost more global atomics at
+    // the end), so a lane walks ~400 codes and every trip is an HBM round trip — with four loads per trip the kernel's
+    // time WAS those ~100 round trips (round 3: 4 → 16 loads per trip)
+    constexpr uint32_t HLOADS = 16;
+    for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += HLOADS * 256) {
+        uint32_t v[HLOADS];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) v[q] = i0 + 256 * q < hi ? p[i0 + 256 * q] : 0u;
+        for (uint32_t q = 0; q < HLOADS; ++q) v[q] = p[min(i0 + 256 * q, hi - 1)];
 #pragma unroll
-        for (uint32_t q = 0; q < 4; ++q) {
+        for (uint32_t q = 0; q < HLOADS; ++q) {
             if (i0 + 256 * q >= hi) break;
             const uint32_t dist = v[q] & 0xFFFFu, val = v[q] >> 16;
             if (dist == 0) {

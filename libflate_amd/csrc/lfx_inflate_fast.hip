@@ -760,7 +760,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
     if (tabs) {   // the tables the scan kernel built for this block
         const uint32_t *srcw = (const uint32_t *)&tabs[job.cand];
         uint32_t *dst = (uint32_t *)&T;
-        for (uint32_t i = tid; i < sizeof(FastTabs) / 4; i += SCAN_THREADS) dst[i] = srcw[i];
+        constexpr uint32_t TW = sizeof(FastTabs) / 4, TPER = (TW + SCAN_THREADS - 1) / SCAN_THREADS;
+        uint32_t tv[TPER];                      // (all of a lane's loads in flight, then the LDS stores)
+#pragma unroll
+        for (uint32_t k = 0; k < TPER; ++k) tv[k] = srcw[min(tid + k * SCAN_THREADS, TW - 1)];
+#pragma unroll
+        for (uint32_t k = 0; k < TPER; ++k) if (tid + k * SCAN_THREADS < TW) dst[tid + k * SCAN_THREADS] = tv[k];
         __syncthreads();
     } else parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
     const uint64_t t_hdr = clock64();
