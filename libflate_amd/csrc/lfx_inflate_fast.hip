@@ -1289,7 +1289,8 @@ __global__ __launch_bounds__(256) void sym_substitute_kernel(const uint16_t *__r
         const uint32_t s8[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
         uint32_t b8[8];
 #pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) b8[j] = w[s8[j] >= 256 ? s8[j] - 256 : 0];     // (a plain byte reads window entry 0: ignored)
+        for (uint32_t j = 0; j < 8; ++j) b8[j] = w[s8[j] >= 256 ? min(s8[j] - 256, 32767u) : 0];   // (a plain byte reads window entry 0: ignored; an
+                                                                                                 //  element outside [A, B) may be anything: clamped)
         uint64_t v = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 8; ++j) v |= (uint64_t)((s8[j] < 256 ? s8[j] : b8[j]) & 0xFFu) << (8 * j);
