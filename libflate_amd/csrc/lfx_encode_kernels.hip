@@ -436,7 +436,8 @@ __global__ __launch_bounds__(256) void histogram_kernel(const ChunkDesc *__restr
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int HUFF_THREADS = 256;   // four wavefronts per block: the rank / merge / code passes stride over the lanes
+constexpr int HUFF_THREADS = 320;   // five wavefronts per block: the rank / merge / code passes stride over the lanes, and 286 symbols
+                                    // on 256 lanes made every such pass two trips for thirty symbols (round 3)
 __global__ __launch_bounds__(HUFF_THREADS) void huffman_kernel(const BlockDesc *__restrict__ blocks,
                                                                const uint32_t *__restrict__ hist,
                                                                BlockCodes *__restrict__ bc, uint64_t *__restrict__ dbg) {
