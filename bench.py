@@ -299,12 +299,38 @@ def sub_cfg5(ctx, torch, synth, _ffi, C, dev, reps=2):
             "round_trip_ok": ok, "hbm_frac_algorithmic": round((n + m) / best / 1e9 / HBM_PEAK_GBPS, 5)}
 
 
+def launch_plan(gpus, env, device_count, argv):
+    """Decide how `bench.py --gpus N` runs.  → ("inline", None) when this process IS the job (N = 1, or a launcher
+    already set WORLD_SIZE: the driver's `python -m torch.distributed.run ... bench.py --gpus N`), ("spawn", cmd) when
+    --gpus N > 1 was given to a bare `python bench.py`: the script re-executes itself under torch.distributed.run with one
+    rank per GPU (RCCL), so that `python bench.py --gpus 8` measures eight GPUs and not one.  Raises when the box has
+    fewer than N devices, unless LFX_BENCH_ONE_GPU=1 (every rank on GPU 0 over gloo: the self-test on a one-GPU box)."""
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if gpus != world:
+            raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (gpus, world))
+        return "inline", None
+    if gpus <= 1:
+        return "inline", None
+    if device_count < gpus and env.get("LFX_BENCH_ONE_GPU") != "1":
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) visible (LFX_BENCH_ONE_GPU=1 runs all ranks on "
+                         "GPU 0 over gloo as a self-test)" % (gpus, device_count))
+    port = env.get("MASTER_PORT") or str(29500 + (os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    return "spawn", cmd
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node.  Without a launcher (no WORLD_SIZE in the environment) N > 1 re-executes "
+                         "this script under torch.distributed.run with one rank per GPU (RCCL)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bytes", type=int, default=N_BYTES)
+    ap.add_argument("--bytes", type=int, default=N_BYTES,
+                    help="uncompressed bytes PER RANK (weak scaling).  Default 256 MiB = the metric's configuration; the cfg4 "
+                         "shape (8-way sharded gzip encode of 8 GiB) is `--gpus 8 --bytes 1073741824`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes")
     ap.add_argument("--no-s1", action="store_true", help="skip the S1 sub-record")
@@ -317,6 +343,11 @@ def main():
 
     import numpy as np  # noqa: F401
     import torch
+    mode, cmd = launch_plan(args.gpus, os.environ, torch.cuda.device_count(), sys.argv[1:])
+    if mode == "spawn":
+        # one rank per GPU; the ranks' stdout is ours, rank 0 prints the JSON line last
+        sys.stdout.flush()
+        raise SystemExit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
     import __graft_entry__ as g
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

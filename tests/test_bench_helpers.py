@@ -27,3 +27,22 @@ def test_phase_kernel_table_names_existing_kernels():
     for phase, kernel in bench.PHASE_KERNEL.items():
         assert "void %s(" % kernel in src, (phase, kernel)    # a renamed kernel must not silently lose its traffic figure
     assert "void %s(" % bench.CALIBRATION_KERNEL in src
+
+
+def test_gpus_flag_launches_the_ranks_itself():
+    """`python bench.py --gpus N` without a launcher must start N ranks, not run one."""
+    import bench
+    import pytest
+    assert bench.launch_plan(1, {}, 0, []) == ("inline", None)
+    # the driver's own launcher already made the ranks: run inline, but the flag must agree with the world size
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8"}, 8, []) == ("inline", None)
+    with pytest.raises(SystemExit):
+        bench.launch_plan(8, {"WORLD_SIZE": "2"}, 8, [])
+    mode, cmd = bench.launch_plan(8, {}, 8, ["--gpus", "8", "--steps", "3"])
+    assert mode == "spawn"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    with pytest.raises(SystemExit):             # fewer devices than ranks: fail loudly ...
+        bench.launch_plan(8, {}, 1, [])
+    mode, cmd = bench.launch_plan(3, {"LFX_BENCH_ONE_GPU": "1"}, 1, ["--gpus", "3"])    # ... unless it is the one-GPU self-test
+    assert mode == "spawn" and cmd[cmd.index("--nproc-per-node") + 1] == "3"
