@@ -61,7 +61,9 @@ typedef struct lfx_encode_opts {
     uint8_t os;                /* gzip.rs:173    default 3 (Unix) */
     uint8_t is_text;           /* gzip.rs:179 */
     uint8_t hcrc;              /* gzip.rs:185    verify() */
-    uint8_t _pad;
+    uint8_t lz77_level;        /* 0: the level of lz77_kind's encoder; 1 + LFX_LEVEL_*: E::compression_level() of a caller-supplied
+                                  Lz77Encode (lfx_encoder_write_codes) — it decides zlib's FLEVEL (zlib.rs:59-68,212-220) and gzip's XFL
+                                  (gzip.rs:84-92,684) */
     const uint8_t *extra;      /* gzip.rs:191    serialized subfields (id[2] len[2] data)* */
     uint32_t extra_len;
     const char *filename;      /* gzip.rs:197    NUL-terminated */
@@ -155,11 +157,19 @@ int lfx_decode_shard_device(lfx_ctx *c, const void *d_in, uint64_t n, uint64_t s
  *      are not block starts are never reached.  LFX_E_UNSUPPORTED when the chain breaks (a stored / fixed block the
  *      finder cannot see, damage): decode on one GPU then;
  *   4. lfx_decode_range_emit: materialises the chain blocks owned by `rank` (those that start in its range) into
- *      d_out — the rank's slice of the output, which starts *out_base bytes into the member's output — and returns
+ *      d_out — the rank's slice of the output, which starts *out_base bytes into the member's output.  Must follow the
+ *      same rank's range_scan on the same context (the scan's tables live in its scratch).  *state = 0: the slice holds
+ *      its bytes.  Reference-made blocks never read earlier blocks (default.rs:73), so their slices always do.
+ *      *state = 1: the slice's blocks read output in front of them (another encoder's member — the reference decodes any
+ *      valid stream, src/deflate/decode.rs:112-164, libflate_lz77/src/lib.rs:164-194), possibly bytes another rank
+ *      produces: the slice is held as 16-bit symbols and waits for the 32 KiB window in front of it;
+ *   5. window hand-over, only when some rank reported state 1: every rank writes its slice's action on the 32 KiB in
+ *      front of it as ONE index map (lfx_decode_range_map: 32768 uint16 on the device — a byte value, or 256 + j = "byte
+ *      j of the window in front of my slice"), the ranks all-gather the maps (64 KiB each, rank order);
+ *   6. lfx_decode_range_finish: composes the window in front of the slice from the maps of the ranks before it (d_maps:
+ *      world x 32768 uint16 on the device; NULL when no rank needed a window), replaces the slice's markers, and returns
  *      the slice's CRC-32 / Adler-32 (fold them with lfx_crc32_combine / lfx_adler32_combine and compare with the
- *      trailer).  Must follow the same rank's range_scan on the same context (the scan's tables live in its scratch).
- * Reference-made blocks never read earlier blocks (default.rs:73), which is what makes a slice decodable alone; a
- * member whose blocks do (another encoder's) makes range_emit return LFX_E_UNSUPPORTED. */
+ *      trailer). */
 typedef struct lfx_blk_tuple {
     uint64_t start_bit, end_bit;  /* header bit, bit behind EndOfBlock (relative to the member's first byte) */
     uint64_t n_out;               /* bytes the block produces */
@@ -177,7 +187,9 @@ int lfx_decode_chain(const lfx_blk_tuple *all, uint32_t n_all, uint64_t first_bi
                      uint32_t *n_chain, uint64_t *total_out);
 int lfx_decode_range_emit(lfx_ctx *c, const void *d_part, uint64_t n_part, uint64_t lo_byte, const lfx_blk_tuple *all,
                           const uint32_t *chain, uint32_t n_chain, uint32_t rank, void *d_out, uint64_t cap,
-                          uint64_t *out_len, uint64_t *out_base, uint32_t *crc32, uint32_t *adler32);
+                          uint64_t *out_len, uint64_t *out_base, uint32_t *state);
+int lfx_decode_range_map(lfx_ctx *c, void *d_map);
+int lfx_decode_range_finish(lfx_ctx *c, const void *d_maps, uint32_t rank, uint32_t *crc32, uint32_t *adler32);
 /* stream concatenation on the writer rank: places one shard's bytes (as written by emit(), already
  * on this device — e.g. received over RCCL / xGMI) at byte start_bit/8 of the member buffer; when the shard starts
  * inside a byte (start_bit % 8 != 0) that byte is shared with the shard in front and is OR-ed.  Place the shards in
@@ -202,6 +214,21 @@ lfx_encoder *lfx_encoder_new(lfx_ctx *c, int format, const lfx_encode_opts *o, l
                              lfx_flush_cb f, void *user, int *status);
 /* io::Write::write — always consumes everything (encode.rs:241-244); one call = one write() */
 int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n);
+/* EncodeOptions::with_lz77(E) for a caller-supplied `E: Lz77Encode` (src/deflate/encode.rs:59-65; call sites
+ * CompressBuf::{append, flush}, encode.rs:405-425: the reference Huffman-codes whatever E emits).  E runs on the caller's
+ * side; this call hands over what it produced and the GPU does the rest (histogram, Huffman build, bit packing,
+ * container checksum) exactly as for the built-in encoders:
+ *   write(buf):  E::encode(buf, sink)  → lfx_encoder_write_codes(e, sink's codes, n, buf, len, 0)      (CompressBuf::append)
+ *                then, while the bytes since the last close reach block_size (Block::write, encode.rs:282):
+ *                E::flush(sink)        → lfx_encoder_write_codes(e, codes, n, NULL, 0, 1)              (CompressBuf::flush)
+ *   flush():     E::flush(sink)        → lfx_encoder_write_codes(e, codes, n, NULL, 0, 1); lfx_encoder_flush(e)
+ *   finish():    E::flush(sink)        → lfx_encoder_write_codes(e, codes, n, NULL, 0, 2); lfx_encoder_finish(e)
+ * codes: (val << 16) | dist as in lfx_sink_cb below; end_block: 0 = the block stays open, 1 = EndOfBlock follows the
+ * codes and the block closes, 2 = the same for the stream's final block.  raw: the bytes the codes stand for — only the
+ * container checksum (and gzip's ISIZE) looks at them.  An encoder takes bytes (lfx_encoder_write) or codes, never
+ * both; code words outside Code's domain (lib.rs:27-42) are LFX_E_ARG. */
+int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, size_t n_codes, const uint8_t *raw, size_t n_raw,
+                            int end_block);
 /* io::Write::flush — closes the current block (encode.rs:245-248); zlib Sync adds 00 00 FF FF */
 int lfx_encoder_flush(lfx_encoder *e);
 /* Encoder::finish (encode.rs:203-208, gzip.rs:858-868, zlib.rs:630-639). Everything already

@@ -22,9 +22,9 @@ DEC_NONBLOCKING = 2
 EXPORTS = [
     "lfx_encode_opts_default", "lfx_ctx_new", "lfx_ctx_free", "lfx_ctx_last_error", "lfx_ctx_set_stream",
     "lfx_device_count", "lfx_encode_bound", "lfx_encode_device", "lfx_encode_host", "lfx_decode_device",
-    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device", "lfx_shard_place_device", "lfx_decode_range_scan", "lfx_decode_chain", "lfx_decode_range_emit",
+    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device", "lfx_shard_place_device", "lfx_decode_range_scan", "lfx_decode_chain", "lfx_decode_range_emit", "lfx_decode_range_map", "lfx_decode_range_finish",
     "lfx_crc32_combine", "lfx_adler32_combine", "lfx_container_header_len", "lfx_encoder_new",
-    "lfx_encoder_write", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
+    "lfx_encoder_write", "lfx_encoder_write_codes", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
     "lfx_encoder_free", "lfx_decoder_new", "lfx_decoder_read", "lfx_decoder_unread",
     "lfx_decoder_consumed", "lfx_decoder_buffered", "lfx_decoder_surplus", "lfx_decoder_header", "lfx_decoder_last_error", "lfx_decoder_free", "lfx_lz77_new",
     "lfx_lz77_encode", "lfx_lz77_flush", "lfx_lz77_window_size", "lfx_lz77_compression_level",
@@ -37,7 +37,7 @@ class EncodeOpts(C.Structure):
         ("block_size", C.c_uint64), ("dynamic_huffman", C.c_int32), ("no_compression", C.c_int32),
         ("lz77_kind", C.c_int32), ("window_size", C.c_uint32), ("max_length", C.c_uint32),
         ("zlib_flush_mode", C.c_int32), ("mtime", C.c_uint32), ("os", C.c_uint8), ("is_text", C.c_uint8),
-        ("hcrc", C.c_uint8), ("_pad", C.c_uint8), ("extra", C.c_char_p), ("extra_len", C.c_uint32),
+        ("hcrc", C.c_uint8), ("lz77_level", C.c_uint8), ("extra", C.c_char_p), ("extra_len", C.c_uint32),
         ("filename", C.c_char_p), ("comment", C.c_char_p),
     ]
 
@@ -133,7 +133,9 @@ def lib():
     L.lfx_decode_range_scan.argtypes = [vp, vp, u64, u64, u64, u64, u32, C.POINTER(BlkTuple), u32, C.POINTER(u32)]
     L.lfx_decode_chain.argtypes = [C.POINTER(BlkTuple), u32, u64, C.POINTER(u32), u32, C.POINTER(u32), C.POINTER(u64)]
     L.lfx_decode_range_emit.argtypes = [vp, vp, u64, u64, C.POINTER(BlkTuple), C.POINTER(u32), u32, u32, vp, u64,
-                                        C.POINTER(u64), C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]
+                                        C.POINTER(u64), C.POINTER(u64), C.POINTER(u32)]
+    L.lfx_decode_range_map.argtypes = [vp, vp]
+    L.lfx_decode_range_finish.argtypes = [vp, vp, u32, C.POINTER(u32), C.POINTER(u32)]
     L.lfx_crc32_combine.restype = u32
     L.lfx_crc32_combine.argtypes = [u32, u32, u64]
     L.lfx_adler32_combine.restype = u32
@@ -144,6 +146,7 @@ def lib():
     L.lfx_encoder_new.argtypes = [vp, i32, C.POINTER(EncodeOpts), WRITE_CB, FLUSH_CB, vp, C.POINTER(i32)]
     L.lfx_encoder_write.restype = C.c_int64
     L.lfx_encoder_write.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.lfx_encoder_write_codes.argtypes = [vp, C.POINTER(u32), C.c_size_t, C.c_char_p, C.c_size_t, i32]
     L.lfx_encoder_flush.argtypes = [vp]
     L.lfx_encoder_finish.argtypes = [vp]
     L.lfx_encoder_last_error.restype = C.c_char_p

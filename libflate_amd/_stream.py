@@ -26,6 +26,11 @@ class _EncoderBase:
         self._ctx = context or default_context()
         self._inner = inner
         self._opts = options._to_c() if options is not None else _ffi.make_opts()
+        # a caller-supplied Lz77Encode (EncodeOptions::with_lz77(E), encode.rs:59-65) runs here; its codes go to the GPU
+        self._lz77 = getattr(options, "_foreign", None) if options is not None else None
+        if self._lz77 is not None and self._opts.no_compression:
+            self._lz77 = None                    # RawBuf never calls the Lz77Encode (encode.rs:348-383)
+        self._original_size = 0
         self._wcb = _ffi.WRITE_CB(self._on_write)
         self._fcb = _ffi.FLUSH_CB(self._on_flush)
         st = C.c_int(0)
@@ -53,20 +58,45 @@ class _EncoderBase:
     def write(self, buf):
         """io::Write::write — ONE reference write() call; always consumes everything."""
         buf = bytes(buf)
+        if self._lz77 is not None:
+            sink = []
+            self._lz77.encode(buf, sink)                         # CompressBuf::append encode.rs:405-408
+            self._codes(sink, buf, 0)
+            self._original_size += len(buf)
+            while self._original_size >= self._opts.block_size:  # Block::write encode.rs:282
+                self._close_block(1)
+            return len(buf)
         r = _ffi.lib().lfx_encoder_write(self._h, buf, len(buf))
         if r < 0:
             raise StreamError(-r, self._err())
         return r
 
+    def _codes(self, sink, raw, end_block):
+        from .lz77 import Code
+        words = (C.c_uint32 * max(len(sink), 1))(*[Code.to_word(c) for c in sink])
+        rc = _ffi.lib().lfx_encoder_write_codes(self._h, words, len(sink), raw, len(raw), end_block)
+        if rc:
+            raise StreamError(rc, self._err())
+
+    def _close_block(self, end_block):
+        sink = []
+        self._lz77.flush(sink)                                   # CompressBuf::flush encode.rs:416
+        self._codes(sink, b"", end_block)
+        self._original_size = 0
+
     write_all = write
 
     def flush(self):
+        if self._lz77 is not None:
+            self._close_block(1)
         rc = _ffi.lib().lfx_encoder_flush(self._h)
         if rc:
             raise StreamError(rc, self._err())
 
     def finish(self):
         """Encoder::finish → the inner writer (Finish<W, io::Error>::into_result)."""
+        if self._lz77 is not None:
+            self._close_block(2)
         rc = _ffi.lib().lfx_encoder_finish(self._h)
         msg = self._err()
         _ffi.lib().lfx_encoder_free(self._h)

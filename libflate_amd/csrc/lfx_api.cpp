@@ -107,9 +107,11 @@ static PlanOpts plan_opts(int format, const lfx_encode_opts &o) {
 static void gzip_header(const lfx_encode_opts &o, bool with_hcrc, std::vector<uint8_t> &b) {
     uint8_t flg = (uint8_t)((o.is_text ? 1 : 0) | (with_hcrc ? 2 : 0) | (o.extra ? 4 : 0) |
                             (o.filename ? 8 : 0) | (o.comment ? 16 : 0));
-    // XFL: DefaultLz77Encoder → Balance → Unknown(0); NoCompression → None → Unknown(0) (gzip.rs:84-92)
+    // XFL: DefaultLz77Encoder → Balance → Unknown(0); NoCompression → None → Unknown(0); a caller's E: Fast → Fastest(4),
+    // Best → Slowest(2) (gzip.rs:84-92,684); no_compression() resets it to Unknown (gzip.rs:703)
+    const uint8_t xfl = o.no_compression ? 0 : o.lz77_level == 1 + LFX_LEVEL_FAST ? 4 : o.lz77_level == 1 + LFX_LEVEL_BEST ? 2 : 0;
     const uint8_t h[10] = {31, 139, 8, flg, (uint8_t)o.mtime, (uint8_t)(o.mtime >> 8),
-                           (uint8_t)(o.mtime >> 16), (uint8_t)(o.mtime >> 24), 0, o.os};
+                           (uint8_t)(o.mtime >> 16), (uint8_t)(o.mtime >> 24), xfl, o.os};
     b.insert(b.end(), h, h + 10);
     if (o.extra) {
         b.push_back((uint8_t)o.extra_len);
@@ -137,6 +139,7 @@ static int container_header(int format, const lfx_encode_opts &o, std::vector<ui
         uint8_t cinfo = ws > 16384 ? 7 : ws > 8192 ? 6 : ws > 4096 ? 5 : ws > 2048 ? 4 : ws > 1024 ? 3
                         : ws > 512 ? 2 : ws > 256 ? 1 : 0;
         uint8_t level = (o.no_compression || o.lz77_kind == LFX_LZ77_NOCOMPRESSION) ? 0 : 2;
+        if (o.lz77_level && !o.no_compression) level = (uint8_t)((o.lz77_level - 1) & 3);   // lz77 None/Fast/Balance/Best → 0..3 (zlib.rs:59-68)
         uint8_t cmf = (uint8_t)((cinfo << 4) | 8), flg = (uint8_t)(level << 6);
         uint32_t check = ((uint32_t)cmf << 8) + flg;
         if (check % 31 != 0) flg = (uint8_t)(flg + (31 - check % 31));
@@ -327,7 +330,7 @@ namespace lfx {
 // Stage A: plan upload → match → parse → histogram → Huffman (+ checksum).  Leaves everything the
 // emit stage needs in the context.
 int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *d_in, uint64_t n,
-                   int ck_mode) {
+                   int ck_mode, const HostCodes *hc) {
     const bool want_checksum = ck_mode != 0;   // 1: CRC-32 (gzip), 2: Adler-32 (zlib), 3: both (a shard: the caller folds either)
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
@@ -345,7 +348,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     // inputs are cut finer so that the GPU still fills: halve the segment length until there are >= 512 of them
     // (never below 32 Ki positions: the warm-up would dominate).
     std::vector<SegDesc> segs;
-    {
+    if (!hc) {
         uint64_t seg_len = SEG_POSITIONS;
         for (;;) {
             uint64_t cnt = 0;
@@ -363,7 +366,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     }
     // workgroups of the parse walk: PARSE_WG_SEGS consecutive segments of one chunk each
     std::vector<ParseWg> pwgs;
-    for (uint32_t ci = 0; ci < nchunks; ci++) {
+    for (uint32_t ci = 0; ci < nchunks && !hc; ci++) {
         const ChunkDesc &ch = plan.chunks[ci];
         if (ch.flags & CH_LITERALS) continue;
         for (uint32_t s = 0; s < ch.n_seg; s += PARSE_WG_SEGS) pwgs.push_back(ParseWg{ci, s});
@@ -391,13 +394,13 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_blocks.reserve(sizeof(BlockDesc) * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
     if ((rc = c->d_pwgs.reserve(sizeof(ParseWg) * std::max<size_t>(pwgs.size(), 1)))) return rc;
-    if ((rc = c->d_cd.reserve(2 * n + 64))) return rc;                          // candidate distances, 16 bits per position
-    if (match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
+    if (!hc && (rc = c->d_cd.reserve(2 * n + 64))) return rc;                   // candidate distances, 16 bits per position
+    if (!hc && match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
     if ((rc = c->d_vis.reserve(8 * std::max<uint64_t>(plan.n_vis, 1)))) return rc;
     if ((rc = c->d_segtmp.reserve(24ull * std::max<uint32_t>(plan.n_segs, 1)))) return rc;
-    if ((rc = c->d_stage.reserve(4ull * (n + 64)))) return rc;   // code words staged by the speculative parse walk
+    if (!hc && (rc = c->d_stage.reserve(4ull * (n + 64)))) return rc;   // code words staged by the speculative parse walk
     if ((rc = c->d_chunkmap.reserve(4ull * (plan.n_tiles + plan.n_segs + 2)))) return rc;   // tile → chunk, segment → chunk
     if ((rc = c->d_hist.reserve(4ull * 320 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_bc.reserve(sizeof(BlockCodes) * std::max<size_t>(nblocks, 1)))) return rc;
@@ -444,6 +447,14 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
 
     uint64_t *mdbg = nullptr;
     if (c->diag.debug) mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768);   // per-wavefront cycle counters of workgroup 0
+    if (hc) {
+        // the caller's own Lz77Encode produced the code words (EncodeOptions::with_lz77(E), encode.rs:59-65): they take the
+        // place of the match + parse stages' output — one chunk per block, EndOfBlock included; everything from the
+        // histogram on (CompressBuf::flush, encode.rs:416-425) runs as for the built-in encoders
+        if (hc->n_codes) HIP_TRY(hipMemcpyAsync(c->d_codes.p, hc->codes, 4ull * hc->n_codes, hipMemcpyHostToDevice, st));
+        if (nchunks) HIP_TRY(hipMemcpyAsync(c->d_ncodes.p, hc->chunk_codes, 4ull * nchunks, hipMemcpyHostToDevice, st));
+        c->phase("codes_upload");
+    } else {
     uint32_t *d_match_flags = (uint32_t *)((uint8_t *)c->d_res.p + offsetof(EncodeResult, match_flags));
     uint16_t *d_cd = (uint16_t *)c->d_cd.p;
     if (match_v1) {
@@ -500,6 +511,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 3]);
     }
     c->phase("lz77_parse");
+    }   // !hc
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the histogram
         // and the one-wavefront-per-block Huffman kernel, which leave most of the GPU idle
@@ -780,6 +792,14 @@ struct lfx_encoder {
     bool finished = false, failed = false;
     std::string err;
     DevBuf d_in, d_out;
+    // ---- codes mode (lfx_encoder_write_codes): the caller runs its own Lz77Encode, the GPU Huffman-codes what it emitted.
+    // `pending` then holds the raw bytes whose checksum is still due (they are never matched).
+    int mode = 0;                        // 0 undecided, 1 bytes (lfx_encoder_write), 2 codes
+    struct CodeBlock { uint64_t n_codes; uint32_t type, final; };   // n_codes includes the EndOfBlock; BT_RAW = zlib sync marker
+    std::vector<uint32_t> codes;         // code words of the closed blocks, then of the open one
+    std::vector<CodeBlock> cblocks;      // closed blocks not yet encoded
+    uint64_t closed_codes = 0, open_codes = 0;
+    bool final_closed = false;
 };
 
 static int enc_emit_bytes(lfx_encoder *e, const uint8_t *p, size_t n) {
@@ -827,6 +847,101 @@ static int enc_run(lfx_encoder *e, bool final) {
     return enc_emit_bytes(e, host.data(), whole);
 }
 
+// codes mode: encode every closed block (CompressBuf::flush from the histogram on, encode.rs:416-425)
+static int enc_run_codes(lfx_encoder *e) {
+    Ctx *c = e->c;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    if (e->cblocks.empty()) return LFX_OK;
+    Plan plan;
+    std::vector<uint32_t> chunk_codes;
+    uint64_t code_cursor = 0, tile_cursor = 0;
+    for (const lfx_encoder::CodeBlock &cb : e->cblocks) {
+        BlockDesc b{};
+        b.type = cb.type;
+        b.final = cb.final;
+        b.first_chunk = (uint32_t)plan.chunks.size();
+        if (cb.type != BT_RAW) {
+            ChunkDesc ch{};
+            ch.len = cb.n_codes - 1;            // (slots = len + 1, as for a chunk of len bytes that is all literals + EndOfBlock)
+            ch.code_off = code_cursor;
+            ch.block = (uint32_t)plan.blocks.size();
+            ch.flags = CH_LAST_IN_BLOCK;
+            ch.tile_base = tile_cursor;
+            code_cursor += cb.n_codes;
+            tile_cursor += div_up(cb.n_codes, PACK_TILE);
+            plan.chunks.push_back(ch);
+            chunk_codes.push_back((uint32_t)cb.n_codes);
+            b.n_chunks = 1;
+        }
+        plan.blocks.push_back(b);
+    }
+    if (e->final_closed) plan.blocks.back().align_after = 1;     // Block::finish → BitWriter::flush encode.rs:301
+    plan.n_codes_cap = code_cursor;
+    plan.n_tiles = tile_cursor;
+    const uint64_t n = e->pending.size();
+    int rc;
+    if ((rc = e->d_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
+    // a code costs at most 15 + 5 + 15 + 13 bits
+    const uint64_t bound = 6 * code_cursor + 1024 * (uint64_t)plan.blocks.size() + 128;
+    if ((rc = e->d_out.reserve(bound))) return rc;
+    if (n && hipMemcpyAsync(e->d_in.p, e->pending.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
+    EncodeResult res{};
+    uint8_t prefix[1] = {e->carry};
+    const HostCodes hc{e->codes.data(), code_cursor, chunk_codes.data()};
+    if ((rc = encode_prepare(c, plan, e->po, (const uint8_t *)e->d_in.p, n, e->format == LFX_GZIP ? 1 : e->format == LFX_ZLIB ? 2 : 0, &hc))) { e->err = c->err; return rc; }
+    rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits, (uint8_t *)e->d_out.p, bound & ~3ull, &res);
+    if (rc) { e->err = c->err; return rc; }
+    if (n) {
+        if (e->format == LFX_GZIP) e->crc = e->encoded_in == 0 ? res.crc32 : lfx_crc32_combine(e->crc, res.crc32, n);
+        if (e->format == LFX_ZLIB) e->adler = e->encoded_in == 0 ? res.adler32 : lfx_adler32_combine(e->adler, res.adler32, n);
+        e->encoded_in += n;
+    }
+    const uint64_t whole = e->final_closed ? (res.end_bit + 7) / 8 : res.end_bit / 8;
+    std::vector<uint8_t> host(whole + 1);
+    if (hipMemcpy(host.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
+    e->carry_bits = e->final_closed ? 0 : (uint32_t)(res.end_bit & 7);
+    e->carry = e->carry_bits ? host[whole] : 0;
+    e->pending.clear();
+    e->codes.erase(e->codes.begin(), e->codes.begin() + (std::ptrdiff_t)e->closed_codes);
+    e->closed_codes = 0;
+    e->cblocks.clear();
+    return enc_emit_bytes(e, host.data(), whole);
+}
+
+// closed blocks of the codes mode are encoded once this many code words wait (about 8 MiB of text)
+static const uint64_t ENC_BATCH_CODES = 2ull << 20;
+
+extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, size_t n_codes, const uint8_t *raw, size_t n_raw,
+                                       int end_block) {
+    if (!e || e->finished || e->final_closed || end_block < 0 || end_block > 2 || (n_codes && !codes) || (n_raw && !raw)) return LFX_E_ARG;
+    if (e->failed) return LFX_E_IO;
+    // stored blocks never run an Lz77Encode (RawBuf, encode.rs:348-383); bytes and codes cannot be mixed on one encoder
+    if (e->mode == 1 || e->po.no_compression) { e->err = "lfx_encoder_write_codes on an encoder that takes bytes"; return LFX_E_ARG; }
+    for (size_t i = 0; i < n_codes; i++) {       // Code::Literal(u8) / Code::Pointer{3..=258, 1..=32768} (lib.rs:27-42)
+        const uint32_t dist = codes[i] & 0xFFFFu, val = codes[i] >> 16;
+        if (dist == 0 ? val > 255 : (val < 3 || val > MAX_LENGTH || dist > MAX_WINDOW)) { e->err = "code word outside Code's domain"; return LFX_E_ARG; }
+    }
+    e->mode = 2;
+    e->codes.insert(e->codes.end(), codes, codes + n_codes);
+    e->open_codes += n_codes;
+    e->pending.insert(e->pending.end(), raw, raw + n_raw);
+    e->total_in += n_raw;
+    if (end_block) {
+        e->codes.push_back(CODE_EOB);            // encode.rs:417
+        e->cblocks.push_back(lfx_encoder::CodeBlock{e->open_codes + 1, e->po.dynamic_huffman ? (uint32_t)BT_DYNAMIC : (uint32_t)BT_FIXED,
+                                                    end_block == 2 ? 1u : 0u});
+        e->closed_codes += e->open_codes + 1;
+        e->open_codes = 0;
+        if (end_block == 2) e->final_closed = true;
+        else if (e->closed_codes >= ENC_BATCH_CODES) {
+            int rc = enc_run_codes(e);
+            if (rc) { e->failed = true; return rc; }
+        }
+    }
+    return LFX_OK;
+}
+
 extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encode_opts *o, lfx_write_cb w,
                                         lfx_flush_cb f, void *user, int *status) {
     if (!cc || !w) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
@@ -863,6 +978,8 @@ static const uint64_t ENC_BATCH_BYTES = 8ull << 20;
 extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n) {
     if (!e || e->finished) return -(int64_t)LFX_E_ARG;
     if (e->failed) return -(int64_t)LFX_E_IO;
+    if (e->mode == 2) { e->err = "lfx_encoder_write on an encoder that takes code words"; return -(int64_t)LFX_E_ARG; }
+    e->mode = 1;
     e->pending.insert(e->pending.end(), p, p + n);
     e->pl->write(n);
     e->total_in += n;
@@ -876,8 +993,18 @@ extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n)
 extern "C" int lfx_encoder_flush(lfx_encoder *e) {
     if (!e || e->finished) return LFX_E_ARG;
     if (e->failed) return LFX_E_IO;
+    int rc;
+    if (e->mode == 2) {
+        // the caller closed the block with E::flush()'s codes (end_block = 1) — Encoder::flush is Block::flush (encode.rs:245-248)
+        if (e->open_codes) { e->err = "close the open block first (end_block = 1)"; return LFX_E_ARG; }
+        if (e->po.zlib_sync) { e->cblocks.push_back(lfx_encoder::CodeBlock{0, (uint32_t)BT_RAW, 0u}); }   // zlib_sync_flush encode.rs:225-234
+        rc = enc_run_codes(e);
+        if (rc) { e->failed = true; return rc; }
+        if (e->f && e->f(e->user) != 0) { e->failed = true; e->err = "flush callback failed"; return LFX_E_IO; }
+        return LFX_OK;
+    }
     e->pl->flush();
-    int rc = enc_run(e, false);  // io::Write::flush pushes everything to the inner writer
+    rc = enc_run(e, false);  // io::Write::flush pushes everything to the inner writer
     if (rc) { e->failed = true; return rc; }
     if (e->f && e->f(e->user) != 0) { e->failed = true; e->err = "flush callback failed"; return LFX_E_IO; }
     return LFX_OK;
@@ -886,8 +1013,9 @@ extern "C" int lfx_encoder_flush(lfx_encoder *e) {
 extern "C" int lfx_encoder_finish(lfx_encoder *e) {
     if (!e || e->finished) return LFX_E_ARG;
     if (e->failed) return LFX_E_IO;
+    if (e->mode == 2 && !e->final_closed) { e->err = "close the final block first (end_block = 2)"; return LFX_E_ARG; }
     e->finished = true;
-    int rc = enc_run(e, true);
+    int rc = e->mode == 2 ? enc_run_codes(e) : enc_run(e, true);
     if (rc) return rc;
     uint8_t t[8];
     size_t nt = 0;

@@ -34,8 +34,17 @@ struct Diag {
     void read();
 };
 
+// N-GPU member decode: what lfx_decode_range_emit leaves for lfx_decode_range_map / lfx_decode_range_finish
+struct RangeState {
+    int state = -1;            // -1 none, 0 the slice holds bytes, 1 the slice is held as 16-bit symbols (d_dec_sym) and waits for its window
+    uint64_t total = 0, before = 0, max_len = 0;   // slice bytes, member bytes in front of it, longest symbol unit
+    uint8_t *d_out = nullptr;
+    uint32_t nsu = 0;          // symbol units (their table lives in d_dec_win behind the windows)
+};
+
 struct Ctx {
     int device = 0;
+    RangeState range;
     Diag diag;
     int n_cu = 0;   // compute units of the device
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -87,7 +96,13 @@ struct Ctx {
     void phase(const char *name);
 };
 
+// code words made on the host by a caller-supplied Lz77Encode (lfx_encoder_write_codes): contiguous, chunk after chunk
+struct HostCodes {
+    const uint32_t *codes;        // n_codes words, (val << 16) | dist, every block's EndOfBlock included
+    uint64_t n_codes;
+    const uint32_t *chunk_codes;  // codes per chunk of the plan
+};
 int encode_prepare(Ctx *c, const struct Plan &plan, const struct PlanOpts &po, const uint8_t *d_in,
-                   uint64_t n, int ck_mode);
+                   uint64_t n, int ck_mode, const HostCodes *hc = nullptr);
 
 }  // namespace lfx

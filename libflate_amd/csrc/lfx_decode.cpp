@@ -220,12 +220,12 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                             fprintf(stderr, "[lfx]   piece %u/%u: status=%u btype=%u data=%llu end=%llu prev_end=%llu lanes=%u codes=%u out=%llu\n", q, np,
                                     r.status, r.btype, (unsigned long long)r.data_bit, (unsigned long long)r.end_bit,
                                     (unsigned long long)prev_end, r.nlanes, r.n_codes, (unsigned long long)r.n_out);
-                        if (r.status == BLK_BAD || (q && r.data_bit != prev_end) || r.end_bit <= pos) { fail = true; break; }
+                        if (r.status == BLK_BAD || (q && r.data_bit != prev_end) || r.end_bit <= pos || r.end_bit > end_bits) { fail = true; break; }
                         if (q == 0 && r.btype == 0 && r.status != BLK_OK) { fail = true; break; }
                         BlkEmit e{};
                         e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
                         e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = base + q;
-                        e.hist = total;
+                        e.hist = hist + total;   // (a stream decoder's last window arrives with history)
                         e.end_limit = r.status == BLK_NO_EOB ? r.end_bit : 0;   // an open piece ends where its last lane stopped
                         emit.push_back(e);
                         total += r.n_out;
@@ -290,6 +290,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             std::vector<BlkInfo> bi(nj);
             HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            for (BlkInfo &b : bi) if (b.status == BLK_OK && b.end_bit > n * 8) b.status = BLK_NO_EOB;   // (cut by the input's end)
             c->phase("blk_scan");
             // slot[i]: where candidate i's scan result and lanes live (its own slot or the wider job's)
             std::vector<uint32_t> slot(nc);
@@ -350,6 +351,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     HIP_TRY(hipStreamSynchronize(st));
                     if (r.status == BLK_OK && r.btype != 0) n_extra++;   // the slot stays in use
                 }
+                //  a block the end of the input cuts in half is INCOMPLETE even when its scan reports an EndOfBlock:
+                // the last lane decodes a few symbols past the input (the bit source repeats the last dword there) and one
+                // of them may read as EndOfBlock — end_bit then lies behind the input and n_out counts garbage symbols
+                if (r.status == BLK_OK && r.end_bit > n * 8) r.status = BLK_NO_EOB;
                 if (r.status != BLK_OK || r.end_bit <= pos) { front_bad = emit.empty() && r.status == BLK_BAD; break; }
                 if (partial && total + r.n_out > cap) { mr.need_cap = emit.empty(); break; }   // (the next window takes it)
                 BlkEmit e{};
@@ -800,6 +805,7 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
         std::vector<BlkInfo> bi(nc);
         HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nc, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        for (BlkInfo &b : bi) if (b.status == BLK_OK && b.end_bit > n * 8) b.status = BLK_NO_EOB;
         // a false candidate inside a block cuts that block's range guess short (no EndOfBlock): rescan with wider ranges
         for (uint32_t widen = 2; widen <= 6; widen++) {
             std::vector<uint32_t> redo;
@@ -826,7 +832,8 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
             t.n_codes = bi[i].n_codes;
             t.btype = (uint8_t)bi[i].btype;
             t.bfinal = (uint8_t)bi[i].bfinal;
-            t.status = (uint8_t)bi[i].status;
+            // (a block cut by the end of the local bytes is incomplete whatever its scan says — see inflate_member)
+            t.status = (uint8_t)(bi[i].status == BLK_OK && bi[i].end_bit > n * 8 ? (uint32_t)BLK_NO_EOB : bi[i].status);
             t._pad = 0;
             t.slot = i;
             t.rank = (uint16_t)rank;
@@ -870,7 +877,7 @@ extern "C" int lfx_decode_chain(const lfx_blk_tuple *all, uint32_t n_all, uint64
 
 extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t n_part, uint64_t lo_byte, const lfx_blk_tuple *all,
                                      const uint32_t *chain, uint32_t n_chain, uint32_t rank, void *d_out_, uint64_t cap,
-                                     uint64_t *out_len, uint64_t *out_base, uint32_t *crc32, uint32_t *adler32) {
+                                     uint64_t *out_len, uint64_t *out_base, uint32_t *state) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -879,6 +886,7 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
     const uint8_t *d_in = (const uint8_t *)d_part_;
     uint8_t *d_out = (uint8_t *)d_out_;
     const uint64_t base_bit = lo_byte * 8;
+    c->range = RangeState{};
     // the chain blocks this rank owns (consecutive in stream order: ownership goes by start position)
     std::vector<BlkEmit> emit;
     uint64_t before = 0, total = 0, total_codes = 0;
@@ -897,45 +905,137 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
     }
     if (out_base) *out_base = before;
     if (out_len) *out_len = total;
-    if (crc32) *crc32 = 0;
-    if (adler32) *adler32 = 1;
+    if (state) *state = 0;
     if (total > cap) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
+    c->range.state = 0; c->range.total = total; c->range.d_out = d_out; c->range.before = before;
     if (emit.empty()) return LFX_OK;
     const uint32_t ne = (uint32_t)emit.size();
     int rc;
     if ((rc = c->d_dec_tmp.reserve(sizeof(BlkEmit) * (size_t)ne + 64))) return rc;
     if ((rc = c->d_hist.reserve(sizeof(BlkUnits) * (size_t)ne + 64))) return rc;
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(total_codes, 1)))) return rc;
-    if ((rc = c->d_res.reserve(256))) return rc;
     uint32_t *d_flags = (uint32_t *)c->d_dec_tmp.p;
     BlkEmit *d_emit = (BlkEmit *)((uint8_t *)c->d_dec_tmp.p + 64);
     HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
     HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
     const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
     const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
+    uint32_t free_shift = 17;   // marker units as on one GPU: two resident per CU, as large as that allows
+    while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
     LAUNCH_TRY(launch_blk_emit(st, d_in, n_part, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (uint32_t *)c->d_codes.p, d_flags,
-                               (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, 17));
+                               (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, free_shift));
     c->phase("blk_emit");
-    LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (const BlkUnits *)c->d_hist.p,
-                                      (const uint32_t *)c->d_codes.p, d_out, nullptr));
+    // small blocks smell of another encoder: look at the flags before materialising (as inflate_member does); the reference's
+    // 1 MiB blocks are materialised at once and the flags read afterwards
+    const bool probe = total / ne < (256u << 10);
     uint32_t fl = 0;
-    HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
-    const uint64_t nspans = div_up(std::max<uint64_t>(total, 1), 65536);
-    if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
-    uint32_t *ck = (uint32_t *)c->d_ck.p;
-    LAUNCH_TRY(launch_checksum(st, d_out, total, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, 3));
-    HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    c->phase("lz77_copy");
-    if (fl != 0) {
-        // blocks that read the output of earlier blocks (another encoder's member): the cross-rank window hand-over
-        //  is not built — the caller decodes such a member on one GPU
-        c->set_error("blocks of this member read earlier blocks' output: decode it with lfx_decode_device");
-        return LFX_E_UNSUPPORTED;
+    if (probe) {
+        HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
-    const EncodeResult er = *(EncodeResult *)c->h_res;
-    if (crc32) *crc32 = er.crc32;
-    if (adler32) *adler32 = er.adler32;
+    if (!(probe && fl)) {
+        LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (const BlkUnits *)c->d_hist.p,
+                                          (const uint32_t *)c->d_codes.p, d_out, nullptr));
+        HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    c->phase("lz77_copy");
+    if (fl & 1) {
+        c->range.state = -1;
+        c->set_error("a back-reference reaches in front of the member's first byte: decode it with lfx_decode_device for the exact error");
+        return LFX_E_INVALID_DATA;
+    }
+    if (fl == 2) {
+        // blocks that read the output of earlier blocks (another encoder's member), possibly of blocks another rank owns: the
+        // slice is materialised as 16-bit symbols (a byte, or "byte j of the 32 KiB in front of my unit"); the window in front
+        // of the slice arrives with lfx_decode_range_finish
+        std::vector<BlkUnits> uv(ne);
+        HIP_TRY(hipMemcpyAsync(uv.data(), c->d_hist.p, sizeof(BlkUnits) * ne, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<SymUnit> su;
+        uint64_t max_len = 0;
+        for (uint32_t q = 0; q < ne; q++)
+            for (uint32_t b = 0; b < uv[q].fn && b < MAX_FREE_UNITS; b++) {
+                const uint64_t len = uv[q].fout0[b + 1] - uv[q].fout0[b];
+                if (!len) continue;
+                su.push_back(SymUnit{emit[q].out_off + uv[q].fout0[b], len});
+                max_len = std::max(max_len, len);
+            }
+        const uint32_t nsu = (uint32_t)su.size();
+        if ((rc = c->d_dec_sym.reserve(2 * std::max<uint64_t>(total, 1)))) return rc;
+        if ((rc = c->d_dec_win.reserve(32768ull * (std::max<uint32_t>(nsu, 1) + 1) + sizeof(SymUnit) * (size_t)nsu + 64))) return rc;
+        if ((rc = c->d_dec_maps.reserve(window_prefix_scratch_bytes(std::max<uint32_t>(nsu, 1))))) return rc;
+        SymUnit *d_su = (SymUnit *)((uint8_t *)c->d_dec_win.p + 32768ull * (std::max<uint32_t>(nsu, 1) + 1));
+        HIP_TRY(hipMemcpyAsync(d_su, su.data(), sizeof(SymUnit) * nsu, hipMemcpyHostToDevice, st));
+        LAUNCH_TRY(launch_blk_materialize_sym(st, d_in, d_emit, ne, (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p,
+                                              (uint16_t *)c->d_dec_sym.p));
+        HIP_TRY(hipStreamSynchronize(st));     // (su must outlive its copy)
+        c->phase("lz77_sym");
+        c->range.state = 1; c->range.nsu = nsu; c->range.max_len = max_len;
+        if (state) *state = 1;
+    }
+    return LFX_OK;
+}
+
+extern "C" int lfx_decode_range_map(lfx_ctx *cc, void *d_map) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    if (c->range.state < 0 || !d_map) { c->set_error("lfx_decode_range_map: no range_emit on this context"); return LFX_E_ARG; }
+    if (c->range.state == 1) {
+        const uint32_t nsu = c->range.nsu;
+        const SymUnit *d_su = (const SymUnit *)((uint8_t *)c->d_dec_win.p + 32768ull * (std::max<uint32_t>(nsu, 1) + 1));
+        LAUNCH_TRY(launch_window_rank_map(c->stream, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, (uint16_t *)d_map));
+    } else LAUNCH_TRY(launch_bytes_to_map(c->stream, c->range.d_out, c->range.total, (uint16_t *)d_map));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LFX_OK;
+}
+
+extern "C" int lfx_decode_range_finish(lfx_ctx *cc, const void *d_maps, uint32_t rank, uint32_t *crc32, uint32_t *adler32) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    if (crc32) *crc32 = 0;
+    if (adler32) *adler32 = 1;
+    if (c->range.state < 0) { c->set_error("lfx_decode_range_finish: no range_emit on this context"); return LFX_E_ARG; }
+    const uint64_t total = c->range.total;
+    uint8_t *d_out = c->range.d_out;
+    int rc;
+    if (c->range.state == 1) {
+        const uint32_t nsu = c->range.nsu;
+        uint8_t *d_win = (uint8_t *)c->d_dec_win.p;
+        uint8_t *d_init = d_win + 32768ull * std::max<uint32_t>(nsu, 1);        // the window in front of the slice
+        const SymUnit *d_su = (const SymUnit *)(d_init + 32768);
+        const uint8_t *init_win = nullptr;
+        if (c->range.before) {
+            if (!d_maps || !rank) { c->set_error("this slice reads the output of the ranks in front of it: their maps are needed"); return LFX_E_ARG; }
+            LAUNCH_TRY(launch_window_ranks(st, (const uint16_t *)d_maps, rank, d_init));
+            init_win = d_init;
+        }
+        if (nsu >= 128 && !c->diag.window_chain)
+            LAUNCH_TRY(launch_window_prefix(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, d_win, init_win));
+        else LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, init_win));
+        c->phase("win_chain");
+        LAUNCH_TRY(launch_sym_substitute(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, d_out, c->range.max_len, init_win));
+        c->phase("substitute");
+        c->range.state = 0;        // the slice holds bytes now
+    }
+    if (total) {
+        if ((rc = c->d_res.reserve(256))) return rc;
+        const uint64_t nspans = div_up(total, 65536);
+        if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
+        uint32_t *ck = (uint32_t *)c->d_ck.p;
+        LAUNCH_TRY(launch_checksum(st, d_out, total, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, 3));
+        HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const EncodeResult er = *(EncodeResult *)c->h_res;
+        if (crc32) *crc32 = er.crc32;
+        if (adler32) *adler32 = er.adler32;
+    } else HIP_TRY(hipStreamSynchronize(st));
+    c->phase("checksum");
     return LFX_OK;
 }
 
@@ -1251,7 +1351,10 @@ int dec_header(lfx_decoder *d) {
 // whatever the member's size, and the first byte is served as soon as the first window is decoded.  The container
 // checksum is folded window by window (CRC-32 / Adler-32 combine).  A window without one complete block (a block larger
 // than the window: schedule-S1 members) doubles the window.
-constexpr uint64_t WINDOW_IN = 16ull << 20, WINDOW_OUT = 96ull << 20, WINDOW_IN_MAX = 1ull << 40;
+// WINDOW_IN_MAX bounds the doubling (a damaged stream whose block never reaches an EndOfBlock, on a reader that
+// never ends, must not pull the rest of the input into memory): at the limit the window is decoded WITHOUT `partial` — the
+// exact walk gives a verdict for a damaged stream; a valid block larger than the limit is refused.
+constexpr uint64_t WINDOW_IN = 16ull << 20, WINDOW_OUT = 96ull << 20, WINDOW_IN_MAX = 4ull << 30;
 
 // → LFX_OK when bytes or a verdict are ready (state ST_SERVE), LFX_E_WOULD_BLOCK / LFX_E_IO from the reader, or a device error
 int dec_body(lfx_decoder *d) {
@@ -1345,10 +1448,15 @@ int dec_body(lfx_decoder *d) {
             if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
             if (H && hipMemcpyAsync(d_out - H, d->hist.data(), H, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
             // (once the reader has ended nothing more can arrive: the exact walk gives the member's verdict)
-            const bool partial = !d->reader_eof;
+            const bool at_limit = !d->reader_eof && n >= WINDOW_IN_MAX;
+            const bool partial = !d->reader_eof && !at_limit;
             rc = inflate_member(c, (const uint8_t *)c->d_io_in.p, n, 0, d_out, d->out_cap, mr, d->bit_off, ~0ull, partial, d->member_out);
             if (rc) return rc;
             verdict = mr.status != LFX_OK || !partial;
+            if (at_limit && mr.status == LFX_E_UNEXPECTED_EOF) {
+                mr.status = LFX_E_UNSUPPORTED;
+                mr.msg = "a DEFLATE block exceeds the stream decoder's window limit (4 GiB of compressed bytes)";
+            }
             if (mr.status == LFX_E_NOSPACE && !partial) {     // (the tail of the member does not fit one window: grow and retry)
                 d->out_cap *= 2;
                 continue;

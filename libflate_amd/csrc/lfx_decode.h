@@ -143,6 +143,12 @@ int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *unit
 size_t window_prefix_scratch_bytes(uint32_t nunits);
 int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch,
                          uint8_t *windows, const uint8_t *init_win = nullptr);
+//  N-GPU decode, window hand-over: a rank's slice as ONE index map on the 32 KiB in front of it (from its symbol units, or
+//  from its bytes when the slice was materialised directly), and the window in front of rank `nranks` from the maps of
+//  the ranks before it (maps: nranks x 32768 entries in rank order)
+int launch_window_rank_map(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch, uint16_t *out_map);
+int launch_bytes_to_map(hipStream_t st, const uint8_t *out, uint64_t len, uint16_t *map);
+int launch_window_ranks(hipStream_t st, const uint16_t *maps, uint32_t nranks, uint8_t *win);
 //  out = sym with every marker replaced through the window in front of its unit
 int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits,
                           const uint8_t *windows, uint8_t *out, uint64_t max_len, const uint8_t *init_win = nullptr);   // max_len: longest unit

@@ -1267,6 +1267,55 @@ __global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__res
     }
 }
 
+// ---- N-GPU decode, window hand-over between ranks (round 4).  A rank's slice acts on the 32 KiB of output in
+// front of it as ONE index map (the composition of its units' maps): the ranks all-gather these maps (64 KiB each) and
+// every rank composes the maps of the ranks in front of it into the bytes of its own initial window.
+//  window_rank_map_kernel: the groups' composed maps (window_compose_kernel) folded in order, symbolically → the rank's map
+__global__ __launch_bounds__(1024) void window_rank_map_kernel(const uint16_t *__restrict__ maps, uint32_t nunits,
+                                                               uint16_t *__restrict__ out_map) {
+    extern __shared__ uint16_t mbuf[];   // 2 x 32 Ki entries
+    uint16_t *prev = mbuf, *cur = mbuf + 32768;
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = (uint16_t)(256u + i);   // identity: "byte i of the window in front"
+    __syncthreads();
+    const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        const uint32_t last = (g + 1) * WC_GROUP < nunits ? (g + 1) * WC_GROUP - 1 : nunits - 1;
+        const uint16_t *m = maps + (uint64_t)last * 32768;
+        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
+            const uint32_t s = m[i];
+            cur[i] = s < 256 ? (uint16_t)s : prev[s - 256];
+        }
+        __syncthreads();
+        uint16_t *t = prev; prev = cur; cur = t;
+    }
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) out_map[i] = prev[i];
+}
+//  a slice that was materialised directly (bytes): its map is its last 32 KiB as literals (a slice shorter than 32 KiB:
+//  the head of the map is the shift i -> i + len; an empty slice: the identity)
+__global__ __launch_bounds__(256) void bytes_to_map_kernel(const uint8_t *__restrict__ out, uint64_t len, uint16_t *__restrict__ map) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 32768) return;
+    map[i] = len + i >= 32768 ? (uint16_t)out[len + i - 32768] : (uint16_t)(256u + i + (uint32_t)len);
+}
+//  the window in front of rank `nranks`'s slice: the maps of ranks 0 .. nranks-1 applied in order to "nothing" (a member
+//  starts with an empty Lz77Decoder buffer: a marker that survives to the start is never looked up — K2 flagged it)
+__global__ __launch_bounds__(1024) void window_ranks_kernel(const uint16_t *__restrict__ maps, uint32_t nranks, uint8_t *__restrict__ win) {
+    extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
+    uint8_t *prev = wbuf, *cur = wbuf + 32768;
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r < nranks; ++r) {
+        const uint16_t *m = maps + (uint64_t)r * 32768;
+        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
+            const uint32_t s = m[i];
+            cur[i] = s < 256 ? (uint8_t)s : prev[s - 256];
+        }
+        __syncthreads();
+        uint8_t *t = prev; prev = cur; cur = t;
+    }
+    for (uint32_t i = threadIdx.x; i < 32768; i += 1024) win[i] = prev[i];
+}
+
 // Pass 3: every marker is replaced through the window in front of its unit.
 __global__ __launch_bounds__(256) void sym_substitute_kernel(const uint16_t *__restrict__ sym,
                                                              const SymUnit *__restrict__ units,
@@ -1578,6 +1627,43 @@ int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *uni
     hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 65536, st, maps, nunits, gwin, init_win);
     LFX_LAUNCH_CHECK();
     hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(256), 0, st, maps, gwin, windows, init_win);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+// the rank's map from its symbol units (scratch as for launch_window_prefix) / from its bytes; the window in front of a rank
+int launch_window_rank_map(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch, uint16_t *out_map) {
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
+        (void)hipFuncSetAttribute((const void *)window_compose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        (void)hipFuncSetAttribute((const void *)window_rank_map_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+        attr_set[dev_ & 63] = true;
+    }
+    uint16_t *maps = (uint16_t *)scratch;
+    const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
+    if (nunits) {
+        hipLaunchKernelGGL(window_compose_kernel, dim3(ngroups), dim3(1024), 131072, st, sym, units, nunits, maps);
+        LFX_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(window_rank_map_kernel, dim3(1), dim3(1024), 131072, st, maps, nunits, out_map);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_bytes_to_map(hipStream_t st, const uint8_t *out, uint64_t len, uint16_t *map) {
+    hipLaunchKernelGGL(bytes_to_map_kernel, dim3(128), dim3(256), 0, st, out, len, map);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_window_ranks(hipStream_t st, const uint16_t *maps, uint32_t nranks, uint8_t *win) {
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
+        (void)hipFuncSetAttribute((const void *)window_ranks_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set[dev_ & 63] = true;
+    }
+    hipLaunchKernelGGL(window_ranks_kernel, dim3(1), dim3(1024), 65536, st, maps, nranks, win);
     LFX_LAUNCH_CHECK();
     return 0;
 }

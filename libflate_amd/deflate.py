@@ -11,6 +11,7 @@ class EncodeOptions:
 
     def __init__(self, lz77=None):
         self._kw = {}
+        self._foreign = None
         if lz77 is not None:
             self.with_lz77(lz77)
 
@@ -19,7 +20,17 @@ class EncodeOptions:
         return cls()
 
     def with_lz77(self, lz77):  # encode.rs:59-65
-        self._kw.update(lz77._opts())
+        """`lz77`: one of this package's encoders (DefaultLz77Encoder, NoCompressionLz77Encoder: the whole path runs on the
+        GPU) or ANY object with the Lz77Encode methods encode(buf, sink) / flush(sink) / compression_level() /
+        window_size() (lib.rs:83-107): it then runs on the caller's side and the GPU Huffman-codes what it emits
+        (lfx_encoder_write_codes)."""
+        if hasattr(lz77, "_opts"):
+            self._kw.update(lz77._opts())
+            self._foreign = None
+        else:
+            self._foreign = lz77
+            self._kw.update({"lz77_kind": _ffi.LZ77_DEFAULT, "window_size": min(int(lz77.window_size()), 32768),
+                             "lz77_level": 1 + int(lz77.compression_level())})
         return self
 
     def no_compression(self):  # encode.rs:77-80

@@ -67,6 +67,7 @@ class EncodeOptions(_deflate.EncodeOptions):
 
     def header(self, header):  # gzip.rs:717-720
         self._kw.update(header)
+        self._kw["lz77_level"] = 0       # the header REPLACES the one with_lz77 made: HeaderBuilder's level is Unknown (gzip.rs:157,684)
         return self
 
 

@@ -22,6 +22,11 @@ class Code:
         return ("Pointer", length, backward_distance)
 
     @staticmethod
+    def to_word(code):
+        """the ABI's code word: (val << 16) | dist, dist == 0 for a literal (include/lfx.h, lfx_sink_cb)"""
+        return (code[1] << 16) if code[0] == "Literal" else (code[1] << 16) | code[2]
+
+    @staticmethod
     def from_word(w):
         w = int(w)
         return Code.Literal(w >> 16) if (w & 0xFFFF) == 0 else Code.Pointer(w >> 16, w & 0xFFFF)

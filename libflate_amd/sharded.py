@@ -155,14 +155,31 @@ def chain_of(all_tuples, n_all, first_bit):
 
 
 def range_emit(ctx, rank, d_part_ptr, n_part, lo, all_tuples, chain, n_chain, d_out_ptr, cap):
-    """step 4 on one rank → (bytes written, offset of the slice in the member's output, crc32, adler32)"""
+    """step 4 on one rank → (bytes of the slice, its offset in the member's output, state); state 1: the slice is held as
+    symbols and needs the window in front of it (steps 5-6: range_map, all-gather, range_finish)"""
     L = _ffi.lib()
-    ol, base, crc, ad = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+    ol, base, state = C.c_uint64(0), C.c_uint64(0), C.c_uint32(0)
     rc = L.lfx_decode_range_emit(ctx.handle, d_part_ptr, n_part, lo, all_tuples, chain, n_chain, rank, d_out_ptr, cap,
-                                 C.byref(ol), C.byref(base), C.byref(crc), C.byref(ad))
+                                 C.byref(ol), C.byref(base), C.byref(state))
     if rc:
         raise _ffi.LfxError(rc, ctx.last_error())
-    return ol.value, base.value, crc.value, ad.value
+    return ol.value, base.value, state.value
+
+
+def range_map(ctx, d_map_ptr):
+    """step 5 on one rank: the slice's index map (32768 uint16 on the device)"""
+    rc = _ffi.lib().lfx_decode_range_map(ctx.handle, d_map_ptr)
+    if rc:
+        raise _ffi.LfxError(rc, ctx.last_error())
+
+
+def range_finish(ctx, rank, d_maps_ptr=None):
+    """step 6 on one rank → (crc32, adler32) of the slice; d_maps_ptr: every rank's map in rank order (device), or None"""
+    crc, ad = C.c_uint32(0), C.c_uint32(0)
+    rc = _ffi.lib().lfx_decode_range_finish(ctx.handle, d_maps_ptr, rank, C.byref(crc), C.byref(ad))
+    if rc:
+        raise _ffi.LfxError(rc, ctx.last_error())
+    return crc.value, ad.value
 
 
 def fold_checks(parts):
@@ -175,17 +192,25 @@ def fold_checks(parts):
     return crc, ad
 
 
-def gather_tuples(tuples, cnt, world, dist, device="cpu", group=None):
+def gather_tuples(tuples, cnt, world, dist, device="cpu", group=None, status=0):
     """step 2: all-gather of the ranks' candidate tuples (variable counts: the counts first, then rows padded to the
-    longest) → (ctypes array of all tuples in rank order, their number)"""
+    longest) → (ctypes array of all tuples in rank order, their number).  `status`: this rank's error code of step 1 —
+    it rides with the counts, and a failure on ANY rank is raised on EVERY rank after the collective (a rank
+    that raises before a collective leaves the others waiting in it)."""
     if dist is None or world == 1:
+        if status:
+            raise _ffi.LfxError(status, "range scan failed")
         return tuples, cnt
     import torch
     tsz = C.sizeof(_ffi.BlkTuple)
     dev = "cpu" if dist.get_backend() == "gloo" else device
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([cnt], dtype=torch.int64, device=dev), group=group)
-    counts = [int(x.item()) for x in counts]
+    counts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([cnt, status], dtype=torch.int64, device=dev), group=group)
+    counts = [[int(v) for v in x.cpu().tolist()] for x in counts]
+    bad = [(r, st) for r, (_, st) in enumerate(counts) if st]
+    if bad:
+        raise _ffi.LfxError(bad[0][1], "range scan failed on rank %d: decode the member on one GPU" % bad[0][0])
+    counts = [c0 for c0, _ in counts]
     width = max(max(counts), 1) * tsz
     mine = torch.zeros(width, dtype=torch.uint8)
     if cnt:
@@ -205,21 +230,67 @@ def gather_tuples(tuples, cnt, world, dist, device="cpu", group=None):
 
 def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_out, cap, dist=None, group=None):
     """One rank's side of the N-GPU decode over torch.distributed (RCCL on GPUs, gloo in CPU rigs): scan → all-gather of
-    the tuples → chain → emit → all-gather of (length, crc, adler).  d_part / d_out: torch uint8 tensors on the rank's
-    device; `group`: a process group of its own for these two small collectives, so that they do not queue behind bulk
-    transfers posted on the default group (bench.py: the member's concatenation is in flight).  → (bytes of this rank's slice, its offset in the member's output, total output bytes, crc32, adler32 of the
-    whole member's output)."""
+    the tuples → chain → emit → [window hand-over: all-gather of the ranks' 64 KiB index maps, only for members whose blocks
+    read earlier blocks] → all-gather of (length, crc, adler).  d_part / d_out: torch uint8 tensors on the rank's
+    device; `group`: a process group of its own for these small collectives, so that they do not queue behind bulk
+    transfers posted on the default group (bench.py: the member's concatenation is in flight).  Every failure is carried
+    through the next collective and raised on ALL ranks.  → (bytes of this rank's slice, its offset in the member's
+    output, total output bytes, crc32, adler32 of the whole member's output)."""
     import torch
-    tuples, cnt = range_scan(ctx, rank, d_part.data_ptr(), n_part, lo, hi, first_bit if rank == 0 else None)
-    all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device, group)
-    chain, nch, total = chain_of(all_t, n_all, first_bit)
-    ol, base, crc, ad = range_emit(ctx, rank, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_out.data_ptr(), cap)
+    status = 0
+    tuples, cnt = None, 0
+    try:
+        tuples, cnt = range_scan(ctx, rank, d_part.data_ptr(), n_part, lo, hi, first_bit if rank == 0 else None)
+    except _ffi.LfxError as e:
+        status = e.status or _ffi.E_UNSUPPORTED
+    all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device, group, status)
+    chain, nch, total = chain_of(all_t, n_all, first_bit)        # (deterministic: breaks on every rank alike)
+    ol = base = state = 0
+    crc, ad = 0, 1
+    try:
+        ol, base, state = range_emit(ctx, rank, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_out.data_ptr(), cap)
+        if state == 0:
+            crc, ad = range_finish(ctx, rank)
+    except _ffi.LfxError as e:
+        status = e.status or _ffi.E_UNSUPPORTED
     if dist is None or world == 1:
+        if status:
+            raise _ffi.LfxError(status, ctx.last_error())
+        if state:
+            crc, ad = range_finish(ctx, rank)
         return ol, base, total, crc, ad
     host = dist.get_backend() == "gloo"
     dev = "cpu" if host else d_part.device
-    mine = torch.tensor([ol, crc, ad], dtype=torch.int64, device=dev)
-    parts = [torch.empty(3, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    crc_all, ad_all = fold_checks([tuple(int(v) for v in p.cpu().tolist()) for p in parts])
+
+    def gather5(vals):
+        mine = torch.tensor(vals, dtype=torch.int64, device=dev)
+        parts = [torch.empty(len(vals), dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        return [[int(v) for v in p.cpu().tolist()] for p in parts]
+
+    rows = gather5([status, state, ol, crc, ad])
+    bad = [(r, row[0]) for r, row in enumerate(rows) if row[0]]
+    if bad:
+        raise _ffi.LfxError(bad[0][1], "slice decode failed on rank %d: decode the member on one GPU" % bad[0][0])
+    if any(row[1] for row in rows):
+        # ---- window hand-over (another encoder's member): every rank's slice as one index map, all-gathered
+        d_map = torch.empty(32768, dtype=torch.int16, device=d_part.device)
+        try:
+            range_map(ctx, d_map.data_ptr())
+        except _ffi.LfxError as e:
+            status = e.status or _ffi.E_UNSUPPORTED
+        mine = d_map.cpu() if host else d_map
+        maps = [torch.empty(32768, dtype=torch.int16, device=dev) for _ in range(world)]
+        dist.all_gather(maps, mine, group=group)                 # RCCL over xGMI: 64 KiB per rank
+        d_maps = torch.stack(maps).to(d_part.device).contiguous()
+        try:
+            if not status:
+                crc, ad = range_finish(ctx, rank, d_maps.data_ptr())
+        except _ffi.LfxError as e:
+            status = e.status or _ffi.E_UNSUPPORTED
+        rows = gather5([status, 0, ol, crc, ad])
+        bad = [(r, row[0]) for r, row in enumerate(rows) if row[0]]
+        if bad:
+            raise _ffi.LfxError(bad[0][1], "window hand-over failed on rank %d" % bad[0][0])
+    crc_all, ad_all = fold_checks([(row[2], row[3], row[4]) for row in rows])
     return ol, base, total, crc_all, ad_all

@@ -25,7 +25,7 @@ extern "C" {
 
 enum { LFO_DEFLATE = 0, LFO_ZLIB = 1, LFO_GZIP = 2 };
 enum { LFO_OK = 0, LFO_INVALID_DATA = 1, LFO_UNEXPECTED_EOF = 2 };
-enum { LFO_LZ77_DEFAULT = 0, LFO_LZ77_NOCOMPRESSION = 1 };
+enum { LFO_LZ77_DEFAULT = 0, LFO_LZ77_NOCOMPRESSION = 1, LFO_LZ77_CUSTOM = 2 };
 
 /* growable byte buffer */
 typedef struct lfo_buf {
@@ -66,7 +66,17 @@ typedef struct lfo_opts {
     size_t extra_len;
     const char *filename;    /* NUL-terminated or NULL */
     const char *comment;
+    /* lz77_kind == LFO_LZ77_CUSTOM: the generic parameter `E: Lz77Encode` of EncodeOptions::with_lz77(E)
+     * (src/deflate/encode.rs:59-65).  custom_cb(user, p, n, &codes) is E::encode(p[0..n], sink) when p != NULL and
+     * E::flush(sink) when p == NULL (libflate_lz77/src/lib.rs:83-95); it returns the number of code words it emitted
+     * and points *codes at them ((val << 16) | dist, valid until the next call).  custom_level = E::compression_level()
+     * as LFO_LEVEL_* (lib.rs:96-99), window_size above = E::window_size() (lib.rs:103-106): both only reach the
+     * container header (zlib.rs:212-220, gzip.rs:684). */
+    size_t (*custom_cb)(void *user, const uint8_t *p, size_t n, const uint32_t **codes);
+    void *custom_user;
+    int custom_level;
 } lfo_opts;
+enum { LFO_LEVEL_NONE = 0, LFO_LEVEL_FAST = 1, LFO_LEVEL_BALANCE = 2, LFO_LEVEL_BEST = 3 };
 void lfo_opts_default(lfo_opts *o);
 
 typedef struct lfo_encoder lfo_encoder;

@@ -108,7 +108,16 @@ static void syms_reserve(lfo_encoder *e, size_t extra) {
 }
 
 /* DefaultLz77Encoder::flush → sink = Vec<Symbol> */
+static void lz_custom(lfo_encoder *e, const uint8_t *p, size_t n) {
+    /* a generic E: whatever it hands to the sink is appended to CompressBuf.buf (encode.rs:405-408,416) */
+    const uint32_t *codes = NULL;
+    size_t k = e->o.custom_cb(e->o.custom_user, p, n, &codes);
+    syms_reserve(e, k);
+    memcpy(e->syms + e->nsyms, codes, k * sizeof(uint32_t));
+    e->nsyms += k;
+}
 static void lz_flush(lfo_encoder *e) {
+    if (e->o.lz77_kind == LFO_LZ77_CUSTOM) { lz_custom(e, NULL, 0); return; }
     if (e->o.lz77_kind != LFO_LZ77_DEFAULT) return; /* lib.rs:136-141: no-op */
     syms_reserve(e, e->lzbuf.n + 1);
     e->nsyms += lfo_lz77_chunk(e->lzbuf.p, e->lzbuf.n, e->o.window_size, e->o.max_length,
@@ -117,6 +126,7 @@ static void lz_flush(lfo_encoder *e) {
 }
 /* DefaultLz77Encoder::encode default.rs:60-68 / NoCompressionLz77Encoder lib.rs:127-135 */
 static void lz_encode(lfo_encoder *e, const uint8_t *p, size_t n) {
+    if (e->o.lz77_kind == LFO_LZ77_CUSTOM) { lz_custom(e, p ? p : (const uint8_t *)"", n); return; }
     if (e->o.lz77_kind == LFO_LZ77_NOCOMPRESSION) {
         syms_reserve(e, n);
         for (size_t i = 0; i < n; i++) e->syms[e->nsyms++] = (uint32_t)p[i] << 16;
@@ -333,9 +343,13 @@ void lfo_opts_default(lfo_opts *o) {
 static void gzip_header_bytes(const lfo_opts *o, int with_hcrc, lfo_buf *b) {
     uint8_t flg = (uint8_t)((o->is_text ? 1 : 0) | (with_hcrc ? 2 : 0) | (o->extra ? 4 : 0) |
                             (o->filename ? 8 : 0) | (o->comment ? 16 : 0));
-    /* XFL: lz77 CompressionLevel Balance/None → Unknown → 0 (gzip.rs:69-92) */
+    /* XFL: lz77 CompressionLevel Balance/None → Unknown → 0, Fast → Fastest → 4, Best → Slowest → 2 (gzip.rs:69-92,684);
+     * no_compression() resets it to Unknown (gzip.rs:703) */
+    uint8_t xfl = 0;
+    if (o->lz77_kind == LFO_LZ77_CUSTOM && !o->no_compression)
+        xfl = o->custom_level == LFO_LEVEL_FAST ? 4 : o->custom_level == LFO_LEVEL_BEST ? 2 : 0;
     uint8_t h[10] = {31, 139, 8, flg, (uint8_t)o->mtime, (uint8_t)(o->mtime >> 8),
-                     (uint8_t)(o->mtime >> 16), (uint8_t)(o->mtime >> 24), 0, o->os};
+                     (uint8_t)(o->mtime >> 16), (uint8_t)(o->mtime >> 24), xfl, o->os};
     buf_put(b, h, 10);
     if (o->extra) {
         uint8_t l[2] = {(uint8_t)o->extra_len, (uint8_t)(o->extra_len >> 8)};
@@ -380,6 +394,7 @@ lfo_encoder *lfo_encoder_new(int format, const lfo_opts *o) {
         /* level: lz77 Balance→Default(2); NoCompression encoder → None→Fastest(0);
          * no_compression() option → Fastest(0) (zlib.rs:471-475) */
         uint8_t level = (o->no_compression || o->lz77_kind == LFO_LZ77_NOCOMPRESSION) ? 0 : 2;
+        if (o->lz77_kind == LFO_LZ77_CUSTOM && !o->no_compression) level = (uint8_t)(o->custom_level & 3); /* zlib.rs:59-68 */
         uint8_t cmf = (uint8_t)((cinfo << 4) | 8);
         uint8_t flg = (uint8_t)(level << 6);
         uint32_t check = ((uint32_t)cmf << 8) + flg;

@@ -34,7 +34,35 @@ class Opts(C.Structure):
         ("zlib_sync_flush", C.c_int), ("mtime", C.c_uint32), ("os", C.c_uint8),
         ("is_text", C.c_int), ("hcrc", C.c_int), ("extra", C.c_char_p), ("extra_len", C.c_size_t),
         ("filename", C.c_char_p), ("comment", C.c_char_p),
+        ("custom_cb", C.c_void_p), ("custom_user", C.c_void_p), ("custom_level", C.c_int),
     ]
+
+
+# the generic `E: Lz77Encode` (lfo.h: custom_cb): size_t cb(user, p, n, const uint32_t **codes); p == NULL is E::flush
+CUSTOM_CB = C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.POINTER(C.c_uint32)))
+LZ77_DEFAULT, LZ77_NOCOMPRESSION, LZ77_CUSTOM = 0, 1, 2
+
+
+def custom_lz77(obj):
+    """obj: any object with the Lz77Encode methods encode(buf, sink) / flush(sink) / compression_level() / window_size()
+    whose sink receives ("Literal", b) / ("Pointer", length, distance) tuples → keyword options for Encoder / encode."""
+    keep = {}
+
+    def cb(_user, p, n, out):
+        sink = []
+        if p:
+            obj.encode(C.string_at(p, n), sink)
+        else:
+            obj.flush(sink)
+        words = (C.c_uint32 * max(len(sink), 1))(*[(c[1] << 16) if c[0] == "Literal" else (c[1] << 16) | c[2] for c in sink])
+        keep["words"] = words
+        out[0] = C.cast(words, C.POINTER(C.c_uint32))
+        return len(sink)
+
+    fn = CUSTOM_CB(cb)
+    keep["fn"] = fn
+    return {"lz77_kind": LZ77_CUSTOM, "custom_cb": C.cast(fn, C.c_void_p).value, "custom_level": int(obj.compression_level()),
+            "window_size": min(int(obj.window_size()), 32768), "_keep": keep}
 
 
 class BlockInfo(C.Structure):
@@ -91,6 +119,8 @@ def make_opts(**kw):
     for k, v in kw.items():
         if k == "extra":
             o.extra, o.extra_len = v, len(v)
+        elif k == "_keep":
+            o._keep = v                 # (callback objects of a custom Lz77Encode: alive as long as the options)
         else:
             setattr(o, k, v)
     return o

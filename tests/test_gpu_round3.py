@@ -270,13 +270,23 @@ def _virtual_rank_decode(lfx, ffi, member, hdr_len, world, plain_len):
     chain, nch, total = sharded.chain_of(all_t, total_cnt, hdr_len * 8)
     assert total == plain_len
     out = torch.zeros(plain_len, dtype=torch.uint8, device="cuda")
-    checks, owned = [], []
+    checks, owned, slices, states = [], [], [], []
     for r, (d_part, n_part, lo) in enumerate(parts):
         d_slice = torch.zeros(plain_len, dtype=torch.uint8, device="cuda")
-        ol, base, crc, ad = sharded.range_emit(ctxs[r], r, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_slice.data_ptr(), plain_len)
+        ol, base, state = sharded.range_emit(ctxs[r], r, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_slice.data_ptr(), plain_len)
+        slices.append((d_slice, ol, base))
+        states.append(state)
+        owned.append(ol)
+    d_maps = None
+    if any(states):           # window hand-over (round 4): the ranks' index maps, "all-gathered" = stacked in rank order
+        d_maps = torch.empty((world, 32768), dtype=torch.int16, device="cuda")
+        for r in range(world):
+            sharded.range_map(ctxs[r], d_maps[r].data_ptr())
+    for r in range(world):
+        crc, ad = sharded.range_finish(ctxs[r], r, d_maps.data_ptr() if d_maps is not None else None)
+        d_slice, ol, base = slices[r]
         out[base:base + ol] = d_slice[:ol]
         checks.append((ol, crc, ad))
-        owned.append(ol)
     for c in ctxs:
         c.close()
     return out, sharded.fold_checks(checks), owned, nch, total_cnt
@@ -299,11 +309,12 @@ def test_member_decode_on_virtual_ranks(env, oracle):
         assert crc == zlib.crc32(plain) == int.from_bytes(member[-8:-4], "little") and ad == zlib.adler32(plain)
         assert nch == 65 and min(owned) > (len(plain) // world) // 2, (world, nch, owned)       # 64 blocks + the empty final one
         assert ncand >= nch
-    # a member whose blocks read earlier blocks (python zlib) is refused, not decoded wrongly
+    # a member whose blocks read earlier blocks (python zlib), also across rank boundaries: the window hand-over of round 4
+    # (tests/test_gpu_round4.py::test_foreign_member_on_virtual_ranks has the sweep)
     import gzip as pygzip
     foreign = pygzip.compress(plain[:(16 << 20)], 6, mtime=0)
-    with pytest.raises(ffi.LfxError):
-        _virtual_rank_decode(lfx, ffi, foreign, 10, 4, 16 << 20)
+    out, (crc, ad), owned, nch, ncand = _virtual_rank_decode(lfx, ffi, foreign, 10, 4, 16 << 20)
+    assert torch.equal(out, torch.from_numpy(data[:16 << 20]).cuda()) and crc == zlib.crc32(plain[:16 << 20])
 
 
 def test_gzip_header_empty_name_and_comment(env, oracle):

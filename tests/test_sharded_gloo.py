@@ -170,3 +170,45 @@ def test_member_decode_exchange_world2():
     assert res[0] == "ok", res
     assert res[1], ("chain / checksum fold of the gathered tuples is wrong", res)
     assert res[2] == res[3] and res[4] == res[3] + 2          # every block on the chain; the two false candidates are not
+
+
+def _error_worker(rank, world, port, q):
+    """a rank whose scan fails must not leave the others waiting in the collective — the status rides with the
+    counts and every rank raises after the all-gather."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from libflate_amd import _ffi, sharded
+        tuples = (_ffi.BlkTuple * 1)()
+        raised = None
+        try:
+            sharded.gather_tuples(tuples, 0, world, dist, status=_ffi.E_NOSPACE if rank == 1 else 0)
+        except _ffi.LfxError as e:
+            raised = e.status
+        flag = __import__("torch").tensor([1 if raised == _ffi.E_NOSPACE else 0])
+        dist.all_reduce(flag)                                   # (both ranks are still in step: no one hangs)
+        if rank == 0:
+            q.put(("ok", int(flag.item())))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+def test_failure_on_one_rank_is_raised_on_all_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_error_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == ("ok", 2), res
