@@ -1,13 +1,14 @@
 //! `libflate::deflate` (reference `src/deflate/{mod,encode,decode}.rs`).
-use crate::lz77::{DefaultLz77Encoder, GpuLz77};
+use crate::lz77::{DefaultLz77Encoder, GpuLz77, Lz77Stage};
 use crate::{ffi, Finish, RawDecoder, RawEncoder};
 use std::io;
-use std::marker::PhantomData;
 
 pub const DEFAULT_BLOCK_SIZE: usize = 1024 * 1024; // encode.rs:11
 
-/// `deflate::EncodeOptions<E>` (encode.rs:17-128).  `E` is the LZ77 stage — the reference's own parameter; here it must
-/// be one the GPU pipeline implements (`lz77::GpuLz77`: `DefaultLz77Encoder`, `NoCompressionLz77Encoder`), see lz77.rs.
+/// `deflate::EncodeOptions<E>` (encode.rs:17-128).  `E` is the LZ77 stage — the reference's own parameter: ANY
+/// `E: Lz77Encode + 'static` (`lz77::GpuLz77` is implemented for all of them).  This crate's `DefaultLz77Encoder` /
+/// `NoCompressionLz77Encoder` run on the device with the rest of the path; any other `E` runs on the caller's side and the
+/// device Huffman-codes what it emits, see lz77.rs.
 #[derive(Debug)]
 pub struct EncodeOptions<E = DefaultLz77Encoder>
 where
@@ -39,23 +40,28 @@ where
     /// encode.rs:107-110
     pub fn fixed_huffman_codes(mut self) -> Self { self.dynamic_huffman = false; self }
 
-    pub(crate) fn to_ffi(&self) -> ffi::lfx_encode_opts {
+    /// → the C options and whether the whole path runs on the device for this `E` (else `E` runs on the caller's side)
+    pub(crate) fn to_ffi(&self) -> (ffi::lfx_encode_opts, bool) {
         let mut o: ffi::lfx_encode_opts = unsafe { std::mem::zeroed() };
         unsafe { ffi::lfx_encode_opts_default(&mut o) };
         o.block_size = self.block_size as u64;
         o.dynamic_huffman = self.dynamic_huffman as i32;
-        match self.lz77 {
+        let on_device = match self.lz77 {
             Some(ref e) => e.configure(&mut o),
-            None => o.no_compression = 1,
-        }
-        o
+            None => { o.no_compression = 1; true }      // RawBuf never calls the Lz77Encode (encode.rs:348-383)
+        };
+        (o, on_device)
+    }
+    /// the caller-side stage of an encoder built from these options (`E` moves into it when it is not a device stage)
+    pub(crate) fn into_stage(self, on_device: bool) -> Lz77Stage<E> {
+        Lz77Stage { lz77: if on_device { None } else { self.lz77 }, block_size: self.block_size, original_size: 0 }
     }
 }
 
 /// `deflate::Encoder<W, E>` (encode.rs:132-249)
 pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> {
     raw: RawEncoder<W>,
-    _lz77: PhantomData<E>,
+    stage: Lz77Stage<E>,
 }
 impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
     /// encode.rs:156-158
@@ -64,25 +70,27 @@ impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
     }
 }
 impl<W: io::Write, E: GpuLz77> Encoder<W, E> {
-    /// encode.rs:182-189.  Panics when no GPU is usable (the reference constructor is infallible; there is no CPU
-    /// fallback here) — `try_with_options` reports it instead.
+    /// encode.rs:182-189.  Panics when the encoder cannot be made — no usable GPU (there is no CPU fallback here), or an
+    /// option outside the reference's domain; the reference constructor is infallible — `try_with_options` reports it.
     pub fn with_options(inner: W, options: EncodeOptions<E>) -> Self {
-        Self::try_with_options(inner, options).expect("libflate-amd: no usable MI355X device")
+        Self::try_with_options(inner, options).unwrap_or_else(|e| panic!("libflate-amd: {}", e))
     }
     pub fn try_with_options(inner: W, options: EncodeOptions<E>) -> io::Result<Self> {
-        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_DEFLATE, &options.to_ffi(), inner)?, _lz77: PhantomData })
+        let (o, on_device) = options.to_ffi();
+        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_DEFLATE, &o, inner)?, stage: options.into_stage(on_device) })
     }
-    pub fn finish(self) -> Finish<W, io::Error> {
+    pub fn finish(mut self) -> Finish<W, io::Error> {
+        let closed = self.stage.close(&mut self.raw, 2);
         let (w, e) = self.raw.finish();
-        Finish::new(w, e)
+        Finish::new(w, closed.err().or(e))
     }
     pub fn as_inner_ref(&self) -> &W { self.raw.inner_ref() }
     pub fn as_inner_mut(&mut self) -> &mut W { self.raw.inner_mut() }
     pub fn into_inner(self) -> W { self.raw.into_inner() }
 }
-impl<W: io::Write, E> io::Write for Encoder<W, E> {
-    fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.raw.write(buf) }
-    fn flush(&mut self) -> io::Result<()> { self.raw.flush() }
+impl<W: io::Write, E: GpuLz77> io::Write for Encoder<W, E> {
+    fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.stage.write(&mut self.raw, buf) }
+    fn flush(&mut self) -> io::Result<()> { self.stage.close(&mut self.raw, 1)?; self.raw.flush() }
 }
 
 /// `deflate::Decoder` (decode.rs:8-164)

@@ -39,7 +39,7 @@ pub struct lfx_encode_opts {
     pub os: u8,
     pub is_text: u8,
     pub hcrc: u8,
-    pub _pad: u8,
+    pub lz77_level: u8,
     pub extra: *const u8,
     pub extra_len: u32,
     pub filename: *const c_char,
@@ -85,6 +85,8 @@ extern "C" {
     pub fn lfx_encoder_new(c: *mut lfx_ctx, format: c_int, o: *const lfx_encode_opts, w: lfx_write_cb,
                            f: Option<lfx_flush_cb>, user: *mut c_void, status: *mut c_int) -> *mut lfx_encoder;
     pub fn lfx_encoder_write(e: *mut lfx_encoder, p: *const u8, n: usize) -> i64;
+    pub fn lfx_encoder_write_codes(e: *mut lfx_encoder, codes: *const u32, n_codes: usize, raw: *const u8, n_raw: usize,
+                                   end_block: c_int) -> c_int;
     pub fn lfx_encoder_flush(e: *mut lfx_encoder) -> c_int;
     pub fn lfx_encoder_finish(e: *mut lfx_encoder) -> c_int;
     pub fn lfx_encoder_last_error(e: *const lfx_encoder) -> *const c_char;

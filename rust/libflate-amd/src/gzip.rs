@@ -1,9 +1,8 @@
 //! `libflate::gzip` (reference `src/gzip.rs`).
-use crate::lz77::{DefaultLz77Encoder, GpuLz77};
+use crate::lz77::{DefaultLz77Encoder, GpuLz77, Lz77Stage};
 use crate::{ffi, Finish, RawDecoder, RawEncoder};
 use std::ffi::{CStr, CString};
 use std::io;
-use std::marker::PhantomData;
 
 /// gzip.rs:58-92 (XFL)
 #[derive(Debug, Clone, PartialEq, Eq)]
@@ -110,24 +109,25 @@ where
 {
     inner: crate::deflate::EncodeOptions<E>,
     header: Header,
+    level_from_lz77: bool,      // the header still is the one with_lz77 made (its XFL follows E::compression_level, gzip.rs:684)
 }
 impl Default for EncodeOptions<DefaultLz77Encoder> {
     fn default() -> Self { Self::new() }
 }
 impl EncodeOptions<DefaultLz77Encoder> {
-    pub fn new() -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::new(), header: HeaderBuilder::new().finish() } }
+    pub fn new() -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::new(), header: HeaderBuilder::new().finish(), level_from_lz77: true } }
 }
 impl<E: GpuLz77> EncodeOptions<E> {
     /// gzip.rs:667-672
-    pub fn with_lz77(lz77: E) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), header: HeaderBuilder::new().finish() } }
-    pub fn no_compression(mut self) -> Self { self.inner = self.inner.no_compression(); self }
-    pub fn header(mut self, header: Header) -> Self { self.header = header; self }
+    pub fn with_lz77(lz77: E) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), header: HeaderBuilder::new().finish(), level_from_lz77: true } }
+    pub fn no_compression(mut self) -> Self { self.inner = self.inner.no_compression(); self.level_from_lz77 = false; self }
+    pub fn header(mut self, header: Header) -> Self { self.header = header; self.level_from_lz77 = false; self }
     pub fn block_size(mut self, size: usize) -> Self { self.inner = self.inner.block_size(size); self }
     pub fn fixed_huffman_codes(mut self) -> Self { self.inner = self.inner.fixed_huffman_codes(); self }
 }
 
 /// `gzip::Encoder<W, E>` (gzip.rs:754-908)
-pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> { raw: RawEncoder<W>, header: Header, _lz77: PhantomData<E> }
+pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> { raw: RawEncoder<W>, header: Header, stage: Lz77Stage<E> }
 impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
     /// writes the header immediately and can fail (gzip.rs:804-812)
     pub fn new(inner: W) -> io::Result<Self> { Self::with_options(inner, EncodeOptions::default()) }
@@ -135,29 +135,37 @@ impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
 impl<W: io::Write, E: GpuLz77> Encoder<W, E> {
     /// gzip.rs:830-838
     pub fn with_options(inner: W, options: EncodeOptions<E>) -> io::Result<Self> {
-        let mut o = options.inner.to_ffi();
+        let (mut o, on_device) = options.inner.to_ffi();
         let h = &options.header;
         let extra = h.extra_field.as_ref().map(|e| e.to_bytes());
         o.mtime = h.modification_time;
         o.os = h.os.0;
         o.is_text = h.is_text as u8;
         o.hcrc = h.is_verified as u8;
+        // XFL comes from the header the options hold: with_lz77 sets it from E::compression_level (gzip.rs:684), header()
+        // replaces it with the builder's Unknown (gzip.rs:157,717-720), no_compression() resets it (gzip.rs:703)
+        if !options.level_from_lz77 { o.lz77_level = 0; }
         if let Some(ref e) = extra { o.extra = e.as_ptr(); o.extra_len = e.len() as u32; }
         if let Some(ref f) = h.filename { o.filename = f.as_ptr(); }
         if let Some(ref c) = h.comment { o.comment = c.as_ptr(); }
         // (lfx_encoder_new copies the strings and the extra field before it returns)
         let raw = RawEncoder::new(ffi::LFX_GZIP, &o, inner)?;
-        Ok(Encoder { raw, header: options.header.clone(), _lz77: PhantomData })
+        let header = options.header.clone();
+        Ok(Encoder { raw, header, stage: options.inner.into_stage(on_device) })
     }
     pub fn header(&self) -> &Header { &self.header }
-    pub fn finish(self) -> Finish<W, io::Error> { let (w, e) = self.raw.finish(); Finish::new(w, e) }
+    pub fn finish(mut self) -> Finish<W, io::Error> {
+        let closed = self.stage.close(&mut self.raw, 2);
+        let (w, e) = self.raw.finish();
+        Finish::new(w, closed.err().or(e))
+    }
     pub fn as_inner_ref(&self) -> &W { self.raw.inner_ref() }
     pub fn as_inner_mut(&mut self) -> &mut W { self.raw.inner_mut() }
     pub fn into_inner(self) -> W { self.raw.into_inner() }
 }
-impl<W: io::Write, E> io::Write for Encoder<W, E> {
-    fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.raw.write(buf) }
-    fn flush(&mut self) -> io::Result<()> { self.raw.flush() }
+impl<W: io::Write, E: GpuLz77> io::Write for Encoder<W, E> {
+    fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.stage.write(&mut self.raw, buf) }
+    fn flush(&mut self) -> io::Result<()> { self.stage.close(&mut self.raw, 1)?; self.raw.flush() }
 }
 
 /// `gzip::Decoder` (gzip.rs:912-1047): one member; bytes behind its trailer are not decoded

@@ -126,6 +126,11 @@ impl<W: io::Write> RawEncoder<W> {
         let r = unsafe { ffi::lfx_encoder_write(self.h, buf.as_ptr(), buf.len()) };
         if r < 0 { Err(self.err((-r) as c_int)) } else { Ok(r as usize) }
     }
+    /// the code words a caller-side `Lz77Encode` emitted, with the bytes they stand for (`lfx_encoder_write_codes`)
+    pub(crate) fn write_codes(&mut self, codes: &[u32], raw: &[u8], end_block: c_int) -> io::Result<()> {
+        let st = unsafe { ffi::lfx_encoder_write_codes(self.h, codes.as_ptr(), codes.len(), raw.as_ptr(), raw.len(), end_block) };
+        if st != 0 { Err(self.err(st)) } else { Ok(()) }
+    }
     pub(crate) fn flush(&mut self) -> io::Result<()> {
         let st = unsafe { ffi::lfx_encoder_flush(self.h) };
         if st != 0 { Err(self.err(st)) } else { Ok(()) }

@@ -27,8 +27,7 @@ impl GpuLz77Encoder {
     pub fn with_window_size_and_max_length(window_size: u16, max_length: u16) -> io::Result<Self> {
         let ctx = default_context()?;
         let mut st: c_int = 0;
-        let w = if window_size == 0 { 32768 } else { window_size as u32 };
-        let h = unsafe { ffi::lfx_lz77_new(ctx.0, w, max_length as u32, &mut st) };
+        let h = unsafe { ffi::lfx_lz77_new(ctx.0, window_size as u32, max_length as u32, &mut st) };
         if h.is_null() {
             return Err(io_error(st, "lfx_lz77_new failed".to_string()));
         }
@@ -79,18 +78,89 @@ impl Lz77Encode for GpuLz77Encoder {
 // ------------------------------------------------------------------------------------------------------------------
 // The `E` of `EncodeOptions<E>` / `Encoder<W, E>` (src/deflate/encode.rs:17,132; src/gzip.rs:639,754; src/zlib.rs:414,522).
 //
-// The reference runs ANY `E: Lz77Encode` on the CPU and Huffman-codes what it emits.  Here the whole path — match search,
-// parse, Huffman, bit packing — is one GPU pipeline, so `E` has to be an LZ77 stage that pipeline implements: the trait
-// `GpuLz77` below (sealed) is the bound, implemented by this module's `DefaultLz77Encoder` and
-// `NoCompressionLz77Encoder` — the two implementations the reference ships (default.rs:14-109, lib.rs:111-145), under the
-// reference's names, so that `EncodeOptions::with_lz77(DefaultLz77EncoderBuilder::new().window_size(1024).build())`
-// compiles unchanged.  A user-defined `E: Lz77Encode` is a COMPILE ERROR here ("the trait bound `E: GpuLz77` is not
-// satisfied"), by design: running foreign CPU code per chunk in the middle of the device pipeline is what the plug-in
-// direction is for — give the ORIGINAL crate's encoder a `GpuLz77Encoder` instead.
-mod sealed { pub trait Sealed {} }
-pub trait GpuLz77: Lz77Encode + sealed::Sealed {
+// The reference runs ANY `E: Lz77Encode` and Huffman-codes what it emits (CompressBuf::{append, flush}, encode.rs:405-425).
+// So do the encoders of this crate: `GpuLz77` is implemented for EVERY `E: Lz77Encode + 'static`.
+//  * this module's `DefaultLz77Encoder` / `NoCompressionLz77Encoder` — the two implementations the reference ships
+//    (default.rs:14-109, lib.rs:111-145), under the reference's names — only configure the device pipeline: match search,
+//    parse, Huffman and bit packing all run on the GPU and `E`'s methods are never called;
+//  * any other `E` (a user's own `impl Lz77Encode`) runs on the caller's side, exactly where the reference calls it, and
+//    its code words go to the GPU Huffman / pack stages through `lfx_encoder_write_codes` (`Lz77Stage` below).
+pub trait GpuLz77: Lz77Encode {
+    /// true: the whole path runs on the device for this `E`; false: `E` runs here, the device takes its codes
     #[doc(hidden)]
-    fn configure(&self, o: &mut ffi::lfx_encode_opts);
+    fn configure(&self, o: &mut ffi::lfx_encode_opts) -> bool;
+}
+impl<E: Lz77Encode + 'static> GpuLz77 for E {
+    fn configure(&self, o: &mut ffi::lfx_encode_opts) -> bool {
+        let any = self as &dyn std::any::Any;
+        if let Some(d) = any.downcast_ref::<DefaultLz77Encoder>() {
+            o.lz77_kind = ffi::LFX_LZ77_DEFAULT;
+            o.window_size = d.window_size as u32;
+            o.max_length = d.max_length as u32;
+            true
+        } else if any.is::<NoCompressionLz77Encoder>() {
+            o.lz77_kind = ffi::LFX_LZ77_NOCOMPRESSION;
+            true
+        } else {
+            // only the container header looks at these two (zlib.rs:212-220, gzip.rs:684)
+            o.lz77_kind = ffi::LFX_LZ77_DEFAULT;
+            o.window_size = self.window_size() as u32;
+            o.lz77_level = 1 + match self.compression_level() {
+                CompressionLevel::None => 0,
+                CompressionLevel::Fast => 1,
+                CompressionLevel::Balance => 2,
+                CompressionLevel::Best => 3,
+            };
+            false
+        }
+    }
+}
+
+/// `Vec<u32>` as a `Sink`: code words as the C ABI takes them, (val << 16) | dist, dist == 0 for a literal
+#[derive(Default)]
+pub(crate) struct CodeWords(pub(crate) Vec<u32>);
+impl Sink for CodeWords {
+    fn consume(&mut self, code: Code) {
+        self.0.push(match code {
+            Code::Literal(b) => (b as u32) << 16,
+            Code::Pointer { length, backward_distance } => (length as u32) << 16 | backward_distance as u32,
+        });
+    }
+}
+
+/// What `Block` / `CompressBuf` do around a caller-side `E` (encode.rs:277-303, 386-426): `lz77` is `Some` only for an
+/// `E` the device pipeline does not implement itself.
+pub(crate) struct Lz77Stage<E> {
+    pub(crate) lz77: Option<E>,
+    pub(crate) block_size: usize,
+    pub(crate) original_size: usize,
+}
+impl<E: Lz77Encode> Lz77Stage<E> {
+    /// `Block::write`: append, then close blocks while `block_size` is reached (encode.rs:277-286)
+    pub(crate) fn write<W: io::Write>(&mut self, raw: &mut crate::RawEncoder<W>, buf: &[u8]) -> io::Result<usize> {
+        let lz77 = match self.lz77 { Some(ref mut e) => e, None => return raw.write(buf) };
+        let mut sink = CodeWords::default();
+        lz77.encode(buf, &mut sink);                                        // CompressBuf::append encode.rs:405-408
+        raw.write_codes(&sink.0, buf, 0)?;
+        self.original_size += buf.len();
+        while self.original_size >= self.block_size {
+            sink.0.clear();
+            lz77.flush(&mut sink);                                          // CompressBuf::flush encode.rs:416
+            raw.write_codes(&sink.0, &[], 1)?;
+            self.original_size = 0;
+        }
+        Ok(buf.len())
+    }
+    /// the block closes: `end_block` 1 = `Encoder::flush` (encode.rs:245-248), 2 = `Block::finish` (encode.rs:296-303)
+    pub(crate) fn close<W: io::Write>(&mut self, raw: &mut crate::RawEncoder<W>, end_block: c_int) -> io::Result<()> {
+        if let Some(ref mut lz77) = self.lz77 {
+            let mut sink = CodeWords::default();
+            lz77.flush(&mut sink);
+            raw.write_codes(&sink.0, &[], end_block)?;
+            self.original_size = 0;
+        }
+        Ok(())
+    }
 }
 
 /// `libflate_lz77::DefaultLz77Encoder` (default.rs:14-109) — as the `E` of this crate's encoders it only carries the
@@ -109,8 +179,8 @@ impl Default for DefaultLz77Encoder {
     fn default() -> Self { Self::new() }
 }
 impl DefaultLz77Encoder {
-    /// default.rs:32-36 (`MAX_WINDOW_SIZE` does not fit u16 + 1: 0 stands for 32768 like the reference's wrap)
-    pub fn new() -> Self { DefaultLz77Encoder { window_size: 0, max_length: MAX_LENGTH, gpu: None } }
+    /// default.rs:32-36
+    pub fn new() -> Self { DefaultLz77Encoder { window_size: MAX_WINDOW_SIZE, max_length: MAX_LENGTH, gpu: None } }
     /// default.rs:49-57
     pub fn with_window_size(size: u16) -> Self {
         DefaultLz77Encoder { window_size: std::cmp::min(size, MAX_WINDOW_SIZE), max_length: MAX_LENGTH, gpu: None }
@@ -118,7 +188,7 @@ impl DefaultLz77Encoder {
     fn gpu(&mut self) -> &mut GpuLz77Encoder {
         if self.gpu.is_none() {
             self.gpu = Some(GpuLz77Encoder::with_window_size_and_max_length(self.window_size, self.max_length)
-                .expect("libflate-amd: no usable MI355X device"));
+                .unwrap_or_else(|e| panic!("libflate-amd: {}", e)));
         }
         self.gpu.as_mut().unwrap()
     }
@@ -127,15 +197,7 @@ impl Lz77Encode for DefaultLz77Encoder {
     fn encode<S: Sink>(&mut self, buf: &[u8], sink: S) { self.gpu().encode(buf, sink) }
     fn flush<S: Sink>(&mut self, sink: S) { self.gpu().flush(sink) }
     fn compression_level(&self) -> CompressionLevel { CompressionLevel::Balance }
-    fn window_size(&self) -> u16 { if self.window_size == 0 { MAX_WINDOW_SIZE } else { self.window_size } }
-}
-impl sealed::Sealed for DefaultLz77Encoder {}
-impl GpuLz77 for DefaultLz77Encoder {
-    fn configure(&self, o: &mut ffi::lfx_encode_opts) {
-        o.lz77_kind = ffi::LFX_LZ77_DEFAULT;
-        o.window_size = if self.window_size == 0 { 32768 } else { self.window_size as u32 };
-        o.max_length = self.max_length as u32;
-    }
+    fn window_size(&self) -> u16 { self.window_size }
 }
 
 /// `libflate_lz77::DefaultLz77EncoderBuilder` (default.rs:202-249)
@@ -163,8 +225,4 @@ impl Lz77Encode for NoCompressionLz77Encoder {
     }
     fn flush<S: Sink>(&mut self, _sink: S) {}
     fn compression_level(&self) -> CompressionLevel { CompressionLevel::None }
-}
-impl sealed::Sealed for NoCompressionLz77Encoder {}
-impl GpuLz77 for NoCompressionLz77Encoder {
-    fn configure(&self, o: &mut ffi::lfx_encode_opts) { o.lz77_kind = ffi::LFX_LZ77_NOCOMPRESSION; }
 }

@@ -1,8 +1,7 @@
 //! `libflate::zlib` (reference `src/zlib.rs`).
-use crate::lz77::{DefaultLz77Encoder, GpuLz77};
+use crate::lz77::{DefaultLz77Encoder, GpuLz77, Lz77Stage};
 use crate::{ffi, Finish, RawDecoder, RawEncoder};
 use std::io;
-use std::marker::PhantomData;
 
 /// zlib.rs:28-58
 #[derive(Debug, Clone, Copy, PartialEq, Eq)]
@@ -46,15 +45,15 @@ impl<E: GpuLz77> EncodeOptions<E> {
     pub fn block_size(mut self, size: usize) -> Self { self.inner = self.inner.block_size(size); self }
     pub fn fixed_huffman_codes(mut self) -> Self { self.inner = self.inner.fixed_huffman_codes(); self }
     pub fn flush_mode(mut self, mode: FlushMode) -> Self { self.flush_mode = mode; self }
-    fn to_ffi(&self) -> ffi::lfx_encode_opts {
-        let mut o = self.inner.to_ffi();
+    fn to_ffi(&self) -> (ffi::lfx_encode_opts, bool) {
+        let (mut o, on_device) = self.inner.to_ffi();
         o.zlib_flush_mode = if self.flush_mode == FlushMode::Sync { ffi::LFX_FLUSH_SYNC } else { ffi::LFX_FLUSH_NONE };
-        o
+        (o, on_device)
     }
 }
 
 /// `zlib::Encoder<W, E>` (zlib.rs:522-681)
-pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> { raw: RawEncoder<W>, _lz77: PhantomData<E> }
+pub struct Encoder<W: io::Write, E = DefaultLz77Encoder> { raw: RawEncoder<W>, stage: Lz77Stage<E> }
 impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
     /// writes the 2-byte header immediately and can fail (zlib.rs:577-585)
     pub fn new(inner: W) -> io::Result<Self> { Self::with_options(inner, EncodeOptions::default()) }
@@ -62,17 +61,22 @@ impl<W: io::Write> Encoder<W, DefaultLz77Encoder> {
 impl<W: io::Write, E: GpuLz77> Encoder<W, E> {
     /// zlib.rs:603-611
     pub fn with_options(inner: W, options: EncodeOptions<E>) -> io::Result<Self> {
-        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_ZLIB, &options.to_ffi(), inner)?, _lz77: PhantomData })
+        let (o, on_device) = options.to_ffi();
+        Ok(Encoder { raw: RawEncoder::new(ffi::LFX_ZLIB, &o, inner)?, stage: options.inner.into_stage(on_device) })
     }
-    pub fn finish(self) -> Finish<W, io::Error> { let (w, e) = self.raw.finish(); Finish::new(w, e) }
+    pub fn finish(mut self) -> Finish<W, io::Error> {
+        let closed = self.stage.close(&mut self.raw, 2);
+        let (w, e) = self.raw.finish();
+        Finish::new(w, closed.err().or(e))
+    }
     pub fn as_inner_ref(&self) -> &W { self.raw.inner_ref() }
     pub fn as_inner_mut(&mut self) -> &mut W { self.raw.inner_mut() }
     pub fn into_inner(self) -> W { self.raw.into_inner() }
 }
-impl<W: io::Write, E> io::Write for Encoder<W, E> {
-    fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.raw.write(buf) }
+impl<W: io::Write, E: GpuLz77> io::Write for Encoder<W, E> {
+    fn write(&mut self, buf: &[u8]) -> io::Result<usize> { self.stage.write(&mut self.raw, buf) }
     /// `FlushMode::Sync` appends the empty stored block `00 00 FF FF` (zlib.rs:666-671)
-    fn flush(&mut self) -> io::Result<()> { self.raw.flush() }
+    fn flush(&mut self) -> io::Result<()> { self.stage.close(&mut self.raw, 1)?; self.raw.flush() }
 }
 
 /// `zlib::Decoder` (zlib.rs:284-410)

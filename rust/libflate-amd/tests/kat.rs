@@ -152,3 +152,31 @@ fn lz77_plugin_aaaaa() {
     assert_eq!(codes[0], Code::Literal(97));
     assert_eq!(codes[1], Code::Pointer { length: 4, backward_distance: 1 });
 }
+
+
+/// A user-defined `Lz77Encode` (EncodeOptions::with_lz77(E), src/deflate/encode.rs:59-65): it runs on the caller's side and
+/// the device Huffman-codes what it emits.  "Every byte a literal, CompressionLevel::None" must give the stream the device
+/// pipeline makes for the reference's own NoCompressionLz77Encoder (libflate_lz77/src/lib.rs:111-145).
+struct EveryByteALiteral;
+impl libflate_amd::lz77::Lz77Encode for EveryByteALiteral {
+    fn encode<S: libflate_amd::lz77::Sink>(&mut self, buf: &[u8], mut sink: S) {
+        for &b in buf { sink.consume(libflate_amd::lz77::Code::Literal(b)); }
+    }
+    fn flush<S: libflate_amd::lz77::Sink>(&mut self, _sink: S) {}
+    fn compression_level(&self) -> libflate_amd::lz77::CompressionLevel { libflate_amd::lz77::CompressionLevel::None }
+}
+
+#[test]
+fn user_defined_lz77_encoder() {
+    let data: Vec<u8> = (0..300_000u32).map(|i| (i % 251) as u8 ^ (i / 7 % 13) as u8).collect();
+    let mut a = zlib::Encoder::with_options(Vec::new(), zlib::EncodeOptions::with_lz77(EveryByteALiteral).block_size(100_000)).unwrap();
+    let mut b = zlib::Encoder::with_options(Vec::new(), zlib::EncodeOptions::with_lz77(libflate_amd::lz77::NoCompressionLz77Encoder::new()).block_size(100_000)).unwrap();
+    for chunk in data.chunks(8192) { a.write_all(chunk).unwrap(); b.write_all(chunk).unwrap(); }
+    a.flush().unwrap();
+    b.flush().unwrap();
+    let (a, b) = (a.finish().into_result().unwrap(), b.finish().into_result().unwrap());
+    assert_eq!(a, b);
+    let mut out = Vec::new();
+    zlib::Decoder::new(&a[..]).unwrap().read_to_end(&mut out).unwrap();
+    assert_eq!(out, data);
+}

@@ -126,6 +126,29 @@ int main(void) {
         CHECK(read_all(d, out, sizeof out, &got, NULL) == 0 && got == 12 && !memcmp(out, HELLO, 12));
         lfx_decoder_free(d);
     }
+    /* ---- a caller-side Lz77Encode (EncodeOptions::with_lz77(E), encode.rs:59-65): the shim's Lz77Stage hands E's code words
+     *      to lfx_encoder_write_codes.  E = "every byte a literal, CompressionLevel::None": the stream must equal the one the
+     *      device pipeline makes for NoCompressionLz77Encoder (lib.rs:111-145) */
+    {
+        sink_t s = {{0}, 0, 0}, s2 = {{0}, 0, 0};
+        lfx_encode_opts_default(&o);
+        o.lz77_level = 1 + LFX_LEVEL_NONE;
+        lfx_encoder *e = lfx_encoder_new(c, LFX_ZLIB, &o, on_write, on_flush, &s, &st);
+        CHECK(e && st == LFX_OK);
+        uint32_t codes[12];
+        for (int i = 0; i < 12; i++) codes[i] = (uint32_t)HELLO[i] << 16;
+        CHECK(lfx_encoder_write_codes(e, codes, 5, HELLO, 5, 0) == LFX_OK);          /* write("Hello"): E::encode's codes */
+        CHECK(lfx_encoder_write_codes(e, codes + 5, 7, HELLO + 5, 7, 0) == LFX_OK);
+        CHECK(lfx_encoder_write_codes(e, NULL, 0, NULL, 0, 2) == LFX_OK);            /* finish(): E::flush's codes (none), final block */
+        CHECK(lfx_encoder_finish(e) == LFX_OK);
+        lfx_encoder_free(e);
+        lfx_encode_opts_default(&o);
+        o.lz77_kind = LFX_LZ77_NOCOMPRESSION;
+        lfx_encoder *e2 = lfx_encoder_new(c, LFX_ZLIB, &o, on_write, on_flush, &s2, &st);
+        CHECK(e2 && lfx_encoder_write(e2, HELLO, 5) == 5 && lfx_encoder_write(e2, HELLO + 5, 7) == 7 && lfx_encoder_finish(e2) == LFX_OK);
+        lfx_encoder_free(e2);
+        CHECK(s.n == s2.n && s.n > 6 && !memcmp(s.b, s2.b, s.n));
+    }
     /* ---- decoder: header first, getters, one member of two, surplus, consumed */
     {
         unsigned char both[sizeof MEMBER_A + sizeof MEMBER_B];
