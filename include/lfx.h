@@ -99,6 +99,13 @@ int lfx_device_count(void);
 uint64_t lfx_encode_bound(uint64_t n, const lfx_encode_opts *o, const lfx_schedule *s);
 int lfx_encode_device(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                       const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len);
+/* `count` independent streams in one call (BASELINE.json configs[2] needs thousands of 64 KiB streams): stream i is what
+ * lfx_encode_device makes of d_in[in_off[i] .. +in_len[i]) with the same options and the schedule applied to it alone, and
+ * lies at d_out[out_off[i] .. +out_len[i]) (out_off 4-byte aligned, out_cap[i] >= lfx_encode_bound(in_len[i])).  Offsets and
+ * lengths are HOST arrays.  A stream that does not fit its capacity voids the call (LFX_E_NOSPACE, status[i] says which). */
+int lfx_encode_batch_device(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s, uint32_t count,
+                            const void *d_in, const uint64_t *in_off, const uint64_t *in_len, void *d_out,
+                            const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status);
 /* same, host buffers (stages through HBM; PCIe-inclusive) */
 int lfx_encode_host(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                     const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len);
@@ -151,7 +158,10 @@ int lfx_decode_shard_device(lfx_ctx *c, const void *d_in, uint64_t n, uint64_t s
  * that starts inside the range can be scanned to its end.
  *   1. lfx_decode_range_scan: block finder + speculative scan of every candidate that STARTS inside the range →
  *      one tuple per candidate (bit offsets relative to the member).  first_bit: the known start of the member's first
- *      block, on the rank whose range holds it (right behind the container header), ~0 elsewhere.
+ *      block, on the rank whose range holds it (right behind the container header), ~0 elsewhere.  final_from_bit:
+ *      headers with BFINAL set are reported only from this bit of the member on (0: everywhere) — a member's last block
+ *      is the only one that carries the flag, so looking for it near the end halves the finder's and the scan's work;
+ *      when the chain of step 3 then breaks at the last block, scan again with 0;
  *   2. the ranks all-gather their tuples (the only collective: 56 bytes per candidate, a few hundred per rank);
  *   3. lfx_decode_chain (host only, deterministic): the true block list from the known first block; candidates that
  *      are not block starts are never reached.  LFX_E_UNSUPPORTED when the chain breaks (a stored / fixed block the
@@ -182,7 +192,8 @@ typedef struct lfx_blk_tuple {
     uint32_t _pad3;
 } lfx_blk_tuple;                  /* 56 bytes */
 int lfx_decode_range_scan(lfx_ctx *c, const void *d_part, uint64_t n_part, uint64_t lo_byte, uint64_t hi_byte,
-                          uint64_t first_bit, uint32_t rank, lfx_blk_tuple *tuples, uint32_t cap, uint32_t *count);
+                          uint64_t first_bit, uint64_t final_from_bit, uint32_t rank, lfx_blk_tuple *tuples, uint32_t cap,
+                          uint32_t *count);
 int lfx_decode_chain(const lfx_blk_tuple *all, uint32_t n_all, uint64_t first_bit, uint32_t *chain, uint32_t cap,
                      uint32_t *n_chain, uint64_t *total_out);
 int lfx_decode_range_emit(lfx_ctx *c, const void *d_part, uint64_t n_part, uint64_t lo_byte, const lfx_blk_tuple *all,

@@ -655,6 +655,99 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
     return LFX_OK;
 }
 
+// ---- batch encode: `count` independent streams in ONE launch set (thousands of small streams).
+// Every stream is what lfx_encode_device would make of its bytes alone (same options, the schedule applied to each
+// stream); the streams' chunks and blocks form one merged plan, so that the match / parse / Huffman / pack kernels see
+// thousands of chunks at once instead of one launch set per 64 KiB.
+extern "C" int lfx_encode_batch_device(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s, uint32_t count,
+                                       const void *d_in, const uint64_t *in_off, const uint64_t *in_len, void *d_out,
+                                       const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status) {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (format < 0 || format > 2 || (count && (!in_off || !in_len || !out_off || !out_cap))) return LFX_E_ARG;
+    lfx_encode_opts d = norm_opts(o);
+    int rc = check_opts(d);
+    if (rc) { c->set_error("option outside the reference's domain"); return rc; }
+    std::vector<uint8_t> hdr;
+    if ((rc = container_header(format, d, hdr))) { c->set_error("bad container options"); return rc; }
+    if (!count) return LFX_OK;
+    (void)hipSetDevice(c->device);
+    hipStream_t st = c->stream;
+    const PlanOpts po = plan_opts(format, d);
+    const uint32_t trailer = format == LFX_GZIP ? 8 : format == LFX_ZLIB ? 4 : 0;
+    // ---- the merged plan: every stream planned alone, its descriptors shifted into the shared index spaces
+    Plan plan;
+    std::vector<BatchStream> streams(count);
+    uint64_t in_extent = 0, out_lo = ~0ull, out_hi = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        if (out_off[i] & 3) { c->set_error("output offsets must be 4-byte aligned"); return LFX_E_ARG; }
+        Planner pl(po);
+        apply_schedule(pl, s, in_len[i]);
+        Plan &p = pl.finish();
+        const uint32_t c0 = (uint32_t)plan.chunks.size(), b0 = (uint32_t)plan.blocks.size();
+        for (ChunkDesc ch : p.chunks) {
+            ch.in_off += in_off[i]; ch.code_off += plan.n_codes_cap; ch.block += b0; ch.tile_base += plan.n_tiles;
+            ch.vis_base += plan.n_vis; ch.seg_base += plan.n_segs;
+            plan.chunks.push_back(ch);
+        }
+        for (BlockDesc b : p.blocks) { b.in_off += in_off[i]; b.first_chunk += c0; plan.blocks.push_back(b); }
+        plan.n_codes_cap += p.n_codes_cap; plan.n_tiles += p.n_tiles; plan.n_vis += p.n_vis; plan.n_segs += p.n_segs;
+        streams[i] = BatchStream{in_off[i], in_len[i], out_off[i], out_cap[i], b0, (uint32_t)p.blocks.size()};
+        in_extent = std::max(in_extent, in_off[i] + in_len[i]);
+        out_lo = std::min(out_lo, out_off[i]);
+        out_hi = std::max(out_hi, out_off[i] + out_cap[i]);
+    }
+    const uint32_t nblocks = (uint32_t)plan.blocks.size();
+    // per-stream scratch: descriptors, checksums, end bits, status, lengths (+ the header bytes)
+    const size_t sz_streams = sizeof(BatchStream) * count;
+    DevBuf &sb = c->d_dec_streams;     // (decode scratch: free during an encode)
+    if ((rc = sb.reserve(sz_streams + (4 + 4 + 8 + 4 + 8) * (size_t)count + hdr.size() + 64))) return rc;
+    BatchStream *d_streams = (BatchStream *)sb.p;
+    uint64_t *d_end = (uint64_t *)((uint8_t *)sb.p + sz_streams);
+    uint64_t *d_len = d_end + count;
+    uint32_t *d_crc = (uint32_t *)(d_len + count), *d_adler = d_crc + count;
+    int32_t *d_status = (int32_t *)(d_adler + count);
+    uint8_t *d_hdr = (uint8_t *)(d_status + count);
+    std::vector<uint64_t> h_len(count);
+    std::vector<int32_t> h_status(count);
+    EncodeResult res{};
+    for (;;) {
+        if ((rc = encode_prepare(c, plan, po, (const uint8_t *)d_in, in_extent, 0))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_streams, streams.data(), sz_streams, hipMemcpyHostToDevice, st));
+        if (!hdr.empty()) HIP_TRY(hipMemcpyAsync(d_hdr, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
+        if (trailer)
+            LAUNCH_TRY(launch_checksum_ranges(st, (const uint8_t *)d_in, count, (const uint64_t *)d_streams, sizeof(BatchStream) / 8,
+                                              (const uint64_t *)d_streams + 1, sizeof(BatchStream) / 8, d_crc, d_adler));
+        c->phase("checksum");
+        HIP_TRY(hipMemsetAsync((uint8_t *)d_out + out_lo, 0, out_hi - out_lo, st));
+        EncodeResult *dres = (EncodeResult *)c->d_res.p;
+        LAUNCH_TRY(launch_offsets_batch(st, d_streams, count, (const BlockDesc *)c->d_blocks.p, (const BlockCodes *)c->d_bc.p,
+                                        (uint32_t)hdr.size(), trailer, (uint64_t *)c->d_block_start.p, d_end, d_status, dres));
+        LAUNCH_TRY(launch_pack(st, (const uint8_t *)d_in, in_extent, (const ChunkDesc *)c->d_chunks.p, c->cur_nchunks,
+                               (const BlockDesc *)c->d_blocks.p, nblocks, c->cur_ntiles, (const uint32_t *)c->d_codes.p,
+                               (const uint32_t *)c->d_ncodes.p, (const BlockCodes *)c->d_bc.p, (const uint64_t *)c->d_block_start.p,
+                               (uint32_t *)c->d_tile_bits.p, (uint64_t *)c->d_tile_start.p, dres, 0, (uint32_t *)d_out, c->cur_tile_map));
+        c->phase("pack");
+        LAUNCH_TRY(launch_frame_batch(st, format, d_streams, count, d_hdr, (uint32_t)hdr.size(), d_end, d_crc, d_adler, dres,
+                                      (uint32_t *)d_out, d_len));
+        HIP_TRY(hipMemcpyAsync(c->h_res, dres, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_len.data(), d_len, 8ull * count, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_status.data(), d_status, 4ull * count, hipMemcpyDeviceToHost, st));
+        c->phase("frame");
+        HIP_TRY(hipStreamSynchronize(st));
+        res = *(EncodeResult *)c->h_res;
+        if (match_violation(c, res)) continue;
+        break;
+    }
+    for (uint32_t i = 0; i < count; i++) {
+        if (status) status[i] = res.status ? (h_status[i] ? h_status[i] : LFX_E_NOSPACE) : LFX_OK;
+        if (out_len) out_len[i] = res.status ? 0 : h_len[i];
+    }
+    if (res.status) { c->set_error("output capacity of a stream too small (status[] says which): nothing was written"); return LFX_E_NOSPACE; }
+    return LFX_OK;
+}
+
 extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                                const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len) {
     if (!cc) return LFX_E_DEVICE;

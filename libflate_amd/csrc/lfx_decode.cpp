@@ -130,48 +130,62 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         // ---- speculative block-start search
         // survivors of stage 1 are ~0.1 % of the bit offsets (more on incompressible data): room for 0.4 % of them, so
         // that a gibibyte-sized stream does not overflow the lists and fall back to the serial walk
-        const uint32_t shard_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 17, comp / 1000), 1u << 26);
-        const uint32_t final_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 16, comp / 4096), 1u << 24);
         int rc;
-        if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 512))) return rc;
-        uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // FIND_SHARDS + 1 words, then final count
-        uint32_t *d_final_count = d_count + 64;
-        uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 512);
-        uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
-        HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
-        // (the member's last block is looked for in the final eighth of the input, at least 8 MiB of it: one that starts
-        //  earlier — a last block of more than that — is scanned on demand by the chain walk below)
-        const uint64_t tail_bytes = std::max<uint64_t>(comp / 8, 8ull << 20);
-        const uint64_t final_from = c->diag.no_final_cand ? ~0ull >> 1 : comp > tail_bytes ? (n - tail_bytes) * 8 : 0;
-        LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap, final_from));
-        c->phase("find1");
-        // stage 2 takes the survivor counts from the device (persistent grid): no host round trip between the stages; the
-        // counts, the overflow marker, the number of results and the first results come back in ONE round trip
-        LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
-                                      (uint32_t)std::max(c->n_cu, 1)));
-        uint32_t hc[66];
-        constexpr uint32_t HEAD_N = 1024;      // (results that come back with the counts; a stream has a few hundred)
-        const uint32_t head_n = std::min<uint32_t>(HEAD_N, final_cap);
-        std::vector<uint64_t> cand(head_n);
-        HIP_TRY(hipMemcpyAsync(hc, d_count, sizeof hc, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(cand.data(), d_final, 8ull * head_n, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        bool overflow = hc[FIND_SHARDS] != 0;
+        bool overflow = false;
         uint32_t n1 = 0;
-        for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (hc[k] > shard_cap) overflow = true; n1 += hc[k]; }
-        if (!overflow) {
+        std::vector<uint64_t> starts;
+        auto find_candidates = [&]() -> int {
+            const uint32_t shard_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 17, comp / 1000), 1u << 26);
+            const uint32_t final_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 16, comp / 4096), 1u << 24);
+            int rc;
+            if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 512))) return rc;
+            uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // FIND_SHARDS + 1 words, then final count
+            uint32_t *d_final_count = d_count + 64;
+            uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 512);
+            uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
+            HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
+            // (the member's last block is looked for in the final eighth of the input, at least 8 MiB of it: one that starts
+            //  earlier — a last block of more than that — is scanned on demand by the chain walk below)
+            const uint64_t tail_bytes = std::max<uint64_t>(comp / 8, 8ull << 20);
+            const uint64_t final_from = c->diag.no_final_cand ? ~0ull >> 1 : comp > tail_bytes ? (n - tail_bytes) * 8 : 0;
+            LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap, final_from));
+            c->phase("find1");
+            // stage 2 takes the survivor counts from the device (persistent grid): no host round trip between the stages; the
+            // counts, the overflow marker, the number of results and the first results come back in ONE round trip
+            LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
+                                          (uint32_t)std::max(c->n_cu, 1)));
+            uint32_t hc[66];
+            constexpr uint32_t HEAD_N = 1024;      // (results that come back with the counts; a stream has a few hundred)
+            const uint32_t head_n = std::min<uint32_t>(HEAD_N, final_cap);
+            std::vector<uint64_t> cand(head_n);
+            HIP_TRY(hipMemcpyAsync(hc, d_count, sizeof hc, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(cand.data(), d_final, 8ull * head_n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            overflow = hc[FIND_SHARDS] != 0;
+            n1 = 0;
+            for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (hc[k] > shard_cap) overflow = true; n1 += hc[k]; }
+            starts.clear();
+            starts.push_back(first_bit);  // the first block's start is known
+            if (overflow) return LFX_OK;
             uint32_t nf = hc[64];
             if (nf > final_cap) nf = final_cap;
             cand.resize(nf);
             if (nf > head_n) HIP_TRY(hipMemcpy(cand.data() + head_n, d_final + head_n, 8ull * (nf - head_n), hipMemcpyDeviceToHost));
             c->phase("find2");
-            std::vector<uint64_t> starts;
-            starts.push_back(first_bit);  // the first block's start is known
             for (uint32_t i = 0; i < nf; i++) if (cand[i] != first_bit) starts.push_back(cand[i]);
             std::sort(starts.begin(), starts.end());
+            return LFX_OK;
+        };
+        // A small stream (round 4) does not start with the finder (0.23 ms of fixed cost): reference-made streams of this
+        // size are one block plus the empty final one, which the piece scan below walks from the known first block in two
+        // steps.  A stream that turns out to have many blocks (another encoder's) gets the finder after all.
+        const bool small_first = comp >= (128u << 10) && comp < (4u << 20) && stop_bit == ~0ull && !partial && !c->diag.no_pieces;
+        if (small_first) starts.push_back(first_bit);
+        else if ((rc = find_candidates())) return rc;
+        if (!overflow) {
             // ---- K1: every candidate block is scanned by a 1024-lane workgroup (speculative slices,
             //      chained exits) for its end bit, byte and code counts
-            const uint32_t nc = (uint32_t)starts.size();
+            uint32_t nc = (uint32_t)starts.size();
             auto start_at = [&](uint32_t i) { return i < nc ? starts[i] : n * 8; };
             std::vector<BlkEmit> emit;
             uint64_t pos = first_bit, total = 0, total_codes = 0;
@@ -186,9 +200,13 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // decode that starts a few Kbit early; it is accepted iff that boundary equals the exit of the piece in
             // front of it (piece 0 starts exactly behind the header), so the chain of pieces is proven, not assumed.
             // Pieces behave like blocks from here on (their back-references cross pieces: marker path).
-            if (nc <= 8 && comp >= (8u << 20) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
-                constexpr uint64_t PIECE_BITS = 4ull << 20, OVERLAP = 8192;
+            // Piece size (round 4): a 1 MiB stream is ONE block too — one workgroup in K1 and K2, four units in K3 (2.1 ms).
+            // Pieces adapt to the stream: enough of them to give every CU two, between 256 Kbit and 4 Mbit each.
+            if ((small_first || nc <= 8) && comp >= (128u << 10) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
+                constexpr uint64_t OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
+                const uint64_t PIECE_BITS = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(256ull << 10,
+                                            ((end_bits - first_bit) / (2ull * (uint64_t)std::max(c->n_cu, 1)) + 63) & ~63ull));
                 const uint32_t cap_slots = (uint32_t)std::min<uint64_t>((end_bits - first_bit) / PIECE_BITS * 2 + 64, 1u << 20);
                 int rc2;
                 if ((rc2 = c->d_dec_streams.reserve(sizeof(BlkJob) * cap_slots))) return rc2;
@@ -197,7 +215,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 if ((rc2 = c->d_dec_tabs.reserve(tab_bytes * cap_slots))) return rc2;
                 uint32_t base = 0;
                 bool fail = false;
-                for (uint32_t iter = 0; iter < 64 && !fail && !ok_chain; iter++) {
+                for (uint32_t iter = 0; iter < (small_first ? 3u : 64u) && !fail && !ok_chain; iter++) {
                     const uint32_t np = (uint32_t)((end_bits - pos + PIECE_BITS - 1) / PIECE_BITS);
                     if (np == 0 || base + np > cap_slots) { fail = true; break; }
                     std::vector<BlkJob> pj(np);
@@ -245,8 +263,12 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; last_end = 0; }
                 else pieces_mode = true;
                 c->phase("pieces");
+                if (small_first && !pieces_mode) {     // many blocks after all: the finder, then one workgroup per block
+                    if ((rc = find_candidates())) return rc;
+                    nc = (uint32_t)starts.size();
+                }
             }
-            if (!pieces_mode) {
+            if (!pieces_mode && !overflow) {
             std::vector<BlkJob> bj(nc);
             for (uint32_t i = 0; i < nc; i++) bj[i] = BlkJob{starts[i], start_at(i + 1)};
             // A false candidate inside a block cuts that block's range in two, and the first part then has
@@ -405,7 +427,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 // symbol kernel's time does not depend on the unit size as long as every slot has a unit, while every
                 // unit costs the window resolution 32 Ki lookups (256 MiB: 128 KiB units 1.31 + 0.74 ms, 512 KiB units
                 // 0.59 + 0.64 ms for window resolution + substitution)
-                uint32_t free_shift = 17;
+                uint32_t free_shift = 15;
                 while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
                 if (c->diag.free_shift >= 0) free_shift = (uint32_t)c->diag.free_shift;
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
@@ -415,7 +437,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
                 // the marker path, which may cut anywhere
                 bool giant = pieces_mode;   // (pieces of one block read each other's output)
-                for (const BlkEmit &e : emit) giant |= e.n_out >= (8ull << 20);
+                for (const BlkEmit &e : emit) giant |= e.n_out >= (8ull << 20);   // (a block that big has too few legal cuts for K3's resident units)
                 // small blocks smell of another encoder (zlib cuts every ~50-100 KiB of output; the reference at
                 // block_size = 1 MiB): look at the emit flags BEFORE materialising, so that a stream which needs
                 // the marker path does not pay for a discarded direct pass (costs one round trip otherwise saved)
@@ -740,7 +762,8 @@ extern "C" int lfx_decode_shard_device(lfx_ctx *cc, const void *d_in, uint64_t n
 static_assert(sizeof(lfx_blk_tuple) == 56, "tuple layout (all-gathered as raw bytes)");
 
 extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t n_part, uint64_t lo_byte, uint64_t hi_byte,
-                                     uint64_t first_bit, uint32_t rank, lfx_blk_tuple *tuples, uint32_t cap, uint32_t *count) {
+                                     uint64_t first_bit, uint64_t final_from_bit, uint32_t rank, lfx_blk_tuple *tuples, uint32_t cap,
+                                     uint32_t *count) {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -765,7 +788,13 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
     HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
     std::vector<uint64_t> starts;
     if (n >= 16) {
-        LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap, 0));   // (the chain is walked on tuples: every start is needed)
+        // headers with BFINAL set are reported from member bit `final_from_bit` on (the finder's tail rule, inflate_member: a
+        // member's last block is the only one that carries the flag — everywhere else the offsets whose bit 0 is set are
+        // dropped, which halves the candidates of both stages and the scan jobs).  The chain is walked on tuples, so a last
+        // block that starts in front of that bit breaks the chain: the caller then scans again with final_from_bit = 0.
+        const uint64_t base0 = lo_byte * 8;
+        const uint64_t final_local = final_from_bit <= base0 ? 0 : std::min<uint64_t>(final_from_bit - base0, ~0ull >> 1);
+        LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap, final_local));
         LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
                                       (uint32_t)std::max(c->n_cu, 1)));
         uint32_t hc[66];
@@ -920,7 +949,7 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
     HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
     const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
     const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
-    uint32_t free_shift = 17;   // marker units as on one GPU: two resident per CU, as large as that allows
+    uint32_t free_shift = 15;   // marker units as on one GPU: two resident per CU, as large as that allows
     while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
     LAUNCH_TRY(launch_blk_emit(st, d_in, n_part, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (uint32_t *)c->d_codes.p, d_flags,
                                (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, free_shift));

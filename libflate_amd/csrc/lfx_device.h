@@ -26,6 +26,13 @@ struct EncodeResult {
     uint32_t match_flags;  // bit 0: the second-generation match kernel saw an LDS lane-order violation (results void)
 };
 
+// one stream of a batch encode: where its bytes lie, where its output goes, which blocks of the merged plan are its own
+struct BatchStream {
+    uint64_t in_off, in_len;
+    uint64_t out_off, out_cap;
+    uint32_t first_block, n_blocks;
+};
+
 // one workgroup of the parse walk: PARSE_WG_SEGS consecutive parse segments of one chunk, from segment seg0 on
 struct ParseWg {
     uint32_t chunk;
@@ -55,6 +62,12 @@ int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, co
                    BlockCodes *bc, uint64_t *dbg = nullptr);
 int launch_offsets(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const BlockCodes *bc,
                    uint64_t start_bit, uint64_t cap_bits, uint64_t *block_start, EncodeResult *res);
+int launch_offsets_batch(hipStream_t st, const BatchStream *streams, uint32_t count, const BlockDesc *blocks, const BlockCodes *bc,
+                         uint32_t hdr_len, uint32_t trailer_len, uint64_t *block_start, uint64_t *stream_end, int32_t *status,
+                         EncodeResult *res);
+int launch_frame_batch(hipStream_t st, int format, const BatchStream *streams, uint32_t count, const uint8_t *hdr, uint32_t hdr_len,
+                       const uint64_t *stream_end, const uint32_t *crc, const uint32_t *adler, const EncodeResult *res, uint32_t *out,
+                       uint64_t *out_len);
 int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                 uint32_t nchunks, const BlockDesc *blocks, uint32_t nblocks, uint64_t ntiles,
                 const uint32_t *codes, const uint32_t *ncodes, const BlockCodes *bc,

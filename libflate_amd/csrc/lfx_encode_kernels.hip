@@ -489,6 +489,56 @@ __global__ __launch_bounds__(256) void offsets_kernel(const BlockDesc *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// batch encode (lfx_encode_batch_device: many independent streams in one launch set): a stream's blocks start right
+// behind its own container header; one lane per stream folds its few blocks (the same fold as offsets_kernel) and checks
+// the stream's capacity — one stream that does not fit voids the launch (res->status), its status word says which.
+__global__ __launch_bounds__(256) void offsets_batch_kernel(const BatchStream *__restrict__ streams, uint32_t count,
+                                                            const BlockDesc *__restrict__ blocks, const BlockCodes *__restrict__ bc,
+                                                            uint32_t hdr_len, uint32_t trailer_len, uint64_t *__restrict__ block_start,
+                                                            uint64_t *__restrict__ stream_end, int32_t *__restrict__ status,
+                                                            EncodeResult *__restrict__ res) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= count) return;
+    const BatchStream bs = streams[s];
+    uint64_t bit = (bs.out_off + hdr_len) * 8;
+    for (uint32_t b = bs.first_block; b < bs.first_block + bs.n_blocks; ++b) {
+        const BlockDesc bd = blocks[b];
+        block_start[b] = bit;
+        if (bd.type == BT_RAW) { bit += 3; bit = (bit + 7) & ~7ull; bit += 32 + 8 * bd.in_len; }
+        else bit += bc[b].body_bits;
+        if (bd.align_after) bit = (bit + 7) & ~7ull;
+    }
+    stream_end[s] = bit;
+    const bool over = bs.out_cap < hdr_len + trailer_len || bit > (bs.out_off + bs.out_cap - trailer_len) * 8;
+    status[s] = over ? 7 : 0;                 // LFX_E_NOSPACE
+    if (over) atomicOr(&res->status, 1u);
+}
+// container header (the same bytes for every stream: shared options) and trailer of every stream
+__global__ __launch_bounds__(256) void frame_batch_kernel(int format, const BatchStream *__restrict__ streams, uint32_t count,
+                                                          const uint8_t *__restrict__ hdr, uint32_t hdr_len,
+                                                          const uint64_t *__restrict__ stream_end, const uint32_t *__restrict__ crc,
+                                                          const uint32_t *__restrict__ adler, const EncodeResult *__restrict__ res,
+                                                          uint32_t *__restrict__ out, uint64_t *__restrict__ out_len) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= count || res->status != 0) return;
+    const BatchStream bs = streams[s];
+    auto put = [&](uint64_t ob, uint32_t byte) { atomicOr(&out[ob >> 2], byte << (8 * (ob & 3))); };
+    for (uint32_t i = 0; i < hdr_len; ++i) put(bs.out_off + i, hdr[i]);
+    const uint64_t at = stream_end[s] >> 3;          // (the final block byte-aligns)
+    uint32_t nt = 0;
+    if (format == 2) {                               // gzip.rs:114-121: CRC-32 LE + ISIZE LE
+        const uint32_t c = bs.in_len ? crc[s] : 0u, sz = (uint32_t)bs.in_len;
+        for (uint32_t i = 0; i < 4; ++i) { put(at + i, (c >> (8 * i)) & 255u); put(at + 4 + i, (sz >> (8 * i)) & 255u); }
+        nt = 8;
+    } else if (format == 1) {                        // zlib.rs:630-639: Adler-32 BE
+        const uint32_t a = bs.in_len ? adler[s] : 1u;
+        for (uint32_t i = 0; i < 4; ++i) put(at + i, (a >> (8 * (3 - i))) & 255u);
+        nt = 4;
+    }
+    out_len[s] = at + nt - bs.out_off;
+}
+
+// ------------------------------------------------------------------------------------------------
 // pack: bits of one code word
 __device__ __forceinline__ uint32_t code_bits(uint32_t v, const uint32_t *lit, const uint32_t *dst,
                                               uint64_t &bits) {
@@ -1210,6 +1260,24 @@ int launch_offsets(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, co
                    uint64_t start_bit, uint64_t cap_bits, uint64_t *block_start, EncodeResult *res) {
     hipLaunchKernelGGL(offsets_kernel, dim3(1), dim3(256), 0, st, blocks, nblocks, bc, start_bit,
                        cap_bits, block_start, res);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_offsets_batch(hipStream_t st, const BatchStream *streams, uint32_t count, const BlockDesc *blocks, const BlockCodes *bc,
+                         uint32_t hdr_len, uint32_t trailer_len, uint64_t *block_start, uint64_t *stream_end, int32_t *status,
+                         EncodeResult *res) {
+    if (!count) return 0;
+    hipLaunchKernelGGL(offsets_batch_kernel, dim3((count + 255) / 256), dim3(256), 0, st, streams, count, blocks, bc, hdr_len,
+                       trailer_len, block_start, stream_end, status, res);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+int launch_frame_batch(hipStream_t st, int format, const BatchStream *streams, uint32_t count, const uint8_t *hdr, uint32_t hdr_len,
+                       const uint64_t *stream_end, const uint32_t *crc, const uint32_t *adler, const EncodeResult *res, uint32_t *out,
+                       uint64_t *out_len) {
+    if (!count) return 0;
+    hipLaunchKernelGGL(frame_batch_kernel, dim3((count + 255) / 256), dim3(256), 0, st, format, streams, count, hdr, hdr_len,
+                       stream_end, crc, adler, res, out, out_len);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -855,7 +855,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         U->code0[nu] = job.n_codes; U->out0[nu] = job.n_out;
         U->n = nu;
         // ... and cut at slice boundaries without regard to back-references (marker-based materialisation)
-        // (units of 2^free_shift bytes, 128 KiB and up: every unit costs the window resolution 32 Ki lookups; the host
+        // (units of 2^free_shift bytes, 32 KiB and up: every unit costs the window resolution 32 Ki lookups; the host
         // sizes them so that the stream still has a few units per resident slot)
         uint32_t fn = 0;
         uint32_t fwant = (uint32_t)(job.n_out >> free_shift);
@@ -1570,7 +1570,7 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
         attr_set[dev_ & 63] = true;
     }
     hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes, flags, units,
-                       unit_target ? unit_target : 1u, free_shift < 17 ? 17u : free_shift, job_flags, (const FastTabs *)tabs);
+                       unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags, (const FastTabs *)tabs);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -131,13 +131,20 @@ def byte_ranges(first_byte, member_len, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def range_scan(ctx, rank, d_part_ptr, n_part, lo, hi, first_bit=None, cap=1 << 16):
+def final_from(member_len):
+    """the finder's tail rule for a member of member_len bytes: BFINAL headers are looked for in its last eighth (at least
+    8 MiB) — the same rule the one-GPU decode applies (lfx_decode.cpp, inflate_member) → member bit"""
+    tail = max(member_len // 8, 8 << 20)
+    return max(member_len - tail, 0) * 8
+
+
+def range_scan(ctx, rank, d_part_ptr, n_part, lo, hi, first_bit=None, cap=1 << 16, final_from_bit=0):
     """step 1 on one rank → list of BlkTuple (ctypes array slice)"""
     L = _ffi.lib()
     tuples = (_ffi.BlkTuple * cap)()
     cnt = C.c_uint32(0)
     rc = L.lfx_decode_range_scan(ctx.handle, d_part_ptr, n_part, lo, hi, (1 << 64) - 1 if first_bit is None else first_bit,
-                                 rank, tuples, cap, C.byref(cnt))
+                                 final_from_bit, rank, tuples, cap, C.byref(cnt))
     if rc:
         raise _ffi.LfxError(rc, ctx.last_error())
     return tuples, cnt.value
@@ -228,7 +235,7 @@ def gather_tuples(tuples, cnt, world, dist, device="cpu", group=None, status=0):
     return all_t, n_all
 
 
-def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_out, cap, dist=None, group=None):
+def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_out, cap, dist=None, group=None, member_len=None):
     """One rank's side of the N-GPU decode over torch.distributed (RCCL on GPUs, gloo in CPU rigs): scan → all-gather of
     the tuples → chain → emit → [window hand-over: all-gather of the ranks' 64 KiB index maps, only for members whose blocks
     read earlier blocks] → all-gather of (length, crc, adler).  d_part / d_out: torch uint8 tensors on the rank's
@@ -237,14 +244,24 @@ def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_o
     through the next collective and raised on ALL ranks.  → (bytes of this rank's slice, its offset in the member's
     output, total output bytes, crc32, adler32 of the whole member's output)."""
     import torch
-    status = 0
-    tuples, cnt = None, 0
-    try:
-        tuples, cnt = range_scan(ctx, rank, d_part.data_ptr(), n_part, lo, hi, first_bit if rank == 0 else None)
-    except _ffi.LfxError as e:
-        status = e.status or _ffi.E_UNSUPPORTED
-    all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device, group, status)
-    chain, nch, total = chain_of(all_t, n_all, first_bit)        # (deterministic: breaks on every rank alike)
+    # `member_len` (bytes of the whole member, when the caller knows it): the finder looks for the BFINAL header only near
+    # the member's end; if the chain then breaks (a last block that starts earlier) every rank scans again without the rule
+    ffb = final_from(member_len) if member_len else 0
+    while True:
+        status = 0
+        tuples, cnt = None, 0
+        try:
+            tuples, cnt = range_scan(ctx, rank, d_part.data_ptr(), n_part, lo, hi, first_bit if rank == 0 else None, final_from_bit=ffb)
+        except _ffi.LfxError as e:
+            status = e.status or _ffi.E_UNSUPPORTED
+        all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device, group, status)
+        try:
+            chain, nch, total = chain_of(all_t, n_all, first_bit)        # (deterministic: breaks on every rank alike)
+            break
+        except _ffi.LfxError:
+            if not ffb:
+                raise
+            ffb = 0
     ol = base = state = 0
     crc, ad = 0, 1
     try:

@@ -253,21 +253,31 @@ def _virtual_rank_decode(lfx, ffi, member, hdr_len, world, plain_len):
     d_member = torch.frombuffer(bytearray(member), dtype=torch.uint8).cuda()
     ranges = sharded.byte_ranges(hdr_len, len(member), world)
     ctxs = [lfx.Context(0) for _ in range(world)]
-    parts, rows, total_cnt = [], [], 0
-    for r, (lo, hi) in enumerate(ranges):
-        n_part = min(hi + sharded.RANGE_TAIL, len(member)) - lo
-        d_part = d_member[lo:lo + n_part].clone()                     # (its own buffer: nothing outside it can be read)
-        tuples, cnt = sharded.range_scan(ctxs[r], r, d_part.data_ptr(), n_part, lo, hi, hdr_len * 8 if r == 0 else None)
-        parts.append((d_part, n_part, lo))
-        rows.append((tuples, cnt))
-        total_cnt += cnt
-    tsz = C.sizeof(ffi.BlkTuple)
-    all_t = (ffi.BlkTuple * max(total_cnt, 1))()
-    at = 0
-    for tuples, cnt in rows:
-        C.memmove(C.byref(all_t, at * tsz), tuples, cnt * tsz)
-        at += cnt
-    chain, nch, total = sharded.chain_of(all_t, total_cnt, hdr_len * 8)
+    # the finder's tail rule (BFINAL headers only near the member's end), and the retry without it when the chain breaks
+    ffb = sharded.final_from(len(member))
+    while True:
+        parts, rows, total_cnt = [], [], 0
+        for r, (lo, hi) in enumerate(ranges):
+            n_part = min(hi + sharded.RANGE_TAIL, len(member)) - lo
+            d_part = d_member[lo:lo + n_part].clone()                     # (its own buffer: nothing outside it can be read)
+            tuples, cnt = sharded.range_scan(ctxs[r], r, d_part.data_ptr(), n_part, lo, hi, hdr_len * 8 if r == 0 else None,
+                                             final_from_bit=ffb)
+            parts.append((d_part, n_part, lo))
+            rows.append((tuples, cnt))
+            total_cnt += cnt
+        tsz = C.sizeof(ffi.BlkTuple)
+        all_t = (ffi.BlkTuple * max(total_cnt, 1))()
+        at = 0
+        for tuples, cnt in rows:
+            C.memmove(C.byref(all_t, at * tsz), tuples, cnt * tsz)
+            at += cnt
+        try:
+            chain, nch, total = sharded.chain_of(all_t, total_cnt, hdr_len * 8)
+            break
+        except ffi.LfxError:
+            if not ffb:
+                raise
+            ffb = 0
     assert total == plain_len
     out = torch.zeros(plain_len, dtype=torch.uint8, device="cuda")
     checks, owned, slices, states = [], [], [], []

@@ -179,3 +179,58 @@ def test_stream_decoder_long_fixed_huffman_member(env):
         for step in ((1 << 20) + 4099, 3 << 20):
             crc, total, first_pos, peak, status, consumed = _stream_decode(ctx, ffi, ffi.GZIP, stream, step, 8 << 20)
             assert status == 0 and total == n and crc == crc_want and consumed == len(stream), (block_size, step, status, total)
+
+
+# ------------------------------------------------------------------ b-4: batch encode
+def test_encode_batch_vs_oracle(env, oracle):
+    """lfx_encode_batch_device: many independent streams in one launch set.  Stream i must be what the reference makes of its
+    bytes alone (Encoder::new + write_all + finish per stream: encode.rs:182-249, zlib.rs:577-681, gzip.rs:804-908) — ragged
+    sizes including empty and tiny ones, all three containers, both schedules, fixed codes and stored blocks; a stream
+    whose capacity is too small voids the call with LFX_E_NOSPACE and status[] names it."""
+    import ctypes as C
+    import torch
+    lfx, ctx, ffi, synth = env
+    L = ffi.lib()
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 2, 3, 4, 70000, 65536, 65535, 8192, 8193, 300000, 13312, 5, 262144, 262147, 40000] + [int(x) for x in rng.integers(1, 100000, 40)]
+    text = synth.text(sum(sizes) + 16).tobytes()
+    low = synth.lowent(300000).tobytes()
+    bufs, at = [], 0
+    for k, n in enumerate(sizes):
+        bufs.append(low[:n] if k % 5 == 4 else text[at:at + n])
+        at += n
+    count = len(bufs)
+    in_off = np.zeros(count, dtype=np.uint64)
+    in_len = np.array([len(b) for b in bufs], dtype=np.uint64)
+    pos = 0
+    for i, b in enumerate(bufs):
+        in_off[i] = pos
+        pos += len(b) + (7 * i) % 5                    # (gaps and unaligned starts)
+    host = np.zeros(pos + 8, dtype=np.uint8)
+    for i, b in enumerate(bufs):
+        host[int(in_off[i]):int(in_off[i]) + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    d_in = torch.from_numpy(host).cuda()
+    cases = [(ffi.ZLIB, oracle.ZLIB, {}, {}, 0), (ffi.GZIP, oracle.GZIP, {"mtime": 7}, {"mtime": 7}, 8192), (ffi.DEFLATE, oracle.DEFLATE, {"dynamic_huffman": 0}, {"dynamic_huffman": 0}, 0),
+             (ffi.ZLIB, oracle.ZLIB, {"no_compression": 1}, {"no_compression": 1}, 8192), (ffi.DEFLATE, oracle.DEFLATE, {"block_size": 30000}, {"block_size": 30000}, 1000)]
+    for fmt, ofmt, kw, okw, ws in cases:
+        opts, sched = ffi.make_opts(**kw), ffi.make_schedule(ws)
+        out_cap = np.array([(L.lfx_encode_bound(len(b), C.byref(opts), C.byref(sched)) + 3) & ~3 for b in bufs], dtype=np.uint64)
+        out_off = np.concatenate(([0], np.cumsum(out_cap)[:-1])).astype(np.uint64)
+        d_out = torch.full((int(out_cap.sum()),), 0xAA, dtype=torch.uint8, device="cuda")
+        out_len = np.zeros(count, dtype=np.uint64)
+        status = np.zeros(count, dtype=np.int32)
+        rc = L.lfx_encode_batch_device(ctx.handle, fmt, C.byref(opts), C.byref(sched), count, d_in.data_ptr(), in_off.ctypes.data,
+                                       in_len.ctypes.data, d_out.data_ptr(), out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
+                                       status.ctypes.data)
+        assert rc == 0 and not status.any(), (rc, ctx.last_error())
+        got = d_out.cpu().numpy()
+        for i, b in enumerate(bufs):
+            want = oracle.encode(ofmt, b, write_size=ws, **okw)
+            assert got[int(out_off[i]):int(out_off[i]) + int(out_len[i])].tobytes() == want, (fmt, kw, i, len(b))
+        # one stream too small: nothing is written, the call and the stream say NOSPACE
+        small = out_cap.copy()
+        small[5] = 64
+        rc = L.lfx_encode_batch_device(ctx.handle, fmt, C.byref(opts), C.byref(sched), count, d_in.data_ptr(), in_off.ctypes.data,
+                                       in_len.ctypes.data, d_out.data_ptr(), out_off.ctypes.data, small.ctypes.data, out_len.ctypes.data,
+                                       status.ctypes.data)
+        assert rc == ffi.E_NOSPACE and status[5] == ffi.E_NOSPACE and not out_len.any()
