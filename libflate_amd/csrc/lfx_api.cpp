@@ -407,7 +407,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_block_start.reserve(8 * std::max<size_t>(nblocks, 1)))) return rc;
     if ((rc = c->d_tile_bits.reserve(4 * std::max<uint64_t>(plan.n_tiles, 1)))) return rc;
     if ((rc = c->d_tile_start.reserve(8 * std::max<uint64_t>(plan.n_tiles, 1)))) return rc;
-    const uint64_t nspans = div_up(std::max<uint64_t>(n, 1), 65536);   // CK_SPAN of the checksum kernels
+    const uint64_t nspans = ck_nspans(n);   // partial results of the checksum kernels
     if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
     if ((rc = c->d_res.reserve(256))) return rc;
     if ((rc = c->d_small.reserve(70000))) return rc;

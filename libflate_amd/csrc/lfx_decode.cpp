@@ -179,7 +179,9 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         // A small stream (round 4) does not start with the finder (0.23 ms of fixed cost): reference-made streams of this
         // size are one block plus the empty final one, which the piece scan below walks from the known first block in two
         // steps.  A stream that turns out to have many blocks (another encoder's) gets the finder after all.
-        const bool small_first = comp >= (128u << 10) && comp < (4u << 20) && stop_bit == ~0ull && !partial && !c->diag.no_pieces;
+        // (measured, profiles/r04_small_sizes.json: every dependent block step costs about 0.2 ms — header parse and table
+        //  build of one workgroup — so the walk pays for up to three blocks: streams below 1.5 MiB)
+        const bool small_first = comp >= (32u << 10) && comp < (1536u << 10) && stop_bit == ~0ull && !partial && !c->diag.no_pieces;
         if (small_first) starts.push_back(first_bit);
         else if ((rc = find_candidates())) return rc;
         if (!overflow) {
@@ -202,7 +204,9 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // Pieces behave like blocks from here on (their back-references cross pieces: marker path).
             // Piece size (round 4): a 1 MiB stream is ONE block too — one workgroup in K1 and K2, four units in K3 (2.1 ms).
             // Pieces adapt to the stream: enough of them to give every CU two, between 256 Kbit and 4 Mbit each.
-            if ((small_first || nc <= 8) && comp >= (128u << 10) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
+            // (few candidates in a long stream = few, huge blocks — at least 2 MiB of stream per candidate; a 4 MiB stream of four
+            //  ordinary blocks is not that case: walking it block by block costs a dependent step per block)
+            if ((small_first || (nc <= 8 && comp / nc >= (2u << 20))) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
                 constexpr uint64_t OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
                 const uint64_t PIECE_BITS = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(256ull << 10,
@@ -215,7 +219,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 if ((rc2 = c->d_dec_tabs.reserve(tab_bytes * cap_slots))) return rc2;
                 uint32_t base = 0;
                 bool fail = false;
-                for (uint32_t iter = 0; iter < (small_first ? 3u : 64u) && !fail && !ok_chain; iter++) {
+                for (uint32_t iter = 0; iter < (small_first ? 4u : 64u) && !fail && !ok_chain; iter++) {
                     const uint32_t np = (uint32_t)((end_bits - pos + PIECE_BITS - 1) / PIECE_BITS);
                     if (np == 0 || base + np > cap_slots) { fail = true; break; }
                     std::vector<BlkJob> pj(np);
@@ -294,7 +298,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
             // few candidates = few, huge blocks (schedule S1: one): a false candidate would cost a full rescan of
             // such a block, so the known first block also gets a job that runs to the end of the stream
-            if (nc > 1 && nc <= 8 && alt[0] < 0) {
+            if (nc > 1 && nc <= 8 && alt[0] < 0 && comp / nc >= (2u << 20)) {
                 alt[0] = (int32_t)bj.size();
                 bj.push_back(BlkJob{starts[0], n * 8});
             }
@@ -680,7 +684,7 @@ int decode_stream(Ctx *c, int format, uint32_t flags, const uint8_t *d_in, uint6
                 return LFX_OK;
             }
             uint8_t t[8];
-            const uint64_t nspans = div_up(std::max<uint64_t>(mr.out_len, 1), 65536);   // CK_SPAN
+            const uint64_t nspans = ck_nspans(mr.out_len);
             if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
             uint32_t *ck = (uint32_t *)c->d_ck.p;
             LAUNCH_TRY(launch_checksum(st, d_out + out_at, mr.out_len, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,
@@ -1054,7 +1058,7 @@ extern "C" int lfx_decode_range_finish(lfx_ctx *cc, const void *d_maps, uint32_t
     }
     if (total) {
         if ((rc = c->d_res.reserve(256))) return rc;
-        const uint64_t nspans = div_up(total, 65536);
+        const uint64_t nspans = ck_nspans(total);
         if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
         uint32_t *ck = (uint32_t *)c->d_ck.p;
         LAUNCH_TRY(launch_checksum(st, d_out, total, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, 3));
@@ -1492,7 +1496,7 @@ int dec_body(lfx_decoder *d) {
             }
             const uint64_t keep = mr.status == LFX_OK ? mr.out_len : mr.out_len;   // bytes produced (also on failure)
             if (keep && mr.status == LFX_OK && trailer) {
-                const uint64_t nspans = div_up(keep, 65536);                       // CK_SPAN
+                const uint64_t nspans = ck_nspans(keep);
                 if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
                 uint32_t *ck = (uint32_t *)c->d_ck.p;
                 if (int e_ = launch_checksum(c->stream, d_out, keep, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,

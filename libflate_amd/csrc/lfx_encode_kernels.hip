@@ -1046,7 +1046,7 @@ __device__ __forceinline__ CkPartial ck_span_partial(const uint8_t *p, uint32_t 
 
 template <int MODE>
 __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__restrict__ in,
-                                                            uint64_t n, uint32_t *__restrict__ crc_part,
+                                                            uint64_t n, uint32_t span, uint32_t *__restrict__ crc_part,
                                                             uint32_t *__restrict__ a_part,
                                                             uint32_t *__restrict__ b_part) {
     __shared__ uint32_t tab[4][256];   // slice-by-4: four independent lookups per input dword
@@ -1054,9 +1054,9 @@ __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__res
     ck_tables(tab, advt);
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t region = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t r0 = region * CK_SPAN;
+    const uint64_t r0 = region * span;      // (span: 64 KiB, or 8 KiB for small inputs — ck_span(): a wavefront's serial share)
     if (r0 >= n) return;
-    const uint32_t rlen = (uint32_t)min((uint64_t)CK_SPAN, n - r0);
+    const uint32_t rlen = (uint32_t)min((uint64_t)span, n - r0);
     const CkPartial r = ck_span_partial<MODE>(in + r0, rlen, lane, tab, advt);
     if (lane == 0) { crc_part[region] = r.crc; a_part[region] = r.a; b_part[region] = r.b; }
 }
@@ -1099,21 +1099,21 @@ __global__ __launch_bounds__(256) void checksum_ranges_kernel(const uint8_t *__r
 __global__ __launch_bounds__(1024) void checksum_combine_kernel(const uint32_t *__restrict__ crc_part,
                                                                 const uint32_t *__restrict__ a_part,
                                                                 const uint32_t *__restrict__ b_part,
-                                                                uint64_t n,
+                                                                uint64_t n, uint32_t span,
                                                                 EncodeResult *__restrict__ res) {
     __shared__ uint32_t s_crc[1024];
     __shared__ uint64_t s_len[1024];
     __shared__ uint32_t s_a[1024], s_b[1024];
-    const uint64_t nspans = div_up(n, CK_SPAN);
+    const uint64_t nspans = div_up(n, span);
     const uint64_t per = div_up(nspans, 1024);
     const uint64_t lo = (uint64_t)threadIdx.x * per, hi = min(nspans, lo + per);
     // serial fold of this lane's consecutive spans
     uint32_t crc = 0, a = 0, b = 0;
     uint64_t len = 0;
-    const uint32_t xs = gf2_xpow8n(CK_SPAN);
+    const uint32_t xs = gf2_xpow8n(span);
     for (uint64_t s = lo; s < hi; ++s) {
-        const uint64_t sl = min((uint64_t)CK_SPAN, n - s * CK_SPAN);
-        const uint32_t sh = sl == CK_SPAN ? xs : gf2_xpow8n(sl);
+        const uint64_t sl = min((uint64_t)span, n - s * span);
+        const uint32_t sh = sl == span ? xs : gf2_xpow8n(sl);
         crc = gf2_mulmod(crc, sh) ^ crc_part[s];
         // Adler: A += a2 ; B += b2 + len2 * A_before
         b = (uint32_t)((b + b_part[s] + (sl % 65521u) * (uint64_t)a) % 65521u);
@@ -1125,10 +1125,10 @@ __global__ __launch_bounds__(1024) void checksum_combine_kernel(const uint32_t *
     s_a[threadIdx.x] = a;
     s_b[threadIdx.x] = b;
     __syncthreads();
-    // tree: at level k a full right-hand operand is `per * CK_SPAN << k` bytes long; its shift is the
+    // tree: at level k a full right-hand operand is `per * span << k` bytes long; its shift is the
     // square of the previous level's, only the (single) short tail needs a fresh x^n
-    uint32_t lvl_shift = gf2_xpow8n(per * (uint64_t)CK_SPAN);
-    uint64_t lvl_len = per * (uint64_t)CK_SPAN;
+    uint32_t lvl_shift = gf2_xpow8n(per * (uint64_t)span);
+    uint64_t lvl_len = per * (uint64_t)span;
     for (uint32_t step = 1; step < 1024; step <<= 1) {
         uint32_t c2 = 0, a2 = 0, b2 = 0;
         uint64_t l2 = 0;
@@ -1307,16 +1307,17 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
 }
 int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
                     uint32_t *a_part, uint32_t *b_part, EncodeResult *res, int mode) {
-    const uint64_t nspans = div_up(n, CK_SPAN);
+    const uint32_t span = ck_span(n);
+    const uint64_t nspans = div_up(n, span);
     if (nspans) {
         const dim3 grid((uint32_t)div_up(nspans, 4));
-        if (mode == 1) hipLaunchKernelGGL(checksum_span_kernel<1>, grid, dim3(256), 0, st, in, n, crc_part, a_part, b_part);
-        else if (mode == 2) hipLaunchKernelGGL(checksum_span_kernel<2>, grid, dim3(256), 0, st, in, n, crc_part, a_part, b_part);
-        else hipLaunchKernelGGL(checksum_span_kernel<3>, grid, dim3(256), 0, st, in, n, crc_part, a_part, b_part);
+        if (mode == 1) hipLaunchKernelGGL(checksum_span_kernel<1>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part);
+        else if (mode == 2) hipLaunchKernelGGL(checksum_span_kernel<2>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part);
+        else hipLaunchKernelGGL(checksum_span_kernel<3>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part);
         LFX_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(checksum_combine_kernel, dim3(1), dim3(1024), 0, st, crc_part, a_part, b_part,
-                       n, res);
+                       n, span, res);
     LFX_LAUNCH_CHECK();
     return 0;
 }
