@@ -224,6 +224,7 @@ void Diag::read() {
     auto on = [](const char *k) { return getenv(k) != nullptr; };
     debug = on("LFX_DEBUG");
     match_v1 = on("LFX_MATCH_V1");
+    match_v3 = on("LFX_MATCH_V3");
     no_serial = on("LFX_NO_SERIAL");
     batch_serial = on("LFX_BATCH_SERIAL");
     no_markers = on("LFX_NO_MARKERS");
@@ -364,6 +365,13 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                 segs.push_back(SegDesc{ci, (uint32_t)s, (uint32_t)std::min<uint64_t>(seg_len, ch.len - s), 0});
         }
     }
+    // lfx_match5: every segment keeps the final links of its positions — its warm-up included — in a region of its own
+    uint64_t lnk_units = 0;
+    for (SegDesc &sg : segs) {
+        if (lnk_units > 0xFFFFFFFFull) { c->set_error("input too large for the link scratch"); return LFX_E_ARG; }
+        sg.lnk_base = (uint32_t)lnk_units;
+        lnk_units += div_up((uint64_t)sg.len + std::min<uint64_t>(sg.start, MAX_WINDOW) + 4, 64);
+    }
     // workgroups of the parse walk: PARSE_WG_SEGS consecutive segments of one chunk each
     std::vector<ParseWg> pwgs;
     for (uint32_t ci = 0; ci < nchunks && !hc; ci++) {
@@ -395,6 +403,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
     if ((rc = c->d_pwgs.reserve(sizeof(ParseWg) * std::max<size_t>(pwgs.size(), 1)))) return rc;
     if (!hc && (rc = c->d_cd.reserve(2 * n + 64))) return rc;                   // candidate distances, 16 bits per position
+    if (!hc && !match_v1 && !c->diag.match_v3 && (rc = c->d_glnk.reserve(128 * std::max<uint64_t>(lnk_units, 1)))) return rc;
     if (!hc && match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
@@ -462,21 +471,32 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
         LAUNCH_TRY(launch_md_to_cd(st, (const uint32_t *)c->d_md.p, n, d_cd));
     } else {
-        LAUNCH_TRY(launch_match3(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                 (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
+        if (c->diag.match_v3)
+            LAUNCH_TRY(launch_match3(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                     (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
+        else
+            LAUNCH_TRY(launch_match5(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                     (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, d_match_flags, mdbg));
     }
     if (mdbg) {
-        uint64_t hv[128];
+        uint64_t hv[256];
         (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
+        if (!match_v1) {
+            uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+            for (int w = 1; w < 16; w++) for (int k = 0; k < 6; k++) t[k] += hv[128 + w * 8 + k];
+            fprintf(stderr, "[lfx] match3 workgroup 0: positions whose chain walk took more than 2/4/8/12/16 hops in the loop, handed over to wave 0 (match5): %llu %llu %llu %llu %llu %llu of %llu\n",
+                    (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2], (unsigned long long)t[3], (unsigned long long)t[4],
+                    (unsigned long long)t[5], (unsigned long long)hv[5] * 960ull);
+        }
         for (int w = 0; w < 16; w++)
             fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "3", w,
                     match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
         if (!match_v1)
             for (int w = 1; w < 16; w++)
-                fprintf(stderr, "[lfx] match3 wave%d loop trips: sum=%u max=%u tiles>4=%u tiles>8=%u trips-without-pointers=%u\n", w,
+                fprintf(stderr, "[lfx] match3 wave%d loop trips: sum=%u max=%u tiles>4=%u tiles>8=%u trips-without-pointers=%u trips-with<=4-lanes=%u\n", w,
                         (unsigned)hv[w * 8 + 3], (unsigned)(hv[w * 8 + 3] >> 32), (unsigned)hv[w * 8 + 4], (unsigned)(hv[w * 8 + 4] >> 32),
-                        (unsigned)hv[w * 8 + 6]);
+                        (unsigned)hv[w * 8 + 6], (unsigned)hv[w * 8 + 7]);
     }
     c->phase("lz77_match");
     if (c->diag.debug && getenv("LFX_DUMP_SEG")) {

@@ -13,7 +13,7 @@ struct SegDesc {
     uint32_t chunk;
     uint32_t start;
     uint32_t len;
-    uint32_t _pad;
+    uint32_t lnk_base;   // lfx_match5: first entry of the segment's private link region, in units of 64 entries (128 bytes)
 };
 constexpr uint32_t SEG_POSITIONS = 256 * 1024;
 
@@ -46,6 +46,10 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
 // (0 = none) → cd.  flags[0] |= 1 on a lane-order violation.
 int launch_match3(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg = nullptr);
+// the same stage with its deep chain walks handed over to wave 0 (lfx_match5.hip, round 4): the default.
+// glnk: scratch for the final link of every position of every segment (warm-up included), regions by SegDesc::lnk_base
+int launch_match5(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg = nullptr);
 // the first-generation kernel's answers (length << 16 | distance) → cd
 int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd);
 // the greedy walk with lazy match lengths (lfx_parse2.hip) → code words per chunk

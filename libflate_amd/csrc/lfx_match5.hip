@@ -1,39 +1,30 @@
-// lfx_match3.hip — LZ77 candidate stage for gfx950: per position, the DISTANCE to the most recent earlier occurrence of
-// its 3-byte prefix inside the chunk (0 = none inside the window), written to cd[] as 16 bits per position.
+// lfx_match5.hip — LZ77 candidate stage for gfx950, round 4: lfx_match3.hip (see there for the stages P / H / F1 / F2 / R1,
+// the ordered head pass by ds_mskor_rtn_b32 and the exactness argument) with its DEEP CHAIN WALKS TAKEN OFF THE TILE'S
+// CRITICAL PATH.
 //
-// Replaces, bit for bit, the table probe of DefaultLz77Encoder::flush (libflate_lz77/src/default.rs:76-87,146-182).
-// Parse independence (tests/test_host_pipeline.py): the reference inserts EVERY position < end exactly once and in
-// order (default.rs:78,92-97), so cand(i) = max{ j < i : buf[j..j+3] == buf[i..i+3] } does not depend on which
-// positions the walk visits.  The match LENGTH (longest_common_prefix, default.rs:122-129) is only ever needed at the
-// positions the greedy walk visits (about a quarter of them on text): it is computed by the walk itself
-// (lfx_parse2.hip), not here — the third generation of this kernel is the second one without its length stage (40 % of
-// its instructions, and 4 bytes of output per position instead of 2).
+// Replaces, bit for bit, the table probe of DefaultLz77Encoder::flush (libflate_lz77/src/default.rs:76-87,146-182): per
+// position the distance to the most recent earlier occurrence of its 3-byte prefix inside the window (0 = none) → cd[].
 //
-// One workgroup of 16 wavefronts per segment, a software pipeline over tiles of 960 positions (15 resolver
-// wavefronts x 64 lanes), two LDS-only barriers per tile:
+// What was measured on lfx_match3 (profiles/r04_m3_trips.txt, tools/exp/m3_cap.py): the phase-B loop runs 3.3 trips per
+// wavefront and tile on average, but a tile waits for its SLOWEST wavefront (8-9 trips), and more than half of all trips
+// carry four lanes or fewer: 0.6 % of the positions walk more than two links of their bucket's chain inside the loop,
+// 0.24 % more than four, 0.07 % more than eight (a rare prefix in a bucket that two frequent ones alternate in).  Ending
+// every walk after three trips — wrong answers, timing only — takes 30 % off the kernel (2.86 → 2.00 ms).
 //
-//   phase A   resolvers: F1(k+1) what the head pass returned → raw predecessor → same prefix? (answer known) :
-//                                plain link ; first link state lk[]
-//                        P(k+2)  3-byte prefix, hash, request word of the head pass
-//             wave 0:    window bytes: stores of the previous iteration's loads, then this iteration's loads;
-//                        incremental sweep of stale head fields
-//   phase B   wave 0:    H(k+2)  ordered head pass.  head[] holds 2^14 16-bit fields (low 16 bits of the most recent
-//                                position per hash) packed two per dword; ONE ds_mskor_rtn_b32 per 64 positions
-//                                exchanges the field and returns the old dword.  The LDS serves the lanes of one
-//                                instruction that hit the same field in ascending lane order and a wavefront's
-//                                instructions in issue order (measured: tools/exp/mskor_test.hip,
-//                                profiles/r03_mskor_order.txt), so every lane receives exactly its raw predecessor
-//                                ph(p) = most recent earlier position with the same hash.  A lane that observes a
-//                                value "from the future" (distance >= 65536-64) proves a violation: the kernel
-//                                raises a flag and the host re-runs the first-generation kernel.
-//             resolvers: F2(k+1) duplicate-collapsed link by pointer jumping → prevd[]
-//                        R1(k)   chain walk for the positions whose answer is not known yet → cd[]
-//                                (reads link-ring entries of tiles <= k only, final since the previous iteration)
+// Nothing in the kernel consumes a walk's answer (only cd[] does).  So a walk that is still running when the loop has
+// done DEFER_TRIPS trips and the tile's pointer jumps are settled is HANDED OVER to wave 0 through a small LDS queue
+// (position, prefix, distance so far, next link).  Wave 0 holds up to 64 such walks in its registers and advances every
+// one of them by ONE link per service call (two calls per tile: phase A, where it is otherwise idle, and phase B behind
+// its head pass) — through GLOBAL memory: F2 also writes every final link to a 16-bit array in HBM (`glnk`, 2 bytes per
+// position, scratch of the parse stage), the prefix bytes are the input itself.  A service call consumes the loads the
+// previous call issued (a tile ago: no latency is ever waited for) and issues the next ones, so a walk of forty links
+// simply finishes forty calls later — no ring slack is needed, nothing expires, and the tile never waits for it.  When
+// wave 0 has no lane free the walks stay in the loop as in lfx_match3.
 //
-// Duplicate collapsing (exactness argument as in the first-generation kernel): link(p) = ph(p) if the
-// prefixes differ, else link(ph(p)); the chain from p therefore visits the most recent member of every run of equal
-// prefixes in its bucket, in decreasing position order, and the walk stops at the first exact 3-byte match (the most
-// recent occurrence) or when the distance exceeds the window (default.rs:81).
+// Visibility of glnk: the stores of tile k's links are issued in iteration k-1 (F2 runs a tile ahead of R1); every
+// resolver wavefront starts phase B of iteration k with s_waitcnt vmcnt(0), so those stores are acknowledged by the L2
+// before a walk of tile k is queued, and wave 0's loads (agent scope: served by the L2, never by a stale L1 line) are issued in
+// iteration k+1 at the earliest, behind a workgroup barrier.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -43,7 +34,7 @@
 
 namespace lfx {
 
-namespace m3 {
+namespace m5 {
 
 constexpr int THREADS = 1024;
 constexpr uint32_t RW = 15;                   // resolver wavefronts (waves 1..15; wave 0: head pass + window)
@@ -69,10 +60,15 @@ constexpr uint32_t LK_PTR = 0xC000;
 constexpr uint32_t OFF_WIN = 0;                                    // RING + 8 bytes (+ pad)
 constexpr uint32_t OFF_LK = OFF_WIN + RING + 16;                   // TILE u16: link states of the tile being finalized
 constexpr uint32_t OFF_PREVD = OFF_LK + TILE * 2;                  // RING u16
-constexpr uint32_t OFF_REQ = OFF_PREVD + RING * 2;                 // TILE u32: head-pass requests (hash, valid, position)
-constexpr uint32_t OFF_OLD = OFF_REQ + TILE * 4;                   // TILE u32: the dwords the exchanges returned
-constexpr uint32_t OFF_HEAD = OFF_OLD + TILE * 4;                  // 8192 dwords
-constexpr uint32_t LDS_BYTES = OFF_HEAD + (2u << HASH_BITS);
+constexpr uint32_t OFF_REQ = OFF_PREVD + RING * 2;                 // TILE u32: head-pass requests (hash, valid, position); the head pass
+                                                                   // puts the dword each exchange returned into the SAME slot
+constexpr uint32_t OFF_HEAD = OFF_REQ + TILE * 4;                  // 8192 dwords
+// walks handed over to wave 0: entries {position, prefix, distance so far, next link}, a count and wave 0's free lanes
+constexpr uint32_t QCAP = 64;
+constexpr uint32_t OFF_Q = OFF_HEAD + (2u << HASH_BITS);
+constexpr uint32_t OFF_QCTL = OFF_Q + QCAP * 16;                   // [0] entries pushed since the last service, [1] free lanes of wave 0
+constexpr uint32_t LDS_BYTES = OFF_QCTL + 16;
+constexpr uint32_t DEFER_TRIPS = 3;           // trips of the phase-B loop after which a wavefront hands its walks over
 static_assert(OFF_PREVD < 65536 && OFF_LK < 65536, "offset field");
 static_assert(NSUB % HB == 0, "the head pass issues whole batches");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -139,22 +135,23 @@ __device__ __forceinline__ void mskor_batch(uint32_t (&old)[HB], const uint32_t 
         : "memory");
 }
 
-}  // namespace m3
+}  // namespace m5
 
 // flags[0] |= 1 when the head pass observed a lane-order violation (results are then discarded by the host).
 // DBG: per-wavefront cycle stamps of workgroup 0 (LFX_DEBUG); the production instance carries none of it.
 template <bool DBG>
-__global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
+__global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
     const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd,
-    uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg, uint32_t dbg_cap) {
-    using namespace m3;
+    uint16_t *__restrict__ glnk, uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg) {
+    using namespace m5;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     uint32_t *head32 = (uint32_t *)(smem + OFF_HEAD);
     uint16_t *prevd = (uint16_t *)(smem + OFF_PREVD);
     uint32_t *win32 = (uint32_t *)(smem + OFF_WIN);
     uint32_t *reqb = (uint32_t *)(smem + OFF_REQ);
-    uint32_t *oldb = (uint32_t *)(smem + OFF_OLD);
+    uint32_t *qent = (uint32_t *)(smem + OFF_Q);          // QCAP x 4 dwords
+    uint32_t *qctl = (uint32_t *)(smem + OFF_QCTL);
     uint16_t *lk = (uint16_t *)(smem + OFF_LK);
     // LDS byte address of head[] for the asm exchanges (taking it from the pointer also makes the array escape)
     const uint32_t head_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)head32;
@@ -171,6 +168,9 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
         src.nbytes = in_bytes - ch.in_off;
     }
     uint16_t *cd_c = cd + ch.in_off;              // this chunk's answers
+    // ... and this SEGMENT's final links, for the walks wave 0 takes over: a region of its own (entry 0 = position l0) — the
+    // warm-up positions of a segment are another segment's own positions, and the two link structures differ there
+    uint16_t *glnk_s = glnk + (uint64_t)sg.lnk_base * 64u;
     if (ch.flags & CH_LITERALS) return;           // NoCompressionLz77Encoder chunks never come here
     const uint32_t end = (n > 3 ? n : 3) - 3;     // default.rs:75
     const uint32_t q0 = sg.start;                 // first position answered by this segment
@@ -186,6 +186,7 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
         const uint32_t f = (base - HEAD_FAR) & 0xFFFFu;
         head32[i] = f | f << 16;
     }
+    if (tid == 0) { qctl[0] = 0; qctl[1] = 64; }
     uint32_t loaded_to = base;                                    // window holds [.., loaded_to) (wave 0 keeps it)
     {
         const uint32_t need = min(base + 2 * TILE + 4, n_pad);    // (P(0) and P(1) read it before the first fill lands)
@@ -208,6 +209,61 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
     uint32_t e_f = NONE, e_r = NONE;               // own final link distance
     uint32_t lk_f = NONE;                          // F1 → F2: first link state
     bool viol = false;                             // a lane-order violation seen by this lane (reported once, at the end)
+    // ---- wave 0: the walks it holds, one per lane: position, prefix, distance walked so far, the link to add next; and the
+    //      loads in flight for the position that link leads to (the two dwords that hold its prefix, its own link)
+    uint32_t w_p = 0, w_key = 0, w_dist = 0, w_d = 0;
+    uint32_t w_b0 = 0, w_b1 = 0, w_ln = 0, w_free = 64;    // (w_free: the free lanes wave 0 last published)
+    bool w_act = false, w_pend = false;
+    // One service call: consume what the previous call loaded, take over what the resolvers queued, issue the next loads.
+    // `take`: also take over queued walks and publish the number of free lanes — only in phase A, when no resolver pushes
+    auto w_service = [&](bool take) {
+        bool done = false;
+        uint32_t found = 0;
+        if (w_pend) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (issued a tile ago)
+            const uint32_t kq = __builtin_amdgcn_alignbyte(w_b1, w_b0, (w_p - w_dist + (uint32_t)src.shift) & 3u) & 0xFFFFFFu;
+            const bool hit = kq == w_key;                              // the most recent occurrence of the prefix: the answer
+            found = hit ? 1u : 0u;
+            done = hit;
+            w_d = w_ln;
+            w_pend = false;
+        }
+        if (take) {
+            const uint32_t n_new = min(qctl[0], w_free);         // (the count also holds the walks that found no slot)
+            const uint64_t fb = __ballot(!w_act);
+            const uint32_t rank = (uint32_t)__popcll(fb & ((1ull << lane) - 1ull));
+            if (!w_act && rank < n_new) {
+                const uint4 q = *(const uint4 *)&qent[rank * 4];
+                w_p = q.x; w_key = q.y; w_dist = q.z; w_d = q.w;
+                w_act = true;
+            }
+        }
+        if (w_act && !done) {
+            w_dist += w_d;
+            // default.rs:81 (inclusive window); NONE (no link) ends here as well (a link never reaches in front of l0, the
+            // first position of the segment's chain structure: the second test is a guard, not a case)
+            if (w_dist > window || w_dist > w_p - l0) done = true;
+            else {
+                const uint32_t a = w_p - w_dist;
+                const uint64_t ab = (uint64_t)a + src.shift, wi = ab >> 2;
+                const uint64_t last = (src.nbytes + src.shift + 3) >> 2;
+                w_b0 = src.w[wi];
+                w_b1 = (wi + 1 < last) ? src.w[wi + 1] : 0u;
+                // (an agent-scope load: served by the L2 — a line of glnk is written tile by tile, and a copy of it that this
+                //  CU's L1 took while only its first entries existed must never be read again)
+                w_ln = __hip_atomic_load(&glnk_s[a - l0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w_pend = true;
+            }
+        }
+        if (w_act && done) {
+            cd_c[w_p] = (uint16_t)(found ? w_dist : 0u);
+            w_act = false;
+        }
+        if (take) {
+            w_free = (uint32_t)__popcll(__ballot(!w_act));
+            if (lane == 0) { qctl[0] = 0; qctl[1] = w_free; }
+        }
+    };
     // (tile 0 = position `base` sits at ring offset 0; the loop starts two tiles early)
     uint32_t ok = RING - 2 * TILE;                 // ring offset of tile `it`
     uint32_t fill_off = loaded_to - base;          // wave 0: ring offset of position loaded_to
@@ -255,7 +311,7 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
             uint32_t found = (known && dist <= window) ? 1u : 0u;
             // -- step 0: loads
             const uint32_t d0 = prevd[walk ? ring_back(o_r, dist) : o_r];
-            const uint32_t ow = oldb[idx];
+            const uint32_t ow = reqb[idx];                      // (what the head pass left in the request's slot)
             const uint32_t kp_raw = win4(win32, o_p);
             // (the incremental sweep of stale head fields — older than the window → "far" — rides along: lanes [0, 256))
             const uint32_t slice = (uint32_t)(it + 2) % SWEEP_SLICES;
@@ -325,6 +381,8 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
                 fill_w0 = fill_w1 = 0;
                 if (loaded_to + f4 < fill_need) src.load_raw(loaded_to + f4, fill_w0, fill_w1);
             }
+        } else if (wave == 0) {
+            w_service(true);  // the walks handed over by the resolvers: one link each (wave 0 has nothing else to do in phase A)
         }
         pend_lo = loaded_to; pend_hi = fill_need; pend_off = fill_off;
         fill_off = ring_wrap(fill_off + (fill_need - loaded_to));
@@ -348,13 +406,20 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
                     }
                     mskor_batch(old, addr, mask, val);
 #pragma unroll
-                    for (uint32_t s = 0; s < HB; ++s) oldb[(h * HB + s) * 64 + lane] = old[s];
+                    for (uint32_t s = 0; s < HB; ++s) reqb[(h * HB + s) * 64 + lane] = old[s];
                 }
             }
+            w_service(false); // (behind the head pass: the resolvers' loop is still running and may be queueing walks)
         } else if (wave <= RW) {
+            // this wavefront's stores of the previous iteration (the links of tile `it` among them) are complete — acknowledged
+            // by the L2 — before any walk of this tile can be handed over.  (vmcnt(0), not a partial count: loads and stores
+            // share the counter on gfx9-class hardware and may complete out of order with respect to each other.  What is
+            // still in flight here was issued a whole phase A ago.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t p_r = t_r + idx;
             const uint32_t o_r = ok + idx, o_f = o1 + idx;
             const bool act_r = do_r && val_r && p_r >= q0;
+            const bool act_f = do_f && val_f;
             // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed: every
             //      state a reader can observe is valid and the oldest member of a run is final from the start)
             // ---- R1(it), further hops (a few percent of the positions, but nearly every wavefront holds one).  They read
@@ -371,9 +436,10 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
             //      fifteen wavefronts, not by the slowest of them.)
             uint32_t e = lk_f;                                         // (NONE where the position takes no part)
             uint32_t dist = r_dist, d = r_d, found = r_found;
-            uint32_t trips = 0, hops = 0, ntrip = 0;
+            uint32_t trips = 0, hops = 0;
+            bool may_defer = true, deferred = false;
             for (;;) {
-                if (DBG) { trips++; if (__ballot(e >= LK_PTR) == 0) tr_r1++; hops += d != 0; }
+                if (DBG) { if (__ballot(e >= LK_PTR) == 0) tr_r1++; hops += d != 0; }
                 // loads (a lane whose link state is final reads its own slot, which holds that state: the update is the
                 // identity; a lane whose walk has ended reads its own position)
                 const uint32_t j = min(e - LK_PTR, idx);
@@ -394,21 +460,39 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
                     found = hit ? 1u : found;
                     d = (d == 0 || hit) ? 0u : dn;
                 }
-                if (!__ballot(e >= LK_PTR || d != 0)) break;
-                if (DBG) tr_thin += __popcll(__ballot(e >= LK_PTR || d != 0)) <= 4;
-                // (LFX_M3_CAP: timing-only experiment — the loop ends after dbg_cap trips whatever is left: WRONG answers;
-                //  bit 8 set: only the chain walks are cut, the pointer jumps run to the end)
-                if (dbg_cap && ++ntrip >= (dbg_cap & 0xFF) && (!(dbg_cap & 0x100) || __ballot(e >= LK_PTR) == 0)) break;
+                const uint64_t ptrs = __ballot(e >= LK_PTR), walks = __ballot(d != 0);
+                ++trips;
+                if (!(ptrs | walks)) break;
+                if (DBG) tr_thin += __popcll(ptrs | walks) <= 4;
+                // ---- only walks are left (the pointer jumps — the links the next tile needs — are settled) and the loop has
+                //      run its share: hand the walks over to wave 0 instead of keeping fifteen wavefronts waiting for them
+                if (!ptrs && trips >= DEFER_TRIPS && may_defer) {
+                    // slots are handed out by ONE atomic add and never given back: a wavefront fills the part of its range
+                    // that lies below wave 0's number of free lanes, so the filled slots are always [0, min(count, free))
+                    // whatever the interleaving; the walks that found no slot stay in this loop
+                    const uint32_t nw = (uint32_t)__popcll(walks);
+                    uint32_t qb = 0;
+                    if (lane == 0) qb = atomicAdd(&qctl[0], nw);
+                    qb = (uint32_t)__builtin_amdgcn_readfirstlane((int)qb);
+                    const uint32_t r = qb + (uint32_t)__popcll(walks & ((1ull << lane) - 1ull));
+                    if (d != 0 && r < qctl[1]) {
+                        *(uint4 *)&qent[r * 4] = make_uint4(p_r, key_r, dist, d);
+                        deferred = true;
+                        d = 0;
+                    }
+                    may_defer = false;
+                    if (!__ballot(d != 0)) break;
+                }
             }
             if (DBG) {
                 tr_sum += trips; tr_max = max(tr_max, trips); tr_gt4 += trips > 4; tr_gt8 += trips > 8;
-                // positions by the hops their chain walk took in this loop (the first hop ran in phase A)
                 hop_n[0] += __popcll(__ballot(hops > 2)); hop_n[1] += __popcll(__ballot(hops > 4)); hop_n[2] += __popcll(__ballot(hops > 8));
-                hop_n[3] += __popcll(__ballot(hops > 12)); hop_n[4] += __popcll(__ballot(hops > 16)); hop_n[5] += __popcll(__ballot(hops > 24));
+                hop_n[3] += __popcll(__ballot(hops > 12)); hop_n[4] += __popcll(__ballot(hops > 16)); hop_n[5] += __popcll(__ballot(deferred));
             }
             e_f = e;
             prevd[o_f] = (uint16_t)e;        // (positions outside the chain structure: their slot is never read)
-            if (act_r) cd_c[p_r] = (uint16_t)(found ? dist : 0u);
+            if (act_f) glnk_s[t_f + idx - l0] = (uint16_t)e;                 // the same link for the walks wave 0 takes over
+            if (act_r && !deferred) cd_c[p_r] = (uint16_t)(found ? dist : 0u);
         }
         const uint64_t c2 = DBG ? clock64() : 0;
         // ---- rotate the stage registers
@@ -420,6 +504,10 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
         const uint64_t c3 = DBG ? clock64() : 0;
         if (DBG) { cy_a += c1 - c0; cy_b += c2 - c1; cy_w += c3 - c2; }
     }
+    // the walks wave 0 still holds (and what the last tile queued): to their end, a link per round trip
+    if (wave == 0) {
+        do { w_service(true); } while (__ballot(w_act));
+    }
     if (__ballot(viol) && lane == 0) atomicOr(flags, 1u);             // lane-order violation (never observed)
     if (DBG && dbg && blockIdx.x == 0 && lane == 0) {
         uint64_t *d = dbg + wave * 8;
@@ -430,16 +518,15 @@ __global__ __launch_bounds__(m3::THREADS) void lz77_match3_kernel(
     }
 }
 
-int launch_match3(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg) {
+int launch_match5(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg) {
     if (nsegs == 0) return 0;
-    static const uint32_t cap = getenv("LFX_M3_CAP") ? (uint32_t)atoi(getenv("LFX_M3_CAP")) : 0u;   // (diagnostics, with LFX_DEBUG only)
     if (dbg)
-        hipLaunchKernelGGL(lz77_match3_kernel<true>, dim3(nsegs), dim3(m3::THREADS), 0, st, in, in_bytes, chunks, segs, window,
-                           cd, flags, dbg, cap);
+        hipLaunchKernelGGL(lz77_match5_kernel<true>, dim3(nsegs), dim3(m5::THREADS), 0, st, in, in_bytes, chunks, segs, window,
+                           cd, glnk, flags, dbg);
     else
-        hipLaunchKernelGGL(lz77_match3_kernel<false>, dim3(nsegs), dim3(m3::THREADS), 0, st, in, in_bytes, chunks, segs, window,
-                           cd, flags, dbg, cap);
+        hipLaunchKernelGGL(lz77_match5_kernel<false>, dim3(nsegs), dim3(m5::THREADS), 0, st, in, in_bytes, chunks, segs, window,
+                           cd, glnk, flags, dbg);
     const hipError_t e_ = hipGetLastError();
     return e_ != hipSuccess ? (int)e_ : 0;
 }

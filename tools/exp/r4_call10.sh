@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; O=gpurun_out
+timeout 100 python tools/exp/m3_cap.py 2>/dev/null | tail -1
+timeout 600 python tools/exp/m5_stress.py 300 2>&1 | tail -4
+for i in 1 2; do timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round3.py -m gpu -x -q > $O/par$i.log 2>&1; grep -a "^E  \|^FAILED\|passed\|failed" $O/par$i.log | cut -c1-250 | head -8; done
+timeout 900 python -m pytest tests/test_gpu_round2.py tests/test_gpu_large.py tests/test_gpu_round4.py -m gpu -x -q 2>&1 | tail -2
