@@ -68,7 +68,7 @@ constexpr uint32_t QCAP = 64;
 constexpr uint32_t OFF_Q = OFF_HEAD + (2u << HASH_BITS);
 constexpr uint32_t OFF_QCTL = OFF_Q + QCAP * 16;                   // [0] entries pushed since the last service, [1] free lanes of wave 0
 constexpr uint32_t LDS_BYTES = OFF_QCTL + 16;
-constexpr uint32_t DEFER_TRIPS = 3;           // trips of the phase-B loop after which a wavefront hands its walks over
+constexpr uint32_t DEFER_TRIPS = 2;           // trips of the phase-B loop after which a wavefront hands its walks over
 static_assert(OFF_PREVD < 65536 && OFF_LK < 65536, "offset field");
 static_assert(NSUB % HB == 0, "the head pass issues whole batches");
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");

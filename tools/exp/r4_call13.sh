@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; O=gpurun_out
+timeout 100 python tools/exp/m3_cap.py 2>/dev/null | tail -1
+timeout 600 python tools/exp/m5_stress.py 300 2>&1 | tail -2
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/r4_suite_b.log 2>&1; tail -3 $O/r4_suite_b.log
+timeout 300 python bench.py --steps 10 --warmup 3 --no-subs --no-cpu-baseline --no-s1 > $O/r4_bench_b.log 2>&1; tail -c 1500 $O/r4_bench_b.log | head -c 700
