@@ -435,6 +435,23 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
             //      more than the waiting they remove — the tile is bound by the sum of the LDS and vector work of its
             //      fifteen wavefronts, not by the slowest of them.)
             uint32_t e = lk_f;                                         // (NONE where the position takes no part)
+            // A RUN (every position repeats the prefix of the position right in front of it: zero-filled and constant regions,
+            // BASELINE cfg5) is a pointer chain as long as the tile — ten rounds of pointer jumping.  Inside a wavefront it
+            // collapses at once: every lane of a run takes the state of the run's first lane (a final link grows by the
+            // lane distance, a pointer is shared).  Here, not in phase A: this phase waits for LDS round trips, not for
+            // issue slots.  (Other wavefronts may read lk[] before or after the update: both states are valid.)
+            {
+                const uint64_t rm = __ballot(e == LK_PTR + idx - 1 && lane != 0);
+                if (__popcll(rm) >= 8) {
+                    const uint64_t below = ~rm & ((2ull << lane) - 1ull);            // lanes at or below me that start a run (or stand alone)
+                    const uint32_t h = 63u - (uint32_t)__builtin_clzll(below);
+                    const uint32_t eh = (uint32_t)__shfl((int)e, (int)h);
+                    if ((rm >> lane) & 1) {
+                        e = eh >= LK_PTR ? eh : min(eh + (lane - h), NONE);
+                        lk[idx] = (uint16_t)e;
+                    }
+                }
+            }
             uint32_t dist = r_dist, d = r_d, found = r_found;
             uint32_t trips = 0, hops = 0;
             bool may_defer = true, deferred = false;
