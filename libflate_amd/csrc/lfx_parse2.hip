@@ -184,6 +184,48 @@ __device__ __forceinline__ void resolve(const WalkCtx &w, bool act, uint32_t in,
     if (act) { m_out = m; x_out = x; }
 }
 
+
+// One walk step at a UNIFORM position by the whole wavefront: lane k compares bytes [4k, 4k + 4) behind the prefix, so one
+// LDS round trip settles a match of any length (the repair of the entry chain walks ONE group at a time: with a single
+// lane at work a 258-byte match cost six dependent round trips — that chain is what made the walk of low-entropy data,
+// BASELINE cfg5, three times as slow as a text's).
+__device__ __forceinline__ uint32_t walk_step_coop(const WalkCtx &w, uint32_t pos, uint32_t lane) {
+    const uint32_t d = w.cd16[pos - w.c0];                         // (one address: a broadcast read)
+    if (d == 0) return 1;
+    uint32_t lim = w.n - (pos + 3);                                 // default.rs:125
+    lim = lim > w.max_len - 3 ? w.max_len - 3 : lim;
+    const uint32_t off = 4 * lane;
+    uint32_t x = 0;
+    if (off < lim) {
+        const uint32_t oa = pos + 3 - w.w0 + off, ob = oa - d;
+        const uint32_t a0 = w.win32[oa >> 2], a1 = w.win32[(oa >> 2) + 1], b0 = w.win32[ob >> 2], b1 = w.win32[(ob >> 2) + 1];
+        x = __builtin_amdgcn_alignbyte(a1, a0, oa & 3) ^ __builtin_amdgcn_alignbyte(b1, b0, ob & 3);
+    }
+    const uint64_t mis = __ballot(x != 0);
+    uint32_t l = lim;
+    if (mis) {
+        const uint32_t fl = (uint32_t)__builtin_ctzll(mis);
+        const uint32_t cand = off + ((uint32_t)__builtin_ctz(x | 0x80000000u) >> 3);
+        l = (uint32_t)__builtin_amdgcn_readlane((int)cand, (int)fl);
+        l = l > lim ? lim : l;
+    }
+    return 3 + l;
+}
+// resolve() for ONE group with everything uniform (the group's first position a, its end, its speculative mask and exit):
+// the true walk enters at `in` → the visited mask and the exit for that entry
+__device__ __forceinline__ void resolve_one(const WalkCtx &w, uint32_t lane, uint32_t in, uint32_t a, uint32_t stop, uint64_t mask,
+                                            uint32_t exit_spec, uint64_t &m_out, uint32_t &x_out) {
+    uint64_t walked = 0;
+    uint32_t pos = in;
+    for (uint32_t guard = 0; guard <= U + 1; ++guard) {
+        if (pos >= stop) { m_out = walked; x_out = pos; return; }
+        if ((mask >> (pos - a)) & 1) { m_out = walked | (mask & bits_from(pos - a)); x_out = exit_spec; return; }
+        walked |= 1ull << (pos - a);
+        pos += walk_step_coop(w, pos, lane);
+    }
+    m_out = walked; x_out = pos;
+}
+
 }  // namespace p2
 
 // workgroup → (chunk, first segment of the chunk it walks)
@@ -311,7 +353,17 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
         const uint32_t tin = __builtin_amdgcn_readlane(x_fin, j - 1);
         const bool me = lane == j;
         used_in = me ? tin : used_in;
-        resolve(w, me, tin, a, stop, mask, exit_spec, m_fin, x_fin);
+        {
+            // lane j's group, walked by the whole wavefront (its parameters made uniform)
+            const uint32_t ja = s0 + j * U, jstop = min(ja + U, s1);
+            const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, (int)j);
+            const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mask >> 32), (int)j);
+            const uint32_t jx = (uint32_t)__builtin_amdgcn_readlane((int)exit_spec, (int)j);
+            uint64_t mj = 0;
+            uint32_t xj0 = tin;
+            resolve_one(w, lane, tin, ja, jstop, (uint64_t)mlo | (uint64_t)mhi << 32, jx, mj, xj0);
+            if (me) { m_fin = mj; x_fin = xj0; }
+        }
         // the groups this lane's walk jumps over entirely are settled with it (a 258-byte match passes four of them)
         const uint32_t xj = __builtin_amdgcn_readlane(x_fin, j);
         if (lane > j && lane < nact && stop <= xj) { used_in = xj; m_fin = 0; x_fin = xj; }
