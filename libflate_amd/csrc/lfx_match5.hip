@@ -21,10 +21,10 @@
 // simply finishes forty calls later — no ring slack is needed, nothing expires, and the tile never waits for it.  When
 // wave 0 has no lane free the walks stay in the loop as in lfx_match3.
 //
-// Visibility of glnk: the stores of tile k's links are issued in iteration k-1 (F2 runs a tile ahead of R1); every
-// resolver wavefront starts phase B of iteration k with s_waitcnt vmcnt(0), so those stores are acknowledged by the L2
-// before a walk of tile k is queued, and wave 0's loads (agent scope: served by the L2, never by a stale L1 line) are issued in
-// iteration k+1 at the earliest, behind a workgroup barrier.
+// Visibility of glnk: the links of tile k (final since the end of iteration k-1) are stored at the START of phase B of
+// iteration k, and every resolver wavefront ends that phase with s_waitcnt vmcnt(0): they are acknowledged by the L2
+// before the barrier behind which wave 0 takes over the walks of tile k, and wave 0's loads are agent-scope loads (served
+// by the L2, never by a stale L1 line).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -34,6 +34,9 @@
 
 namespace lfx {
 
+#ifndef LFX_M5_TWO_SERVICES
+#define LFX_M5_TWO_SERVICES 0
+#endif
 namespace m5 {
 
 constexpr int THREADS = 1024;
@@ -409,17 +412,14 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
                     for (uint32_t s = 0; s < HB; ++s) reqb[(h * HB + s) * 64 + lane] = old[s];
                 }
             }
-            w_service(false); // (behind the head pass: the resolvers' loop is still running and may be queueing walks)
+            if (LFX_M5_TWO_SERVICES) w_service(false); // (behind the head pass: the resolvers' loop is still running and may be queueing walks)
         } else if (wave <= RW) {
-            // this wavefront's stores of the previous iteration (the links of tile `it` among them) are complete — acknowledged
-            // by the L2 — before any walk of this tile can be handed over.  (vmcnt(0), not a partial count: loads and stores
-            // share the counter on gfx9-class hardware and may complete out of order with respect to each other.  What is
-            // still in flight here was issued a whole phase A ago.)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t p_r = t_r + idx;
             const uint32_t o_r = ok + idx, o_f = o1 + idx;
             const bool act_r = do_r && val_r && p_r >= q0;
-            const bool act_f = do_f && val_f;
+            // the final links of tile `it` (settled at the end of the previous iteration) go to glnk FIRST: the store has the
+            // whole phase to reach the L2 before the wait at its end
+            if (do_r && val_r) glnk_s[p_r - l0] = (uint16_t)e_r;
             // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed: every
             //      state a reader can observe is valid and the oldest member of a run is final from the start)
             // ---- R1(it), further hops (a few percent of the positions, but nearly every wavefront holds one).  They read
@@ -456,7 +456,6 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
             uint32_t trips = 0, hops = 0;
             bool may_defer = true, deferred = false;
             for (;;) {
-                if (DBG) { if (__ballot(e >= LK_PTR) == 0) tr_r1++; hops += d != 0; }
                 // loads (a lane whose link state is final reads its own slot, which holds that state: the update is the
                 // identity; a lane whose walk has ended reads its own position)
                 const uint32_t j = min(e - LK_PTR, idx);
@@ -480,7 +479,6 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
                 const uint64_t ptrs = __ballot(e >= LK_PTR), walks = __ballot(d != 0);
                 ++trips;
                 if (!(ptrs | walks)) break;
-                if (DBG) tr_thin += __popcll(ptrs | walks) <= 4;
                 // ---- only walks are left (the pointer jumps — the links the next tile needs — are settled) and the loop has
                 //      run its share: hand the walks over to wave 0 instead of keeping fifteen wavefronts waiting for them
                 if (!ptrs && trips >= DEFER_TRIPS && may_defer) {
@@ -503,12 +501,15 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
             }
             if (DBG) {
                 tr_sum += trips; tr_max = max(tr_max, trips); tr_gt4 += trips > 4; tr_gt8 += trips > 8;
-                hop_n[0] += __popcll(__ballot(hops > 2)); hop_n[1] += __popcll(__ballot(hops > 4)); hop_n[2] += __popcll(__ballot(hops > 8));
-                hop_n[3] += __popcll(__ballot(hops > 12)); hop_n[4] += __popcll(__ballot(hops > 16)); hop_n[5] += __popcll(__ballot(deferred));
+                hop_n[5] += __popcll(__ballot(deferred));      // (the hop statistics are lfx_match3's: LFX_MATCH_V3 + LFX_DEBUG)
             }
             e_f = e;
             prevd[o_f] = (uint16_t)e;        // (positions outside the chain structure: their slot is never read)
-            if (act_f) glnk_s[t_f + idx - l0] = (uint16_t)e;                 // the same link for the walks wave 0 takes over
+            // Everything this wavefront has in flight — the links of tile `it` stored at the start of this phase, the previous
+            // iteration's answers, the window bytes requested in phase A — is complete before the barrier: a walk of tile `it`
+            // that wave 0 takes over behind it reads those links from the L2.  (vmcnt(0), not a partial count: loads and
+            // stores share the counter on gfx9-class hardware and may complete out of order with respect to each other.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (act_r && !deferred) cd_c[p_r] = (uint16_t)(found ? dist : 0u);
         }
         const uint64_t c2 = DBG ? clock64() : 0;
