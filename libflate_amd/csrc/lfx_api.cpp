@@ -492,6 +492,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "3", w,
                     match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
+        if (!match_v1 && !c->diag.match_v3)
+            fprintf(stderr, "[lfx] match5 wave0: %llu cycles waiting for the loads of the walks it holds (of phaseA)\n", (unsigned long long)hv[6]);
         if (!match_v1)
             for (int w = 1; w < 16; w++)
                 fprintf(stderr, "[lfx] match3 wave%d loop trips: sum=%u max=%u tiles>4=%u tiles>8=%u trips-without-pointers=%u trips-with<=4-lanes=%u\n", w,

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
     bool viol = false;                             // a lane-order violation seen by this lane (reported once, at the end)
     // ---- wave 0: the walks it holds, one per lane: position, prefix, distance walked so far, the link to add next; and the
     //      loads in flight for the position that link leads to (the two dwords that hold its prefix, its own link)
+    uint64_t cy_svc_wait = 0;                      // DBG: cycles wave 0 waited for the loads of the previous call
     uint32_t w_p = 0, w_key = 0, w_dist = 0, w_d = 0;
     uint32_t w_b0 = 0, w_b1 = 0, w_ln = 0, w_free = 64;    // (w_free: the free lanes wave 0 last published)
     bool w_act = false, w_pend = false;
@@ -222,8 +223,10 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
     auto w_service = [&](bool take) {
         bool done = false;
         uint32_t found = 0;
+        const uint64_t cw0 = DBG ? clock64() : 0;
+        if (__ballot(w_pend)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (issued a tile ago)
+        if (DBG) { cy_svc_wait += clock64() - cw0; }
         if (w_pend) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (issued a tile ago)
             const uint32_t kq = __builtin_amdgcn_alignbyte(w_b1, w_b0, (w_p - w_dist + (uint32_t)src.shift) & 3u) & 0xFFFFFFu;
             const bool hit = kq == w_key;                              // the most recent occurrence of the prefix: the answer
             found = hit ? 1u : 0u;
@@ -232,11 +235,18 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
             w_pend = false;
         }
         if (take) {
-            const uint32_t n_new = min(qctl[0], w_free);         // (the count also holds the walks that found no slot)
+            // (the count and the entry a free lane would take are read together: one LDS round trip — they cost 300-500
+            //  cycles each while the resolvers' phase A keeps the LDS busy, and wave 0's phase A must not outlast theirs)
             const uint64_t fb = __ballot(!w_act);
             const uint32_t rank = (uint32_t)__popcll(fb & ((1ull << lane) - 1ull));
+            const uint32_t qc = qctl[0];
+            const uint4 q = *(const uint4 *)&qent[(rank & (QCAP - 1)) * 4];
+            const uint32_t n_new = min(qc, w_free);              // (the count also holds the walks that found no slot)
+            // the queue is handed back at once — the free lanes counted without those that finish in this very call — so that
+            // the LDS write is long complete when wave 0 reaches the barrier
+            w_free = (uint32_t)__popcll(fb) - n_new;
+            if (lane == 0) { qctl[0] = 0; qctl[1] = w_free; }
             if (!w_act && rank < n_new) {
-                const uint4 q = *(const uint4 *)&qent[rank * 4];
                 w_p = q.x; w_key = q.y; w_dist = q.z; w_d = q.w;
                 w_act = true;
             }
@@ -261,10 +271,6 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
         if (w_act && done) {
             cd_c[w_p] = (uint16_t)(found ? w_dist : 0u);
             w_act = false;
-        }
-        if (take) {
-            w_free = (uint32_t)__popcll(__ballot(!w_act));
-            if (lane == 0) { qctl[0] = 0; qctl[1] = w_free; }
         }
     };
     // (tile 0 = position `base` sits at ring offset 0; the loop starts two tiles early)
@@ -385,7 +391,9 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
                 if (loaded_to + f4 < fill_need) src.load_raw(loaded_to + f4, fill_w0, fill_w1);
             }
         } else if (wave == 0) {
-            w_service(true);  // the walks handed over by the resolvers: one link each (wave 0 has nothing else to do in phase A)
+            // the walks handed over by the resolvers: one link each (wave 0 has nothing else to do in phase A; at its usual
+            // priority: with priority 0 here the kernel takes 2.45 ms instead of 2.24 — the tile waits for this call)
+            w_service(true);
         }
         pend_lo = loaded_to; pend_hi = fill_need; pend_off = fill_off;
         fill_off = ring_wrap(fill_off + (fill_need - loaded_to));
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
                 }
             }
             uint32_t dist = r_dist, d = r_d, found = r_found;
-            uint32_t trips = 0, hops = 0;
+            uint32_t trips = 0;
             bool may_defer = true, deferred = false;
             for (;;) {
                 // loads (a lane whose link state is final reads its own slot, which holds that state: the update is the
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
     if (DBG && dbg && blockIdx.x == 0 && lane == 0) {
         uint64_t *d = dbg + wave * 8;
         d[0] = cy_a; d[1] = cy_b; d[2] = cy_w; d[3] = (uint64_t)tr_sum | (uint64_t)tr_max << 32; d[4] = (uint64_t)tr_gt4 | (uint64_t)tr_gt8 << 32;
-        d[5] = (uint64_t)ntiles; d[6] = tr_r1; d[7] = tr_thin;
+        d[5] = (uint64_t)ntiles; d[6] = wave == 0 ? cy_svc_wait : (uint64_t)tr_r1; d[7] = tr_thin;
         uint64_t *h = dbg + 128 + wave * 8;       // (behind the sixteen 8-word rows)
         for (int k = 0; k < 6; ++k) h[k] = hop_n[k];
     }
