@@ -88,6 +88,15 @@ struct MemberResult {
     uint64_t end_bit = 0;
     bool final_seen = false;
     bool need_cap = false;       // nothing decoded because the first block does not fit the output capacity
+    // in: the container checksum the caller will need (launch_checksum mode: 1 CRC-32, 2 Adler-32, 0 none) and how many
+    // trailer bytes follow the member; out (ck_done): checksum of the output and the trailer bytes, fetched in the SAME
+    // host round trip as the materialisation's verdict (the checksum kernels are queued behind it before that verdict is
+    // known: on the clean path one synchronisation less; a failed path simply ignores them)
+    int ck_mode = 0;
+    uint32_t trailer_len = 0;
+    bool ck_done = false;
+    uint32_t crc32 = 0, adler32 = 1;
+    uint8_t trailer[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // run `njobs` inflate jobs and fetch their results
@@ -289,6 +298,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 const uint32_t max_extra = nc / 4 + 4;
                 for (uint32_t i = 0; i + 1 < nc && bj.size() - nc < max_extra; i++) {
                     if (len[i] >= thresh && len[i + 1] >= thresh) continue;
+                    // (the LAST range is short because the stream ends there — a member's final block is often tiny or empty —
+                    //  not because a false candidate cut it: a full-size alternative job for it is a second workgroup on one
+                    //  CU, and that CU decides the kernel's duration: 0.74 against 0.62 ms at 256 blocks on 256 CUs)
+                    if (i + 2 == nc && len[i] >= thresh) continue;
                     // a block cut in two is about one block long when put together; anything much longer
                     // would only be a slow job that decides the kernel's duration
                     if (len[i] + len[i + 1] > median + median / 4) continue;
@@ -323,7 +336,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             for (uint32_t i = 0; i < nc; i++)
                 slot[i] = (bi[i].status == BLK_NO_EOB && alt[i] >= 0 && bi[alt[i]].status == BLK_OK) ? (uint32_t)alt[i] : i;
             if (c->diag.debug) {
-                fprintf(stderr, "[lfx] finder: stage1=%u candidates=%u\n", n1, nc);
+                fprintf(stderr, "[lfx] finder: stage1=%u candidates=%u scan jobs=%u (alternatives: %u)\n", n1, nc, nj, nj - nc);
                 for (uint32_t i = 0; i < nc && i < 12; i++)
                     fprintf(stderr, "[lfx]  cand %u start=%llu status=%u btype=%u final=%u end=%llu n_out=%llu n_codes=%u lanes=%u rounds=%u cyc_hdr=%u cyc_total=%u\n",
                             i, (unsigned long long)starts[i], bi[i].status, bi[i].btype, bi[i].bfinal,
@@ -451,18 +464,39 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
                 }
-                if (!giant && !(probe && fl == 2 && !c->diag.no_markers))
+                bool ck_spec = false;
+                if (!giant && !(probe && fl == 2 && !c->diag.no_markers)) {
                     LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                       (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
+                    const uint64_t tb = (pos == stop_bit ? pos : last_end), tpos = tb / 8 + ((tb & 7) ? 1 : 0);
+                    if (mr.ck_mode && total && !partial && !c->diag.debug && tpos + mr.trailer_len <= n) {
+                        // the checksum of what is being materialised, and the trailer bytes, behind the same synchronisation
+                        c->phase("lz77_copy");
+                        const uint64_t nspans = ck_nspans(total);
+                        if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
+                        if ((rc = c->d_res.reserve(256))) return rc;
+                        uint32_t *ck = (uint32_t *)c->d_ck.p;
+                        LAUNCH_TRY(launch_checksum(st, d_out, total, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, mr.ck_mode));
+                        HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+                        if (mr.trailer_len) HIP_TRY(hipMemcpyAsync((uint8_t *)c->h_res + 256, d_in + tpos, mr.trailer_len, hipMemcpyDeviceToHost, st));
+                        ck_spec = true;
+                    }
+                }
                 HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
+                if (ck_spec && fl == 0) {
+                    const EncodeResult er = *(EncodeResult *)c->h_res;
+                    mr.ck_done = true; mr.crc32 = er.crc32; mr.adler32 = er.adler32;
+                    memcpy(mr.trailer, (uint8_t *)c->h_res + 256, mr.trailer_len);
+                    c->phase("checksum");
+                }
                 if (giant && !(fl & 1) && !c->diag.no_markers) fl = 2;
                 else if (giant) {   // (markers switched off, or an invalid reference: materialise normally / fall back)
                     LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                       (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, dbgbuf));
                     HIP_TRY(hipStreamSynchronize(st));
                 }
-                c->phase("lz77_copy");
+                if (!ck_spec) c->phase("lz77_copy");
                 if (c->diag.debug) {
                     fprintf(stderr, "[lfx]  emit flags=%u\n", fl);
                     std::vector<BlkUnits> uv(ne);
@@ -668,6 +702,8 @@ int decode_stream(Ctx *c, int format, uint32_t flags, const uint8_t *d_in, uint6
             off0 = dh.deflate_off;
         }
         MemberResult mr;
+        mr.ck_mode = format == LFX_GZIP ? 1 : format == LFX_ZLIB ? 2 : 0;
+        mr.trailer_len = format == LFX_GZIP ? 8 : format == LFX_ZLIB ? 4 : 0;
         if ((rc = inflate_member(c, d_in + base, n - base, off0, d_out + out_at, cap - out_at, mr))) return rc;
         oc.out_len = out_at + mr.out_len;
         oc.delivered_len = out_at + mr.blk_out_start;
@@ -684,16 +720,22 @@ int decode_stream(Ctx *c, int format, uint32_t flags, const uint8_t *d_in, uint6
                 return LFX_OK;
             }
             uint8_t t[8];
-            const uint64_t nspans = ck_nspans(mr.out_len);
-            if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
-            uint32_t *ck = (uint32_t *)c->d_ck.p;
-            LAUNCH_TRY(launch_checksum(st, d_out + out_at, mr.out_len, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,
-                                       format == LFX_GZIP ? 1 : format == LFX_ZLIB ? 2 : 3));
-            HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(t, d_in + tpos, need, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            c->phase("checksum");
-            const EncodeResult er = *(EncodeResult *)c->h_res;
+            EncodeResult er{};
+            if (mr.ck_done) {                   // (came back with the materialisation's verdict)
+                er.crc32 = mr.crc32; er.adler32 = mr.adler32;
+                memcpy(t, mr.trailer, need);
+            } else {
+                const uint64_t nspans = ck_nspans(mr.out_len);
+                if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
+                uint32_t *ck = (uint32_t *)c->d_ck.p;
+                LAUNCH_TRY(launch_checksum(st, d_out + out_at, mr.out_len, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,
+                                           format == LFX_GZIP ? 1 : format == LFX_ZLIB ? 2 : 3));
+                HIP_TRY(hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(t, d_in + tpos, need, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                c->phase("checksum");
+                er = *(EncodeResult *)c->h_res;
+            }
             oc.consumed = tpos + need;
             if (format == LFX_GZIP) {
                 const uint32_t crc = (uint32_t)t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
