@@ -215,7 +215,77 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // Pieces adapt to the stream: enough of them to give every CU two, between 256 Kbit and 4 Mbit each.
             // (few candidates in a long stream = few, huge blocks — at least 2 MiB of stream per candidate; a 4 MiB stream of four
             //  ordinary blocks is not that case: walking it block by block costs a dependent step per block)
-            if ((small_first || (nc <= 8 && comp / nc >= (2u << 20))) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
+            // ---- a stream of a FEW ordinary blocks (round 4: 9 … 32 candidates, at least 128 KiB of stream each — a 16 MiB
+            // member is 16 blocks for 256 CUs: K1 and K2 ran on sixteen of them, K3 on sixty-four chunk units, 2.3 ms): every
+            // candidate's range [start, next candidate) is scanned in pieces at once, with the tables of the block that
+            // starts there.  Accepted only if every block's pieces chain, the piece that holds its EndOfBlock ends exactly
+            // where the next candidate starts, and the last block is final; anything else (a false candidate, a stored or
+            // fixed block in between, damage) leaves the stream to the one-workgroup-per-block path below.
+            // (Measured, profiles/r04_small_sizes.json: 16 MiB 2.25 -> 1.75 ms; at 64 blocks the marker path's fixed costs — window
+            //  resolution 0.6 ms, symbol units — outweigh what K1 / K2 gain: 2.87 against 2.40 ms.  Hence up to 32 candidates.)
+            if (!small_first && nc > 8 && nc <= 32 && comp / nc >= (128u << 10) && stop_bit == ~0ull &&
+                !partial && !c->diag.no_pieces) {
+                constexpr uint64_t OVERLAP = 8192;
+                const uint64_t end_bits = n * 8;
+                const uint64_t PIECE_BITS = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(256ull << 10,
+                                            ((end_bits - first_bit) / (2ull * (uint64_t)std::max(c->n_cu, 1)) + 63) & ~63ull));
+                std::vector<BlkJob> pj;
+                std::vector<uint32_t> first_piece(nc + 1, 0);
+                for (uint32_t i = 0; i < nc; i++) {
+                    first_piece[i] = (uint32_t)pj.size();
+                    const uint64_t s0 = starts[i], s1 = start_at(i + 1);
+                    const uint32_t np = (uint32_t)std::max<uint64_t>((s1 - s0 + PIECE_BITS - 1) / PIECE_BITS, 1);
+                    for (uint32_t q = 0; q < np; q++) {
+                        const uint64_t lo = s0 + q * PIECE_BITS;
+                        pj.push_back(BlkJob{s0, std::min(lo + PIECE_BITS, s1), q ? lo : 0, q ? lo - OVERLAP : 0, 1u, 0u});
+                    }
+                }
+                first_piece[nc] = (uint32_t)pj.size();
+                const uint32_t npj = (uint32_t)pj.size();
+                int rc2;
+                if ((rc2 = c->d_dec_streams.reserve(sizeof(BlkJob) * npj))) return rc2;
+                if ((rc2 = c->d_dec_state.reserve(sizeof(BlkInfo) * npj))) return rc2;
+                if ((rc2 = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)npj))) return rc2;
+                if ((rc2 = c->d_dec_tabs.reserve(tab_bytes * npj))) return rc2;
+                HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, pj.data(), sizeof(BlkJob) * npj, hipMemcpyHostToDevice, st));
+                LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, npj, (BlkInfo *)c->d_dec_state.p,
+                                           (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
+                std::vector<BlkInfo> pi(npj);
+                HIP_TRY(hipMemcpyAsync(pi.data(), c->d_dec_state.p, sizeof(BlkInfo) * npj, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                bool fail = false;
+                for (uint32_t i = 0; i < nc && !fail && !ok_chain; i++) {
+                    if (starts[i] != pos) { fail = true; break; }             // (the chain must pass through every candidate)
+                    bool closed = false;
+                    uint64_t prev_end = 0;
+                    for (uint32_t k = first_piece[i]; k < first_piece[i + 1] && !closed; k++) {
+                        const BlkInfo &r = pi[k];
+                        const uint32_t q = k - first_piece[i];
+                        if (r.status == BLK_BAD || r.btype == 0 || (q && r.data_bit != prev_end) || r.end_bit <= pos || r.end_bit > end_bits) { fail = true; break; }
+                        BlkEmit e{};
+                        e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
+                        e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
+                        e.hist = hist + total;
+                        e.end_limit = r.status == BLK_NO_EOB ? r.end_bit : 0;
+                        emit.push_back(e);
+                        total += r.n_out;
+                        total_codes += r.n_codes;
+                        prev_end = r.end_bit;
+                        if (r.status == BLK_OK) {
+                            closed = true;
+                            last_end = r.end_bit;
+                            if (r.bfinal) { ok_chain = true; chain_final = true; } else pos = r.end_bit;
+                        }
+                    }
+                    if (!closed) fail = true;
+                }
+                if (c->diag.debug) fprintf(stderr, "[lfx]  pieces over %u candidate ranges: ok=%d fail=%d pieces=%zu of %u total=%llu\n", nc, (int)ok_chain, (int)fail,
+                                           emit.size(), npj, (unsigned long long)total);
+                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; chain_final = false; last_end = 0; }
+                else pieces_mode = true;
+                c->phase("pieces");
+            }
+            if (!pieces_mode && (small_first || (nc <= 8 && comp / nc >= (2u << 20))) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
                 constexpr uint64_t OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
                 const uint64_t PIECE_BITS = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(256ull << 10,
