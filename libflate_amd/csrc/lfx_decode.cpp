@@ -215,7 +215,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // Pieces adapt to the stream: enough of them to give every CU two, between 256 Kbit and 4 Mbit each.
             // (few candidates in a long stream = few, huge blocks — at least 2 MiB of stream per candidate; a 4 MiB stream of four
             //  ordinary blocks is not that case: walking it block by block costs a dependent step per block)
-            // ---- a stream of a FEW ordinary blocks (round 4: 9 … 32 candidates, at least 128 KiB of stream each — a 16 MiB
+            // ---- a stream of a FEW ordinary blocks (round 4: 2 … 32 candidates, at least 128 KiB of stream each — a 16 MiB
             // member is 16 blocks for 256 CUs: K1 and K2 ran on sixteen of them, K3 on sixty-four chunk units, 2.3 ms): every
             // candidate's range [start, next candidate) is scanned in pieces at once, with the tables of the block that
             // starts there.  Accepted only if every block's pieces chain, the piece that holds its EndOfBlock ends exactly
@@ -223,7 +223,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // fixed block in between, damage) leaves the stream to the one-workgroup-per-block path below.
             // (Measured, profiles/r04_small_sizes.json: 16 MiB 2.25 -> 1.75 ms; at 64 blocks the marker path's fixed costs — window
             //  resolution 0.6 ms, symbol units — outweigh what K1 / K2 gain: 2.87 against 2.40 ms.  Hence up to 32 candidates.)
-            if (!small_first && nc > 8 && nc <= 32 && comp / nc >= (128u << 10) && stop_bit == ~0ull &&
+            const bool giant_blocks = nc <= 8 && comp / nc >= (2u << 20);     // (schedule S1: the block-by-block piece walk below)
+            if (!small_first && !giant_blocks && nc >= 2 && nc <= 32 && comp / nc >= (128u << 10) && stop_bit == ~0ull &&
                 !partial && !c->diag.no_pieces) {
                 constexpr uint64_t OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
@@ -622,7 +623,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     LAUNCH_TRY(launch_blk_materialize_sym(st, d_in, d_emit, ne, (const BlkUnits *)c->d_hist.p,
                                                           (const uint32_t *)c->d_codes.p, (uint16_t *)c->d_dec_sym.p));
                     c->phase("lz77_sym");
-                    if (nsu >= 128 && !c->diag.window_chain) {   // long stream: blocked parallel prefix over the units
+                    if (nsu >= 16 && !c->diag.window_chain) {   // blocked parallel prefix over the units (groups of about sqrt(nsu))
                         if ((rc = c->d_dec_maps.reserve(window_prefix_scratch_bytes(nsu)))) return rc;
                         LAUNCH_TRY(launch_window_prefix(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, d_win, init_win));
                     } else LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, init_win));
@@ -1160,7 +1161,7 @@ extern "C" int lfx_decode_range_finish(lfx_ctx *cc, const void *d_maps, uint32_t
             LAUNCH_TRY(launch_window_ranks(st, (const uint16_t *)d_maps, rank, d_init));
             init_win = d_init;
         }
-        if (nsu >= 128 && !c->diag.window_chain)
+        if (nsu >= 16 && !c->diag.window_chain)
             LAUNCH_TRY(launch_window_prefix(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, c->d_dec_maps.p, d_win, init_win));
         else LAUNCH_TRY(launch_window_chain(st, (const uint16_t *)c->d_dec_sym.p, d_su, nsu, d_win, init_win));
         c->phase("win_chain");

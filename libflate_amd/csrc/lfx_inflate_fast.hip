@@ -1210,13 +1210,19 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
 //  (b) window_groups_kernel: one workgroup walks the GROUPS in order: window after group g = C_last(window
 //      after group g-1);
 //  (c) window_apply_kernel: every unit's window = its C_k applied to the window in front of its group.
-constexpr uint32_t WC_GROUP = 32;
+// Group size (round 4: chosen per call, about the square root of the number of units — compose costs G dependent steps, the
+// walk over the groups nunits / G: 128 units of a 4 MiB stream took 127 serial steps of the chain kernel, 0.95 ms)
+__host__ __device__ inline uint32_t wc_group(uint32_t nunits) {
+    uint32_t g = 4;
+    while (g * g < nunits && g < 64) ++g;
+    return g;
+}
 __device__ __forceinline__ uint32_t unit_map_symbol(const uint16_t *__restrict__ sym, const SymUnit &su, uint32_t i) {
     return su.len + i >= 32768 ? (uint32_t)sym[su.start + su.len - 32768 + i] : 256u + i + (uint32_t)su.len;
 }
 __global__ __launch_bounds__(1024) void window_compose_kernel(const uint16_t *__restrict__ sym,
                                                               const SymUnit *__restrict__ units, uint32_t nunits,
-                                                              uint16_t *__restrict__ maps) {
+                                                              uint16_t *__restrict__ maps, uint32_t WC_GROUP) {
     extern __shared__ uint16_t mbuf[];   // 2 x 32 Ki entries
     uint16_t *prev = mbuf, *cur = mbuf + 32768;
     const uint32_t u0 = blockIdx.x * WC_GROUP, u1 = u0 + WC_GROUP < nunits ? u0 + WC_GROUP : nunits;
@@ -1234,7 +1240,8 @@ __global__ __launch_bounds__(1024) void window_compose_kernel(const uint16_t *__
     }
 }
 __global__ __launch_bounds__(1024) void window_groups_kernel(const uint16_t *__restrict__ maps, uint32_t nunits,
-                                                             uint8_t *__restrict__ gwin, const uint8_t *__restrict__ init_win) {
+                                                             uint8_t *__restrict__ gwin, const uint8_t *__restrict__ init_win,
+                                                             uint32_t WC_GROUP) {
     extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
     uint8_t *prev = wbuf, *cur = wbuf + 32768;
     for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = init_win ? init_win[i] : (uint8_t)0;
@@ -1255,7 +1262,8 @@ __global__ __launch_bounds__(1024) void window_groups_kernel(const uint16_t *__r
     }
 }
 __global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__restrict__ maps, const uint8_t *__restrict__ gwin,
-                                                           uint8_t *__restrict__ windows, const uint8_t *__restrict__ init_win) {
+                                                           uint8_t *__restrict__ windows, const uint8_t *__restrict__ init_win,
+                                                           uint32_t WC_GROUP) {
     const uint32_t u = blockIdx.x, g = u / WC_GROUP;
     const uint16_t *m = maps + (uint64_t)u * 32768;
     // (group 0: the member's earlier output, or nothing in front — then no markers are left)
@@ -1272,7 +1280,7 @@ __global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__res
 // every rank composes the maps of the ranks in front of it into the bytes of its own initial window.
 //  window_rank_map_kernel: the groups' composed maps (window_compose_kernel) folded in order, symbolically → the rank's map
 __global__ __launch_bounds__(1024) void window_rank_map_kernel(const uint16_t *__restrict__ maps, uint32_t nunits,
-                                                               uint16_t *__restrict__ out_map) {
+                                                               uint16_t *__restrict__ out_map, uint32_t WC_GROUP) {
     extern __shared__ uint16_t mbuf[];   // 2 x 32 Ki entries
     uint16_t *prev = mbuf, *cur = mbuf + 32768;
     for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = (uint16_t)(256u + i);   // identity: "byte i of the window in front"
@@ -1606,7 +1614,8 @@ int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *unit
 // blocked parallel prefix of the window chain (see window_compose_kernel); scratch: nunits * 64 KiB of maps and
 // ceil(nunits / WC_GROUP) * 32 KiB of group windows
 size_t window_prefix_scratch_bytes(uint32_t nunits) {
-    return (size_t)nunits * 65536 + (size_t)((nunits + WC_GROUP - 1) / WC_GROUP) * 32768;
+    const uint32_t g = wc_group(nunits);
+    return (size_t)nunits * 65536 + (size_t)((nunits + g - 1) / g) * 32768;
 }
 int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, void *scratch,
                          uint8_t *windows, const uint8_t *init_win) {
@@ -1621,12 +1630,13 @@ int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *uni
     }
     uint16_t *maps = (uint16_t *)scratch;
     uint8_t *gwin = (uint8_t *)scratch + (size_t)nunits * 65536;
-    const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
-    hipLaunchKernelGGL(window_compose_kernel, dim3(ngroups), dim3(1024), 131072, st, sym, units, nunits, maps);
+    const uint32_t G = wc_group(nunits);
+    const uint32_t ngroups = (nunits + G - 1) / G;
+    hipLaunchKernelGGL(window_compose_kernel, dim3(ngroups), dim3(1024), 131072, st, sym, units, nunits, maps, G);
     LFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 65536, st, maps, nunits, gwin, init_win);
+    hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 65536, st, maps, nunits, gwin, init_win, G);
     LFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(256), 0, st, maps, gwin, windows, init_win);
+    hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(256), 0, st, maps, gwin, windows, init_win, G);
     LFX_LAUNCH_CHECK();
     return 0;
 }
@@ -1641,12 +1651,13 @@ int launch_window_rank_map(hipStream_t st, const uint16_t *sym, const SymUnit *u
         attr_set[dev_ & 63] = true;
     }
     uint16_t *maps = (uint16_t *)scratch;
-    const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
+    const uint32_t G = wc_group(nunits);
+    const uint32_t ngroups = (nunits + G - 1) / G;
     if (nunits) {
-        hipLaunchKernelGGL(window_compose_kernel, dim3(ngroups), dim3(1024), 131072, st, sym, units, nunits, maps);
+        hipLaunchKernelGGL(window_compose_kernel, dim3(ngroups), dim3(1024), 131072, st, sym, units, nunits, maps, G);
         LFX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(window_rank_map_kernel, dim3(1), dim3(1024), 131072, st, maps, nunits, out_map);
+    hipLaunchKernelGGL(window_rank_map_kernel, dim3(1), dim3(1024), 131072, st, maps, nunits, out_map, G);
     LFX_LAUNCH_CHECK();
     return 0;
 }
