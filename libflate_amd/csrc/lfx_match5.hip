@@ -171,8 +171,9 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
         src.nbytes = in_bytes - ch.in_off;
     }
     uint16_t *cd_c = cd + ch.in_off;              // this chunk's answers
-    // ... and this SEGMENT's final links, for the walks wave 0 takes over: a region of its own (entry 0 = position l0) — the
-    // warm-up positions of a segment are another segment's own positions, and the two link structures differ there
+    // ... and this SEGMENT's final links, for the walks wave 0 takes over: a region of its own (entry 0 = the tile origin
+    // `base`, so that a wavefront's 64 links are one aligned 128-byte line) — the warm-up positions of a segment are another
+    // segment's own positions, and the two link structures differ there
     uint16_t *glnk_s = glnk + (uint64_t)sg.lnk_base * 64u;
     if (ch.flags & CH_LITERALS) return;           // NoCompressionLz77Encoder chunks never come here
     const uint32_t end = (n > 3 ? n : 3) - 3;     // default.rs:75
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
                 w_b1 = (wi + 1 < last) ? src.w[wi + 1] : 0u;
                 // (an agent-scope load: served by the L2 — a line of glnk is written tile by tile, and a copy of it that this
                 //  CU's L1 took while only its first entries existed must never be read again)
-                w_ln = __hip_atomic_load(&glnk_s[a - l0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w_ln = __hip_atomic_load(&glnk_s[a - base], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 w_pend = true;
             }
         }
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(m5::THREADS) void lz77_match5_kernel(
             const bool act_r = do_r && val_r && p_r >= q0;
             // the final links of tile `it` (settled at the end of the previous iteration) go to glnk FIRST: the store has the
             // whole phase to reach the L2 before the wait at its end
-            if (do_r && val_r) glnk_s[p_r - l0] = (uint16_t)e_r;
+            if (do_r && val_r) glnk_s[p_r - base] = (uint16_t)e_r;
             // ---- F2(it+1): inherit the link of the same-prefix predecessor (pointer jumping, no ordering needed: every
             //      state a reader can observe is valid and the oldest member of a run is final from the start)
             // ---- R1(it), further hops (a few percent of the positions, but nearly every wavefront holds one).  They read
