@@ -38,7 +38,7 @@ WRITE = 8192
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
 
 # phase (HIP-event bracket in the library) -> the kernel that fills it
-PHASE_KERNEL = {"enc:lz77_match": "lz77_match6_kernel", "dec:lz77_copy": "blk_materialize2_kernel",
+PHASE_KERNEL = {"enc:lz77_match": "lz77_match5_kernel", "dec:lz77_copy": "blk_materialize2_kernel",
                 "dec:blk_scan": "blk_scan_kernel", "dec:blk_emit": "blk_emit_kernel", "enc:lz77_parse": "parse_walk_kernel"}
 CALIBRATION_KERNEL = "checksum_span_kernel"   # reads its input exactly once with wide coalesced loads
 

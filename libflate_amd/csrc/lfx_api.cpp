@@ -225,7 +225,6 @@ void Diag::read() {
     debug = on("LFX_DEBUG");
     match_v1 = on("LFX_MATCH_V1");
     match_v3 = on("LFX_MATCH_V3");
-    match_v5 = on("LFX_MATCH_V5");
     no_serial = on("LFX_NO_SERIAL");
     batch_serial = on("LFX_BATCH_SERIAL");
     no_markers = on("LFX_NO_MARKERS");
@@ -405,13 +404,6 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_pwgs.reserve(sizeof(ParseWg) * std::max<size_t>(pwgs.size(), 1)))) return rc;
     if (!hc && (rc = c->d_cd.reserve(2 * n + 64))) return rc;                   // candidate distances, 16 bits per position
     if (!hc && !match_v1 && !c->diag.match_v3 && (rc = c->d_glnk.reserve(128 * std::max<uint64_t>(lnk_units, 1)))) return rc;
-    uint32_t wcap6 = 0;
-    if (!hc && !match_v1 && !c->diag.match_v3 && !c->diag.match_v5) {
-        uint32_t longest = 0;
-        for (const SegDesc &sg : segs) longest = std::max(longest, sg.len);
-        wcap6 = match6_list_cap(longest);
-        if ((rc = c->d_wlist.reserve(match6_list_bytes((uint32_t)std::max<size_t>(segs.size(), 1), wcap6)))) return rc;
-    }
     if (!hc && match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
@@ -482,13 +474,9 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         if (c->diag.match_v3)
             LAUNCH_TRY(launch_match3(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                                      (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
-        else if (c->diag.match_v5)
+        else
             LAUNCH_TRY(launch_match5(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                                      (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, d_match_flags, mdbg));
-        else
-            LAUNCH_TRY(launch_match6(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                     (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, c->d_wlist.p, wcap6,
-                                     d_match_flags, mdbg));
     }
     if (mdbg) {
         uint64_t hv[256];
@@ -504,7 +492,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "3", w,
                     match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
-        if (!match_v1 && !c->diag.match_v3 && c->diag.match_v5)
+        if (!match_v1 && !c->diag.match_v3)
             fprintf(stderr, "[lfx] match5 wave0: %llu cycles waiting for the loads of the walks it holds (of phaseA)\n", (unsigned long long)hv[6]);
         if (!match_v1)
             for (int w = 1; w < 16; w++)

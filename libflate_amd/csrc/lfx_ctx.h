@@ -25,7 +25,6 @@ struct Diag {
     bool debug = false;          // LFX_DEBUG: per-stage counters and cycle stamps on stderr
     bool match_v1 = false;       // LFX_MATCH_V1: first-generation match kernel (+ md → cd)
     bool match_v3 = false;       // LFX_MATCH_V3: lfx_match3.hip (round 3: every chain walk inside the tile loop)
-    bool match_v5 = false;       // LFX_MATCH_V5: lfx_match5.hip (deep walks handed to wave 0) instead of lfx_match6.hip (written out)
     bool no_serial = false;      // LFX_NO_SERIAL: the serial fallback of the single-stream decoder is an error
     bool batch_serial = false;   // LFX_BATCH_SERIAL: every stream of a batch through the serial kernel
     bool no_markers = false;     // LFX_NO_MARKERS
@@ -65,7 +64,7 @@ struct Ctx {
 
     // encode scratch
     DevBuf d_chunks, d_blocks, d_segs, d_pwgs, d_cd, d_md, d_codes, d_ncodes, d_hist, d_bc, d_block_start, d_tile_bits,
-        d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage, d_chunkmap, d_glnk, d_wlist;
+        d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage, d_chunkmap, d_glnk;
     // decode scratch
     // host shadows of the plan tables last uploaded (chunks, blocks, segments, parse workgroups) and the device buffers they
     // went to: an encode with the same plan (same size, schedule and options — every step of a loop) uploads nothing, and a
@@ -75,7 +74,7 @@ struct Ctx {
     DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks, d_dec_tabs, d_dec_sym, d_dec_win, d_dec_maps;
     std::vector<DevBuf *> all_bufs() {
         return {&d_chunks, &d_blocks, &d_segs, &d_pwgs, &d_cd, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
-                &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage, &d_chunkmap, &d_glnk, &d_wlist,
+                &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage, &d_chunkmap, &d_glnk,
                 &d_dec_streams, &d_dec_state, &d_dec_tmp, &d_dec_cand, &d_dec_blocks, &d_dec_tabs, &d_dec_sym, &d_dec_win, &d_dec_maps};
     }
     void *h_res = nullptr;  // pinned, 4 KiB

@@ -46,17 +46,10 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
 // (0 = none) → cd.  flags[0] |= 1 on a lane-order violation.
 int launch_match3(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg = nullptr);
-// the same stage with its deep chain walks handed over to wave 0 (lfx_match5.hip, round 4; LFX_MATCH_V5).
+// the same stage with its deep chain walks handed over to wave 0 (lfx_match5.hip, round 4): the default.
 // glnk: scratch for the final link of every position of every segment (warm-up included), regions by SegDesc::lnk_base
 int launch_match5(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg = nullptr);
-// ... and with those walks written out and finished by a second kernel (lfx_match6.hip, round 4): the default.
-// lists: match6_list_bytes(nsegs, wcap) bytes of scratch, wcap = match6_list_cap(longest segment)
-uint32_t match6_list_cap(uint32_t max_seg_len);
-size_t match6_list_bytes(uint32_t nsegs, uint32_t wcap);
-int launch_match6(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, void *lists, uint32_t wcap, uint32_t *flags,
-                  uint64_t *dbg = nullptr);
 // the first-generation kernel's answers (length << 16 | distance) → cd
 int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd);
 // the greedy walk with lazy match lengths (lfx_parse2.hip) → code words per chunk
