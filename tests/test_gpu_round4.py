@@ -262,3 +262,34 @@ def test_mid_size_members_scanned_in_pieces(env, oracle):
         got = ctx.decode_host(ffi.ZLIB, s)
         assert got[0] == {1: ffi.E_INVALID_DATA, 2: ffi.E_UNEXPECTED_EOF}[want[0]], (name, got[0], want[0], want[3])
         assert got[1] == want[1], (name, len(got[1]), len(want[1]))
+
+
+def test_with_lz77_foreign_encoder_many_codes(env, oracle):
+    """More than ENC_BATCH_CODES (2 Mi) code words between two flushes: closed blocks leave the encoder in batches while later
+    ones are still being collected (the carry of a partial last byte, the running checksum across batches)."""
+    import io
+    lfx, ctx, ffi, synth = env
+
+    class EveryByteALiteral:
+        def encode(self, buf, sink):
+            sink.extend(("Literal", b) for b in buf)
+
+        def flush(self, sink):
+            pass
+
+        def compression_level(self):
+            return 0
+
+        def window_size(self):
+            return 32768
+
+    data = synth.text(5 << 19).tobytes()                       # 2.5 MiB = 2.6 M codes, blocks of 300000 bytes
+    want = oracle.encode(oracle.GZIP, data, write_size=70000, mtime=0, block_size=300000, **oracle.custom_lz77(EveryByteALiteral()))
+    sink = io.BytesIO()
+    enc = lfx.gzip.Encoder.with_options(sink, lfx.gzip.EncodeOptions().with_lz77(EveryByteALiteral()).block_size(300000))
+    for a in range(0, len(data), 70000):
+        enc.write(data[a:a + 70000])
+    enc.finish()
+    assert sink.getvalue() == want
+    # ... and the same stream is what the device pipeline makes for NoCompressionLz77Encoder (lib.rs:111-145)
+    assert want == oracle.encode(oracle.GZIP, data, write_size=70000, mtime=0, block_size=300000, lz77_kind=1)
