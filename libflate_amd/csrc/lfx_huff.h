@@ -64,14 +64,22 @@ struct HuffScratch {
     uint16_t listlen[16];
     uint16_t acnt[16];
     uint8_t qd[HMAX];            // depth calc: internal-node depths
-    uint8_t width[HMAX];         // result: code width per symbol
+    alignas(4) uint8_t width[HMAX];   // result: code width per symbol (read as dwords by the canonical-code pass)
     uint16_t code[HMAX];         // result: bit-reversed code per symbol
     uint32_t freq[HMAX];         // input frequencies (with the dist[0] dummy applied)
     int32_t n;                   // used symbols
     int32_t L;                   // max bitwidth in force
+    alignas(16) uint32_t key[HMAX + 4];   // rank sort: (frequency << 9) | symbol when every frequency is below 2^23
+    uint32_t big;                // some frequency is 2^23 or more: the rank sort compares (frequency, symbol) pairs instead
+    uint32_t wcnt[16];           // canonical codes: symbols per width
+    // run-length pass (build_bitwidth_codes): run starts as a bit set over the nl + nd widths (+ a sentinel behind
+    // them), entries per run, last used symbols
+    uint32_t rbits[12];
+    alignas(4) uint16_t rcnt[HMAX + 34];
+    int32_t lit_used, dist_used;
     // header builder
     uint8_t rl_code[HMAX + 32], rl_bits[HMAX + 32], rl_extra[HMAX + 32];
-    uint8_t rl_w[HMAX + 32];     // header assembly: bits of entry i (its code-length code + extra bits)
+    alignas(4) uint8_t rl_w[HMAX + 32];     // header assembly: bits of entry i (its code-length code + extra bits; read as dwords)
     int32_t rl_n;
     uint8_t clw[19];
     uint16_t clc[19];
@@ -85,6 +93,7 @@ struct HuffScratch {
 #define LFX_SYNC() __syncthreads()
 #define LFX_ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define LFX_ATOMIC_OR(p, v) atomicOr((p), (v))
+#define LFX_ATOMIC_MAX(p, v) atomicMax((p), (v))
 #define LFX_STAMP(S, k) do { if (lane == 0) (S).stamp[k] = clock64(); } while (0)   /* LFX_DEBUG: where the kernel's time goes */
 #define LFX_UNROLL8 _Pragma("unroll 8")   /* independent LDS reads of a counting loop: issue them in batches, not one round trip each */
 #else
@@ -93,31 +102,56 @@ struct HuffScratch {
 #define LFX_SYNC() ((void)0)
 #define LFX_ATOMIC_ADD(p, v) (*(p) += (v))       /* (the host runs the shared code with one lane) */
 #define LFX_ATOMIC_OR(p, v) (*(p) |= (v))
+#define LFX_ATOMIC_MAX(p, v) (*(p) = *(p) > (v) ? *(p) : (v))
 #endif
+
+// number of zero bytes of x (exact: no borrow runs from one byte into the next)
+LFX_HD inline uint32_t zero_bytes(uint32_t x) {
+    const uint32_t t = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in every zero byte
+    return (uint32_t)__builtin_popcount(t);
+}
 
 // Code widths for S.freq[0..nsym) with limit `limit` → S.width[], S.code[] (bit-reversed).
 // All lanes of the (single-wave) workgroup must call it.
 LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int nlanes, int stamp0 = -1) {
     (void)stamp0;
     // 1. used symbols, stable order by weight (huffman.rs:309-315)
+    //    rank = #{used t : f_t < f or (f_t == f and t < s)}.  Round 4: with every frequency below 2^23 (any block of
+    //    less than 8 Mi symbols) the pair (f, s) is ONE 32-bit key (f << 9) | s, and the rank is a count of smaller
+    //    keys — a compare and an add per element instead of seven instructions; the unused symbols (keys below 512,
+    //    smaller than every used key) are counted too and taken off again.  Keys behind the alphabet are all-ones.
     for (int i = lane; i < HMAX; i += nlanes) { S.width[i] = 0; S.code[i] = 0; }
+    for (int i = lane; i < 16; i += nlanes) S.wcnt[i] = 0;
+    if (lane == 0) { S.n = 0; S.big = 0; }
     LFX_SYNC();
-    if (lane == 0) {
-        int n = 0;
-        LFX_UNROLL8
-        for (int s = 0; s < nsym; s++) n += S.freq[s] > 0;
-        S.n = n;
+    const int nsym4 = (nsym + 3) & ~3;
+    for (int s = lane; s < nsym4; s += nlanes) {
+        const uint32_t f = s < nsym ? S.freq[s] : 0u;
+        if (f) LFX_ATOMIC_ADD(&S.n, 1);
+        if (f >> 23) LFX_ATOMIC_OR(&S.big, 1u);
+        S.key[s] = s < nsym ? (f << 9) | (uint32_t)s : 0xFFFFFFFFu;
     }
     LFX_SYNC();
     const int n = S.n;
+    const bool big = S.big != 0;
     for (int s = lane; s < nsym; s += nlanes) {
         uint32_t f = S.freq[s];
         if (f == 0) continue;
-        int r = 0;  // rank = #{used t : f_t < f or (f_t == f and t < s)}
-        LFX_UNROLL8
-        for (int t = 0; t < nsym; t++) {
-            uint32_t g = S.freq[t];
-            r += (g != 0) & ((g < f) | ((g == f) & (t < s)));
+        int r = 0;
+        if (!big) {
+            const uint32_t key = (f << 9) | (uint32_t)s;
+            uint32_t cnt = 0;
+            for (int t = 0; t < nsym4; t += 4) {
+                const uint32_t k0 = S.key[t], k1 = S.key[t + 1], k2 = S.key[t + 2], k3 = S.key[t + 3];
+                cnt += (uint32_t)(k0 < key) + (uint32_t)(k1 < key) + (uint32_t)(k2 < key) + (uint32_t)(k3 < key);
+            }
+            r = (int)cnt - (nsym - n);
+        } else {
+            LFX_UNROLL8
+            for (int t = 0; t < nsym; t++) {
+                uint32_t g = S.freq[t];
+                r += (g != 0) & ((g < f) | ((g == f) & (t < s)));
+            }
         }
         S.sw[r] = f;
         S.ssym[r] = (uint16_t)s;
@@ -134,121 +168,146 @@ LFX_HD inline void huff_build(HuffScratch &S, int nsym, int limit, int lane, int
     //    leaves have depth 0, so on equal weight an internal node goes first, and among internal
     //    nodes of equal weight (a contiguous run at the queue head, weights are created in
     //    non-decreasing order) the deepest goes first.
-    //    Serial on lane 0, one dependent LDS round trip after the other: the two queue heads (next leaf weight, weight
-    //    at the head of the internal-node queue) are kept in registers and reloaded only when consumed (round 3: 7n → 4n
-    //    dependent reads).
+    //    Serial on lane 0.  Round 4: no pick waits for an LDS round trip — the next three leaf weights and the first
+    //    three queue entries (weight << 8 | depth, one 64-bit word) are held in registers, refilled two picks ahead of
+    //    their use, and a new node that lands inside the window goes into its register as well.  Only a run of equal
+    //    weights at the queue head walks the queue in LDS (round 3: four dependent reads per merge, 62 K cycles).
     if (lane == 0) {
-        int li = 0, qh = 0, qt = 0, depth = 0;
-        uint64_t lw = S.sw[0];     // weight of the leaf at li (while li < n)
-        uint64_t qw0 = 0;          // weight at the queue head (while qh < qt)
+        uint64_t *Q = S.qw;
+        int li = 0, qh = 0, qt = 0;
+        uint32_t depth = 0;
+        uint64_t l0 = S.sw[0], l1 = S.sw[1], l2 = n > 2 ? S.sw[2] : 0;     // (n >= 2 here)
+        uint64_t q0 = 0, q1 = 0, q2 = 0;
         for (int m = 0; m < n - 1; m++) {
             uint64_t w2[2];
-            int d2[2];
+            uint32_t d2[2];
             for (int k = 0; k < 2; k++) {
-                const bool takeq = qh < qt && (li >= n || qw0 <= lw);
+                const bool takeq = qh < qt && (li >= n || (q0 >> 8) <= l0);
                 if (takeq) {
-                    const uint64_t w = qw0;
-                    int best = qh;
-                    for (int g = qh + 1; g < qt && S.qw[g] == w; g++)
-                        if (S.qd[g] > S.qd[best]) best = g;
-                    d2[k] = S.qd[best];
-                    if (best != qh) S.qd[best] = S.qd[qh];  // weights in the run are equal: only depths move
+                    const uint64_t w = q0 >> 8;
+                    uint32_t d = (uint32_t)(q0 & 0xFF);
+                    if (qh + 1 < qt && (q1 >> 8) == w) {
+                        int best = qh;
+                        uint32_t bd = d;
+                        for (int g = qh + 1; g < qt; g++) {
+                            const uint64_t e = Q[g];
+                            if ((e >> 8) != w) break;
+                            if ((uint32_t)(e & 0xFF) > bd) { bd = (uint32_t)(e & 0xFF); best = g; }
+                        }
+                        if (best != qh) {   // weights in the run are equal: only depths move (the head's goes to the slot taken)
+                            const uint64_t moved = (w << 8) | d;
+                            Q[best] = moved;
+                            if (best == qh + 1) q1 = moved;
+                            if (best == qh + 2) q2 = moved;
+                            d = bd;
+                        }
+                    }
                     w2[k] = w;
+                    d2[k] = d;
                     qh++;
-                    if (qh < qt) qw0 = S.qw[qh];
+                    q0 = q1; q1 = q2;
+                    if (qh + 2 < qt) q2 = Q[qh + 2];
                 } else {
-                    w2[k] = lw;
+                    w2[k] = l0;
                     d2[k] = 0;
                     li++;
-                    if (li < n) lw = S.sw[li];
+                    l0 = l1; l1 = l2;
+                    if (li + 2 < n) l2 = S.sw[li + 2];
                 }
             }
-            int d = 1 + (d2[0] > d2[1] ? d2[0] : d2[1]);
-            const uint64_t ws = w2[0] + w2[1];
-            S.qw[qt] = ws;
-            S.qd[qt] = (uint8_t)(d > 255 ? 255 : d);
-            if (qh == qt) qw0 = ws;   // the queue was empty: the new node is its head
+            uint32_t d = 1 + (d2[0] > d2[1] ? d2[0] : d2[1]);
+            if (d > 255) d = 255;       // (only compared with a limit of at most 15)
+            const uint64_t e = ((w2[0] + w2[1]) << 8) | d;
+            Q[qt] = e;
+            if (qt == qh) q0 = e; else if (qt == qh + 1) q1 = e; else if (qt == qh + 2) q2 = e;
             qt++;
             depth = d;  // the last node created is the root
         }
-        int opt = depth > 1 ? depth : 1;
+        const int opt = depth > 1 ? (int)depth : 1;
         S.L = limit < opt ? limit : opt;
     }
     LFX_SYNC();
     if (stamp0 >= 0) LFX_STAMP(S, stamp0 + 1);       // depth done
     const int L = S.L;
-    // 3. package-merge forward (huffman.rs:317-318): level 0 = source
-    for (int i = lane; i < n; i += nlanes) { S.cur[i] = S.sw[i]; S.leafpos[0][i] = (uint16_t)i; }
+    // 3. package-merge forward (huffman.rs:317-318): level 0 = source.
+    //    Round 4: the two weighted lists swap roles instead of being copied (one barrier less per level), and a lane's two
+    //    rank searches — its leaf among the packages, its package among the leaves — run in lockstep, branch-free, so that
+    //    their LDS reads overlap (they were eighteen dependent round trips per level).
+    uint64_t *cur = S.cur, *nxt = S.nxt;
+    for (int i = lane; i < n; i += nlanes) { cur[i] = S.sw[i]; S.leafpos[0][i] = (uint16_t)i; }
     if (lane == 0) S.listlen[0] = (uint16_t)n;
     LFX_SYNC();
     for (int k = 1; k < L; k++) {
         const int len = S.listlen[k - 1];
         const int np = len / 2;  // package(): pairs (2p, 2p+1), odd tail dropped (n >= 2 here)
-        for (int p = lane; p < np; p += nlanes) S.pk[p] = S.cur[2 * p] + S.cur[2 * p + 1];
-        LFX_SYNC();
-        // merge(packages, source): a package goes first only if strictly lighter (huffman.rs:342-346)
-        for (int i = lane; i < n; i += nlanes) {
-            uint64_t w = S.sw[i];
-            int lo = 0, hi = np;  // #{p : P[p] < w}
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (S.pk[mid] < w) lo = mid + 1; else hi = mid;
-            }
-            S.nxt[i + lo] = w;
-            S.leafpos[k][i] = (uint16_t)(i + lo);
-        }
-        for (int p = lane; p < np; p += nlanes) {
-            uint64_t w = S.pk[p];
-            int lo = 0, hi = n;  // #{i : S[i] <= w}
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (S.sw[mid] <= w) lo = mid + 1; else hi = mid;
-            }
-            S.nxt[p + lo] = w;
-        }
-        LFX_SYNC();
-        for (int i = lane; i < np + n; i += nlanes) S.cur[i] = S.nxt[i];
+        for (int p = lane; p < np; p += nlanes) S.pk[p] = cur[2 * p] + cur[2 * p + 1];
         if (lane == 0) S.listlen[k] = (uint16_t)(np + n);
         LFX_SYNC();
+        // merge(packages, source): a package goes first only if strictly lighter (huffman.rs:342-346)
+        //   leaf i lands at i + #{p : P[p] < S[i]}, package p at p + #{i : S[i] <= P[p]}
+        const int top = n > np ? n : np;                                   // (np >= 1)
+        const int step0 = 1 << (31 - __builtin_clz((unsigned)top));      // counts up to 2 * step0 - 1 >= top
+        for (int i = lane; i < top; i += nlanes) {
+            const bool isleaf = i < n, ispk = i < np;
+            const uint64_t wl = S.sw[isleaf ? i : 0], wp = S.pk[ispk ? i : 0];
+            int cl = 0, cp = 0;
+            for (int step = step0; step; step >>= 1) {
+                const int il = cl + step, ip = cp + step;
+                const uint64_t xl = S.pk[(il <= np ? il : np) - 1];       // (np >= 1, n >= 2: the clamped indices are valid)
+                const uint64_t xp = S.sw[(ip <= n ? ip : n) - 1];
+                cl = (il <= np && xl < wl) ? il : cl;
+                cp = (ip <= n && xp <= wp) ? ip : cp;
+            }
+            if (isleaf) { nxt[i + cl] = wl; S.leafpos[k][i] = (uint16_t)(i + cl); }
+            if (ispk) nxt[i + cp] = wp;
+        }
+        LFX_SYNC();
+        uint64_t *t = cur; cur = nxt; nxt = t;
     }
     if (stamp0 >= 0) LFX_STAMP(S, stamp0 + 2);       // forward passes done
     // 4. backward: the final package() keeps the first 2*floor(len/2) items of the last list; a
-    //    selected package at level k expands to two items of level k-1 (a prefix, merge is stable)
-    if (lane == 0) {
+    //    selected package at level k expands to two items of level k-1 (a prefix, merge is stable).
+    //    a_k = #{i : leafpos[k][i] < m}: the positions grow strictly with i, so a_k is found by the ONE leaf that is
+    //    below m while its successor is not — every lane looks at its own leaf (round 4; a binary search on lane 0 was
+    //    nine dependent LDS round trips per level).
+    for (int k = lane; k < L; k += nlanes) S.acnt[k] = 0;
+    LFX_SYNC();
+    {
         int m = 2 * (S.listlen[L - 1] / 2);
         for (int k = L - 1; k >= 0; k--) {
-            int lo = 0, hi = n;  // a = #{i : leafpos[k][i] < m}
-            while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (S.leafpos[k][mid] < m) lo = mid + 1; else hi = mid;
-            }
-            S.acnt[k] = (uint16_t)lo;
-            m = 2 * (m - lo);
+            for (int i = lane; i < n; i += nlanes)
+                if (S.leafpos[k][i] < m && (i + 1 == n || S.leafpos[k][i + 1] >= m)) S.acnt[k] = (uint16_t)(i + 1);
+            LFX_SYNC();
+            m = 2 * (m - (int)S.acnt[k]);
         }
     }
-    LFX_SYNC();
     for (int i = lane; i < n; i += nlanes) {
         int w = 0;
         LFX_UNROLL8
         for (int k = 0; k < L; k++) w += i < S.acnt[k];
         S.width[S.ssym[i]] = (uint8_t)w;
+        LFX_ATOMIC_ADD(&S.wcnt[w], 1u);
     }
     LFX_SYNC();
     if (stamp0 >= 0) LFX_STAMP(S, stamp0 + 3);       // widths done
-    // 5. canonical codes (huffman.rs:35-55): symbols in (width, symbol) order
-    for (int s = lane; s < nsym; s += nlanes) {
-        int w = S.width[s];
-        if (w == 0) continue;
-        // code = (number of codes before me, each scaled to my width)
-        uint32_t c = 0;
-        LFX_UNROLL8
-        for (int t = 0; t < nsym; t++) {
-            int wt = S.width[t];
-            if (wt == 0) continue;
-            if (wt < w) c += 1u << (w - wt);
-            else if (wt == w && t < s) c += 1;
+    // 5. canonical codes (huffman.rs:35-55): symbols in (width, symbol) order.  The code of symbol s of width w =
+    //    (codes of the shorter widths, each scaled to w) + (symbols of width w in front of s): the first from the
+    //    per-width counts, the second by counting equal bytes in the width array a dword at a time (round 4: the
+    //    loop over all symbols was ~4000 instructions per lane).
+    {
+        const uint32_t *w32 = (const uint32_t *)S.width;
+        for (int s = lane; s < nsym; s += nlanes) {
+            const uint32_t w = S.width[s];
+            if (w == 0) continue;
+            uint32_t c = 0;
+            for (uint32_t v = 1; v < w; v++) c += S.wcnt[v] << (w - v);
+            const uint32_t pat = w * 0x01010101u;
+            const int full = s >> 2;
+            LFX_UNROLL8
+            for (int j = 0; j < full; j++) c += zero_bytes(w32[j] ^ pat);
+            if (s & 3) c += zero_bytes((w32[full] ^ pat) | (0xFFFFFFFFu << (8 * (s & 3))));
+            S.code[s] = (uint16_t)bitrev(c & 0xFFFF, w);
         }
-        S.code[s] = (uint16_t)bitrev(c & 0xFFFF, (uint32_t)w);
     }
     LFX_SYNC();
 }
@@ -304,12 +363,15 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
     // DynamicHuffmanCodec::build symbol.rs:321-342 — literal/length alphabet
     LFX_STAMP(S, 0);
     for (int s = lane; s < HMAX; s += nlanes) S.freq[s] = s < 286 ? hist[s] : 0;
+    for (int i = lane; i < 12; i += nlanes) S.rbits[i] = 0;
+    if (lane == 0) { S.lit_used = 0; S.dist_used = 0; S.rl_n = 0; }
     LFX_SYNC();
     huff_build(S, 286, 15, lane, nlanes, 1);
     LFX_STAMP(S, 5);
     for (int s = lane; s < 288; s += nlanes) {
         out->lit[s] = (uint32_t)S.code[s] | ((uint32_t)S.width[s] << 16);
         S.lw[s] = S.width[s];
+        if (s < 286 && S.width[s]) LFX_ATOMIC_MAX(&S.lit_used, s);      // used_max_symbol().unwrap_or(0), huffman.rs:246-253
     }
     LFX_SYNC();
     // distance alphabet, with the dist[0] = 1 dummy when the block has no pointer (symbol.rs:332-337)
@@ -327,59 +389,84 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
     for (int s = lane; s < 32; s += nlanes) {
         out->dist[s] = s < 30 ? ((uint32_t)S.code[s] | ((uint32_t)S.width[s] << 16)) : 0;
         S.dw[s] = s < 30 ? S.width[s] : 0;
+        if (s < 30 && S.width[s]) LFX_ATOMIC_MAX(&S.dist_used, s);
     }
     LFX_SYNC();
-    // DynamicHuffmanCodec::save symbol.rs:343-386 (serial: ~300 short steps)
-    if (lane == 0) {
-        int lit_used = 0, dist_used = 0;  // used_max_symbol().unwrap_or(0)
-        for (int s = 285; s >= 0; s--) if (S.lw[s]) { lit_used = s; break; }
-        for (int s = 29; s >= 0; s--) if (S.dw[s]) { dist_used = s; break; }
-        int nl = lit_used + 1 < 257 ? 257 : lit_used + 1;
-        int nd = dist_used + 1 < 1 ? 1 : dist_used + 1;
-        // build_bitwidth_codes symbol.rs:486-540
-        int rn = 0;
-        for (int t = 0; t < 2; t++) {
-            // (the widths are read a dword at a time: every read is a dependent LDS round trip on this one lane)
-            const uint32_t *w32 = (const uint32_t *)(t ? S.dw : S.lw);
-            int size = t ? nd : nl;
-            int i = 0;
-            int cidx = -1;
-            uint32_t cw = 0;
-            auto wat = [&](int q) -> uint8_t {
-                if ((q >> 2) != cidx) { cidx = q >> 2; cw = w32[cidx]; }
-                return (uint8_t)(cw >> (8 * (q & 3)));
-            };
-            while (i < size) {
-                uint8_t v = wat(i);
-                int c = 1;
-                while (i + c < size && wat(i + c) == v) c++;  // a run never crosses into the next table
-                i += c;
-                if (v == 0) {
-                    while (c >= 11) {
-                        int k = c < 138 ? c : 138;
-                        S.rl_code[rn] = 18; S.rl_bits[rn] = 7; S.rl_extra[rn] = (uint8_t)(k - 11); rn++;
-                        c -= k;
-                    }
-                    if (c >= 3) { S.rl_code[rn] = 17; S.rl_bits[rn] = 3; S.rl_extra[rn] = (uint8_t)(c - 3); rn++; c = 0; }
-                    for (; c > 0; c--) { S.rl_code[rn] = 0; S.rl_bits[rn] = 0; S.rl_extra[rn] = 0; rn++; }
+    // DynamicHuffmanCodec::save symbol.rs:343-386; build_bitwidth_codes symbol.rs:486-540.
+    // Round 4: by all lanes (on lane 0 the pass was ~300 dependent steps, a sixth of the kernel).  The nl literal widths
+    // and the nd distance widths are one sequence of nl + nd positions in which a run never crosses into the second table
+    // (symbol.rs:501-507).  (A) every position decides whether a run starts at it and sets its bit; (B) a run's first
+    // position finds the next start (its length), and from value and length the number of entries the reference's loops
+    // emit for it; (C) the entries of the runs in front of it give the run its place, and it writes its entries.
+    {
+        const int nl = S.lit_used + 1 < 257 ? 257 : S.lit_used + 1;
+        const int nd = S.dist_used + 1 < 1 ? 1 : S.dist_used + 1;
+        const int tot = nl + nd;
+        auto width_at = [&](int i) -> uint32_t { return i < nl ? S.lw[i] : S.dw[i - nl]; };
+        for (int i = lane; i <= tot; i += nlanes) {
+            const bool st = i == tot || i == 0 || i == nl || width_at(i - 1) != width_at(i);    // (i == tot: the sentinel)
+            if (st) LFX_ATOMIC_OR(&S.rbits[i >> 5], 1u << (i & 31));
+        }
+        LFX_SYNC();
+        auto run_len = [&](int i) -> int {                   // i: a run's first position
+            int p = i + 1, wd = p >> 5;
+            uint32_t x = S.rbits[wd] >> (p & 31);
+            if (x) return p + __builtin_ctz(x) - i;
+            for (;;) {                                       // (ends at the sentinel's word at the latest)
+                x = S.rbits[++wd];
+                if (x) return wd * 32 + __builtin_ctz(x) - i;
+            }
+        };
+        for (int i = lane; i < tot; i += nlanes) {
+            uint32_t e = 0;
+            if ((S.rbits[i >> 5] >> (i & 31)) & 1) {
+                const uint32_t c = (uint32_t)run_len(i);
+                if (width_at(i) == 0) {
+                    // while c >= 11 { 18: min(c, 138) }; then c >= 3: one 17; else c plain zeros
+                    const uint32_t q = c / 138, r = c % 138;
+                    e = q + (r >= 3 ? 1u : r);
                 } else {
-                    S.rl_code[rn] = v; S.rl_bits[rn] = 0; S.rl_extra[rn] = 0; rn++;
-                    c -= 1;
-                    while (c >= 3) {
-                        int k = c < 6 ? c : 6;
-                        S.rl_code[rn] = 16; S.rl_bits[rn] = 2; S.rl_extra[rn] = (uint8_t)(k - 3); rn++;
-                        c -= k;
-                    }
-                    for (; c > 0; c--) { S.rl_code[rn] = v; S.rl_bits[rn] = 0; S.rl_extra[rn] = 0; rn++; }
+                    // the value once; then while c >= 3 { 16: min(c, 6) }; the rest as plain values
+                    const uint32_t c1 = c - 1, q = c1 / 6, r = c1 % 6;
+                    e = 1 + q + (r >= 3 ? 1u : r);
                 }
             }
+            S.rcnt[i] = (uint16_t)e;
         }
-        S.rl_n = rn;
-        // stash nl/nd for the emit step
-        S.listlen[15] = (uint16_t)nl;
-        S.acnt[15] = (uint16_t)nd;
+        LFX_SYNC();
+        const uint32_t *r32 = (const uint32_t *)S.rcnt;
+        for (int i = lane; i < tot; i += nlanes) {
+            const uint32_t e = S.rcnt[i];
+            if (e == 0) continue;
+            uint32_t at = 0;
+            LFX_UNROLL8
+            for (int j = 0; j < (i >> 1); j++) { const uint32_t x = r32[j]; at += (x & 0xFFFFu) + (x >> 16); }
+            if (i & 1) at += S.rcnt[i - 1];
+            uint32_t c = (uint32_t)run_len(i);
+            const uint32_t v = width_at(i);
+            if (i + (int)c == tot) S.rl_n = (int32_t)(at + e);
+            uint32_t rn = at;
+            auto put = [&](uint32_t code, uint32_t bits, uint32_t extra) {
+                S.rl_code[rn] = (uint8_t)code; S.rl_bits[rn] = (uint8_t)bits; S.rl_extra[rn] = (uint8_t)extra; rn++;
+            };
+            if (v == 0) {
+                while (c >= 11) { const uint32_t k = c < 138 ? c : 138; put(18, 7, k - 11); c -= k; }
+                if (c >= 3) { put(17, 3, c - 3); c = 0; }
+                for (; c > 0; c--) put(0, 0, 0);
+            } else {
+                put(v, 0, 0);
+                c -= 1;
+                while (c >= 3) { const uint32_t k = c < 6 ? c : 6; put(16, 2, k - 3); c -= k; }
+                for (; c > 0; c--) put(v, 0, 0);
+            }
+        }
+        if (lane == 0) {
+            // stash nl/nd for the emit step
+            S.listlen[15] = (uint16_t)nl;
+            S.acnt[15] = (uint16_t)nd;
+        }
     }
-    LFX_STAMP(S, 7);                                   // run-length pass done (lane 0)
+    LFX_STAMP(S, 7);                                   // run-length pass done
     for (int s = lane; s < HMAX; s += nlanes) S.freq[s] = 0;
     LFX_SYNC();
     // code-length-symbol counts and the header's bit assembly are spread over the lanes (round 3: on lane 0 they were
@@ -419,7 +506,14 @@ LFX_HD inline void huff_block_build(const uint32_t *hist, uint32_t type, BlockCo
         const int rn = S.rl_n;
         for (int i = lane; i < rn; i += nlanes) {
             uint32_t at = base;
-            for (int j = 0; j < i; j++) at += S.rl_w[j];
+            {   // Σ widths of the entries in front: four at a time (each at most 14 bits wide)
+                const uint32_t *w32 = (const uint32_t *)S.rl_w;
+                uint32_t acc = 0;
+                LFX_UNROLL8
+                for (int j = 0; j < (i >> 2); j++) { const uint32_t x = w32[j]; acc += (x & 0x00FF00FFu) + ((x >> 8) & 0x00FF00FFu); }
+                at += (acc & 0xFFFFu) + (acc >> 16);
+                for (int j = i & ~3; j < i; j++) at += S.rl_w[j];
+            }
             const uint32_t cw = S.clw[S.rl_code[i]];
             const uint32_t v = (uint32_t)S.clc[S.rl_code[i]] | ((uint32_t)S.rl_extra[i] << cw);
             const uint32_t word = at >> 5, sh = at & 31, wd = S.rl_w[i];

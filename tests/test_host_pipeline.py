@@ -174,6 +174,104 @@ def test_huffman_vs_oracle(ffi, oracle):
         assert list(dst[:30] & 0xFFFF) == list(oracle.huff_codes(dw))
 
 
+class _CannedCodes:
+    """An `E: Lz77Encode` that ignores its input and hands out a prepared code list on the first flush."""
+    def __init__(self, codes):
+        self.codes = list(codes)
+
+    def encode(self, buf, sink):
+        pass
+
+    def flush(self, sink):
+        sink.extend(self.codes)
+        self.codes = []
+
+    def compression_level(self):
+        return 2
+
+    def window_size(self):
+        return 32768
+
+
+def _one_final_block(ffi, codes):
+    """raw DEFLATE of ONE final dynamic block holding `codes`, header and code tables from lfx_huff.h"""
+    words = [(c[1] << 16) if c[0] == "Literal" else (c[1] << 16) | c[2] for c in codes] + [256 << 16]
+    hist = np.zeros(320, np.uint32)
+    syms = []
+    for w in words:
+        val, dist = w >> 16, w & 0xFFFF
+        if dist == 0:
+            hist[val] += 1
+            syms.append(None)
+        else:
+            s = symbols(ffi, val, dist)
+            hist[s[0]] += 1
+            hist[288 + s[3]] += 1
+            syms.append(s)
+    lit, dst, hdr, hbits, body = huff_block(ffi, hist, 2)
+    bw = Bits()
+    bw.put(1, 1); bw.put(2, 2)
+    for i in range(hbits):
+        bw.put(1, (int(hdr[i >> 5]) >> (i & 31)) & 1)
+    for w, s in zip(words, syms):
+        if s is None:
+            e = int(lit[w >> 16]); bw.put(e >> 16, e & 0xFFFF)
+        else:
+            e = int(lit[s[0]]); bw.put(e >> 16, e & 0xFFFF)
+            if s[1]: bw.put(s[1], s[2])
+            e = int(dst[s[3]]); bw.put(e >> 16, e & 0xFFFF)
+            if s[4]: bw.put(s[4], s[5])
+    assert bw.n == body
+    bw.align()
+    return bw.bytes()
+
+
+def test_block_headers_of_crafted_alphabets(ffi, oracle):
+    """DynamicHuffmanCodec::save / build_bitwidth_codes (symbol.rs:343-386,486-540) on alphabets made to hit every branch
+    of the run-length code: zero runs of 1..2, 3..10, 11..138, 139, 148, 149, 276 and more, runs of equal widths of every
+    length around the groups of six, a run that ends where the distance table starts, one-symbol and empty tables.  The
+    reference side is the oracle's encoder fed the same code words through a caller-made `E: Lz77Encode`."""
+    rng = np.random.default_rng(23)
+    LENS = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    DISTS = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097,
+             6145, 8193, 12289, 16385, 24577]
+    cases = []
+    # literal i used iff it lies in one of the ranges; every used literal once → long runs of one width
+    def lits(ranges, rep=1):
+        out = []
+        for lo, hi in ranges:
+            for v in range(lo, hi):
+                out.extend([("Literal", v)] * rep)
+        return out
+    for gap in (1, 2, 3, 4, 10, 11, 12, 137, 138, 139, 140, 148, 149, 150, 200, 254):
+        cases.append(lits([(0, 1), (gap + 1, min(gap + 3, 256))]))           # a zero run of `gap` between used literals
+    for run in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 64, 65, 128, 255, 256):
+        cases.append(lits([(0, run)]) + [("Literal", 0)] * 3)                 # `run` literals, equal widths for most
+    cases.append(lits([(0, 256)]))                                            # 256 equal widths + EOB
+    cases.append([])                                                          # the empty block: EOB only, dist[0] dummy
+    cases.append([("Pointer", 258, 32768)] * 5 + [("Literal", 255)])
+    cases.append([("Pointer", LENS[k], DISTS[k]) for k in range(29)] + [("Pointer", 3, DISTS[29])])   # every length / distance symbol once
+    cases.append(lits([(0, 256)]) + [("Pointer", LENS[k], DISTS[k]) for k in range(29)] + [("Pointer", 3, DISTS[29])])
+    cases.append(lits([(250, 256)]) + [("Pointer", 258, 1)])                  # widths up to symbol 285, one distance
+    cases.append(lits([(250, 256)], rep=2) + [("Pointer", 258, 24577)] * 2)   # ... the last distance symbol: zero run of 29 in the distance table
+    for trial in range(60):
+        codes = []
+        k = int(rng.integers(1, 6))
+        for _ in range(k):
+            lo = int(rng.integers(0, 256)); hi = min(256, lo + int(rng.integers(1, 80)))
+            codes += lits([(lo, hi)], rep=int(rng.integers(1, 4)))
+        for _ in range(int(rng.integers(0, 40))):
+            codes.append(("Pointer", int(rng.choice(LENS)) if rng.random() < 0.7 else int(rng.integers(3, 259)),
+                          int(rng.choice(DISTS)) if rng.random() < 0.7 else int(rng.integers(1, 32769))))
+        rng.shuffle(codes)
+        cases.append([tuple(c) for c in codes])
+    for codes in cases:
+        codes = [(c[0], int(c[1])) if c[0] == "Literal" else (c[0], int(c[1]), int(c[2])) for c in codes]
+        want = oracle.encode(oracle.DEFLATE, b"x", **oracle.custom_lz77(_CannedCodes(codes)))
+        got = _one_final_block(ffi, codes)
+        assert got == want, codes[:8]
+
+
 def test_emulated_pipeline_matches_oracle(ffi, oracle):
     rng = np.random.default_rng(5)
     text = kat.test_i()
