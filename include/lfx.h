@@ -177,7 +177,7 @@ int lfx_decode_shard_device(lfx_ctx *c, const void *d_in, uint64_t n, uint64_t s
  *      front of it as ONE index map (lfx_decode_range_map: 32768 uint16 on the device — a byte value, or 256 + j = "byte
  *      j of the window in front of my slice"), the ranks all-gather the maps (64 KiB each, rank order);
  *   6. lfx_decode_range_finish: composes the window in front of the slice from the maps of the ranks before it (d_maps:
- *      world x 32768 uint16 on the device; NULL when no rank needed a window), replaces the slice's markers, and returns
+ *      world x 32768 uint16 on the device, 16-byte aligned; NULL when no rank needed a window), replaces the slice's markers, and returns
  *      the slice's CRC-32 / Adler-32 (fold them with lfx_crc32_combine / lfx_adler32_combine and compare with the
  *      trailer). */
 typedef struct lfx_blk_tuple {

@@ -1158,6 +1158,7 @@ extern "C" int lfx_decode_range_finish(lfx_ctx *cc, const void *d_maps, uint32_t
         const uint8_t *init_win = nullptr;
         if (c->range.before) {
             if (!d_maps || !rank) { c->set_error("this slice reads the output of the ranks in front of it: their maps are needed"); return LFX_E_ARG; }
+            if ((uintptr_t)d_maps & 15) { c->set_error("the gathered maps must be 16-byte aligned"); return LFX_E_ARG; }
             LAUNCH_TRY(launch_window_ranks(st, (const uint16_t *)d_maps, rank, d_init));
             init_win = d_init;
         }

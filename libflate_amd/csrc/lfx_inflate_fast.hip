@@ -920,6 +920,8 @@ struct M2 {
     static_assert(RING % 4 == 0 && TILE >= 258 && TILE < 0xFFFFu && RING + 64 < 65536, "tile");
 };
 constexpr uint32_t M2_THREADS = 256;                      // direct path
+constexpr uint32_t M2_WIDE_THREADS = 1024;                // direct path of a stream of at most M2_FEW_JOBS blocks
+constexpr uint32_t M2_FEW_JOBS = 4;
 constexpr uint32_t M2_SYM_THREADS = 256;                  // marker path
 constexpr uint32_t M2_DONE = 0xFFFFu;
 
@@ -1156,18 +1158,20 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
     // gathers, one dword LDS store and one dword global store per row.  The symbols of unit u+1's tail do not
     // depend on the chain: they are loaded while unit u is being resolved, so the walk itself only touches LDS.
     uint32_t sn[16];                    // two symbols per register
+    // (round 4) the loads carry no branch: a symbol that lies in front of the unit — the window entry is then a byte of
+    // the window before it — is read from index 0 and ignored.  Under a lane-dependent branch every load was followed
+    // by its own s_waitcnt: thirty-two HBM round trips per unit, 24 us of a step that computes for one.
     auto fetch = [&](uint32_t u) {
         if (u >= nunits) return;
         const SymUnit su = units[u];
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
             const uint32_t i = 4 * (threadIdx.x + 1024 * k);
-            uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            const uint16_t *p = sym + (su.start + su.len - 32768 + i);   // (only dereferenced when inside the unit)
-            if (su.len + i >= 32768) s0 = p[0];
-            if (su.len + i + 1 >= 32768) s1 = p[1];
-            if (su.len + i + 2 >= 32768) s2 = p[2];
-            if (su.len + i + 3 >= 32768) s3 = p[3];
+            const uint64_t at = su.start + su.len - 32768 + i;   // (wraps when the entry lies in front of the unit: not used then)
+            const uint32_t s0 = sym[su.len + i >= 32768 ? at : 0];
+            const uint32_t s1 = sym[su.len + i + 1 >= 32768 ? at + 1 : 0];
+            const uint32_t s2 = sym[su.len + i + 2 >= 32768 ? at + 2 : 0];
+            const uint32_t s3 = sym[su.len + i + 3 >= 32768 ? at + 3 : 0];
             sn[2 * k] = s0 | s1 << 16;
             sn[2 * k + 1] = s2 | s3 << 16;
         }
@@ -1184,15 +1188,19 @@ __global__ __launch_bounds__(1024) void window_chain_kernel(const uint16_t *__re
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) {
             const uint32_t i = 4 * (threadIdx.x + 1024 * k);
-            uint32_t packed = 0;
+            uint32_t lb[4], sv[4];
+            bool own[4];
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) {
-                const uint32_t s = (sc[2 * k + (q >> 1)] >> (16 * (q & 1))) & 0xFFFFu;
-                uint32_t b;
-                if (len + i + q >= 32768) b = s < 256 ? s : prev[s - 256];   // a byte of this unit
-                else b = prev[i + q + (uint32_t)len];                          // still a byte of the window in front of it
-                packed |= b << (8 * q);
+                sv[q] = (sc[2 * k + (q >> 1)] >> (16 * (q & 1))) & 0xFFFFu;
+                own[q] = len + i + q >= 32768;                                  // a byte of this unit
+                // a marker looks into the window in front; an entry in front of the unit IS a byte of that window
+                const uint32_t at = own[q] ? (sv[q] >= 256 ? sv[q] - 256 : 0u) : i + q + (uint32_t)len;
+                lb[q] = prev[at];
             }
+            uint32_t packed = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) packed |= ((own[q] && sv[q] < 256) ? sv[q] : lb[q]) << (8 * q);
             ((uint32_t *)cur)[i >> 2] = packed;
             wout[i >> 2] = packed;
         }
@@ -1217,8 +1225,15 @@ __host__ __device__ inline uint32_t wc_group(uint32_t nunits) {
     while (g * g < nunits && g < 64) ++g;
     return g;
 }
-__device__ __forceinline__ uint32_t unit_map_symbol(const uint16_t *__restrict__ sym, const SymUnit &su, uint32_t i) {
-    return su.len + i >= 32768 ? (uint32_t)sym[su.start + su.len - 32768 + i] : 256u + i + (uint32_t)su.len;
+// entry i of a unit's map: its tail symbol, or — in front of a unit shorter than 32 KiB — the shift i -> i + len.  The load
+// carries no branch (an entry in front of the unit reads index 0 and ignores it): the thirty-two loads of a step are
+// then in flight together (round 4; one load and one s_waitcnt per entry made every step of the chains below thirty-two
+// dependent HBM round trips — the window resolution of a 256 MiB single-block stream took 0.59 ms).
+__device__ __forceinline__ uint32_t unit_map_load(const uint16_t *__restrict__ sym, const SymUnit &su, uint32_t i) {
+    return sym[su.len + i >= 32768 ? su.start + su.len - 32768 + i : 0];
+}
+__device__ __forceinline__ uint32_t unit_map_value(uint32_t loaded, const SymUnit &su, uint32_t i) {
+    return su.len + i >= 32768 ? loaded : 256u + i + (uint32_t)su.len;
 }
 __global__ __launch_bounds__(1024) void window_compose_kernel(const uint16_t *__restrict__ sym,
                                                               const SymUnit *__restrict__ units, uint32_t nunits,
@@ -1226,52 +1241,150 @@ __global__ __launch_bounds__(1024) void window_compose_kernel(const uint16_t *__
     extern __shared__ uint16_t mbuf[];   // 2 x 32 Ki entries
     uint16_t *prev = mbuf, *cur = mbuf + 32768;
     const uint32_t u0 = blockIdx.x * WC_GROUP, u1 = u0 + WC_GROUP < nunits ? u0 + WC_GROUP : nunits;
+    if (u0 >= u1) return;
+    // thread t owns the entries t + 1024 k (two per register); the symbols of unit u+1 are loaded while unit u is composed
+    uint32_t nx[16];
+    auto load_unit = [&](const SymUnit &su) {
+        if (su.len >= 32768) {                                   // (uniform) every entry is a symbol of the unit's tail
+            const uint16_t *p = sym + (su.start + su.len - 32768) + threadIdx.x;
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k) nx[k] = (uint32_t)p[1024 * (2 * k)] | (uint32_t)p[1024 * (2 * k + 1)] << 16;
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 16; ++k)
+                nx[k] = unit_map_load(sym, su, threadIdx.x + 1024 * (2 * k)) | unit_map_load(sym, su, threadIdx.x + 1024 * (2 * k + 1)) << 16;
+        }
+    };
+    SymUnit sun = units[u0];
+    load_unit(sun);
     for (uint32_t u = u0; u < u1; ++u) {
-        const SymUnit su = units[u];
+        const SymUnit su = sun;
+        uint32_t sc[16];
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) sc[k] = nx[k];
+        if (u + 1 < u1) {
+            sun = units[u + 1];
+            load_unit(sun);
+        }
         uint16_t *mout = maps + (uint64_t)u * 32768;
-        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
-            uint32_t s = unit_map_symbol(sym, su, i);
-            if (u != u0 && s >= 256) s = prev[s - 256];
-            cur[i] = (uint16_t)s;
-            mout[i] = (uint16_t)s;
+        const bool first = u == u0;
+#pragma unroll
+        for (uint32_t h = 0; h < 4; ++h) {                       // eight entries at a time (register pressure)
+            uint32_t sv[8], g[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t k = 8 * h + j;
+                sv[j] = unit_map_value((sc[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, su, threadIdx.x + 1024 * k);
+                g[j] = prev[sv[j] >= 256 ? sv[j] - 256 : 0u];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t k = 8 * h + j;
+                const uint32_t v = (!first && sv[j] >= 256) ? g[j] : sv[j];
+                cur[threadIdx.x + 1024 * k] = (uint16_t)v;
+                mout[threadIdx.x + 1024 * k] = (uint16_t)v;
+            }
         }
         __syncthreads();
         uint16_t *t = prev; prev = cur; cur = t;
     }
 }
+// eight map entries (one 16-byte load) as eight symbols
+__device__ __forceinline__ void map_octet(const uint4 &q, uint32_t (&s8)[8]) {
+    s8[0] = q.x & 0xFFFFu; s8[1] = q.x >> 16; s8[2] = q.y & 0xFFFFu; s8[3] = q.y >> 16;
+    s8[4] = q.z & 0xFFFFu; s8[5] = q.z >> 16; s8[6] = q.w & 0xFFFFu; s8[7] = q.w >> 16;
+}
+// one step of a chain over BYTE windows in LDS: cur = map(prev); thread t owns the octets t + 1024 k of the 4096
+__device__ __forceinline__ void window_step_bytes(const uint4 (&mq)[4], const uint8_t *prev, uint8_t *cur, uint8_t *gout) {
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t o = threadIdx.x + 1024 * k;
+        uint32_t s8[8], b8[8];
+        map_octet(mq[k], s8);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) b8[j] = prev[s8[j] >= 256 ? s8[j] - 256 : 0u];
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            lo |= ((s8[j] < 256 ? s8[j] : b8[j]) & 0xFFu) << (8 * j);
+            hi |= ((s8[j + 4] < 256 ? s8[j + 4] : b8[j + 4]) & 0xFFu) << (8 * j);
+        }
+        *(uint2 *)(cur + 8 * o) = make_uint2(lo, hi);
+        if (gout) *(uint2 *)(gout + 8 * o) = make_uint2(lo, hi);
+    }
+}
 __global__ __launch_bounds__(1024) void window_groups_kernel(const uint16_t *__restrict__ maps, uint32_t nunits,
                                                              uint8_t *__restrict__ gwin, const uint8_t *__restrict__ init_win,
                                                              uint32_t WC_GROUP) {
-    extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
+    extern __shared__ __attribute__((aligned(16))) uint8_t wbuf[];   // 2 x 32 KiB
     uint8_t *prev = wbuf, *cur = wbuf + 32768;
     for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = init_win ? init_win[i] : (uint8_t)0;
-    __syncthreads();
     const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
+    auto last_of = [&](uint32_t g) { return (g + 1) * WC_GROUP < nunits ? (g + 1) * WC_GROUP - 1 : nunits - 1; };
+    // (the maps do not depend on the chain: group g+1's is loaded while group g is resolved)
+    uint4 nx[4];
+    if (ngroups) {
+        const uint4 *m = (const uint4 *)(maps + (uint64_t)last_of(0) * 32768);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) nx[k] = m[threadIdx.x + 1024 * k];
+    }
+    __syncthreads();
     for (uint32_t g = 0; g < ngroups; ++g) {
-        const uint32_t last = (g + 1) * WC_GROUP < nunits ? (g + 1) * WC_GROUP - 1 : nunits - 1;
-        const uint16_t *m = maps + (uint64_t)last * 32768;
-        uint8_t *wout = gwin + (uint64_t)g * 32768;
-        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
-            const uint32_t s = m[i];
-            const uint8_t b = s < 256 ? (uint8_t)s : prev[s - 256];
-            cur[i] = b;
-            wout[i] = b;
+        uint4 mq[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) mq[k] = nx[k];
+        if (g + 1 < ngroups) {
+            const uint4 *m = (const uint4 *)(maps + (uint64_t)last_of(g + 1) * 32768);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) nx[k] = m[threadIdx.x + 1024 * k];
         }
+        window_step_bytes(mq, prev, cur, gwin + (uint64_t)g * 32768);
         __syncthreads();
         uint8_t *t = prev; prev = cur; cur = t;
     }
 }
-__global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__restrict__ maps, const uint8_t *__restrict__ gwin,
-                                                           uint8_t *__restrict__ windows, const uint8_t *__restrict__ init_win,
-                                                           uint32_t WC_GROUP) {
+// every unit's window = its composed map applied to the window in front of its group (staged in LDS: the gathers are
+// random bytes of 32 KiB)
+__global__ __launch_bounds__(1024) void window_apply_kernel(const uint16_t *__restrict__ maps, const uint8_t *__restrict__ gwin,
+                                                            uint8_t *__restrict__ windows, const uint8_t *__restrict__ init_win,
+                                                            uint32_t WC_GROUP) {
+    __shared__ __attribute__((aligned(16))) uint8_t wl[32768];
     const uint32_t u = blockIdx.x, g = u / WC_GROUP;
-    const uint16_t *m = maps + (uint64_t)u * 32768;
     // (group 0: the member's earlier output, or nothing in front — then no markers are left)
     const uint8_t *w = g ? gwin + (uint64_t)(g - 1) * 32768 : init_win;
+    const uint4 *m = (const uint4 *)(maps + (uint64_t)u * 32768);
+    uint4 mq[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) mq[k] = m[threadIdx.x + 1024 * k];
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        const uint4 *w16 = (const uint4 *)w;            // (gwin rows and init_win: 16-byte aligned? gwin yes; init_win by bytes)
+        if (w && ((uint64_t)w & 15) == 0) {
+            ((uint4 *)wl)[threadIdx.x] = w16[threadIdx.x];
+            ((uint4 *)wl)[threadIdx.x + 1024] = w16[threadIdx.x + 1024];
+        } else if (w) {
+            for (uint32_t i = threadIdx.x; i < 32768; i += 1024) wl[i] = w[i];
+        } else {
+            ((uint4 *)wl)[threadIdx.x] = z;
+            ((uint4 *)wl)[threadIdx.x + 1024] = z;
+        }
+    }
+    __syncthreads();
     uint8_t *wout = windows + (uint64_t)u * 32768;
-    for (uint32_t i = threadIdx.x; i < 32768; i += 256) {
-        const uint32_t s = m[i];
-        wout[i] = s < 256 ? (uint8_t)s : (w ? w[s - 256] : (uint8_t)0);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t o = threadIdx.x + 1024 * k;
+        uint32_t s8[8], b8[8];
+        map_octet(mq[k], s8);
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) b8[j] = wl[s8[j] >= 256 ? s8[j] - 256 : 0u];
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            lo |= ((s8[j] < 256 ? s8[j] : b8[j]) & 0xFFu) << (8 * j);
+            hi |= ((s8[j + 4] < 256 ? s8[j + 4] : b8[j + 4]) & 0xFFu) << (8 * j);
+        }
+        *(uint2 *)(wout + 8 * o) = make_uint2(lo, hi);
     }
 }
 
@@ -1281,17 +1394,37 @@ __global__ __launch_bounds__(256) void window_apply_kernel(const uint16_t *__res
 //  window_rank_map_kernel: the groups' composed maps (window_compose_kernel) folded in order, symbolically → the rank's map
 __global__ __launch_bounds__(1024) void window_rank_map_kernel(const uint16_t *__restrict__ maps, uint32_t nunits,
                                                                uint16_t *__restrict__ out_map, uint32_t WC_GROUP) {
-    extern __shared__ uint16_t mbuf[];   // 2 x 32 Ki entries
-    uint16_t *prev = mbuf, *cur = mbuf + 32768;
+    extern __shared__ __attribute__((aligned(16))) uint16_t mbuf2[];   // 2 x 32 Ki entries
+    uint16_t *prev = mbuf2, *cur = mbuf2 + 32768;
     for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = (uint16_t)(256u + i);   // identity: "byte i of the window in front"
-    __syncthreads();
     const uint32_t ngroups = (nunits + WC_GROUP - 1) / WC_GROUP;
+    auto last_of = [&](uint32_t g) { return (g + 1) * WC_GROUP < nunits ? (g + 1) * WC_GROUP - 1 : nunits - 1; };
+    uint4 nx[4];
+    if (ngroups) {
+        const uint4 *m = (const uint4 *)(maps + (uint64_t)last_of(0) * 32768);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) nx[k] = m[threadIdx.x + 1024 * k];
+    }
+    __syncthreads();
     for (uint32_t g = 0; g < ngroups; ++g) {
-        const uint32_t last = (g + 1) * WC_GROUP < nunits ? (g + 1) * WC_GROUP - 1 : nunits - 1;
-        const uint16_t *m = maps + (uint64_t)last * 32768;
-        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
-            const uint32_t s = m[i];
-            cur[i] = s < 256 ? (uint16_t)s : prev[s - 256];
+        uint4 mq[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) mq[k] = nx[k];
+        if (g + 1 < ngroups) {
+            const uint4 *m = (const uint4 *)(maps + (uint64_t)last_of(g + 1) * 32768);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) nx[k] = m[threadIdx.x + 1024 * k];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) {
+            const uint32_t o = threadIdx.x + 1024 * k;
+            uint32_t s8[8], g8[8];
+            map_octet(mq[k], s8);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) g8[j] = prev[s8[j] >= 256 ? s8[j] - 256 : 0u];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) s8[j] = s8[j] < 256 ? s8[j] : g8[j];
+            *(uint4 *)(cur + 8 * o) = make_uint4(s8[0] | s8[1] << 16, s8[2] | s8[3] << 16, s8[4] | s8[5] << 16, s8[6] | s8[7] << 16);
         }
         __syncthreads();
         uint16_t *t = prev; prev = cur; cur = t;
@@ -1308,16 +1441,25 @@ __global__ __launch_bounds__(256) void bytes_to_map_kernel(const uint8_t *__rest
 //  the window in front of rank `nranks`'s slice: the maps of ranks 0 .. nranks-1 applied in order to "nothing" (a member
 //  starts with an empty Lz77Decoder buffer: a marker that survives to the start is never looked up — K2 flagged it)
 __global__ __launch_bounds__(1024) void window_ranks_kernel(const uint16_t *__restrict__ maps, uint32_t nranks, uint8_t *__restrict__ win) {
-    extern __shared__ uint8_t wbuf[];   // 2 x 32 KiB
-    uint8_t *prev = wbuf, *cur = wbuf + 32768;
+    extern __shared__ __attribute__((aligned(16))) uint8_t wbuf3[];   // 2 x 32 KiB
+    uint8_t *prev = wbuf3, *cur = wbuf3 + 32768;
     for (uint32_t i = threadIdx.x; i < 32768; i += 1024) prev[i] = 0;
+    uint4 nx[4];
+    if (nranks) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) nx[k] = ((const uint4 *)maps)[threadIdx.x + 1024 * k];
+    }
     __syncthreads();
     for (uint32_t r = 0; r < nranks; ++r) {
-        const uint16_t *m = maps + (uint64_t)r * 32768;
-        for (uint32_t i = threadIdx.x; i < 32768; i += 1024) {
-            const uint32_t s = m[i];
-            cur[i] = s < 256 ? (uint8_t)s : prev[s - 256];
+        uint4 mq[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) mq[k] = nx[k];
+        if (r + 1 < nranks) {
+            const uint4 *m = (const uint4 *)(maps + (uint64_t)(r + 1) * 32768);
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) nx[k] = m[threadIdx.x + 1024 * k];
         }
+        window_step_bytes(mq, prev, cur, nullptr);
         __syncthreads();
         uint8_t *t = prev; prev = cur; cur = t;
     }
@@ -1586,7 +1728,13 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_materialize2_kernel<M2_THREADS>, dim3(njobs * MAX_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
+    // A stream of a few blocks fills a handful of CUs whatever the geometry: what counts then is a unit's own time, and a
+    // tile of 1024 codes on sixteen wavefronts pays the per-tile latencies (barriers, owner search, pointer rounds) once
+    // for four times the codes (round 4; a 64 KiB stream is ONE unit: 68 tiles of 256 codes, 0.22 of its 0.75 ms).
+    if (njobs <= M2_FEW_JOBS)
+        hipLaunchKernelGGL(blk_materialize2_kernel<M2_WIDE_THREADS>, dim3(njobs * MAX_UNITS), dim3(M2_WIDE_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
+    else
+        hipLaunchKernelGGL(blk_materialize2_kernel<M2_THREADS>, dim3(njobs * MAX_UNITS), dim3(M2_THREADS), 0, st, in, jobs, units, codes, out, njobs, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
@@ -1636,7 +1784,7 @@ int launch_window_prefix(hipStream_t st, const uint16_t *sym, const SymUnit *uni
     LFX_LAUNCH_CHECK();
     hipLaunchKernelGGL(window_groups_kernel, dim3(1), dim3(1024), 65536, st, maps, nunits, gwin, init_win, G);
     LFX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(256), 0, st, maps, gwin, windows, init_win, G);
+    hipLaunchKernelGGL(window_apply_kernel, dim3(nunits), dim3(1024), 0, st, maps, gwin, windows, init_win, G);
     LFX_LAUNCH_CHECK();
     return 0;
 }
