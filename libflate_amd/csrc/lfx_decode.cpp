@@ -190,7 +190,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         // steps.  A stream that turns out to have many blocks (another encoder's) gets the finder after all.
         // (measured, profiles/r04_small_sizes.json: every dependent block step costs about 0.2 ms — header parse and table
         //  build of one workgroup — so the walk pays for up to three blocks: streams below 1.5 MiB)
-        const bool small_first = comp >= (32u << 10) && comp < (1536u << 10) && stop_bit == ~0ull && !partial && !c->diag.no_pieces;
+        const bool small_first = comp < (1536u << 10) && stop_bit == ~0ull && !partial && !c->diag.no_pieces;
         if (small_first) starts.push_back(first_bit);
         else if ((rc = find_candidates())) return rc;
         if (!overflow) {
@@ -204,6 +204,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             bool front_bad = false;      // the window's FIRST block does not scan: damaged rather than incomplete
             uint64_t last_end = 0;   // end bit of the last block of the chain
             bool pieces_mode = false;
+            bool pieces_multi = false;   // some block was scanned in more than one piece (its pieces read each other's output)
             const size_t tab_bytes = blk_tabs_bytes();
             // ---- few candidates in a long stream = few, huge blocks (schedule S1: ONE block for the whole input).
             // One workgroup per block would scan it alone; instead the block is scanned in PIECES of 4 Mbit, one
@@ -226,10 +227,14 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             const bool giant_blocks = nc <= 8 && comp / nc >= (2u << 20);     // (schedule S1: the block-by-block piece walk below)
             if (!small_first && !giant_blocks && nc >= 2 && nc <= 32 && comp / nc >= (128u << 10) && stop_bit == ~0ull &&
                 !partial && !c->diag.no_pieces) {
-                constexpr uint64_t OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
                 const uint64_t PIECE_BITS = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(256ull << 10,
                                             ((end_bits - first_bit) / (2ull * (uint64_t)std::max(c->n_cu, 1)) + 63) & ~63ull));
+                // warm-up in front of a piece: ONE lane decodes it, 0.2 us per symbol on an otherwise idle CU — 8 Kbit are 550
+                // symbols, 115 us, most of a small stream's scan step (round 4, profiles/r04_small_sizes.json).  A speculative
+                // decode is in step within a few dozen symbols; small pieces get 2 Kbit.  (A piece whose warm-up did not get in
+                // step is rejected by the chain check below, and the stream takes the one-workgroup-per-block path.)
+                const uint64_t OVERLAP = PIECE_BITS <= (1ull << 20) ? 2048 : 8192;
                 std::vector<BlkJob> pj;
                 std::vector<uint32_t> first_piece(nc + 1, 0);
                 for (uint32_t i = 0; i < nc; i++) {
@@ -275,6 +280,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                         if (r.status == BLK_OK) {
                             closed = true;
                             last_end = r.end_bit;
+                            pieces_multi |= q > 0;
                             if (r.bfinal) { ok_chain = true; chain_final = true; } else pos = r.end_bit;
                         }
                     }
@@ -282,15 +288,19 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 }
                 if (c->diag.debug) fprintf(stderr, "[lfx]  pieces over %u candidate ranges: ok=%d fail=%d pieces=%zu of %u total=%llu\n", nc, (int)ok_chain, (int)fail,
                                            emit.size(), npj, (unsigned long long)total);
-                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; chain_final = false; last_end = 0; }
+                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; chain_final = false; last_end = 0; pieces_multi = false; }
                 else pieces_mode = true;
                 c->phase("pieces");
             }
             if (!pieces_mode && (small_first || (nc <= 8 && comp / nc >= (2u << 20))) && stop_bit == ~0ull && !partial && !c->diag.no_pieces) {
-                constexpr uint64_t OVERLAP = 8192;
                 const uint64_t end_bits = n * 8;
                 const uint64_t PIECE_BITS = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(256ull << 10,
                                             ((end_bits - first_bit) / (2ull * (uint64_t)std::max(c->n_cu, 1)) + 63) & ~63ull));
+                // warm-up in front of a piece: ONE lane decodes it, 0.2 us per symbol on an otherwise idle CU — 8 Kbit are 550
+                // symbols, 115 us, most of a small stream's scan step (round 4, profiles/r04_small_sizes.json).  A speculative
+                // decode is in step within a few dozen symbols; small pieces get 2 Kbit.  (A piece whose warm-up did not get in
+                // step is rejected by the chain check below, and the stream takes the one-workgroup-per-block path.)
+                const uint64_t OVERLAP = PIECE_BITS <= (1ull << 20) ? 2048 : 8192;
                 const uint32_t cap_slots = (uint32_t)std::min<uint64_t>((end_bits - first_bit) / PIECE_BITS * 2 + 64, 1u << 20);
                 int rc2;
                 if ((rc2 = c->d_dec_streams.reserve(sizeof(BlkJob) * cap_slots))) return rc2;
@@ -337,6 +347,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                         if (r.status == BLK_OK) {          // the piece that holds EndOfBlock (or a whole stored block)
                             closed = true;
                             last_end = r.end_bit;
+                            pieces_multi |= q > 0;
                             if (r.bfinal) { ok_chain = true; chain_final = true; } else pos = r.end_bit;
                         }
                     }
@@ -344,7 +355,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     base += used;
                 }
                 if (c->diag.debug) fprintf(stderr, "[lfx]  pieces: ok=%d fail=%d pieces=%zu total=%llu\n", (int)ok_chain, (int)fail, emit.size(), (unsigned long long)total);
-                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; last_end = 0; }
+                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; last_end = 0; pieces_multi = false; }
                 else pieces_mode = true;
                 c->phase("pieces");
                 if (small_first && !pieces_mode) {     // many blocks after all: the finder, then one workgroup per block
@@ -524,7 +535,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 c->phase("blk_emit");
                 // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
                 // the marker path, which may cut anywhere
-                bool giant = pieces_mode;   // (pieces of one block read each other's output)
+                bool giant = pieces_multi;   // (pieces of one block read each other's output; blocks scanned in ONE piece each are ordinary blocks)
                 for (const BlkEmit &e : emit) giant |= e.n_out >= (8ull << 20);   // (a block that big has too few legal cuts for K3's resident units)
                 // small blocks smell of another encoder (zlib cuts every ~50-100 KiB of output; the reference at
                 // block_size = 1 MiB): look at the emit flags BEFORE materialising, so that a stream which needs

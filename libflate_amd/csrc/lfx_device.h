@@ -77,9 +77,9 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
                 const uint32_t *codes, const uint32_t *ncodes, const BlockCodes *bc,
                 const uint64_t *block_start, uint32_t *tile_bits, uint64_t *tile_start,
                 const EncodeResult *res, uint64_t out_base_bit, uint32_t *out, const uint32_t *tile_map);
-// span of the checksum kernels = the bytes one wavefront folds serially: 64 KiB; 8 KiB for small inputs (a 1 MiB buffer is
-// sixteen 64 KiB spans — sixteen wavefronts on the whole GPU, each walking sixteen dependent pieces: 0.12 ms)
-inline uint32_t ck_span(uint64_t n) { return n <= (8ull << 20) ? 8192u : 65536u; }
+// span of the checksum kernels = the bytes one wavefront folds serially: 64 KiB; 8 KiB up to 64 MiB (a 1 MiB buffer is
+// sixteen 64 KiB spans — sixteen wavefronts on the whole GPU, each walking sixteen dependent pieces: 0.12 ms; 16 MiB are 256)
+inline uint32_t ck_span(uint64_t n) { return n <= (64ull << 20) ? 8192u : 65536u; }
 inline uint64_t ck_nspans(uint64_t n) { return div_up(n ? n : 1, ck_span(n)); }   // partials needed: 3 x 4 bytes each
 int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
                     uint32_t *a_part, uint32_t *b_part, EncodeResult *res,
