@@ -329,9 +329,9 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     for (uint32_t q = 0; q < np && !closed; q++) {
                         const BlkInfo &r = pi[q];
                         if (c->diag.debug && (q < 3 || r.status != BLK_NO_EOB))
-                            fprintf(stderr, "[lfx]   piece %u/%u: status=%u btype=%u data=%llu end=%llu prev_end=%llu lanes=%u codes=%u out=%llu\n", q, np,
+                            fprintf(stderr, "[lfx]   piece %u/%u: status=%u btype=%u data=%llu end=%llu prev_end=%llu lanes=%u codes=%u out=%llu rounds=%u cyc_hdr=%u cyc_total=%u\n", q, np,
                                     r.status, r.btype, (unsigned long long)r.data_bit, (unsigned long long)r.end_bit,
-                                    (unsigned long long)prev_end, r.nlanes, r.n_codes, (unsigned long long)r.n_out);
+                                    (unsigned long long)prev_end, r.nlanes, r.n_codes, (unsigned long long)r.n_out, r.rounds, r.cyc_hdr, r.cyc_total);
                         if (r.status == BLK_BAD || (q && r.data_bit != prev_end) || r.end_bit <= pos || r.end_bit > end_bits) { fail = true; break; }
                         if (q == 0 && r.btype == 0 && r.status != BLK_OK) { fail = true; break; }
                         BlkEmit e{};
@@ -632,7 +632,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     SymUnit *d_su = (SymUnit *)(d_win + 32768ull * std::max<uint32_t>(nsu, 1));
                     HIP_TRY(hipMemcpyAsync(d_su, su.data(), sizeof(SymUnit) * nsu, hipMemcpyHostToDevice, st));
                     LAUNCH_TRY(launch_blk_materialize_sym(st, d_in, d_emit, ne, (const BlkUnits *)c->d_hist.p,
-                                                          (const uint32_t *)c->d_codes.p, (uint16_t *)c->d_dec_sym.p));
+                                                          (const uint32_t *)c->d_codes.p, (uint16_t *)c->d_dec_sym.p,
+                                                          nsu <= (uint32_t)std::max(c->n_cu, 1) && !c->diag.window_chain));
                     c->phase("lz77_sym");
                     if (nsu >= 16 && !c->diag.window_chain) {   // blocked parallel prefix over the units (groups of about sqrt(nsu))
                         if ((rc = c->d_dec_maps.reserve(window_prefix_scratch_bytes(nsu)))) return rc;
@@ -1125,7 +1126,7 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
         SymUnit *d_su = (SymUnit *)((uint8_t *)c->d_dec_win.p + 32768ull * (std::max<uint32_t>(nsu, 1) + 1));
         HIP_TRY(hipMemcpyAsync(d_su, su.data(), sizeof(SymUnit) * nsu, hipMemcpyHostToDevice, st));
         LAUNCH_TRY(launch_blk_materialize_sym(st, d_in, d_emit, ne, (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p,
-                                              (uint16_t *)c->d_dec_sym.p));
+                                              (uint16_t *)c->d_dec_sym.p, nsu <= (uint32_t)std::max(c->n_cu, 1)));
         HIP_TRY(hipStreamSynchronize(st));     // (su must outlive its copy)
         c->phase("lz77_sym");
         c->range.state = 1; c->range.nsu = nsu; c->range.max_len = max_len;

@@ -134,7 +134,8 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
 // marker-based materialisation (streams whose blocks read earlier blocks):
 //  sym: one 16-bit symbol per output byte — a byte value, or 256 + j = byte j of the 32 KiB in front of the unit
 int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
-                               const BlkUnits *units, const uint32_t *codes, uint16_t *sym);
+                               const BlkUnits *units, const uint32_t *codes, uint16_t *sym,
+                               bool few_units = false /* at most one unit per CU: the 1024-lane variant */);
 //  windows[u] = the final 32 KiB of output up to the end of unit u (units in stream order, one workgroup walks them)
 // init_win: the 32 KiB of output in front of the first unit (a later window of a member), or null (start of a member)
 int launch_window_chain(hipStream_t st, const uint16_t *sym, const SymUnit *units, uint32_t nunits, uint8_t *windows,

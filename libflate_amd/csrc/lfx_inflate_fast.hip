@@ -192,21 +192,54 @@ __device__ bool build_fast(FastTabs &T, const uint8_t *lw, uint32_t nl, const ui
         const uint8_t *bw = t ? dw : lw;
         const uint32_t w = bw[sym];
         if (w == 0) continue;
+        // symbols of the same width in front of this one.  Literal/length widths (the array is dword-aligned): four at a
+        // time (round 4 — the byte loop was up to 285 LDS reads per lane)
         uint32_t rank = 0;
-        for (uint32_t q = 0; q < sym; ++q) rank += bw[q] == w;
+        if (t == 0 && ((uint32_t)(uintptr_t)lw & 3) == 0) {
+            const uint32_t *w32 = (const uint32_t *)lw;
+            const uint32_t pat = w * 0x01010101u, full = sym >> 2;
+            auto zero_bytes = [](uint32_t x) { return (uint32_t)__builtin_popcount(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu)); };
+#pragma unroll 8
+            for (uint32_t q = 0; q < full; ++q) rank += zero_bytes(w32[q] ^ pat);
+            if (sym & 3) rank += zero_bytes((w32[full] ^ pat) | (0xFFFFFFFFu << (8 * (sym & 3))));
+        } else {
+            for (uint32_t q = 0; q < sym; ++q) rank += bw[q] == w;
+        }
         (t ? T.dist_sorted : T.lit_sorted)[s_off[t][w] + rank] = (uint16_t)sym;
     }
     __syncthreads();
-    for (uint32_t i = tid; i < (1u << LIT_BITS) + (1u << DIST_BITS); i += nthreads) {
-        const uint32_t t = i >= (1u << LIT_BITS);
-        const uint32_t idx = t ? i - (1u << LIT_BITS) : i;
-        uint32_t w = 0;
-        const uint32_t sym = short_decode(t ? T.dist_count : T.lit_count, t ? T.dist_sorted : T.lit_sorted, idx,
-                                          t ? DIST_BITS : LIT_BITS, w);
-        uint32_t e;
-        if (w) e = t ? (sym < 30 ? (T.dist_info[sym] | w) : 0) : (sym < 286 ? (T.lit_info[sym] | w) : 0);
-        else e = s_long[t] ? E_LONG : 0;             // a longer code may start with these bits
-        (t ? T.dist : T.lit)[idx] = e;
+    // the primary tables, entry by entry: each entry walks the canonical code of its own index.  The per-width counts are
+    // taken into registers once (round 4: the walk read them from LDS, a dependent round trip per width and entry)
+    {
+        uint32_t cr[2][8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) {
+            cr[0][k] = ((const uint32_t *)T.lit_count)[k];
+            cr[1][k] = ((const uint32_t *)T.dist_count)[k];
+        }
+        for (uint32_t i = tid; i < (1u << LIT_BITS) + (1u << DIST_BITS); i += nthreads) {
+            const uint32_t t = i >= (1u << LIT_BITS);
+            const uint32_t idx = t ? i - (1u << LIT_BITS) : i;
+            const uint32_t maxw = t ? DIST_BITS : LIT_BITS;
+            uint32_t w = 0, pos = 0, code = 0, first = 0, index = 0;
+#pragma unroll
+            for (uint32_t ww = 1; ww <= LIT_BITS; ++ww) {
+                const uint32_t cnt = ((t ? cr[1][ww >> 1] : cr[0][ww >> 1]) >> (16 * (ww & 1))) & 0xFFFFu;
+                code |= (idx >> (ww - 1)) & 1;
+                const bool hit = w == 0 && ww <= maxw && code < first + cnt;
+                w = hit ? ww : w;
+                pos = hit ? index + (code - first) : pos;
+                index += cnt;
+                first = (first + cnt) << 1;
+                code <<= 1;
+            }
+            uint32_t e;
+            if (w) {
+                const uint32_t sym = (t ? T.dist_sorted : T.lit_sorted)[pos];
+                e = t ? (sym < 30 ? (T.dist_info[sym] | w) : 0) : (sym < 286 ? (T.lit_info[sym] | w) : 0);
+            } else e = s_long[t] ? E_LONG : 0;             // a longer code may start with these bits
+            (t ? T.dist : T.lit)[idx] = e;
+        }
     }
     __syncthreads();
     return true;
@@ -934,7 +967,19 @@ template <uint32_t RING> __device__ __forceinline__ uint32_t m2_back(uint32_t id
 // One body for both materialisations: SYM = false writes BYTES (direct path: the unit's history is known or empty),
 // SYM = true writes 16-bit SYMBOLS for the marker path (below): the 32 Ki entries in front of the unit start out as the
 // markers 256 + j, and the units are the ones cut without regard to back-references (fcode0 / fout0).
+// LDS of one unit: ring, pointer states, per-code offsets, two small exchange arrays.  DYN: carved out of the dynamic
+// allocation (the 1024-lane symbol variant needs 103 KB, more than a static allocation may hold)
 template <bool SYM, uint32_t THREADS>
+struct M2Lds {
+    using elem_t = typename std::conditional<SYM, uint16_t, uint8_t>::type;
+    using G = M2<THREADS>;
+    static constexpr uint32_t RING_BYTES = ((G::RING + 64) * (uint32_t)sizeof(elem_t) + 15u) & ~15u;
+    static constexpr uint32_t P_BYTES = G::PASSES * 4 * THREADS * 2;
+    static constexpr uint32_t XC_BYTES = (THREADS + 4) * 8;
+    static constexpr uint32_t SW_BYTES = 2 * G::WAVES * 4, SANY_BYTES = 2 * G::WAVES * 4;
+    static constexpr uint32_t BYTES = RING_BYTES + P_BYTES + XC_BYTES + SW_BYTES + SANY_BYTES;
+};
+template <bool SYM, uint32_t THREADS, bool DYN = false>
 __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in, const BlkEmit *__restrict__ jobs,
                                                   const BlkUnits *__restrict__ units,
                                                   const uint32_t *__restrict__ codes,
@@ -942,14 +987,30 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
                                                   uint32_t njobs, uint64_t *__restrict__ dbg) {
     using elem_t = typename std::conditional<SYM, uint16_t, uint8_t>::type;
     using G = M2<THREADS>;
+    using LD = M2Lds<SYM, THREADS>;
     constexpr uint32_t WAVES = G::WAVES, TILE = G::TILE, RING = G::RING, PASSES = G::PASSES;
     constexpr uint32_t EPD = 4 / sizeof(elem_t);                                // elements per dword (flush granule)
-    __shared__ __attribute__((aligned(16))) elem_t ring[RING + 64];   // (+ a dump for the stores of idle bytes)
-    __shared__ __attribute__((aligned(8))) uint16_t P[PASSES * 4 * THREADS];
+    elem_t *ring;             // RING + 64 (+ a dump for the stores of idle bytes)
+    uint16_t *P;              // PASSES * 4 * THREADS
     // per code of the tile: x = inclusive end offset, y = code word; four sentinels behind the last (never passed)
-    __shared__ __attribute__((aligned(8))) uint2 XC[THREADS + 4];
-    __shared__ uint32_t s_w[2 * WAVES];
-    __shared__ uint32_t s_any[2][WAVES];
+    uint2 *XC;                // THREADS + 4
+    uint32_t *s_w;            // 2 * WAVES
+    uint32_t (*s_any)[WAVES]; // [2][WAVES]
+    if constexpr (DYN) {
+        extern __shared__ __attribute__((aligned(16))) uint8_t m2_dyn[];
+        ring = (elem_t *)m2_dyn;
+        P = (uint16_t *)(m2_dyn + LD::RING_BYTES);
+        XC = (uint2 *)(m2_dyn + LD::RING_BYTES + LD::P_BYTES);
+        s_w = (uint32_t *)(m2_dyn + LD::RING_BYTES + LD::P_BYTES + LD::XC_BYTES);
+        s_any = (uint32_t (*)[WAVES])(m2_dyn + LD::RING_BYTES + LD::P_BYTES + LD::XC_BYTES + LD::SW_BYTES);
+    } else {
+        __shared__ __attribute__((aligned(16))) elem_t ring_s[RING + 64];
+        __shared__ __attribute__((aligned(8))) uint16_t P_s[PASSES * 4 * THREADS];
+        __shared__ __attribute__((aligned(8))) uint2 XC_s[THREADS + 4];
+        __shared__ uint32_t s_w_s[2 * WAVES];
+        __shared__ uint32_t s_any_s[2][WAVES];
+        ring = ring_s; P = P_s; XC = XC_s; s_w = s_w_s; s_any = s_any_s;
+    }
     const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;   // unit-major (XCD balance, see K3)
     const BlkEmit job = jobs[bidx];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1690,6 +1751,15 @@ __global__ __launch_bounds__(M2_SYM_THREADS) void blk_materialize2_sym_kernel(co
                                                                           uint16_t *__restrict__ sym, uint32_t njobs) {
     materialize2_body<true, M2_SYM_THREADS>(in, jobs, units, codes, sym, njobs, nullptr);
 }
+// the same on 1024 lanes, one unit per CU (103 KB of LDS): for a stream whose units do not fill the GPU anyway — a unit's
+// own time is what counts then, and a tile of 1024 codes pays the per-tile latencies once for four times the codes
+__global__ __launch_bounds__(M2_WIDE_THREADS) void blk_materialize2_sym_wide_kernel(const uint8_t *__restrict__ in,
+                                                                                const BlkEmit *__restrict__ jobs,
+                                                                                const BlkUnits *__restrict__ units,
+                                                                                const uint32_t *__restrict__ codes,
+                                                                                uint16_t *__restrict__ sym, uint32_t njobs) {
+    materialize2_body<true, M2_WIDE_THREADS, true>(in, jobs, units, codes, sym, njobs, nullptr);
+}
 
 // ------------------------------------------------------------------------------------------------
 #define LFX_LAUNCH_CHECK()                          \
@@ -1739,9 +1809,20 @@ int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *job
     return 0;
 }
 int launch_blk_materialize_sym(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
-                               const BlkUnits *units, const uint32_t *codes, uint16_t *sym) {
+                               const BlkUnits *units, const uint32_t *codes, uint16_t *sym, bool few_units) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_materialize2_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_SYM_THREADS), 0, st, in, jobs, units, codes, sym, njobs);
+    if (few_units) {
+        constexpr int lds = (int)M2Lds<true, M2_WIDE_THREADS>::BYTES;
+        static bool attr_set[64] = {};
+        int dev_ = 0;
+        (void)hipGetDevice(&dev_);
+        if (!attr_set[dev_ & 63]) {
+            (void)hipFuncSetAttribute((const void *)blk_materialize2_sym_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set[dev_ & 63] = true;
+        }
+        hipLaunchKernelGGL(blk_materialize2_sym_wide_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_WIDE_THREADS), lds, st, in, jobs, units, codes, sym, njobs);
+    } else
+        hipLaunchKernelGGL(blk_materialize2_sym_kernel, dim3(njobs * MAX_FREE_UNITS), dim3(M2_SYM_THREADS), 0, st, in, jobs, units, codes, sym, njobs);
     LFX_LAUNCH_CHECK();
     return 0;
 }
