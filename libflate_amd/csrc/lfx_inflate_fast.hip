@@ -1178,7 +1178,18 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
         }
         produced = upto;
         tr = m2_wrap<RING>(tr + total);
-        c_cur = take == THREADS ? c_pref : ((uint64_t)base + tid < n ? cp[base + tid] : 0);   // rare path: reload
+        if (take == THREADS) c_cur = c_pref;
+        else {
+            // Only some of the tile's codes were taken (data made of long matches: 1536 bytes are six codes of 258).  The
+            // window of codes moves by `take`: its tail is still in XC, the head of the prefetched codes follows it — through
+            // LDS (P is dead between tiles).  Round 4: a reload from global memory stood here, one exposed round trip per
+            // tile; cfg5's 1 GiB of LOWENT took 7.9 ms in this kernel.
+            uint32_t *scratch = (uint32_t *)P;
+            scratch[tid] = c_pref;
+            __syncthreads();
+            const uint32_t j = tid + take;
+            c_cur = j < THREADS ? XC[j].y : scratch[j - THREADS];
+        }
     }
     if (!SYM && dbg && tid == 0) {
         uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
