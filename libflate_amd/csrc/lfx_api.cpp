@@ -232,6 +232,7 @@ void Diag::read() {
     no_final_cand = on("LFX_NO_FINAL_CAND");
     window_chain = on("LFX_WINDOW_CHAIN");
     if (const char *fs = getenv("LFX_FREE_SHIFT")) free_shift = atoi(fs);
+    if (const char *pm = getenv("LFX_POCR_MAX")) pocr_max = atoi(pm);
 }
 
 void Ctx::phase(const char *name) {

@@ -205,6 +205,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             uint64_t last_end = 0;   // end bit of the last block of the chain
             bool pieces_mode = false;
             bool pieces_multi = false;   // some block was scanned in more than one piece (its pieces read each other's output)
+            bool units_per_piece = false; // (pieces over candidate ranges that fill the GPU: one symbol unit per piece)
             const size_t tab_bytes = blk_tabs_bytes();
             // ---- few candidates in a long stream = few, huge blocks (schedule S1: ONE block for the whole input).
             // One workgroup per block would scan it alone; instead the block is scanned in PIECES of 4 Mbit, one
@@ -225,11 +226,15 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // (Measured, profiles/r04_small_sizes.json: 16 MiB 2.25 -> 1.75 ms; at 64 blocks the marker path's fixed costs — window
             //  resolution 0.6 ms, symbol units — outweigh what K1 / K2 gain: 2.87 against 2.40 ms.  Hence up to 32 candidates.)
             const bool giant_blocks = nc <= 8 && comp / nc >= (2u << 20);     // (schedule S1: the block-by-block piece walk below)
-            if (!small_first && !giant_blocks && nc >= 2 && nc <= 32 && comp / nc >= (128u << 10) && stop_bit == ~0ull &&
+            if (!small_first && !giant_blocks && nc >= 2 && nc <= (uint32_t)c->diag.pocr_max && comp / nc >= (128u << 10) && stop_bit == ~0ull &&
                 !partial && !c->diag.no_pieces) {
                 const uint64_t end_bits = n * 8;
+                // two pieces per CU over the whole stream, every block split EVENLY (a block of 4.7 Mbit in pieces of 4 Mbit is
+                // a long piece and a short one: the symbol kernel's time is that of its largest unit) — the blocks' rounding
+                // taken off the target, so that the pieces, one symbol unit each, are all resident at once
+                const uint64_t ptarget = (uint64_t)std::max<int64_t>(2ll * std::max(c->n_cu, 1) - (int64_t)nc, (int64_t)nc);
                 const uint64_t PIECE_BITS = std::min<uint64_t>(4ull << 20, std::max<uint64_t>(256ull << 10,
-                                            ((end_bits - first_bit) / (2ull * (uint64_t)std::max(c->n_cu, 1)) + 63) & ~63ull));
+                                            ((end_bits - first_bit) / ptarget + 63) & ~63ull));
                 // warm-up in front of a piece: ONE lane decodes it, 0.2 us per symbol on an otherwise idle CU — 8 Kbit are 550
                 // symbols, 115 us, most of a small stream's scan step (round 4, profiles/r04_small_sizes.json).  A speculative
                 // decode is in step within a few dozen symbols; small pieces get 2 Kbit.  (A piece whose warm-up did not get in
@@ -239,15 +244,18 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 std::vector<uint32_t> first_piece(nc + 1, 0);
                 for (uint32_t i = 0; i < nc; i++) {
                     first_piece[i] = (uint32_t)pj.size();
-                    const uint64_t s0 = starts[i], s1 = start_at(i + 1);
-                    const uint32_t np = (uint32_t)std::max<uint64_t>((s1 - s0 + PIECE_BITS - 1) / PIECE_BITS, 1);
+                    const uint64_t s0 = starts[i], s1 = start_at(i + 1), len = s1 - s0;
+                    const uint64_t np0 = std::max<uint64_t>((len + PIECE_BITS - 1) / PIECE_BITS, 1);
+                    const uint64_t pb = std::max<uint64_t>(((len + np0 - 1) / np0 + 63) & ~63ull, 64);     // this block's piece
+                    const uint32_t np = (uint32_t)std::max<uint64_t>((len + pb - 1) / pb, 1);
                     for (uint32_t q = 0; q < np; q++) {
-                        const uint64_t lo = s0 + q * PIECE_BITS;
-                        pj.push_back(BlkJob{s0, std::min(lo + PIECE_BITS, s1), q ? lo : 0, q ? lo - OVERLAP : 0, 1u, 0u});
+                        const uint64_t lo = s0 + q * pb;
+                        pj.push_back(BlkJob{s0, std::min(lo + pb, s1), q ? lo : 0, q ? lo - OVERLAP : 0, 1u, 0u});
                     }
                 }
                 first_piece[nc] = (uint32_t)pj.size();
                 const uint32_t npj = (uint32_t)pj.size();
+                units_per_piece = npj >= (uint32_t)std::max(c->n_cu, 1);
                 int rc2;
                 if ((rc2 = c->d_dec_streams.reserve(sizeof(BlkJob) * npj))) return rc2;
                 if ((rc2 = c->d_dec_state.reserve(sizeof(BlkInfo) * npj))) return rc2;
@@ -288,7 +296,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 }
                 if (c->diag.debug) fprintf(stderr, "[lfx]  pieces over %u candidate ranges: ok=%d fail=%d pieces=%zu of %u total=%llu\n", nc, (int)ok_chain, (int)fail,
                                            emit.size(), npj, (unsigned long long)total);
-                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; chain_final = false; last_end = 0; pieces_multi = false; }
+                if (fail || !ok_chain) { emit.clear(); pos = first_bit; total = 0; total_codes = 0; ok_chain = false; chain_final = false; last_end = 0; pieces_multi = false; units_per_piece = false; }
                 else pieces_mode = true;
                 c->phase("pieces");
             }
@@ -528,6 +536,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 // 0.59 + 0.64 ms for window resolution + substitution)
                 uint32_t free_shift = 15;
                 while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
+                if (pieces_mode && units_per_piece) free_shift = 20;
                 if (c->diag.free_shift >= 0) free_shift = (uint32_t)c->diag.free_shift;
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                            (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
