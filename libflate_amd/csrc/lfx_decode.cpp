@@ -242,25 +242,33 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 const uint64_t OVERLAP = PIECE_BITS <= (1ull << 20) ? 2048 : 8192;
                 std::vector<BlkJob> pj;
                 std::vector<uint32_t> first_piece(nc + 1, 0);
-                for (uint32_t i = 0; i < nc; i++) {
-                    first_piece[i] = (uint32_t)pj.size();
-                    const uint64_t s0 = starts[i], s1 = start_at(i + 1), len = s1 - s0;
+                // the pieces of one range [s0, s1), scanned with the tables of the block whose header is at s0
+                auto add_pieces = [&](std::vector<BlkJob> &jobs, uint64_t s0, uint64_t s1) {
+                    const uint64_t len = s1 - s0;
                     const uint64_t np0 = std::max<uint64_t>((len + PIECE_BITS - 1) / PIECE_BITS, 1);
                     const uint64_t pb = std::max<uint64_t>(((len + np0 - 1) / np0 + 63) & ~63ull, 64);     // this block's piece
                     const uint32_t np = (uint32_t)std::max<uint64_t>((len + pb - 1) / pb, 1);
                     for (uint32_t q = 0; q < np; q++) {
                         const uint64_t lo = s0 + q * pb;
-                        pj.push_back(BlkJob{s0, std::min(lo + pb, s1), q ? lo : 0, q ? lo - OVERLAP : 0, 1u, 0u});
+                        jobs.push_back(BlkJob{s0, std::min(lo + pb, s1), q ? lo : 0, q ? lo - OVERLAP : 0, 1u, 0u});
                     }
+                };
+                for (uint32_t i = 0; i < nc; i++) {
+                    first_piece[i] = (uint32_t)pj.size();
+                    add_pieces(pj, starts[i], start_at(i + 1));
                 }
                 first_piece[nc] = (uint32_t)pj.size();
                 const uint32_t npj = (uint32_t)pj.size();
                 units_per_piece = npj >= (uint32_t)std::max(c->n_cu, 1);
+                // (+ slots for the repair launches below: a range cut in two by a false candidate is scanned again as one)
+                constexpr uint32_t REPAIRS = 2;
+                const uint32_t repair_slots = REPAIRS * (2 * (uint32_t)((end_bits - first_bit) / nc / PIECE_BITS + 2) + 4);
+                const uint32_t nslots = npj + repair_slots;
                 int rc2;
-                if ((rc2 = c->d_dec_streams.reserve(sizeof(BlkJob) * npj))) return rc2;
-                if ((rc2 = c->d_dec_state.reserve(sizeof(BlkInfo) * npj))) return rc2;
-                if ((rc2 = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)npj))) return rc2;
-                if ((rc2 = c->d_dec_tabs.reserve(tab_bytes * npj))) return rc2;
+                if ((rc2 = c->d_dec_streams.reserve(sizeof(BlkJob) * nslots))) return rc2;
+                if ((rc2 = c->d_dec_state.reserve(sizeof(BlkInfo) * nslots))) return rc2;
+                if ((rc2 = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)nslots))) return rc2;
+                if ((rc2 = c->d_dec_tabs.reserve(tab_bytes * nslots))) return rc2;
                 HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, pj.data(), sizeof(BlkJob) * npj, hipMemcpyHostToDevice, st));
                 LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, npj, (BlkInfo *)c->d_dec_state.p,
                                            (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
@@ -268,17 +276,16 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 HIP_TRY(hipMemcpyAsync(pi.data(), c->d_dec_state.p, sizeof(BlkInfo) * npj, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 bool fail = false;
-                for (uint32_t i = 0; i < nc && !fail && !ok_chain; i++) {
-                    if (starts[i] != pos) { fail = true; break; }             // (the chain must pass through every candidate)
-                    bool closed = false;
+                // the pieces of one range in order → emit entries.  0: the block closed (pos / ok_chain updated); 1: every piece is
+                // open (no EndOfBlock in the range); 2: damaged, or the pieces do not chain
+                auto walk_range = [&](const BlkInfo *infos, uint32_t cnt, uint32_t slot0) -> int {
                     uint64_t prev_end = 0;
-                    for (uint32_t k = first_piece[i]; k < first_piece[i + 1] && !closed; k++) {
-                        const BlkInfo &r = pi[k];
-                        const uint32_t q = k - first_piece[i];
-                        if (r.status == BLK_BAD || r.btype == 0 || (q && r.data_bit != prev_end) || r.end_bit <= pos || r.end_bit > end_bits) { fail = true; break; }
+                    for (uint32_t q = 0; q < cnt; q++) {
+                        const BlkInfo &r = infos[q];
+                        if (r.status == BLK_BAD || r.btype == 0 || (q && r.data_bit != prev_end) || r.end_bit <= pos || r.end_bit > end_bits) return 2;
                         BlkEmit e{};
                         e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
-                        e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
+                        e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = slot0 + q;
                         e.hist = hist + total;
                         e.end_limit = r.status == BLK_NO_EOB ? r.end_bit : 0;
                         emit.push_back(e);
@@ -286,13 +293,43 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                         total_codes += r.n_codes;
                         prev_end = r.end_bit;
                         if (r.status == BLK_OK) {
-                            closed = true;
                             last_end = r.end_bit;
                             pieces_multi |= q > 0;
                             if (r.bfinal) { ok_chain = true; chain_final = true; } else pos = r.end_bit;
+                            return 0;
                         }
                     }
-                    if (!closed) fail = true;
+                    return 1;
+                };
+                uint32_t repairs = 0, rslot = npj;
+                for (uint32_t i = 0; i < nc && !fail && !ok_chain; i++) {
+                    if (starts[i] != pos) { fail = true; break; }             // (the chain must pass through every candidate)
+                    const size_t emit_mark = emit.size();
+                    const uint64_t total_mark = total, codes_mark = total_codes;
+                    int res = walk_range(&pi[first_piece[i]], first_piece[i + 1] - first_piece[i], first_piece[i]);
+                    if (res == 1 && i + 1 < nc && repairs < REPAIRS) {
+                        // No EndOfBlock up to the next candidate: that candidate is a false one inside this block (about one
+                        // per 30 MB of stream survives the finder), and the pieces behind it were scanned with tables read from
+                        // data.  The block's true range — up to the candidate after it — is scanned again, alone.
+                        emit.resize(emit_mark); total = total_mark; total_codes = codes_mark;
+                        std::vector<BlkJob> rj;
+                        add_pieces(rj, starts[i], start_at(i + 2));
+                        const uint32_t nr = (uint32_t)rj.size();
+                        if (rslot + nr > nslots) { fail = true; break; }
+                        HIP_TRY(hipMemcpyAsync((BlkJob *)c->d_dec_streams.p + rslot, rj.data(), sizeof(BlkJob) * nr, hipMemcpyHostToDevice, st));
+                        LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p + rslot, nr, (BlkInfo *)c->d_dec_state.p + rslot,
+                                                   (BlkLanes *)c->d_dec_blocks.p + rslot, (uint8_t *)c->d_dec_tabs.p + tab_bytes * rslot));
+                        std::vector<BlkInfo> ri(nr);
+                        HIP_TRY(hipMemcpyAsync(ri.data(), (BlkInfo *)c->d_dec_state.p + rslot, sizeof(BlkInfo) * nr, hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
+                        res = walk_range(ri.data(), nr, rslot);
+                        if (c->diag.debug) fprintf(stderr, "[lfx]  pieces: candidate %u (bit %llu) is a false one, its block scanned again in %u pieces: %d\n", i + 1,
+                                                   (unsigned long long)starts[i + 1], nr, res);
+                        rslot += nr;
+                        repairs++;
+                        i++;                      // (the false candidate is not a block)
+                    }
+                    if (res != 0) fail = true;
                 }
                 if (c->diag.debug) fprintf(stderr, "[lfx]  pieces over %u candidate ranges: ok=%d fail=%d pieces=%zu of %u total=%llu\n", nc, (int)ok_chain, (int)fail,
                                            emit.size(), npj, (unsigned long long)total);

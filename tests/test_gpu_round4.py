@@ -264,6 +264,31 @@ def test_mid_size_members_scanned_in_pieces(env, oracle):
         assert got[1] == want[1], (name, len(got[1]), len(want[1]))
 
 
+def test_pieces_survive_a_false_candidate(env):
+    """About one bit offset per 30 MB of stream passes the block finder without being a block start.  The 48 MiB text of
+    the synthetic corpus holds one (measured, round 4): the candidate range it cuts in two has no EndOfBlock, and the pieces
+    behind it were scanned with tables read from data — the range is scanned again as one and the member still takes the piece
+    path (phases: `pieces`, no `blk_scan`).  Sizes on both sides of it for comparison; all of them byte-exact."""
+    import torch
+    lfx, ctx, ffi, synth = env
+    for mib in (40, 48, 56):
+        data = synth.text(mib << 20)
+        d_in = torch.from_numpy(data).cuda()
+        opts, sched = ffi.make_opts(mtime=0), ffi.make_schedule(8192)
+        import ctypes as C
+        bound = ffi.lib().lfx_encode_bound(data.size, C.byref(opts), C.byref(sched))
+        d_out = torch.empty(bound, dtype=torch.uint8, device="cuda")
+        m = ctx.encode_device(ffi.GZIP, d_in.data_ptr(), data.size, d_out.data_ptr(), bound, opts, sched)
+        d_dec = torch.zeros(data.size, dtype=torch.uint8, device="cuda")
+        ctx.enable_timing(True)
+        rc, ol, used, msg = ctx.decode_device(ffi.GZIP, d_out.data_ptr(), m, d_dec.data_ptr(), data.size)
+        phases = [k for k, _ in (ctx.last_timing() or {"phases": []})["phases"]]
+        ctx.enable_timing(False)
+        assert rc == 0 and ol == data.size and used == m, (mib, rc, msg)
+        assert torch.equal(d_dec, d_in), mib
+        assert "pieces" in phases and "blk_scan" not in phases, (mib, phases)
+
+
 def test_with_lz77_foreign_encoder_many_codes(env, oracle):
     """More than ENC_BATCH_CODES (2 Mi) code words between two flushes: closed blocks leave the encoder in batches while later
     ones are still being collected (the carry of a partial last byte, the running checksum across batches)."""
