@@ -32,7 +32,7 @@ struct Diag {
     bool no_final_cand = false;  // LFX_NO_FINAL_CAND: the finder reports no BFINAL header at all (the chain walk scans the last block on demand)
     bool window_chain = false;   // LFX_WINDOW_CHAIN
     int free_shift = -1;         // LFX_FREE_SHIFT
-    int pocr_max = 80;           // LFX_POCR_MAX: most candidate ranges the decoder scans in pieces at once
+    int pocr_max = 100;          // LFX_POCR_MAX: most candidate ranges the decoder scans in pieces at once
     void read();
 };
 

@@ -24,7 +24,7 @@ rm -rf $O/pmc_r4_lat
 timeout 300 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_VMEM SQ_INSTS_LDS SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_r4_lat -- python $R/bench.py --child --steps 1 --warmup 0 > $O/pmc_r4_lat.log 2>&1
 python $R/tools/pmc_summary.py $O/pmc_r4_lat 2>/dev/null | grep -v "at::native" > $O/r4_pmc_latency.csv; rm -rf $O/pmc_r4_lat; wc -l $O/r4_pmc_latency.csv
 cd $R
-timeout 300 python tools/bench_small.py 8192 65536 262144 1048576 4194304 16777216 67108864 > $O/r4_small.json 2>/dev/null; cut -c1-300 $O/r4_small.json
+timeout 300 python tools/bench_small.py 8192 65536 262144 1048576 4194304 16777216 33554432 67108864 100663296 134217728 > $O/r4_small.json 2>/dev/null; cut -c1-300 $O/r4_small.json
 timeout 300 python bench.py --schedule S1 --no-traffic --no-cpu-baseline --no-s1 --no-subs --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/r4_bench_s1.json; cut -c1-200 $O/r4_bench_s1.json
 LFX_DEBUG=1 timeout 120 python tools/bench_small.py 1048576 2>&1 >/dev/null | grep 'huffman block 0' | tail -1 > $O/r4_huffman_stamps.txt; cat $O/r4_huffman_stamps.txt
 timeout 300 python tools/exp/cfg5_run.py > $O/r4_cfg5.json 2>/dev/null; cut -c1-200 $O/r4_cfg5.json
