@@ -5,7 +5,8 @@ oracle's byte for byte (DefaultLz77Encoder::flush default.rs:69-109 … Encoder:
 returns the input for our stream AND for a python-zlib stream of the same bytes (foreign block structure, back-references
 across blocks: decode.rs:112-164, lib.rs:149-242).
 
-LFX_FUZZ=<n> sets the number of cases (default 24: about ten seconds; the round's soak ran 300, profiles/r04_soak.txt)."""
+LFX_FUZZ=<n> sets the number of cases (default 24: a few seconds), LFX_FUZZ_SEED the seed, LFX_FUZZ_MINLOG2 / LFX_FUZZ_MAXLOG2 the
+size range (default 6 … 23).  The round's soaks: profiles/r04_fuzz.txt."""
 import ctypes as C
 import os
 import sys
@@ -54,9 +55,10 @@ def test_random_round_trips(env, oracle):
     cases = int(os.environ.get("LFX_FUZZ", "24"))
     rng = np.random.default_rng(int(os.environ.get("LFX_FUZZ_SEED", "20260927")))
     fmts = ((ffi.GZIP, oracle.GZIP, 31), (ffi.ZLIB, oracle.ZLIB, 15), (ffi.DEFLATE, oracle.DEFLATE, -15))
+    lo2, hi2 = float(os.environ.get("LFX_FUZZ_MINLOG2", "6")), float(os.environ.get("LFX_FUZZ_MAXLOG2", "23"))
     for case in range(cases):
-        n = int(2 ** rng.uniform(6, 23))                      # 64 B … 8 MiB, log-uniform
-        if case % 8 == 7:
+        n = int(2 ** rng.uniform(lo2, hi2))                   # 64 B … 8 MiB, log-uniform
+        if case % 8 == 7 and hi2 <= 23:
             n = int(rng.choice([4096, 32768, 65536, 262144, 1 << 20, (1 << 20) + 1, 3 << 20]))   # the path boundaries themselves
         data = _data(rng, synth, n, int(rng.integers(0, 5)))
         fmt, ofmt, wbits = fmts[int(rng.integers(0, 3))]
@@ -76,7 +78,7 @@ def test_random_round_trips(env, oracle):
         assert rc == 0 and ol == n and used == m, ("decode own", case, n, rc, msg)
         assert d_dec[:n].cpu().numpy().tobytes() == data, ("decode own: bytes", case, n)
         # the same bytes from zlib (levels 1 / 6 / 9: different block sizes and match policies)
-        co = zlib.compressobj(int(rng.choice([1, 6, 9])), zlib.DEFLATED, wbits)
+        co = zlib.compressobj(int(rng.choice([1, 6, 9] if n <= (16 << 20) else [1, 6])), zlib.DEFLATED, wbits)
         foreign = co.compress(data) + co.flush()
         d_f = torch.from_numpy(np.frombuffer(foreign, dtype=np.uint8).copy()).cuda()
         d_dec.zero_()
