@@ -159,6 +159,32 @@ def test_huffman_vs_oracle(ffi, oracle):
             hist[288 + rng.permutation(30)[:nd]] = rng.integers(1, 5000, nd) if kind != 1 else \
                 np.array([int(1.9 ** i) for i in range(nd)], dtype=np.uint32)
         cases.append(hist)
+    # (round 4) frequencies of 2^23 and more take the rank sort's pair compare instead of the single 32-bit key; Fibonacci
+    # weights and powers of two make the deepest trees and the longest runs of equal weights in the depth merge's queue
+    for trial in range(60):
+        hist = np.zeros(320, np.uint32)
+        nlit = int(rng.integers(2, 286))
+        idx = rng.permutation(286)[:nlit]
+        kind = trial % 5
+        if kind == 0:
+            hist[idx] = rng.integers(1 << 22, 1 << 25, nlit)
+        elif kind == 1:
+            hist[idx] = rng.integers(1, 3, nlit)
+            hist[idx[0]] = 1 << 24
+        elif kind == 2:
+            v = [1, 1]
+            while len(v) < nlit:
+                v.append((v[-1] + v[-2]) % (1 << 31) or 1)
+            hist[idx] = np.array(v[:nlit], dtype=np.uint64)
+        elif kind == 3:
+            hist[idx] = 2 ** rng.integers(0, 6, nlit)
+        else:
+            hist[idx] = np.minimum(rng.geometric(0.3, nlit), 255)
+        hist[256] = max(1, int(hist[256]))
+        nd = int(rng.integers(0, 31))
+        if nd:
+            hist[288 + rng.permutation(30)[:nd]] = rng.integers(1, 4, nd) if kind >= 3 else rng.integers(1, 1 << 26, nd)
+        cases.append(hist)
     e = np.zeros(320, np.uint32); e[256] = 1
     cases.append(e)   # the empty final block
     for hist in cases:
