@@ -326,9 +326,12 @@ struct HdrWriter {
 
 constexpr int CLEN_ORDER_N = 19;
 LFX_HD inline int clen_order(int k) {
-    // BITWIDTH_CODE_ORDER symbol.rs:16-18
-    const uint8_t o[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    return o[k];
+    // BITWIDTH_CODE_ORDER symbol.rs:16-18 — 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 — five bits per entry in two
+    // constants: a local array is a table in global memory on the device, one dependent load per call (tools/isa_scan.py)
+    const uint64_t lo = 16ull | 17ull << 5 | 18ull << 10 | 0ull << 15 | 8ull << 20 | 7ull << 25 | 9ull << 30 | 6ull << 35 |
+                        10ull << 40 | 5ull << 45 | 11ull << 50 | 4ull << 55;
+    const uint64_t hi = 12ull | 3ull << 5 | 13ull << 10 | 2ull << 15 | 14ull << 20 | 1ull << 25 | 15ull << 30;
+    return (int)((k < 12 ? lo >> (5 * k) : hi >> (5 * (k - 12))) & 31);
 }
 
 // Whole per-block Huffman stage.  hist[0..286) literal/length counts (EOB included),
