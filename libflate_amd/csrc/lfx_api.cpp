@@ -224,7 +224,7 @@ void Diag::read() {
     auto on = [](const char *k) { return getenv(k) != nullptr; };
     debug = on("LFX_DEBUG");
     match_v1 = on("LFX_MATCH_V1");
-    match_v3 = on("LFX_MATCH_V3");
+    match_v5 = on("LFX_MATCH_V5");
     no_serial = on("LFX_NO_SERIAL");
     batch_serial = on("LFX_BATCH_SERIAL");
     no_markers = on("LFX_NO_MARKERS");
@@ -404,7 +404,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
     if ((rc = c->d_pwgs.reserve(sizeof(ParseWg) * std::max<size_t>(pwgs.size(), 1)))) return rc;
     if (!hc && (rc = c->d_cd.reserve(2 * n + 64))) return rc;                   // candidate distances, 16 bits per position
-    if (!hc && !match_v1 && !c->diag.match_v3 && (rc = c->d_glnk.reserve(128 * std::max<uint64_t>(lnk_units, 1)))) return rc;
+    if (!hc && !match_v1 && (rc = c->d_glnk.reserve(128 * std::max<uint64_t>(lnk_units, 1)))) return rc;
     if (!hc && match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
@@ -472,9 +472,9 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
         LAUNCH_TRY(launch_md_to_cd(st, (const uint32_t *)c->d_md.p, n, d_cd));
     } else {
-        if (c->diag.match_v3)
-            LAUNCH_TRY(launch_match3(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                     (uint32_t)segs.size(), po.window_size, d_cd, d_match_flags, mdbg));
+        if (!c->diag.match_v5)
+            LAUNCH_TRY(launch_match7(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
+                                     (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, d_match_flags, mdbg));
         else
             LAUNCH_TRY(launch_match5(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                                      (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, d_match_flags, mdbg));
@@ -482,24 +482,27 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if (mdbg) {
         uint64_t hv[256];
         (void)hipMemcpy(hv, mdbg, sizeof hv, hipMemcpyDeviceToHost);
-        if (!match_v1) {
-            uint64_t t[6] = {0, 0, 0, 0, 0, 0};
-            for (int w = 1; w < 16; w++) for (int k = 0; k < 6; k++) t[k] += hv[128 + w * 8 + k];
-            fprintf(stderr, "[lfx] match3 workgroup 0: positions whose chain walk took more than 2/4/8/12/16 hops in the loop, handed over to wave 0 (match5): %llu %llu %llu %llu %llu %llu of %llu\n",
-                    (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2], (unsigned long long)t[3], (unsigned long long)t[4],
-                    (unsigned long long)t[5], (unsigned long long)hv[5] * 960ull);
+        const bool v5 = !match_v1 && c->diag.match_v5, v7 = !match_v1 && !c->diag.match_v5;
+        if (v7) {
+            // lfx_match7: wave 0 = exchange on head, wave 1 = exchange on second, waves 2..15 = helpers
+            for (int w = 0; w < 16; w++)
+                fprintf(stderr, "[lfx] match7 wave%d: work=%llu barrier-wait=%llu tiles=%llu\n", w, (unsigned long long)hv[w * 8],
+                        (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 5]);
+        } else {
+            for (int w = 0; w < 16; w++)
+                fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "5", w,
+                        match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
+                        (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
         }
-        for (int w = 0; w < 16; w++)
-            fprintf(stderr, "[lfx] match%s wave%d: %s=%llu %s=%llu wait=%llu tiles=%llu\n", match_v1 ? "1" : "3", w,
-                    match_v1 ? "load" : "phaseA", (unsigned long long)hv[w * 8], match_v1 ? "work" : "phaseB",
-                    (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 5]);
-        if (!match_v1 && !c->diag.match_v3)
-            fprintf(stderr, "[lfx] match5 wave0: %llu cycles waiting for the loads of the walks it holds (of phaseA)\n", (unsigned long long)hv[6]);
-        if (!match_v1)
+        if (v5) {
+            uint64_t handed = 0;
+            for (int w = 1; w < 16; w++) handed += hv[128 + w * 8 + 5];
+            fprintf(stderr, "[lfx] match5 workgroup 0: %llu walks handed over to wave 0 of %llu positions; wave 0 waited %llu cycles for their loads\n",
+                    (unsigned long long)handed, (unsigned long long)hv[5] * 960ull, (unsigned long long)hv[6]);
             for (int w = 1; w < 16; w++)
-                fprintf(stderr, "[lfx] match3 wave%d loop trips: sum=%u max=%u tiles>4=%u tiles>8=%u trips-without-pointers=%u trips-with<=4-lanes=%u\n", w,
-                        (unsigned)hv[w * 8 + 3], (unsigned)(hv[w * 8 + 3] >> 32), (unsigned)hv[w * 8 + 4], (unsigned)(hv[w * 8 + 4] >> 32),
-                        (unsigned)hv[w * 8 + 6], (unsigned)hv[w * 8 + 7]);
+                fprintf(stderr, "[lfx] match5 wave%d loop trips: sum=%u max=%u tiles>4=%u tiles>8=%u\n", w, (unsigned)hv[w * 8 + 3],
+                        (unsigned)(hv[w * 8 + 3] >> 32), (unsigned)hv[w * 8 + 4], (unsigned)(hv[w * 8 + 4] >> 32));
+        }
     }
     c->phase("lz77_match");
     if (c->diag.debug && getenv("LFX_DUMP_SEG")) {

@@ -24,7 +24,7 @@ struct DevBuf {
 struct Diag {
     bool debug = false;          // LFX_DEBUG: per-stage counters and cycle stamps on stderr
     bool match_v1 = false;       // LFX_MATCH_V1: first-generation match kernel (+ md → cd)
-    bool match_v3 = false;       // LFX_MATCH_V3: lfx_match3.hip (round 3: every chain walk inside the tile loop)
+    bool match_v5 = false;       // LFX_MATCH_V5: lfx_match5.hip (round 4: hash heads, window ring, link ring)
     bool no_serial = false;      // LFX_NO_SERIAL: the serial fallback of the single-stream decoder is an error
     bool batch_serial = false;   // LFX_BATCH_SERIAL: every stream of a batch through the serial kernel
     bool no_markers = false;     // LFX_NO_MARKERS

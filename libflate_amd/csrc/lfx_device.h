@@ -13,7 +13,7 @@ struct SegDesc {
     uint32_t chunk;
     uint32_t start;
     uint32_t len;
-    uint32_t lnk_base;   // lfx_match5: first entry of the segment's private link region, in units of 64 entries (128 bytes)
+    uint32_t lnk_base;   // lfx_match7 / lfx_match5: first entry of the segment's private link region, in units of 64 entries (128 bytes)
 };
 constexpr uint32_t SEG_POSITIONS = 256 * 1024;
 
@@ -42,12 +42,14 @@ struct ParseWg {
 int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks,
                  const SegDesc *segs, uint32_t nsegs, uint32_t window, uint32_t max_len, uint32_t *md,
                  uint64_t *dbg = nullptr);
-// candidate stage (lfx_match3.hip): per position the distance to the most recent earlier occurrence of its 3-byte prefix
-// (0 = none) → cd.  flags[0] |= 1 on a lane-order violation.
-int launch_match3(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *flags, uint64_t *dbg = nullptr);
-// the same stage with its deep chain walks handed over to wave 0 (lfx_match5.hip, round 4): the default.
-// glnk: scratch for the final link of every position of every segment (warm-up included), regions by SegDesc::lnk_base
+// candidate stage: per position the distance to the most recent earlier occurrence of its 3-byte prefix (0 = none) → cd.
+// flags[0] |= 1 on a lane-order violation.
+// lfx_match7.hip (round 5, the default): two-level bucket LRU with exact tags + the resolver kernel for the few positions
+// it leaves open.  glnk: scratch for the duplicate-collapsed link of every position of every segment (warm-up included),
+// regions by SegDesc::lnk_base
+int launch_match7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg = nullptr);
+// lfx_match5.hip (round 4; LFX_MATCH_V5=1): hash heads + window ring + link ring, deep chain walks handed over to wave 0
 int launch_match5(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg = nullptr);
 // the first-generation kernel's answers (length << 16 | distance) → cd
