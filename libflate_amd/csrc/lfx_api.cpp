@@ -404,7 +404,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
     if ((rc = c->d_pwgs.reserve(sizeof(ParseWg) * std::max<size_t>(pwgs.size(), 1)))) return rc;
     if (!hc && (rc = c->d_cd.reserve(2 * n + 64))) return rc;                   // candidate distances, 16 bits per position
-    if (!hc && !match_v1 && (rc = c->d_glnk.reserve(128 * std::max<uint64_t>(lnk_units, 1)))) return rc;
+    if (!hc && !match_v1 && (rc = c->d_glnk.reserve(136 * std::max<uint64_t>(lnk_units, 1)))) return rc;   // links (2 bytes) + lfx_match7's ballot words (8 bytes per 64)
+    if (!hc && !match_v1 && (rc = c->d_ucount.reserve(4 * std::max<size_t>(segs.size(), 1)))) return rc;   // lfx_match7: unresolved positions per segment
     if (!hc && match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
     if ((rc = c->d_ncodes.reserve(4 * std::max<size_t>(nchunks, 1)))) return rc;
@@ -474,7 +475,9 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     } else {
         if (!c->diag.match_v5)
             LAUNCH_TRY(launch_match7(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                     (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, d_match_flags, mdbg));
+                                     (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p,
+                                     (uint64_t *)((uint8_t *)c->d_glnk.p + 128 * std::max<uint64_t>(lnk_units, 1)), (uint32_t *)c->d_stage.p,
+                                     (uint32_t *)c->d_ucount.p, d_match_flags, mdbg));
         else
             LAUNCH_TRY(launch_match5(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                                      (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, d_match_flags, mdbg));

@@ -65,7 +65,7 @@ struct Ctx {
 
     // encode scratch
     DevBuf d_chunks, d_blocks, d_segs, d_pwgs, d_cd, d_md, d_codes, d_ncodes, d_hist, d_bc, d_block_start, d_tile_bits,
-        d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage, d_chunkmap, d_glnk;
+        d_tile_start, d_ck, d_res, d_small, d_hdr, d_io_in, d_io_out, d_vis, d_segtmp, d_stage, d_chunkmap, d_glnk, d_ucount;
     // decode scratch
     // host shadows of the plan tables last uploaded (chunks, blocks, segments, parse workgroups) and the device buffers they
     // went to: an encode with the same plan (same size, schedule and options — every step of a loop) uploads nothing, and a
@@ -75,7 +75,7 @@ struct Ctx {
     DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks, d_dec_tabs, d_dec_sym, d_dec_win, d_dec_maps;
     std::vector<DevBuf *> all_bufs() {
         return {&d_chunks, &d_blocks, &d_segs, &d_pwgs, &d_cd, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
-                &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage, &d_chunkmap, &d_glnk,
+                &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage, &d_chunkmap, &d_glnk, &d_ucount,
                 &d_dec_streams, &d_dec_state, &d_dec_tmp, &d_dec_cand, &d_dec_blocks, &d_dec_tabs, &d_dec_sym, &d_dec_win, &d_dec_maps};
     }
     void *h_res = nullptr;  // pinned, 4 KiB

@@ -48,7 +48,9 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
 // it leaves open.  glnk: scratch for the duplicate-collapsed link of every position of every segment (warm-up included),
 // regions by SegDesc::lnk_base
 int launch_match7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg = nullptr);
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint64_t *umask /* 8 bytes per 64 link entries */,
+                  uint32_t *ulist /* 4 bytes per input byte */, uint32_t *ucount /* 4 bytes per segment */, uint32_t *flags,
+                  uint64_t *dbg = nullptr);
 // lfx_match5.hip (round 4; LFX_MATCH_V5=1): hash heads + window ring + link ring, deep chain walks handed over to wave 0
 int launch_match5(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg = nullptr);

@@ -21,19 +21,28 @@
 // Both exchanges are ordered LDS read-modify-writes (ds_wrxchg_rtn_b32 / ds_mskor_rtn_b32: lanes of one instruction that hit
 // the same dword are served in ascending lane order, a wavefront's instructions in issue order — measured,
 // tools/exp/lds_lru.hip and tools/exp/mskor_test.hip, and checked at run time: a lane that receives a position from its own
-// future raises flags[0] and the host falls back to the first-generation kernel).  So wave 0 issues ONE exchange per 64
-// positions on `head`, wave 1 ONE masked exchange per 64 positions on `second` (a tile behind), and fourteen helper
+// future raises flags[0] and the host falls back to the first-generation kernel).  So ONE exchange per 64 positions on `head`
+// and ONE masked exchange per 64 positions on `second` (a tile behind) are all the ordered work there is; twelve helper
 // wavefronts turn bytes into requests (a tile ahead) and results into cd[] (two tiles behind).  One LDS-only barrier per
-// 896 positions; nobody waits for a chain.
+// 768 positions; nobody waits for a chain.  Each of the two exchange stages is shared by TWO wavefronts (first / second half
+// of the tile): they prepare their operands side by side and only the exchanges themselves take turns, the second half
+// waiting for a tile counter the first half publishes in LDS when its exchanges have returned.
 //
 // The same two values give every position its DUPLICATE-COLLAPSED LINK for free — the most recent position of the bucket
 // with ANOTHER prefix: o1 when the tags differ, the value read from `second` when they are equal — written to glnk[] (2 bytes
-// per position, as lfx_match5 did).  lz77_resolve7_kernel walks those links for the unresolved positions through global
-// memory, compacted to dense lanes: link, compare the 3 bytes, stop at the first exact hit or beyond the window
+// per position, as lfx_match5 did).  The unresolved positions are marked in one 64-bit word per 64 positions (a ballot);
+// lz77_compact7_kernel turns the words into a list per segment (in the parse stage's staging buffer, idle until then) and
+// lz77_resolve7_kernel walks the links for them through global memory: link, compare the 3 bytes, stop at the first exact hit
+// or beyond the window
 // (default.rs:81, inclusive).  Exactness argument as in lfx_match3.hip: the chain visits the most recent member of every run
 // of equal prefixes of the bucket in decreasing position order.
 //
 // Positions are stored in full (segment-relative, 19 bits): nothing aliases, no sweep of stale fields.
+//
+// What bounds the kernel: the workgroup's vector instructions (a SIMD issues one wave-instruction per four cycles: 4 SIMDs
+// = one per cycle), so every stage below is written for instruction count — interior tiles take paths without per-lane
+// validity tests, addresses are one 32-bit offset per wavefront and tile plus immediate offsets, the multiplication is the
+// full-rate 24-bit one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -45,103 +54,107 @@ namespace lfx {
 namespace m7 {
 
 constexpr int THREADS = 1024;
-constexpr uint32_t HW = 14;                    // helper wavefronts (waves 2..15); wave 0: head, wave 1: second
-constexpr uint32_t TILE = HW * 64;             // 896 positions per barrier
+constexpr uint32_t NG = 12;                    // 64-position groups per tile
+constexpr uint32_t TILE = NG * 64;             // 768 positions per barrier
+constexpr uint32_t HALF = NG / 2;              // groups per exchange wavefront
+// wavefront roles: 0 / 1 exchange on head (first / second half of the tile), 2 / 3 exchange on second, 4..9 bytes → requests
+// (loads only), 10..15 results → answers (stores only), two groups each.  (A wavefront that both loads and stores gets
+// `s_waitcnt vmcnt(0)` in front of every use of a loaded value — loads and stores share the counter and may complete out of
+// order with respect to each other — and a look-ahead of two tiles would be worth nothing.)
+constexpr uint32_t W_P0 = 4, W_C0 = 10;
 constexpr uint32_t BUCKET_BITS = 14, TAG_BITS = 24 - BUCKET_BITS;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
-constexpr uint32_t KEY_MULT = 0x00C5A3B5u;     // odd: k → k·M mod 2^24 is a bijection; chosen on text (tools/parse... see DESIGN §3.1b)
+constexpr uint32_t KEY_MULT = 0x00C5A3B5u;     // odd, 24 bits: k → k·M mod 2^24 is a bijection (chosen on text)
 // entry = (spos << TAG_BITS) | tag, spos = position − base + SPOS0: 0 (an empty slot) is further than any window
 constexpr uint32_t SPOS0 = MAX_WINDOW + 1;
 constexpr uint32_t UNRES = 0x8000u;            // cd value UNRES + (d2 − 1), d2 in [2, 32768]: unresolved, the walk continues at p − d2
-constexpr uint32_t RQ_INVALID = 0x80000000u;
 
-// LDS layout (bytes)
-constexpr uint32_t OFF_HEAD = 0;
-constexpr uint32_t OFF_SEC = OFF_HEAD + (4u << BUCKET_BITS);
-constexpr uint32_t OFF_DUMMY = OFF_SEC + (4u << BUCKET_BITS);     // 64 dwords: where the lanes without a position exchange
-constexpr uint32_t OFF_RQ = OFF_DUMMY + 256;                      // 4 tiles of requests (bucket << TAG_BITS | tag, or RQ_INVALID)
-constexpr uint32_t OFF_R1 = OFF_RQ + 4 * TILE * 4;                // 3 tiles: what the exchange on head returned
-constexpr uint32_t OFF_R2 = OFF_R1 + 3 * TILE * 4;                // 2 tiles: what the exchange on second returned
+// LDS layout (bytes).  A bucket is a pair of dwords {head, second}.  A request is (LDS address of the pair) << TAG_BITS | tag.
+// A lane without a position exchanges on a pair of its own among the dummies: no exchange wavefront ever tests for validity.
+constexpr uint32_t OFF_DUMMY = 0;                                   // 64 pairs
+constexpr uint32_t OFF_TAB = 512;                                   // 16 Ki pairs
+constexpr uint32_t OFF_CTL = OFF_TAB + (8u << BUCKET_BITS);         // [0] tile counter of head's first half, [1] of second's
+constexpr uint32_t OFF_RQ = OFF_CTL + 64;                           // 4 tiles of requests
+constexpr uint32_t OFF_R1 = OFF_RQ + 4 * TILE * 4;                  // 3 tiles: what the exchange on head returned
+constexpr uint32_t OFF_R2 = OFF_R1 + 3 * TILE * 4;                  // 2 tiles: what the exchange on second returned
 constexpr uint32_t LDS_BYTES = OFF_R2 + 2 * TILE * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(LDS_BYTES < (1u << (32 - TAG_BITS)), "LDS addresses fit the request");
 static_assert(SEG_POSITIONS + MAX_WINDOW + SPOS0 + 8 * TILE < (1u << (32 - TAG_BITS)), "segment-relative positions fit the entry");
-static_assert(HW == 14, "the exchange waves issue two batches of seven; seven loading and seven storing helpers");
+static_assert(KEY_MULT < (1u << 24) && (KEY_MULT & 1), "24-bit multiplication, bijective");
+static_assert(HALF == 6, "operand lists below");
+static_assert(TILE % 4 == 0, "a lane's byte phase is the same in every tile");
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// seven exchanges, in order; no wait (xchg7_wait below orders the uses of the results)
-__device__ __forceinline__ void xchg7(uint32_t (&old)[7], const uint32_t (&addr)[7], const uint32_t (&val)[7]) {
+// six exchanges on the head entries, in order, one wait
+__device__ __forceinline__ void xchg6(uint32_t (&old)[6], const uint32_t (&addr)[6], const uint32_t (&val)[6]) {
     asm volatile(
-        "ds_wrxchg_rtn_b32 %0, %7, %14\n\t"
-        "ds_wrxchg_rtn_b32 %1, %8, %15\n\t"
-        "ds_wrxchg_rtn_b32 %2, %9, %16\n\t"
-        "ds_wrxchg_rtn_b32 %3, %10, %17\n\t"
-        "ds_wrxchg_rtn_b32 %4, %11, %18\n\t"
-        "ds_wrxchg_rtn_b32 %5, %12, %19\n\t"
-        "ds_wrxchg_rtn_b32 %6, %13, %20"
-        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5]), "=&v"(old[6])
-        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]),
-          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6])
-        : "memory");
-}
-// seven more, then ONE wait for all fourteen: `prev` (the results of the batch before) is an in/out operand, so that no use
-// of it can be scheduled in front of the wait
-__device__ __forceinline__ void xchg7_wait(uint32_t (&old)[7], const uint32_t (&addr)[7], const uint32_t (&val)[7], uint32_t (&prev)[7]) {
-    asm volatile(
-        "ds_wrxchg_rtn_b32 %0, %14, %21\n\t"
-        "ds_wrxchg_rtn_b32 %1, %15, %22\n\t"
-        "ds_wrxchg_rtn_b32 %2, %16, %23\n\t"
-        "ds_wrxchg_rtn_b32 %3, %17, %24\n\t"
-        "ds_wrxchg_rtn_b32 %4, %18, %25\n\t"
-        "ds_wrxchg_rtn_b32 %5, %19, %26\n\t"
-        "ds_wrxchg_rtn_b32 %6, %20, %27\n\t"
+        "ds_wrxchg_rtn_b32 %0, %6, %12\n\t"
+        "ds_wrxchg_rtn_b32 %1, %7, %13\n\t"
+        "ds_wrxchg_rtn_b32 %2, %8, %14\n\t"
+        "ds_wrxchg_rtn_b32 %3, %9, %15\n\t"
+        "ds_wrxchg_rtn_b32 %4, %10, %16\n\t"
+        "ds_wrxchg_rtn_b32 %5, %11, %17\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5]), "=&v"(old[6]),
-          "+v"(prev[0]), "+v"(prev[1]), "+v"(prev[2]), "+v"(prev[3]), "+v"(prev[4]), "+v"(prev[5]), "+v"(prev[6])
-        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]),
-          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6])
+        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5])
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]),
+          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5])
         : "memory");
 }
-// seven masked exchanges (mem = (mem & ~mask) | val, returns the old dword; mask 0 / val 0: an ORDERED READ), one wait
-__device__ __forceinline__ void mskor7(uint32_t (&old)[7], const uint32_t (&addr)[7], const uint32_t (&mask)[7], const uint32_t (&val)[7]) {
+// six masked exchanges on the second entries (pair address + 4; mem = (mem & ~mask) | val, returns the old dword; mask 0 /
+// val 0: an ORDERED READ), one wait
+__device__ __forceinline__ void mskor6(uint32_t (&old)[6], const uint32_t (&addr)[6], const uint32_t (&mask)[6], const uint32_t (&val)[6]) {
     asm volatile(
-        "ds_mskor_rtn_b32 %0, %7, %14, %21\n\t"
-        "ds_mskor_rtn_b32 %1, %8, %15, %22\n\t"
-        "ds_mskor_rtn_b32 %2, %9, %16, %23\n\t"
-        "ds_mskor_rtn_b32 %3, %10, %17, %24\n\t"
-        "ds_mskor_rtn_b32 %4, %11, %18, %25\n\t"
-        "ds_mskor_rtn_b32 %5, %12, %19, %26\n\t"
-        "ds_mskor_rtn_b32 %6, %13, %20, %27\n\t"
+        "ds_mskor_rtn_b32 %0, %6, %12, %18 offset:4\n\t"
+        "ds_mskor_rtn_b32 %1, %7, %13, %19 offset:4\n\t"
+        "ds_mskor_rtn_b32 %2, %8, %14, %20 offset:4\n\t"
+        "ds_mskor_rtn_b32 %3, %9, %15, %21 offset:4\n\t"
+        "ds_mskor_rtn_b32 %4, %10, %16, %22 offset:4\n\t"
+        "ds_mskor_rtn_b32 %5, %11, %17, %23 offset:4\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5]), "=&v"(old[6])
-        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]), "v"(addr[6]),
-          "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]), "v"(mask[6]),
-          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5]), "v"(val[6])
+        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5])
+        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]),
+          "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]),
+          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5])
         : "memory");
 }
-
-struct __attribute__((packed, aligned(4))) U32x2 { uint32_t a, b; };   // an 8-byte load at any dword address
+// the tile counter a first-half wavefront publishes / a second-half wavefront waits for (LDS byte address `a`)
+__device__ __forceinline__ void publish(uint32_t a, int v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void await(uint32_t a, int v) {
+    for (;;) {
+        int got;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(a) : "memory");
+        if (__builtin_amdgcn_readfirstlane(got) - v >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 
 }  // namespace m7
 
 // flags[0] |= 1 when an exchange returned a position from the lane's own future (results are then discarded by the host).
+// umask: one 64-bit word per 64 positions of every segment (index SegDesc::lnk_base + (p − base) / 64): the unresolved ones.
 // DBG: per-wavefront cycle stamps of workgroup 0 (LFX_DEBUG): work / barrier wait.
 template <bool DBG>
 __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
     const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd,
-    uint16_t *__restrict__ glnk, uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg) {
+    uint16_t *__restrict__ glnk, uint64_t *__restrict__ umask, uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg) {
     using namespace m7;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     uint32_t *rqb = (uint32_t *)(smem + OFF_RQ);
     uint32_t *r1b = (uint32_t *)(smem + OFF_R1);
     uint32_t *r2b = (uint32_t *)(smem + OFF_R2);
-    // LDS byte address of the tables for the asm exchanges (taking it from the pointer also makes the array escape)
+    uint32_t *ctl = (uint32_t *)(smem + OFF_CTL);
+    // LDS byte address of the arena for the asm exchanges (taking it from the pointer also makes the array escape)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
     const SegDesc sg = segs[blockIdx.x];
     const ChunkDesc ch = chunks[sg.chunk];
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t n = (uint32_t)ch.len;
     if (ch.flags & CH_LITERALS) return;           // NoCompressionLz77Encoder chunks never come here
     const uint32_t end = (n > 3 ? n : 3) - 3;     // default.rs:75
@@ -151,279 +164,343 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     const uint32_t l0 = q0 > MAX_WINDOW ? q0 - MAX_WINDOW : 0;   // warm-up: inserted and linked, not answered
     const uint32_t base = l0 & ~3u;                               // tile origin
     const int ntiles = (int)((q1 - base + TILE - 1) / TILE);
-    uint16_t *cd_c = cd + ch.in_off;
-    uint16_t *glnk_s = glnk + (uint64_t)sg.lnk_base * 64u;
-    // the chunk's bytes as dwords of the (4-byte aligned) allocation in front of them
-    const uint64_t a0 = (uint64_t)(in + ch.in_off);
-    const gptr_u32 srcw = (gptr_u32)(a0 & ~3ull);
-    const uint32_t shift = (uint32_t)(a0 & 3);
-    const uint64_t lastm1 = ((in_bytes - ch.in_off + shift + 3) >> 2) - 1;   // last dword that holds input bytes
-
-    // ---- prologue: empty tables
-    {
-        uint4 *t4 = (uint4 *)smem;
-        for (uint32_t i = tid; i < (OFF_RQ >> 4); i += THREADS) t4[i] = make_uint4(0, 0, 0, 0);
-    }
-    lds_barrier();
-
-    // helpers: waves 2..8 turn bytes into requests (loads only), waves 9..15 turn results into answers (stores only), two
-    // 64-position groups of the tile each.  (A wavefront that both loads and stores gets `s_waitcnt vmcnt(0)` in front of
-    // every use of a loaded value — loads and stores share the counter and may complete out of order with respect to each
-    // other — and a look-ahead of two tiles would be worth nothing.)
-    const bool is_p = wave >= 2 && wave < 2 + HW / 2, is_c = wave >= 2 + HW / 2;
-    const uint32_t hidx = ((is_c ? wave - (2 + HW / 2) : wave - 2) * 2) * 64 + lane;   // index of the first group's position inside the tile
-    uint64_t cy_work = 0, cy_wait = 0;
-    bool viol = false;
-
-    if (wave < 2) __builtin_amdgcn_s_setprio(3);
 
     // Tiles in flight in iteration i: loads of tile i+3 (consumed two iterations later, so that no wavefront ever waits for
     // HBM), P(i+1) requests, X1(i) exchange on head, X2(i-1) exchange on second, C(i-2) answers.  Every role runs its OWN
     // loop (same trip count, one barrier per trip): inside one loop the role test would be a branch per iteration, and the
     // compiler's wait insertion would have to assume that the other register set's loads were never issued.
     const int i_first = -3, i_end = ntiles + 2;     // i_first .. i_end-1 (+1 when the count is odd: stages are predicated)
+
+    // ---- prologue: empty tables, tile counters behind every tile
+    {
+        uint4 *t4 = (uint4 *)smem;
+        for (uint32_t i = tid; i < (OFF_CTL >> 4); i += THREADS) t4[i] = make_uint4(0, 0, 0, 0);
+        if (tid < 2) ctl[tid] = (uint32_t)(i_first - 1);
+    }
+    lds_barrier();
+
+    uint64_t cy_work = 0, cy_wait = 0;
     auto sync = [&](uint64_t c0) {
         const uint64_t c1 = DBG ? clock64() : 0;
         lds_barrier();
         if (DBG) { cy_work += c1 - c0; cy_wait += clock64() - c1; }
     };
-    if (is_p) {
+    if (wave < 4) __builtin_amdgcn_s_setprio(3);
+
+    if (wave >= W_P0 && wave < W_C0) {
+        // ================================================== P: bytes → prefix → (bucket, tag) → request
+        // The chunk's bytes as dwords of the 4-byte aligned allocation in front of them; a lane's dword pair lies at byte
+        // offset off_lane + tile * TILE (+ 64 for its second group): one 32-bit add per tile, the rest immediate offsets.
+        const uint64_t a0 = (uint64_t)(in + ch.in_off);
+        const gptr_u8 srcb = (gptr_u8)(a0 & ~3ull);
+        const uint32_t shift = (uint32_t)(a0 & 3);
+        const uint32_t hidx = (wave - W_P0) * 128 + lane;     // the first group's position inside the tile
+        const uint32_t off_lane = (base + hidx + shift) & ~3u;
+        const uint32_t sh8 = (base + hidx + shift) & 3u;      // byte phase inside the dword pair (TILE and 64 are multiples of 4)
+        // last dword of the CHUNK (every valid position's pair ends at or in front of it: p + 2 < n)
+        const uint32_t last_off = (uint32_t)min((((uint64_t)n + shift + 3) >> 2 << 2) - 4, (uint64_t)0xFFFFFFFCu);
+        const uint32_t dummy = (lds0 + OFF_DUMMY + lane * 8) << TAG_BITS;
+        const uint32_t tab = lds0 + OFF_TAB;
+        auto ldw = [&](uint32_t off) { return *(gptr_u32)(srcb + off); };
         // the loads alternate between two register sets (an iteration consumes the set that was loaded two iterations ago and
         // reloads it): tiles 0 and 1 are loaded by the first two iterations
         uint32_t ldA[4] = {0, 0, 0, 0}, ldB[4] = {0, 0, 0, 0};
         auto p_iter = [&](int i, uint32_t (&ld)[4]) {
             const uint64_t c0 = DBG ? clock64() : 0;
-            // ---- P(i+1): bytes → prefix → (bucket, tag)
             const int tp = i + 1;
             if (tp >= 0 && tp < ntiles) {
+                const uint32_t t0 = base + (uint32_t)tp * TILE;           // first position of the tile
+                const bool interior = t0 >= l0 && t0 + TILE <= q1;        // every position takes part
+                uint32_t *rq = rqb + (uint32_t)(tp & 3) * TILE + hidx;
 #pragma unroll
                 for (uint32_t g = 0; g < 2; ++g) {
-                    const uint32_t p = base + (uint32_t)tp * TILE + hidx + g * 64;
-                    const uint32_t key = __builtin_amdgcn_alignbyte(ld[2 * g + 1], ld[2 * g], (p + shift) & 3u) & 0xFFFFFFu;
-                    const bool val = p >= l0 && p < q1;
-                    rqb[(uint32_t)(tp & 3) * TILE + hidx + g * 64] = val ? (key * KEY_MULT) & 0xFFFFFFu : RQ_INVALID;
+                    const uint32_t key = __builtin_amdgcn_alignbyte(ld[2 * g + 1], ld[2 * g], sh8) & 0xFFFFFFu;
+                    uint32_t kk;                                          // low 24 bits: bucket << TAG_BITS | tag
+                    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(kk) : "v"(key), "s"(KEY_MULT));   // (full rate; v_mul_lo_u32 is a quarter of it)
+                    // (pair address) << TAG_BITS | tag
+                    uint32_t r = ((((kk >> TAG_BITS) & ((1u << BUCKET_BITS) - 1)) * 8u + tab) << TAG_BITS) | (kk & TAG_MASK);
+                    if (!interior) {
+                        const uint32_t p = t0 + hidx + g * 64;
+                        r = (p >= l0 && p < q1) ? r : dummy;
+                    }
+                    rq[g * 64] = r;
                 }
             }
-            // ---- loads of tile i+3, into the registers P just consumed (unconditional: clamped addresses)
-#pragma unroll
-            for (uint32_t g = 0; g < 2; ++g) {
-                const uint32_t p = base + (uint32_t)(i + 3) * TILE + hidx + g * 64;
-                const uint64_t wi = ((uint64_t)p + shift) >> 2;
-                ld[2 * g] = srcw[min(wi, lastm1)];
-                ld[2 * g + 1] = srcw[min(wi + 1, lastm1)];
+            // ---- loads of tile i+3, into the registers P just consumed (unconditional; clamped where the chunk ends)
+            {
+                const uint32_t toff = (uint32_t)(i + 3) * TILE;
+                const uint32_t off = off_lane + toff;
+                if (((base + shift) & ~3u) + toff + TILE + 72 <= last_off && last_off >= TILE + 72) {   // (uniform)
+                    ld[0] = ldw(off); ld[1] = ldw(off + 4); ld[2] = ldw(off + 64); ld[3] = ldw(off + 68);
+                } else {
+                    ld[0] = ldw(min(off, last_off)); ld[1] = ldw(min(off + 4, last_off));
+                    ld[2] = ldw(min(off + 64, last_off)); ld[3] = ldw(min(off + 68, last_off));
+                }
             }
             sync(c0);
         };
         for (int i = i_first; i < i_end; i += 2) { p_iter(i, ldA); p_iter(i + 1, ldB); }
-    } else if (is_c) {
+    } else if (wave >= W_C0) {
+        // ================================================== C: the two exchanged values → answer, collapsed link
+        const uint32_t hidx = (wave - W_C0) * 128 + lane;
+        // answers and links by one 32-bit byte offset per tile: glnk_s[p - base], cd_c[p] = (cd_c + base)[p - base]
+        uint8_t *glnk_b = (uint8_t *)(glnk + (uint64_t)sg.lnk_base * 64u);
+        uint8_t *cd_b = (uint8_t *)(cd + ch.in_off + base);
+        uint64_t *um_s = umask + sg.lnk_base;
+        int32_t dmin = 1;                                  // smallest distance seen: <= 0 means a position from the future
         auto c_iter = [&](int i) {
             const uint64_t c0 = DBG ? clock64() : 0;
-            // ---- C(i-2): the two exchanged values → answer, collapsed link
             const int tc = i - 2;
             if (tc >= 0 && tc < ntiles) {
-                uint32_t kk[2], o1[2], o2[2];
+                const uint32_t t0 = base + (uint32_t)tc * TILE;
+                const bool interior = t0 >= q0 && t0 + TILE <= q1;        // every position is answered
+                uint32_t rq[2], o1[2], o2[2];
 #pragma unroll
                 for (uint32_t g = 0; g < 2; ++g) {
-                    kk[g] = rqb[(uint32_t)(tc & 3) * TILE + hidx + g * 64];
+                    rq[g] = rqb[(uint32_t)(tc & 3) * TILE + hidx + g * 64];
                     o1[g] = r1b[(uint32_t)(tc % 3) * TILE + hidx + g * 64];
                     o2[g] = r2b[(uint32_t)(tc & 1) * TILE + hidx + g * 64];
                 }
+                const uint32_t rel = (uint32_t)tc * TILE + hidx;          // p - base of the first group
+                const uint32_t boff = rel * 2;
 #pragma unroll
                 for (uint32_t g = 0; g < 2; ++g) {
-                    const uint32_t p = base + (uint32_t)tc * TILE + hidx + g * 64;
-                    const uint32_t sp = p - base + SPOS0;
-                    const uint32_t p1 = o1[g] >> TAG_BITS, p2 = o2[g] >> TAG_BITS;
-                    const bool valid = (int32_t)kk[g] >= 0;
-                    viol |= valid && (p1 >= sp || p2 >= sp);
-                    const uint32_t d1 = sp - p1, d2 = sp - p2;
-                    const bool same1 = ((o1[g] ^ kk[g]) & TAG_MASK) == 0, same2 = ((o2[g] ^ kk[g]) & TAG_MASK) == 0;
+                    const uint32_t sp = rel + g * 64 + SPOS0;
+                    const uint32_t d1 = sp - (o1[g] >> TAG_BITS), d2 = sp - (o2[g] >> TAG_BITS);
+                    const bool same1 = ((o1[g] ^ rq[g]) & TAG_MASK) == 0, same2 = ((o2[g] ^ rq[g]) & TAG_MASK) == 0;
                     // the link: the most recent position of the bucket with another prefix
                     const uint32_t dl = same1 ? d2 : d1;
                     const uint32_t lnk = dl <= MAX_WINDOW ? dl : 0u;
                     // the answer (default.rs:81: inclusive window).  d1 > window: the bucket's most recent position is out of
                     // reach, so is everything; d2 >= 2 always (second lies in front of head)
-                    const uint32_t deep = d2 > window ? 0u : (same2 ? d2 : UNRES + (d2 - 1));
-                    const uint32_t ans = d1 > window ? 0u : (same1 ? d1 : deep);
-                    if (valid) glnk_s[p - base] = (uint16_t)lnk;
-                    if (valid && p >= q0) cd_c[p] = (uint16_t)ans;
+                    uint32_t a2 = same2 ? d2 : d2 + (UNRES - 1);
+                    a2 = d2 > window ? 0u : a2;
+                    const uint32_t a1 = same1 ? d1 : a2;
+                    const uint32_t ans = d1 > window ? 0u : a1;
+                    if (interior) {
+                        dmin = min(dmin, min((int32_t)d1, (int32_t)d2));
+                        *(uint16_t *)(glnk_b + boff + g * 128) = (uint16_t)lnk;
+                        *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
+                        const uint64_t um = __ballot(ans > UNRES);
+                        if (lane == 0) um_s[(rel >> 6) + g] = um;
+                    } else {
+                        const uint32_t p = t0 + hidx + g * 64;
+                        const bool valid = p >= l0 && p < q1, act = valid && p >= q0;
+                        if (valid) dmin = min(dmin, min((int32_t)d1, (int32_t)d2));
+                        if (valid) *(uint16_t *)(glnk_b + boff + g * 128) = (uint16_t)lnk;
+                        if (act) *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
+                        const uint64_t am = __ballot(act), um = __ballot(act && ans > UNRES);
+                        if (am && lane == 0) um_s[(rel >> 6) + g] = um;
+                    }
                 }
             }
             sync(c0);
         };
         for (int i = i_first; i < i_end; i += 2) { c_iter(i); c_iter(i + 1); }
-    } else if (wave == 0) {
+        if (__ballot(dmin <= 0) && lane == 0) atomicOr(flags, 1u);
+    } else if (wave < 2) {
+        // ================================================== X1(i): head ← (position, tag), in position order; the old entries → r1
+        // wave 0: groups 0..5, wave 1: 6..11 (behind wave 0's)
+        const uint32_t g0 = wave * HALF;
+        const uint32_t ctl1 = lds0 + OFF_CTL;
         auto x1_iter = [&](int i) {
             const uint64_t c0 = DBG ? clock64() : 0;
-            // ---- X1(i): head ← (position, tag), in position order; the old entries → r1
             if (i >= 0 && i < ntiles) {
-                const uint32_t *rq = rqb + (uint32_t)(i & 3) * TILE;
-                uint32_t *r1 = r1b + (uint32_t)(i % 3) * TILE;
-                const uint32_t ent0 = ((uint32_t)i * TILE + lane + SPOS0) << TAG_BITS;
-                uint32_t q[HW];
+                const uint32_t *rq = rqb + (uint32_t)(i & 3) * TILE + g0 * 64 + lane;
+                uint32_t *r1 = r1b + (uint32_t)(i % 3) * TILE + g0 * 64 + lane;
+                const uint32_t ent0 = ((uint32_t)i * TILE + g0 * 64 + lane + SPOS0) << TAG_BITS;
+                uint32_t q[HALF], ad[HALF], vl[HALF], od[HALF];
 #pragma unroll
-                for (uint32_t g = 0; g < HW; ++g) q[g] = rq[g * 64 + lane];
-                uint32_t aa[7], va[7], oa[7], ab[7], vb[7], ob[7];
+                for (uint32_t s = 0; s < HALF; ++s) q[s] = rq[s * 64];
 #pragma unroll
-                for (uint32_t s = 0; s < 7; ++s) {
-                    const uint32_t ra = q[s], rb = q[7 + s];
-                    aa[s] = lds0 + ((int32_t)ra < 0 ? OFF_DUMMY + lane * 4 : OFF_HEAD + ((ra >> (TAG_BITS - 2)) & ~3u));
-                    ab[s] = lds0 + ((int32_t)rb < 0 ? OFF_DUMMY + lane * 4 : OFF_HEAD + ((rb >> (TAG_BITS - 2)) & ~3u));
-                    va[s] = (ent0 + ((s * 64u) << TAG_BITS)) | (ra & TAG_MASK);
-                    vb[s] = (ent0 + (((7 + s) * 64u) << TAG_BITS)) | (rb & TAG_MASK);
+                for (uint32_t s = 0; s < HALF; ++s) {
+                    ad[s] = q[s] >> TAG_BITS;
+                    vl[s] = (q[s] & TAG_MASK) | (ent0 + ((s * 64u) << TAG_BITS));
                 }
-                xchg7(oa, aa, va);
-                xchg7_wait(ob, ab, vb, oa);
+                if (wave == 1) await(ctl1, i);
+                xchg6(od, ad, vl);
+                if (wave == 0) publish(ctl1, i);
 #pragma unroll
-                for (uint32_t s = 0; s < 7; ++s) {
-                    r1[s * 64 + lane] = oa[s];
-                    r1[(7 + s) * 64 + lane] = ob[s];
-                }
+                for (uint32_t s = 0; s < HALF; ++s) r1[s * 64] = od[s];
             }
             sync(c0);
         };
         for (int i = i_first; i < i_end; i += 2) { x1_iter(i); x1_iter(i + 1); }
     } else {
+        // ================================================== X2(i-1): second ← old head where the tags differ (an ordered read
+        // where they are equal) → r2
+        const uint32_t g0 = (wave - 2) * HALF;
+        const uint32_t ctl2 = lds0 + OFF_CTL + 4;
         auto x2_iter = [&](int i) {
             const uint64_t c0 = DBG ? clock64() : 0;
-            // ---- X2(i-1): second ← old head where the tags differ (an ordered read where they are equal) → r2
             const int t2 = i - 1;
             if (t2 >= 0 && t2 < ntiles) {
-                const uint32_t *rq = rqb + (uint32_t)(t2 & 3) * TILE;
-                const uint32_t *r1 = r1b + (uint32_t)(t2 % 3) * TILE;
-                uint32_t *r2 = r2b + (uint32_t)(t2 & 1) * TILE;
-                uint32_t q[HW], o[HW];
+                const uint32_t *rq = rqb + (uint32_t)(t2 & 3) * TILE + g0 * 64 + lane;
+                const uint32_t *r1 = r1b + (uint32_t)(t2 % 3) * TILE + g0 * 64 + lane;
+                uint32_t *r2 = r2b + (uint32_t)(t2 & 1) * TILE + g0 * 64 + lane;
+                uint32_t q[HALF], o[HALF], ad[HALF], mk[HALF], vl[HALF], od[HALF];
 #pragma unroll
-                for (uint32_t g = 0; g < HW; ++g) { q[g] = rq[g * 64 + lane]; o[g] = r1[g * 64 + lane]; }
+                for (uint32_t s = 0; s < HALF; ++s) { q[s] = rq[s * 64]; o[s] = r1[s * 64]; }
 #pragma unroll
-                for (uint32_t h = 0; h < HW; h += 7) {
-                    uint32_t ad[7], mk[7], vl[7], od[7];
-#pragma unroll
-                    for (uint32_t s = 0; s < 7; ++s) {
-                        const uint32_t r = q[h + s], o1 = o[h + s];
-                        const bool inval = (int32_t)r < 0;
-                        const bool differ = !inval && ((r ^ o1) & TAG_MASK) != 0;
-                        ad[s] = lds0 + (inval ? OFF_DUMMY + lane * 4 : OFF_SEC + ((r >> (TAG_BITS - 2)) & ~3u));
-                        mk[s] = differ ? 0xFFFFFFFFu : 0u;
-                        vl[s] = differ ? o1 : 0u;
-                    }
-                    mskor7(od, ad, mk, vl);
-#pragma unroll
-                    for (uint32_t s = 0; s < 7; ++s) r2[(h + s) * 64 + lane] = od[s];
+                for (uint32_t s = 0; s < HALF; ++s) {
+                    const bool differ = ((q[s] ^ o[s]) & TAG_MASK) != 0;
+                    ad[s] = q[s] >> TAG_BITS;
+                    mk[s] = differ ? 0xFFFFFFFFu : 0u;
+                    vl[s] = differ ? o[s] : 0u;
                 }
+                if (wave == 3) await(ctl2, t2);
+                mskor6(od, ad, mk, vl);
+                if (wave == 2) publish(ctl2, t2);
+#pragma unroll
+                for (uint32_t s = 0; s < HALF; ++s) r2[s * 64] = od[s];
             }
             sync(c0);
         };
         for (int i = i_first; i < i_end; i += 2) { x2_iter(i); x2_iter(i + 1); }
     }
-    if (__ballot(viol) && lane == 0) atomicOr(flags, 1u);
     if (DBG && dbg && blockIdx.x == 0 && lane == 0) {
         uint64_t *d = dbg + wave * 8;
         d[0] = cy_work; d[1] = cy_wait; d[2] = 0; d[3] = 0; d[4] = 0; d[5] = (uint64_t)ntiles; d[6] = 0; d[7] = 0;
     }
 }
 
-// The unresolved positions (cd >= UNRES + 1: three or more prefixes alternate in the bucket inside one window): follow the
-// duplicate-collapsed links from p - d2 on until the prefix is found or the window ends.  One workgroup per slab of a
-// segment; the slab's unresolved positions are compacted into an LDS list so that the walks run on dense lanes, a walk's two
-// loads per hop (the link of the position reached, the dwords that hold its prefix) issued together.
+// ------------------------------------------------------------------------------------------------------------------------
+// The unresolved positions (three or more prefixes alternate in the bucket inside one window; 1 % of a text, half of random
+// bytes).  lz77_compact7_kernel: the ballot words of a slab of 8192 positions → entries of the segment's list (one global
+// add per workgroup).  lz77_resolve7_kernel: follow the duplicate-collapsed links from p - d2 on until the prefix is found
+// or the window ends.
 namespace r7 {
-constexpr uint32_t SLAB = 8192;
-constexpr uint32_t THREADS = 256;
-constexpr uint32_t SLABS_PER_SEG = SEG_POSITIONS / SLAB;
+constexpr uint32_t SLAB_WORDS = 128;                       // 8192 positions per compaction workgroup
+constexpr uint32_t SLABS = SEG_POSITIONS / 64 / SLAB_WORDS;
+constexpr uint32_t THREADS = 256, WGS = 8;                 // resolver: 8 x 256 lanes per segment stride over its list
 }  // namespace r7
 
-__global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
-    const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
-    const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd, const uint16_t *__restrict__ glnk) {
+__global__ __launch_bounds__(r7::SLAB_WORDS) void lz77_compact7_kernel(
+    const ChunkDesc *__restrict__ chunks, const SegDesc *__restrict__ segs, const uint64_t *__restrict__ umask,
+    uint32_t *__restrict__ ulist, uint32_t *__restrict__ ucount) {
     using namespace r7;
-    __shared__ uint32_t list[SLAB];
-    __shared__ uint32_t cnt;
-    const SegDesc sg = segs[blockIdx.x / SLABS_PER_SEG];
-    const uint32_t slab = blockIdx.x % SLABS_PER_SEG;
-    if (slab * SLAB >= sg.len) return;
+    __shared__ uint32_t wsum[2], gbase;
+    const uint32_t seg = blockIdx.x / (SLABS + 1), slab = blockIdx.x % (SLABS + 1);   // (+1: the first word starts up to 3 positions in front of q0)
+    const SegDesc sg = segs[seg];
+    if (slab * (SLAB_WORDS * 64) >= sg.len + 64) return;
     const ChunkDesc ch = chunks[sg.chunk];
-    if (ch.flags & CH_LITERALS) return;
     const uint32_t n = (uint32_t)ch.len;
     const uint32_t end = (n > 3 ? n : 3) - 3;
     const uint32_t q0 = sg.start, q1 = min(sg.start + sg.len, end);
-    const uint32_t s0 = q0 + slab * SLAB, s1 = min(s0 + SLAB, q1);
-    if (s0 >= s1) return;
+    if (q0 >= q1) return;
+    const uint32_t l0 = q0 > MAX_WINDOW ? q0 - MAX_WINDOW : 0;
+    const uint32_t base = l0 & ~3u;
+    // word w covers positions [base + 64 w, base + 64 w + 64); the slab's words start at the word that holds q0
+    const uint32_t w = (q0 - base) / 64 + slab * SLAB_WORDS + threadIdx.x;
+    const uint32_t p0 = base + w * 64;
+    uint64_t m = 0;
+    if (p0 < q1) m = umask[sg.lnk_base + w];               // (every word with an answered position was written)
+    // positions in front of q0 / behind q1 are never marked (the kernel above ballots `act`), but a word may straddle the
+    // slab's first position only in the segment's first word: nothing to mask
+    if (base + (w - threadIdx.x) * 64 >= q1) return;         // the whole slab lies behind the segment (uniform)
+    const uint32_t c = (uint32_t)__popcll(m);
+    // exclusive scan over the 128 lanes (two wavefronts)
+    uint32_t x = c;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up((int)x, o); if ((threadIdx.x & 63) >= (uint32_t)o) x += y; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    const uint32_t total = wsum[0] + wsum[1];
+    if (total == 0) return;
+    if (threadIdx.x == 0) gbase = atomicAdd(&ucount[seg], total);
+    __syncthreads();
+    uint32_t at = gbase + (x - c) + ((threadIdx.x >> 6) ? wsum[0] : 0u);
+    uint32_t *ul = ulist + ch.in_off + sg.start;
+    while (m) {
+        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1;
+        ul[at++] = p0 + b;
+    }
+}
+
+// A lane strides over its segment's list and walks one entry after the other, on its own: every trip of the loop is ONE
+// memory round trip for every lane — the entry's position, or its answer-so-far and prefix, or a hop (the link of the position
+// reached and the dwords that hold its prefix, loaded together) — so that a lane with a long walk holds nobody up.
+__global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
+    const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
+    const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd, const uint16_t *__restrict__ glnk,
+    const uint32_t *__restrict__ ulist, const uint32_t *__restrict__ ucount) {
+    using namespace r7;
+    const uint32_t seg = blockIdx.x / WGS, part = blockIdx.x % WGS;
+    const uint32_t total = ucount[seg];
+    uint32_t i = part * THREADS + threadIdx.x;
+    if (part * THREADS >= total) return;
+    const SegDesc sg = segs[seg];
+    const ChunkDesc ch = chunks[sg.chunk];
+    const uint32_t q0 = sg.start;
     const uint32_t l0 = q0 > MAX_WINDOW ? q0 - MAX_WINDOW : 0;
     const uint32_t base = l0 & ~3u;
     uint16_t *cd_c = cd + ch.in_off;
     const uint16_t *glnk_s = glnk + (uint64_t)sg.lnk_base * 64u;
+    const uint32_t *ulist_s = ulist + ch.in_off + sg.start;
     const uint64_t a0 = (uint64_t)(in + ch.in_off);
     const gptr_u32 srcw = (gptr_u32)(a0 & ~3ull);
     const uint32_t shift = (uint32_t)(a0 & 3);
     const uint64_t lastm1 = ((in_bytes - ch.in_off + shift + 3) >> 2) - 1;
-    const uint32_t tid = threadIdx.x;
-    if (tid == 0) cnt = 0;
-    __syncthreads();
-    // ---- the slab's answers, sixteen bytes per lane and round (cd_c + s0 is 2-byte aligned only: the head up to the next
-    //      16-byte boundary is taken by single loads)
-    {
-        const uint64_t addr = (uint64_t)(cd_c + s0);
-        const uint32_t head = min((uint32_t)(((16 - (addr & 15)) & 15) >> 1), s1 - s0);
-        if (tid < head) {
-            const uint32_t v = cd_c[s0 + tid];
-            if (v > m7::UNRES) list[atomicAdd(&cnt, 1u)] = s0 + tid;
-        }
-        const uint32_t b0 = s0 + head;
-        const uint32_t nvec = (s1 - b0) >> 3;
-        const uint4 *v4 = (const uint4 *)(cd_c + b0);
-        for (uint32_t i = tid; i < nvec; i += THREADS) {
-            const uint4 q = v4[i];
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (uint32_t k = 0; k < 4; ++k) {
-                if ((w[k] & 0xFFFFu) > m7::UNRES) list[atomicAdd(&cnt, 1u)] = b0 + i * 8 + 2 * k;
-                if ((w[k] >> 16) > m7::UNRES) list[atomicAdd(&cnt, 1u)] = b0 + i * 8 + 2 * k + 1;
+    // lane state: 0 fetch the entry, 1 fetch its prefix and where its walk starts, 2 hop, 3 no more entries
+    uint32_t state = i < total ? 0u : 3u;
+    uint32_t p = 0, key = 0, r = 0, dist = 0;
+    bool first = false;
+    while (__ballot(state != 3u)) {
+        // ---- loads of this trip (addresses clamped: a lane in another state loads something harmless)
+        const uint32_t at = state == 0 ? i : 0u;
+        const uint32_t pos = state == 1 ? p : r;           // (state 2: the position reached)
+        const uint64_t wi = ((uint64_t)pos + shift) >> 2;
+        const uint32_t e = ulist_s[min(at, total - 1)];
+        const uint32_t w0 = srcw[min(wi, lastm1)], w1 = srcw[min(wi + 1, lastm1)];
+        const uint32_t c = cd_c[state == 1 ? p : q0];
+        const uint32_t l = glnk_s[(state == 2 ? r : q0) - base];
+        const uint32_t k = __builtin_amdgcn_alignbyte(w1, w0, (pos + shift) & 3u) & 0xFFFFFFu;
+        // ---- uses
+        if (state == 0) { p = e; state = 1; }
+        else if (state == 1) {
+            key = k;
+            dist = c - m7::UNRES + 1;                      // d2: the position of `second`, known to carry another prefix
+            r = p - dist;
+            first = true;
+            state = 2;
+        } else if (state == 2) {
+            bool done = false;
+            uint32_t ans = 0;
+            if (!first && k == key) { done = true; ans = dist; }
+            else {
+                // (a link never reaches in front of l0, the first inserted position)
+                dist += l;
+                if (l == 0 || dist > window) done = true;             // default.rs:81 (inclusive window)
+                else r -= l;
+            }
+            first = false;
+            if (done) {
+                cd_c[p] = (uint16_t)ans;
+                i += WGS * THREADS;
+                state = i < total ? 0u : 3u;
             }
         }
-        const uint32_t t0 = b0 + nvec * 8;
-        if (t0 + tid < s1) {
-            const uint32_t v = cd_c[t0 + tid];
-            if (v > m7::UNRES) list[atomicAdd(&cnt, 1u)] = t0 + tid;
-        }
-    }
-    __syncthreads();
-    const uint32_t total = cnt;
-    auto key_at = [&](uint32_t p, uint32_t w0, uint32_t w1) { return __builtin_amdgcn_alignbyte(w1, w0, (p + shift) & 3u) & 0xFFFFFFu; };
-    for (uint32_t i = tid; i < total; i += THREADS) {
-        const uint32_t p = list[i];
-        uint32_t dist = (uint32_t)cd_c[p] - m7::UNRES + 1;             // d2: the position of `second`, known to carry another prefix
-        const uint64_t wp = ((uint64_t)p + shift) >> 2;
-        const uint32_t key = key_at(p, srcw[min(wp, lastm1)], srcw[min(wp + 1, lastm1)]);
-        uint32_t r = p - dist;
-        uint32_t l = glnk_s[r - base];
-        uint32_t ans = 0;
-        for (;;) {
-            // (a link never reaches in front of l0, the first inserted position: l <= r - l0 always)
-            dist += l;
-            if (l == 0 || dist > window) break;                         // default.rs:81 (inclusive window)
-            r -= l;
-            const uint64_t wi = ((uint64_t)r + shift) >> 2;
-            const uint32_t w0 = srcw[min(wi, lastm1)], w1 = srcw[min(wi + 1, lastm1)];
-            l = glnk_s[r - base];
-            if (key_at(r, w0, w1) == key) { ans = dist; break; }
-        }
-        cd_c[p] = (uint16_t)ans;
     }
 }
 
 int launch_match7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg) {
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint64_t *umask, uint32_t *ulist,
+                  uint32_t *ucount, uint32_t *flags, uint64_t *dbg) {
     if (nsegs == 0) return 0;
+    hipError_t e_ = hipMemsetAsync(ucount, 0, 4ull * nsegs, st);
+    if (e_ != hipSuccess) return (int)e_;
     if (dbg)
         hipLaunchKernelGGL(lz77_match7_kernel<true>, dim3(nsegs), dim3(m7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
-                           cd, glnk, flags, dbg);
+                           cd, glnk, umask, flags, dbg);
     else
         hipLaunchKernelGGL(lz77_match7_kernel<false>, dim3(nsegs), dim3(m7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
-                           cd, glnk, flags, dbg);
-    hipError_t e_ = hipGetLastError();
-    if (e_ != hipSuccess) return (int)e_;
-    hipLaunchKernelGGL(lz77_resolve7_kernel, dim3(nsegs * r7::SLABS_PER_SEG), dim3(r7::THREADS), 0, st, in, in_bytes, chunks, segs,
-                       window, cd, glnk);
+                           cd, glnk, umask, flags, dbg);
+    if ((e_ = hipGetLastError()) != hipSuccess) return (int)e_;
+    hipLaunchKernelGGL(lz77_compact7_kernel, dim3(nsegs * (r7::SLABS + 1)), dim3(r7::SLAB_WORDS), 0, st, chunks, segs, umask, ulist,
+                       ucount);
+    if ((e_ = hipGetLastError()) != hipSuccess) return (int)e_;
+    hipLaunchKernelGGL(lz77_resolve7_kernel, dim3(nsegs * r7::WGS), dim3(r7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
+                       cd, glnk, ulist, ucount);
     e_ = hipGetLastError();
     return e_ != hipSuccess ? (int)e_ : 0;
 }

@@ -10,3 +10,8 @@ timeout 300 python tools/exp/enc_timing.py 67108864 0 1 2>&1 | grep -E "equal|rr
 timeout 300 python tools/exp/enc_timing.py 268435456 8192 4 2>&1 | grep -E "rep 3|rror" | cut -c1-400
 LFX_MATCH_V5=1 timeout 300 python tools/exp/enc_timing.py 268435456 8192 3 2>&1 | grep -E "rep 2|rror" | cut -c1-200
 LFX_DEBUG=1 timeout 300 python tools/exp/enc_timing.py 268435456 8192 1 2>&1 | grep -E "match7 wave" | head -16
+# per-kernel durations of the same loop
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/r5prof && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/r5prof -- python $GRAFT_REPO_ROOT/tools/exp/enc_timing.py 268435456 8192 5 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/prof_summary.py /tmp/r5prof 2>&1 | grep -v "at::native\|elementwise" | cut -c1-120 | head -30 | tee gpurun_out/r5_kernel_stats.csv
