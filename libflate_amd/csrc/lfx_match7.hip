@@ -22,11 +22,11 @@
 // the same dword are served in ascending lane order, a wavefront's instructions in issue order — measured,
 // tools/exp/lds_lru.hip and tools/exp/mskor_test.hip, and checked at run time: a lane that receives a position from its own
 // future raises flags[0] and the host falls back to the first-generation kernel).  So ONE exchange per 64 positions on `head`
-// and ONE masked exchange per 64 positions on `second` (a tile behind) are all the ordered work there is; twelve helper
-// wavefronts turn bytes into requests (a tile ahead) and results into cd[] (two tiles behind).  One LDS-only barrier per
-// 768 positions; nobody waits for a chain.  Each of the two exchange stages is shared by TWO wavefronts (first / second half
-// of the tile): they prepare their operands side by side and only the exchanges themselves take turns, the second half
-// waiting for a tile counter the first half publishes in LDS when its exchanges have returned.
+// (wave 0) and ONE masked exchange per 64 positions on `second` (wave 1, a tile behind) are all the ordered work there is —
+// fourteen in a row per tile, one wait; fourteen helper wavefronts turn bytes into requests (a tile ahead) and results into
+// cd[] (two tiles behind).  One LDS-only barrier per 896 positions; nobody waits for a chain.  (Measured and dropped: each
+// exchange stage shared by two wavefronts that take turns through a counter in LDS — the hand-over costs an LDS round trip,
+// as much as the second batch of exchanges in the same wavefront.)
 //
 // The same two values give every position its DUPLICATE-COLLAPSED LINK for free — the most recent position of the bucket
 // with ANOTHER prefix: o1 when the tags differ, the value read from `second` when they are equal — written to glnk[] (2 bytes
@@ -54,14 +54,14 @@ namespace lfx {
 namespace m7 {
 
 constexpr int THREADS = 1024;
-constexpr uint32_t NG = 12;                    // 64-position groups per tile
-constexpr uint32_t TILE = NG * 64;             // 768 positions per barrier
-constexpr uint32_t HALF = NG / 2;              // groups per exchange wavefront
-// wavefront roles: 0 / 1 exchange on head (first / second half of the tile), 2 / 3 exchange on second, 4..9 bytes → requests
-// (loads only), 10..15 results → answers (stores only), two groups each.  (A wavefront that both loads and stores gets
-// `s_waitcnt vmcnt(0)` in front of every use of a loaded value — loads and stores share the counter and may complete out of
-// order with respect to each other — and a look-ahead of two tiles would be worth nothing.)
-constexpr uint32_t W_P0 = 4, W_C0 = 10;
+constexpr uint32_t NG = 14;                    // 64-position groups per tile
+constexpr uint32_t TILE = NG * 64;             // 896 positions per barrier
+// wavefront roles: 0 exchange on head, 1 exchange on second, 2..8 bytes → requests (loads only), 9..15 results → answers
+// (stores only), two groups each.  (A wavefront that both loads and stores gets `s_waitcnt vmcnt(0)` in front of every use
+// of a loaded value — loads and stores share the counter and may complete out of order with respect to each other — and a
+// look-ahead of several tiles would be worth nothing.)
+constexpr uint32_t W_P0 = 2, W_C0 = 9;
+constexpr int AHEAD = 4;                       // register sets of the loading wavefronts = iterations between a load and its use
 constexpr uint32_t BUCKET_BITS = 14, TAG_BITS = 24 - BUCKET_BITS;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr uint32_t KEY_MULT = 0x00C5A3B5u;     // odd, 24 bits: k → k·M mod 2^24 is a bijection (chosen on text)
@@ -73,8 +73,7 @@ constexpr uint32_t UNRES = 0x8000u;            // cd value UNRES + (d2 − 1), d
 // A lane without a position exchanges on a pair of its own among the dummies: no exchange wavefront ever tests for validity.
 constexpr uint32_t OFF_DUMMY = 0;                                   // 64 pairs
 constexpr uint32_t OFF_TAB = 512;                                   // 16 Ki pairs
-constexpr uint32_t OFF_CTL = OFF_TAB + (8u << BUCKET_BITS);         // [0] tile counter of head's first half, [1] of second's
-constexpr uint32_t OFF_RQ = OFF_CTL + 64;                           // 4 tiles of requests
+constexpr uint32_t OFF_RQ = OFF_TAB + (8u << BUCKET_BITS);          // 4 tiles of requests
 constexpr uint32_t OFF_R1 = OFF_RQ + 4 * TILE * 4;                  // 3 tiles: what the exchange on head returned
 constexpr uint32_t OFF_R2 = OFF_R1 + 3 * TILE * 4;                  // 2 tiles: what the exchange on second returned
 constexpr uint32_t LDS_BYTES = OFF_R2 + 2 * TILE * 4;
@@ -82,54 +81,51 @@ static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(LDS_BYTES < (1u << (32 - TAG_BITS)), "LDS addresses fit the request");
 static_assert(SEG_POSITIONS + MAX_WINDOW + SPOS0 + 8 * TILE < (1u << (32 - TAG_BITS)), "segment-relative positions fit the entry");
 static_assert(KEY_MULT < (1u << 24) && (KEY_MULT & 1), "24-bit multiplication, bijective");
-static_assert(HALF == 6, "operand lists below");
+static_assert(NG == 14, "operand lists below: two batches of seven");
 static_assert(TILE % 4 == 0, "a lane's byte phase is the same in every tile");
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// six exchanges on the head entries, in order, one wait
-__device__ __forceinline__ void xchg6(uint32_t (&old)[6], const uint32_t (&addr)[6], const uint32_t (&val)[6]) {
+// seven exchanges on the head entries, in order; NO wait (lds_wait14 below orders every use of the results)
+__device__ __forceinline__ void xchg7(uint32_t (&old)[14], const uint32_t (&addr)[14], const uint32_t (&val)[14], const int o) {
     asm volatile(
-        "ds_wrxchg_rtn_b32 %0, %6, %12\n\t"
-        "ds_wrxchg_rtn_b32 %1, %7, %13\n\t"
-        "ds_wrxchg_rtn_b32 %2, %8, %14\n\t"
-        "ds_wrxchg_rtn_b32 %3, %9, %15\n\t"
-        "ds_wrxchg_rtn_b32 %4, %10, %16\n\t"
-        "ds_wrxchg_rtn_b32 %5, %11, %17\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5])
-        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]),
-          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5])
+        "ds_wrxchg_rtn_b32 %0, %7, %14\n\t"
+        "ds_wrxchg_rtn_b32 %1, %8, %15\n\t"
+        "ds_wrxchg_rtn_b32 %2, %9, %16\n\t"
+        "ds_wrxchg_rtn_b32 %3, %10, %17\n\t"
+        "ds_wrxchg_rtn_b32 %4, %11, %18\n\t"
+        "ds_wrxchg_rtn_b32 %5, %12, %19\n\t"
+        "ds_wrxchg_rtn_b32 %6, %13, %20"
+        : "=&v"(old[o]), "=&v"(old[o + 1]), "=&v"(old[o + 2]), "=&v"(old[o + 3]), "=&v"(old[o + 4]), "=&v"(old[o + 5]), "=&v"(old[o + 6])
+        : "v"(addr[o]), "v"(addr[o + 1]), "v"(addr[o + 2]), "v"(addr[o + 3]), "v"(addr[o + 4]), "v"(addr[o + 5]), "v"(addr[o + 6]),
+          "v"(val[o]), "v"(val[o + 1]), "v"(val[o + 2]), "v"(val[o + 3]), "v"(val[o + 4]), "v"(val[o + 5]), "v"(val[o + 6])
         : "memory");
 }
-// six masked exchanges on the second entries (pair address + 4; mem = (mem & ~mask) | val, returns the old dword; mask 0 /
-// val 0: an ORDERED READ), one wait
-__device__ __forceinline__ void mskor6(uint32_t (&old)[6], const uint32_t (&addr)[6], const uint32_t (&mask)[6], const uint32_t (&val)[6]) {
+// seven masked exchanges on the second entries (pair address + 4; mem = (mem & ~mask) | val, returns the old dword; mask 0 /
+// val 0: an ORDERED READ); no wait
+__device__ __forceinline__ void mskor7(uint32_t (&old)[14], const uint32_t (&addr)[14], const uint32_t (&mask)[14],
+                                       const uint32_t (&val)[14], const int o) {
     asm volatile(
-        "ds_mskor_rtn_b32 %0, %6, %12, %18 offset:4\n\t"
-        "ds_mskor_rtn_b32 %1, %7, %13, %19 offset:4\n\t"
-        "ds_mskor_rtn_b32 %2, %8, %14, %20 offset:4\n\t"
-        "ds_mskor_rtn_b32 %3, %9, %15, %21 offset:4\n\t"
-        "ds_mskor_rtn_b32 %4, %10, %16, %22 offset:4\n\t"
-        "ds_mskor_rtn_b32 %5, %11, %17, %23 offset:4\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3]), "=&v"(old[4]), "=&v"(old[5])
-        : "v"(addr[0]), "v"(addr[1]), "v"(addr[2]), "v"(addr[3]), "v"(addr[4]), "v"(addr[5]),
-          "v"(mask[0]), "v"(mask[1]), "v"(mask[2]), "v"(mask[3]), "v"(mask[4]), "v"(mask[5]),
-          "v"(val[0]), "v"(val[1]), "v"(val[2]), "v"(val[3]), "v"(val[4]), "v"(val[5])
+        "ds_mskor_rtn_b32 %0, %7, %14, %21 offset:4\n\t"
+        "ds_mskor_rtn_b32 %1, %8, %15, %22 offset:4\n\t"
+        "ds_mskor_rtn_b32 %2, %9, %16, %23 offset:4\n\t"
+        "ds_mskor_rtn_b32 %3, %10, %17, %24 offset:4\n\t"
+        "ds_mskor_rtn_b32 %4, %11, %18, %25 offset:4\n\t"
+        "ds_mskor_rtn_b32 %5, %12, %19, %26 offset:4\n\t"
+        "ds_mskor_rtn_b32 %6, %13, %20, %27 offset:4"
+        : "=&v"(old[o]), "=&v"(old[o + 1]), "=&v"(old[o + 2]), "=&v"(old[o + 3]), "=&v"(old[o + 4]), "=&v"(old[o + 5]), "=&v"(old[o + 6])
+        : "v"(addr[o]), "v"(addr[o + 1]), "v"(addr[o + 2]), "v"(addr[o + 3]), "v"(addr[o + 4]), "v"(addr[o + 5]), "v"(addr[o + 6]),
+          "v"(mask[o]), "v"(mask[o + 1]), "v"(mask[o + 2]), "v"(mask[o + 3]), "v"(mask[o + 4]), "v"(mask[o + 5]), "v"(mask[o + 6]),
+          "v"(val[o]), "v"(val[o + 1]), "v"(val[o + 2]), "v"(val[o + 3]), "v"(val[o + 4]), "v"(val[o + 5]), "v"(val[o + 6])
         : "memory");
 }
-// the tile counter a first-half wavefront publishes / a second-half wavefront waits for (LDS byte address `a`)
-__device__ __forceinline__ void publish(uint32_t a, int v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
-}
-__device__ __forceinline__ void await(uint32_t a, int v) {
-    for (;;) {
-        int got;
-        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(a) : "memory");
-        if (__builtin_amdgcn_readfirstlane(got) - v >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
+// ONE wait for the fourteen results in flight: they are in/out operands, so that no use of them can be scheduled in front
+__device__ __forceinline__ void lds_wait14(uint32_t (&v)[14]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13])
+                 :
+                 : "memory");
 }
 
 }  // namespace m7
@@ -147,7 +143,6 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     uint32_t *rqb = (uint32_t *)(smem + OFF_RQ);
     uint32_t *r1b = (uint32_t *)(smem + OFF_R1);
     uint32_t *r2b = (uint32_t *)(smem + OFF_R2);
-    uint32_t *ctl = (uint32_t *)(smem + OFF_CTL);
     // LDS byte address of the arena for the asm exchanges (taking it from the pointer also makes the array escape)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
 
@@ -165,17 +160,18 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     const uint32_t base = l0 & ~3u;                               // tile origin
     const int ntiles = (int)((q1 - base + TILE - 1) / TILE);
 
-    // Tiles in flight in iteration i: loads of tile i+3 (consumed two iterations later, so that no wavefront ever waits for
-    // HBM), P(i+1) requests, X1(i) exchange on head, X2(i-1) exchange on second, C(i-2) answers.  Every role runs its OWN
+    // Tiles in flight in iteration i: loads of tile i+1+AHEAD (consumed AHEAD iterations later, so that no wavefront ever
+    // waits for HBM), P(i+1) requests, X1(i) exchange on head, X2(i-1) exchange on second, C(i-2) answers.  Every role runs its OWN
     // loop (same trip count, one barrier per trip): inside one loop the role test would be a branch per iteration, and the
     // compiler's wait insertion would have to assume that the other register set's loads were never issued.
-    const int i_first = -3, i_end = ntiles + 2;     // i_first .. i_end-1 (+1 when the count is odd: stages are predicated)
+    const int i_first = -1 - AHEAD;                                       // tile 0 is loaded by the first iteration
+    const int n_iter = (ntiles + 2 - i_first + AHEAD - 1) / AHEAD * AHEAD;   // (stages are predicated: extra iterations do nothing)
+    const int i_end = i_first + n_iter;
 
-    // ---- prologue: empty tables, tile counters behind every tile
+    // ---- prologue: empty tables
     {
         uint4 *t4 = (uint4 *)smem;
-        for (uint32_t i = tid; i < (OFF_CTL >> 4); i += THREADS) t4[i] = make_uint4(0, 0, 0, 0);
-        if (tid < 2) ctl[tid] = (uint32_t)(i_first - 1);
+        for (uint32_t i = tid; i < (OFF_RQ >> 4); i += THREADS) t4[i] = make_uint4(0, 0, 0, 0);
     }
     lds_barrier();
 
@@ -185,7 +181,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
         lds_barrier();
         if (DBG) { cy_work += c1 - c0; cy_wait += clock64() - c1; }
     };
-    if (wave < 4) __builtin_amdgcn_s_setprio(3);
+    if (wave < 2) __builtin_amdgcn_s_setprio(3);
 
     if (wave >= W_P0 && wave < W_C0) {
         // ================================================== P: bytes → prefix → (bucket, tag) → request
@@ -202,9 +198,9 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
         const uint32_t dummy = (lds0 + OFF_DUMMY + lane * 8) << TAG_BITS;
         const uint32_t tab = lds0 + OFF_TAB;
         auto ldw = [&](uint32_t off) { return *(gptr_u32)(srcb + off); };
-        // the loads alternate between two register sets (an iteration consumes the set that was loaded two iterations ago and
-        // reloads it): tiles 0 and 1 are loaded by the first two iterations
-        uint32_t ldA[4] = {0, 0, 0, 0}, ldB[4] = {0, 0, 0, 0};
+        // the loads rotate through AHEAD register sets (an iteration consumes the set that was loaded AHEAD iterations ago and
+        // reloads it)
+        uint32_t ldA[4] = {0, 0, 0, 0}, ldB[4] = {0, 0, 0, 0}, ldC[4] = {0, 0, 0, 0}, ldD[4] = {0, 0, 0, 0};
         auto p_iter = [&](int i, uint32_t (&ld)[4]) {
             const uint64_t c0 = DBG ? clock64() : 0;
             const int tp = i + 1;
@@ -226,9 +222,9 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                     rq[g * 64] = r;
                 }
             }
-            // ---- loads of tile i+3, into the registers P just consumed (unconditional; clamped where the chunk ends)
+            // ---- loads of tile i+1+AHEAD, into the registers P just consumed (unconditional; clamped where the chunk ends)
             {
-                const uint32_t toff = (uint32_t)(i + 3) * TILE;
+                const uint32_t toff = (uint32_t)(i + 1 + AHEAD) * TILE;
                 const uint32_t off = off_lane + toff;
                 if (((base + shift) & ~3u) + toff + TILE + 72 <= last_off && last_off >= TILE + 72) {   // (uniform)
                     ld[0] = ldw(off); ld[1] = ldw(off + 4); ld[2] = ldw(off + 64); ld[3] = ldw(off + 68);
@@ -239,7 +235,8 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
             }
             sync(c0);
         };
-        for (int i = i_first; i < i_end; i += 2) { p_iter(i, ldA); p_iter(i + 1, ldB); }
+        static_assert(AHEAD == 4, "register sets below");
+        for (int i = i_first; i < i_end; i += 4) { p_iter(i, ldA); p_iter(i + 1, ldB); p_iter(i + 2, ldC); p_iter(i + 3, ldD); }
     } else if (wave >= W_C0) {
         // ================================================== C: the two exchanged values → answer, collapsed link
         const uint32_t hidx = (wave - W_C0) * 128 + lane;
@@ -296,67 +293,60 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
             }
             sync(c0);
         };
-        for (int i = i_first; i < i_end; i += 2) { c_iter(i); c_iter(i + 1); }
+        for (int i = i_first; i < i_end; ++i) c_iter(i);
         if (__ballot(dmin <= 0) && lane == 0) atomicOr(flags, 1u);
-    } else if (wave < 2) {
+    } else if (wave == 0) {
         // ================================================== X1(i): head ← (position, tag), in position order; the old entries → r1
-        // wave 0: groups 0..5, wave 1: 6..11 (behind wave 0's)
-        const uint32_t g0 = wave * HALF;
-        const uint32_t ctl1 = lds0 + OFF_CTL;
-        auto x1_iter = [&](int i) {
+        for (int i = i_first; i < i_end; ++i) {
             const uint64_t c0 = DBG ? clock64() : 0;
             if (i >= 0 && i < ntiles) {
-                const uint32_t *rq = rqb + (uint32_t)(i & 3) * TILE + g0 * 64 + lane;
-                uint32_t *r1 = r1b + (uint32_t)(i % 3) * TILE + g0 * 64 + lane;
-                const uint32_t ent0 = ((uint32_t)i * TILE + g0 * 64 + lane + SPOS0) << TAG_BITS;
-                uint32_t q[HALF], ad[HALF], vl[HALF], od[HALF];
+                const uint32_t *rq = rqb + (uint32_t)(i & 3) * TILE + lane;
+                uint32_t *r1 = r1b + (uint32_t)(i % 3) * TILE + lane;
+                const uint32_t ent0 = ((uint32_t)i * TILE + lane + SPOS0) << TAG_BITS;
+                uint32_t q[NG], ad[NG], vl[NG], od[NG];
 #pragma unroll
-                for (uint32_t s = 0; s < HALF; ++s) q[s] = rq[s * 64];
+                for (uint32_t s = 0; s < NG; ++s) q[s] = rq[s * 64];
 #pragma unroll
-                for (uint32_t s = 0; s < HALF; ++s) {
+                for (uint32_t s = 0; s < NG; ++s) {
                     ad[s] = q[s] >> TAG_BITS;
                     vl[s] = (q[s] & TAG_MASK) | (ent0 + ((s * 64u) << TAG_BITS));
                 }
-                if (wave == 1) await(ctl1, i);
-                xchg6(od, ad, vl);
-                if (wave == 0) publish(ctl1, i);
+                xchg7(od, ad, vl, 0);
+                xchg7(od, ad, vl, 7);
+                lds_wait14(od);
 #pragma unroll
-                for (uint32_t s = 0; s < HALF; ++s) r1[s * 64] = od[s];
+                for (uint32_t s = 0; s < NG; ++s) r1[s * 64] = od[s];
             }
             sync(c0);
-        };
-        for (int i = i_first; i < i_end; i += 2) { x1_iter(i); x1_iter(i + 1); }
+        }
     } else {
         // ================================================== X2(i-1): second ← old head where the tags differ (an ordered read
         // where they are equal) → r2
-        const uint32_t g0 = (wave - 2) * HALF;
-        const uint32_t ctl2 = lds0 + OFF_CTL + 4;
-        auto x2_iter = [&](int i) {
+        for (int i = i_first; i < i_end; ++i) {
             const uint64_t c0 = DBG ? clock64() : 0;
             const int t2 = i - 1;
             if (t2 >= 0 && t2 < ntiles) {
-                const uint32_t *rq = rqb + (uint32_t)(t2 & 3) * TILE + g0 * 64 + lane;
-                const uint32_t *r1 = r1b + (uint32_t)(t2 % 3) * TILE + g0 * 64 + lane;
-                uint32_t *r2 = r2b + (uint32_t)(t2 & 1) * TILE + g0 * 64 + lane;
-                uint32_t q[HALF], o[HALF], ad[HALF], mk[HALF], vl[HALF], od[HALF];
+                const uint32_t *rq = rqb + (uint32_t)(t2 & 3) * TILE + lane;
+                const uint32_t *r1 = r1b + (uint32_t)(t2 % 3) * TILE + lane;
+                uint32_t *r2 = r2b + (uint32_t)(t2 & 1) * TILE + lane;
+                uint32_t q[NG], o[NG], ad[NG], mk[NG], vl[NG], od[NG];
 #pragma unroll
-                for (uint32_t s = 0; s < HALF; ++s) { q[s] = rq[s * 64]; o[s] = r1[s * 64]; }
+                for (uint32_t s = 0; s < NG; ++s) { q[s] = rq[s * 64]; o[s] = r1[s * 64]; }
 #pragma unroll
-                for (uint32_t s = 0; s < HALF; ++s) {
+                for (uint32_t s = 0; s < NG; ++s) {
                     const bool differ = ((q[s] ^ o[s]) & TAG_MASK) != 0;
                     ad[s] = q[s] >> TAG_BITS;
                     mk[s] = differ ? 0xFFFFFFFFu : 0u;
                     vl[s] = differ ? o[s] : 0u;
                 }
-                if (wave == 3) await(ctl2, t2);
-                mskor6(od, ad, mk, vl);
-                if (wave == 2) publish(ctl2, t2);
+                mskor7(od, ad, mk, vl, 0);
+                mskor7(od, ad, mk, vl, 7);
+                lds_wait14(od);
 #pragma unroll
-                for (uint32_t s = 0; s < HALF; ++s) r2[s * 64] = od[s];
+                for (uint32_t s = 0; s < NG; ++s) r2[s * 64] = od[s];
             }
             sync(c0);
-        };
-        for (int i = i_first; i < i_end; i += 2) { x2_iter(i); x2_iter(i + 1); }
+        }
     }
     if (DBG && dbg && blockIdx.x == 0 && lane == 0) {
         uint64_t *d = dbg + wave * 8;
@@ -372,7 +362,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
 namespace r7 {
 constexpr uint32_t SLAB_WORDS = 128;                       // 8192 positions per compaction workgroup
 constexpr uint32_t SLABS = SEG_POSITIONS / 64 / SLAB_WORDS;
-constexpr uint32_t THREADS = 256, WGS = 8;                 // resolver: 8 x 256 lanes per segment stride over its list
+constexpr uint32_t THREADS = 256, WGS = 2;                 // resolver: 2 x 256 lanes per segment stride over its list
 }  // namespace r7
 
 __global__ __launch_bounds__(r7::SLAB_WORDS) void lz77_compact7_kernel(
@@ -446,24 +436,29 @@ __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
     uint32_t p = 0, key = 0, r = 0, dist = 0;
     bool first = false;
     while (__ballot(state != 3u)) {
-        // ---- loads of this trip (addresses clamped: a lane in another state loads something harmless)
-        const uint32_t at = state == 0 ? i : 0u;
-        const uint32_t pos = state == 1 ? p : r;           // (state 2: the position reached)
+        // ---- loads of this trip: only what the lane's state needs (a scattered load costs by its active lanes), all of them
+        //      issued before the first is used
+        const bool s0 = state == 0, s1 = state == 1, s2 = state == 2;
+        const uint32_t pos = s1 ? p : r;                   // (state 2: the position reached)
         const uint64_t wi = ((uint64_t)pos + shift) >> 2;
-        const uint32_t e = ulist_s[min(at, total - 1)];
-        const uint32_t w0 = srcw[min(wi, lastm1)], w1 = srcw[min(wi + 1, lastm1)];
-        const uint32_t c = cd_c[state == 1 ? p : q0];
-        const uint32_t l = glnk_s[(state == 2 ? r : q0) - base];
+        uint32_t e = 0, w0 = 0, w1 = 0, c = 0, l = 0;
+        if (s0) e = ulist_s[i];
+        if (s1 || s2) { w0 = srcw[min(wi, lastm1)]; w1 = srcw[min(wi + 1, lastm1)]; }
+        if (s1) c = cd_c[p];
+        if (s2) l = glnk_s[r - base];
+        // (the loaded values are pinned here: the compiler otherwise sinks a value's first use into the branch that loaded
+        //  it, and the trip becomes three round trips, one per state, instead of one)
+        asm volatile("" : "+v"(e), "+v"(w0), "+v"(w1), "+v"(c), "+v"(l));
         const uint32_t k = __builtin_amdgcn_alignbyte(w1, w0, (pos + shift) & 3u) & 0xFFFFFFu;
         // ---- uses
-        if (state == 0) { p = e; state = 1; }
-        else if (state == 1) {
+        if (s0) { p = e; state = 1; }
+        else if (s1) {
             key = k;
             dist = c - m7::UNRES + 1;                      // d2: the position of `second`, known to carry another prefix
             r = p - dist;
             first = true;
             state = 2;
-        } else if (state == 2) {
+        } else if (s2) {
             bool done = false;
             uint32_t ans = 0;
             if (!first && k == key) { done = true; ans = dist; }
