@@ -225,6 +225,7 @@ void Diag::read() {
     debug = on("LFX_DEBUG");
     match_v1 = on("LFX_MATCH_V1");
     match_v5 = on("LFX_MATCH_V5");
+    if (const char *mp = getenv("LFX_MATCH_PARTS")) match_parts = atoi(mp);
     no_serial = on("LFX_NO_SERIAL");
     batch_serial = on("LFX_BATCH_SERIAL");
     no_markers = on("LFX_NO_MARKERS");
@@ -272,7 +273,12 @@ extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) {
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_zero, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_zero, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_res, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_part[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_part[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_part[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_part[3], hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         if (status) *status = LFX_E_DEVICE;
@@ -298,6 +304,8 @@ extern "C" void lfx_ctx_free(lfx_ctx *cc) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_zero) (void)hipEventDestroy(c->ev_zero);
+    if (c->ev_res) (void)hipEventDestroy(c->ev_res);
+    for (hipEvent_t e : c->ev_part) if (e) (void)hipEventDestroy(e);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -372,6 +380,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         if (lnk_units > 0xFFFFFFFFull) { c->set_error("input too large for the link scratch"); return LFX_E_ARG; }
         sg.lnk_base = (uint32_t)lnk_units;
         lnk_units += div_up((uint64_t)sg.len + std::min<uint64_t>(sg.start, MAX_WINDOW) + 4, 64);
+        lnk_units = (lnk_units + 1) & ~1ull;   // (even: lfx_match7 stores two ballot words, one per unit, as 16 bytes)
     }
     // workgroups of the parse walk: PARSE_WG_SEGS consecutive segments of one chunk each
     std::vector<ParseWg> pwgs;
@@ -473,11 +482,38 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                                 (uint32_t)segs.size(), po.window_size, po.max_length, (uint32_t *)c->d_md.p, mdbg));
         LAUNCH_TRY(launch_md_to_cd(st, (const uint32_t *)c->d_md.p, n, d_cd));
     } else {
-        if (!c->diag.match_v5)
-            LAUNCH_TRY(launch_match7(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
-                                     (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p,
-                                     (uint64_t *)((uint8_t *)c->d_glnk.p + 128 * std::max<uint64_t>(lnk_units, 1)), (uint32_t *)c->d_stage.p,
-                                     (uint32_t *)c->d_ucount.p, d_match_flags, mdbg));
+        if (!c->diag.match_v5) {
+            // lfx_match7: the candidate kernel, then the positions it leaves open (0.5 % of a text): ballot words → lists → walks.
+            // (Measured, round 5: the segments in four parts, the resolver of a part on the side stream beside the next part's
+            //  kernel — `LFX_MATCH_PARTS=4` — 1.10 ms against 1.15 in one piece at 256 MiB: a part of 256 workgroups ends with
+            //  its slowest segment, and the compaction waits for slots behind the kernel.  The resolver with four walks in
+            //  flight per lane made the overlap pointless.)
+            const uint32_t ns = (uint32_t)segs.size();
+            const uint32_t ncu = (uint32_t)std::max(c->n_cu, 1);
+            const uint32_t want_parts = (uint32_t)std::max(c->diag.match_parts, 1);
+            const uint32_t parts = ns >= 2 * ncu ? std::min<uint32_t>(std::min<uint32_t>(4, want_parts), ns / ncu) : 1;
+            const SegDesc *dsegs = (const SegDesc *)c->d_segs.p;
+            uint16_t *d_glnk = (uint16_t *)c->d_glnk.p;
+            uint64_t *d_umask = (uint64_t *)((uint8_t *)c->d_glnk.p + 128 * std::max<uint64_t>(lnk_units, 1));
+            uint32_t *d_ucount = (uint32_t *)c->d_ucount.p;
+            HIP_TRY(hipMemsetAsync(d_ucount, 0, 4ull * std::max<uint32_t>(ns, 1), st));
+            for (uint32_t k = 0; k < parts; k++) {
+                const uint32_t s0 = (uint32_t)((uint64_t)ns * k / parts), s1 = (uint32_t)((uint64_t)ns * (k + 1) / parts);
+                LAUNCH_TRY(launch_match7(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, dsegs + s0, s1 - s0, po.window_size, d_cd,
+                                         d_glnk, d_umask, d_match_flags, k == 0 ? mdbg : nullptr));
+                hipStream_t rs = parts > 1 ? c->side_stream : st;
+                if (parts > 1) {
+                    HIP_TRY(hipEventRecord(c->ev_part[k], st));
+                    HIP_TRY(hipStreamWaitEvent(rs, c->ev_part[k], 0));
+                }
+                LAUNCH_TRY(launch_resolve7(rs, d_in, n, (const ChunkDesc *)c->d_chunks.p, dsegs + s0, s1 - s0, po.window_size, d_cd,
+                                           d_glnk, d_umask, (uint32_t *)c->d_stage.p, d_ucount + s0));
+            }
+            if (parts > 1) {
+                HIP_TRY(hipEventRecord(c->ev_res, c->side_stream));
+                HIP_TRY(hipStreamWaitEvent(st, c->ev_res, 0));
+            }
+        }
         else
             LAUNCH_TRY(launch_match5(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, (const SegDesc *)c->d_segs.p,
                                      (uint32_t)segs.size(), po.window_size, d_cd, (uint16_t *)c->d_glnk.p, d_match_flags, mdbg));

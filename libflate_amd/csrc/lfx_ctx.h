@@ -25,6 +25,7 @@ struct Diag {
     bool debug = false;          // LFX_DEBUG: per-stage counters and cycle stamps on stderr
     bool match_v1 = false;       // LFX_MATCH_V1: first-generation match kernel (+ md → cd)
     bool match_v5 = false;       // LFX_MATCH_V5: lfx_match5.hip (round 4: hash heads, window ring, link ring)
+    int match_parts = 1;         // LFX_MATCH_PARTS: lfx_match7 in up to four launches, each part's resolver on the side stream
     bool no_serial = false;      // LFX_NO_SERIAL: the serial fallback of the single-stream decoder is an error
     bool batch_serial = false;   // LFX_BATCH_SERIAL: every stream of a batch through the serial kernel
     bool no_markers = false;     // LFX_NO_MARKERS
@@ -54,6 +55,7 @@ struct Ctx {
     // main stream: fork / join through these two events
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_zero = nullptr;
+    hipEvent_t ev_part[4] = {}, ev_res = nullptr;   // lfx_match7: the resolver of one part of the segments runs beside the next part's kernel
     // one-shot encode: the output buffer is zero-filled on the side stream while the match kernel runs
     const void *prezero_ptr = nullptr;
     uint64_t prezero_bytes = 0;

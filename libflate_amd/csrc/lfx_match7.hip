@@ -56,28 +56,40 @@ namespace m7 {
 constexpr int THREADS = 1024;
 constexpr uint32_t NG = 14;                    // 64-position groups per tile
 constexpr uint32_t TILE = NG * 64;             // 896 positions per barrier
-// wavefront roles: 0 exchange on head, 1 exchange on second, 2..8 bytes → requests (loads only), 9..15 results → answers
-// (stores only), two groups each.  (A wavefront that both loads and stores gets `s_waitcnt vmcnt(0)` in front of every use
-// of a loaded value — loads and stores share the counter and may complete out of order with respect to each other — and a
-// look-ahead of several tiles would be worth nothing.)
-constexpr uint32_t W_P0 = 2, W_C0 = 9;
+// wavefront roles: 0 exchange on head (X1), 1 exchange on second (X2), seven "P" wavefronts bytes → requests (loads only),
+// seven "C" wavefronts results → answers (stores only), two groups each.  (A wavefront that both loads and stores gets
+// `s_waitcnt vmcnt(0)` in front of every use of a loaded value — loads and stores share the counter and may complete out of
+// order with respect to each other — and a look-ahead of several tiles would be worth nothing.)
+// The kernel is bound by its vector instructions per SIMD (wavefront w runs on SIMD w mod 4), so the roles are dealt by
+// their instruction counts per tile — X1 70, X2 125, P 35, C 55: SIMD 0 = X1 P C C, SIMD 1 = X2 P P P, SIMD 2 = P P C C,
+// SIMD 3 = P C C C.
+//                              wave:  15 14 13 12 11 10  9  8  7  6  5  4  3  2  1  0
+constexpr uint64_t ROLE_IDX = 0x6564325104321000ull;     // index of the wavefront among those of its role (a nibble each)
+constexpr uint32_t ROLE_IS_P = 0x227Cu;                   // waves 2 3 4 5 6 9 13
+constexpr uint32_t ROLE_IS_C = 0xDD80u;                   // waves 7 8 10 11 12 14 15
 constexpr int AHEAD = 4;                       // register sets of the loading wavefronts = iterations between a load and its use
 constexpr uint32_t BUCKET_BITS = 14, TAG_BITS = 24 - BUCKET_BITS;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
-constexpr uint32_t KEY_MULT = 0x00C5A3B5u;     // odd, 24 bits: k → k·M mod 2^24 is a bijection (chosen on text)
+constexpr uint32_t KEY_MULT = 0x00374ADDu;     // odd, 24 bits: k → k·M mod 2^24 is a bijection (chosen on text)
 // entry = (spos << TAG_BITS) | tag, spos = position − base + SPOS0: 0 (an empty slot) is further than any window
 constexpr uint32_t SPOS0 = MAX_WINDOW + 1;
 constexpr uint32_t UNRES = 0x8000u;            // cd value UNRES + (d2 − 1), d2 in [2, 32768]: unresolved, the walk continues at p − d2
 
-// LDS layout (bytes).  A bucket is a pair of dwords {head, second}.  A request is (LDS address of the pair) << TAG_BITS | tag.
-// A lane without a position exchanges on a pair of its own among the dummies: no exchange wavefront ever tests for validity.
-constexpr uint32_t OFF_DUMMY = 0;                                   // 64 pairs
-constexpr uint32_t OFF_TAB = 512;                                   // 16 Ki pairs
-constexpr uint32_t OFF_RQ = OFF_TAB + (8u << BUCKET_BITS);          // 4 tiles of requests
+// LDS layout (bytes).  A request is (LDS address of the bucket's head entry) << TAG_BITS | tag; its entry in `second` lies
+// SEC_DELTA further (two tables, not pairs: an exchange's 64 random buckets then spread over all 32 banks).  A lane without a
+// position exchanges on a slot of its own in dummy 1 (and, SEC_DELTA further, in dummy 2): no exchange wavefront ever tests
+// for validity.
+constexpr uint32_t OFF_DUMMY = 0;                                   // 64 dwords
+constexpr uint32_t OFF_TAB = 256;                                   // head: 16 Ki dwords
+constexpr uint32_t OFF_DUMMY2 = OFF_TAB + (4u << BUCKET_BITS);      // 64 dwords
+constexpr uint32_t OFF_SEC = OFF_DUMMY2 + 256;                      // second: 16 Ki dwords
+constexpr uint32_t SEC_DELTA = OFF_SEC - OFF_TAB;
+constexpr uint32_t OFF_RQ = OFF_SEC + (4u << BUCKET_BITS);          // 4 tiles of requests
 constexpr uint32_t OFF_R1 = OFF_RQ + 4 * TILE * 4;                  // 3 tiles: what the exchange on head returned
 constexpr uint32_t OFF_R2 = OFF_R1 + 3 * TILE * 4;                  // 2 tiles: what the exchange on second returned
 constexpr uint32_t LDS_BYTES = OFF_R2 + 2 * TILE * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(OFF_DUMMY + SEC_DELTA == OFF_DUMMY2, "a dummy request's second entry is a dummy too");
 static_assert(LDS_BYTES < (1u << (32 - TAG_BITS)), "LDS addresses fit the request");
 static_assert(SEG_POSITIONS + MAX_WINDOW + SPOS0 + 8 * TILE < (1u << (32 - TAG_BITS)), "segment-relative positions fit the entry");
 static_assert(KEY_MULT < (1u << 24) && (KEY_MULT & 1), "24-bit multiplication, bijective");
@@ -101,18 +113,18 @@ __device__ __forceinline__ void xchg7(uint32_t (&old)[14], const uint32_t (&addr
           "v"(val[o]), "v"(val[o + 1]), "v"(val[o + 2]), "v"(val[o + 3]), "v"(val[o + 4]), "v"(val[o + 5]), "v"(val[o + 6])
         : "memory");
 }
-// seven masked exchanges on the second entries (pair address + 4; mem = (mem & ~mask) | val, returns the old dword; mask 0 /
+// seven masked exchanges on the second entries (mem = (mem & ~mask) | val, returns the old dword; mask 0 /
 // val 0: an ORDERED READ); no wait
 __device__ __forceinline__ void mskor7(uint32_t (&old)[14], const uint32_t (&addr)[14], const uint32_t (&mask)[14],
                                        const uint32_t (&val)[14], const int o) {
     asm volatile(
-        "ds_mskor_rtn_b32 %0, %7, %14, %21 offset:4\n\t"
-        "ds_mskor_rtn_b32 %1, %8, %15, %22 offset:4\n\t"
-        "ds_mskor_rtn_b32 %2, %9, %16, %23 offset:4\n\t"
-        "ds_mskor_rtn_b32 %3, %10, %17, %24 offset:4\n\t"
-        "ds_mskor_rtn_b32 %4, %11, %18, %25 offset:4\n\t"
-        "ds_mskor_rtn_b32 %5, %12, %19, %26 offset:4\n\t"
-        "ds_mskor_rtn_b32 %6, %13, %20, %27 offset:4"
+        "ds_mskor_rtn_b32 %0, %7, %14, %21 \n\t"
+        "ds_mskor_rtn_b32 %1, %8, %15, %22 \n\t"
+        "ds_mskor_rtn_b32 %2, %9, %16, %23 \n\t"
+        "ds_mskor_rtn_b32 %3, %10, %17, %24 \n\t"
+        "ds_mskor_rtn_b32 %4, %11, %18, %25 \n\t"
+        "ds_mskor_rtn_b32 %5, %12, %19, %26 \n\t"
+        "ds_mskor_rtn_b32 %6, %13, %20, %27"
         : "=&v"(old[o]), "=&v"(old[o + 1]), "=&v"(old[o + 2]), "=&v"(old[o + 3]), "=&v"(old[o + 4]), "=&v"(old[o + 5]), "=&v"(old[o + 6])
         : "v"(addr[o]), "v"(addr[o + 1]), "v"(addr[o + 2]), "v"(addr[o + 3]), "v"(addr[o + 4]), "v"(addr[o + 5]), "v"(addr[o + 6]),
           "v"(mask[o]), "v"(mask[o + 1]), "v"(mask[o + 2]), "v"(mask[o + 3]), "v"(mask[o + 4]), "v"(mask[o + 5]), "v"(mask[o + 6]),
@@ -183,19 +195,20 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     };
     if (wave < 2) __builtin_amdgcn_s_setprio(3);
 
-    if (wave >= W_P0 && wave < W_C0) {
+    const uint32_t ridx = (uint32_t)(ROLE_IDX >> (4 * wave)) & 15u;   // which pair of groups a P / C wavefront takes
+    if ((ROLE_IS_P >> wave) & 1) {
         // ================================================== P: bytes → prefix → (bucket, tag) → request
         // The chunk's bytes as dwords of the 4-byte aligned allocation in front of them; a lane's dword pair lies at byte
         // offset off_lane + tile * TILE (+ 64 for its second group): one 32-bit add per tile, the rest immediate offsets.
         const uint64_t a0 = (uint64_t)(in + ch.in_off);
         const gptr_u8 srcb = (gptr_u8)(a0 & ~3ull);
         const uint32_t shift = (uint32_t)(a0 & 3);
-        const uint32_t hidx = (wave - W_P0) * 128 + lane;     // the first group's position inside the tile
+        const uint32_t hidx = ridx * 128 + lane;              // the first group's position inside the tile
         const uint32_t off_lane = (base + hidx + shift) & ~3u;
         const uint32_t sh8 = (base + hidx + shift) & 3u;      // byte phase inside the dword pair (TILE and 64 are multiples of 4)
         // last dword of the CHUNK (every valid position's pair ends at or in front of it: p + 2 < n)
         const uint32_t last_off = (uint32_t)min((((uint64_t)n + shift + 3) >> 2 << 2) - 4, (uint64_t)0xFFFFFFFCu);
-        const uint32_t dummy = (lds0 + OFF_DUMMY + lane * 8) << TAG_BITS;
+        const uint32_t dummy = (lds0 + OFF_DUMMY + lane * 4) << TAG_BITS;
         const uint32_t tab = lds0 + OFF_TAB;
         auto ldw = [&](uint32_t off) { return *(gptr_u32)(srcb + off); };
         // the loads rotate through AHEAD register sets (an iteration consumes the set that was loaded AHEAD iterations ago and
@@ -213,8 +226,8 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                     const uint32_t key = __builtin_amdgcn_alignbyte(ld[2 * g + 1], ld[2 * g], sh8) & 0xFFFFFFu;
                     uint32_t kk;                                          // low 24 bits: bucket << TAG_BITS | tag
                     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(kk) : "v"(key), "s"(KEY_MULT));   // (full rate; v_mul_lo_u32 is a quarter of it)
-                    // (pair address) << TAG_BITS | tag
-                    uint32_t r = ((((kk >> TAG_BITS) & ((1u << BUCKET_BITS) - 1)) * 8u + tab) << TAG_BITS) | (kk & TAG_MASK);
+                    // (address of the head entry) << TAG_BITS | tag
+                    uint32_t r = ((((kk >> TAG_BITS) & ((1u << BUCKET_BITS) - 1)) * 4u + tab) << TAG_BITS) | (kk & TAG_MASK);
                     if (!interior) {
                         const uint32_t p = t0 + hidx + g * 64;
                         r = (p >= l0 && p < q1) ? r : dummy;
@@ -237,9 +250,9 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
         };
         static_assert(AHEAD == 4, "register sets below");
         for (int i = i_first; i < i_end; i += 4) { p_iter(i, ldA); p_iter(i + 1, ldB); p_iter(i + 2, ldC); p_iter(i + 3, ldD); }
-    } else if (wave >= W_C0) {
+    } else if ((ROLE_IS_C >> wave) & 1) {
         // ================================================== C: the two exchanged values → answer, collapsed link
-        const uint32_t hidx = (wave - W_C0) * 128 + lane;
+        const uint32_t hidx = ridx * 128 + lane;
         // answers and links by one 32-bit byte offset per tile: glnk_s[p - base], cd_c[p] = (cd_c + base)[p - base]
         uint8_t *glnk_b = (uint8_t *)(glnk + (uint64_t)sg.lnk_base * 64u);
         uint8_t *cd_b = (uint8_t *)(cd + ch.in_off + base);
@@ -260,6 +273,8 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                 }
                 const uint32_t rel = (uint32_t)tc * TILE + hidx;          // p - base of the first group
                 const uint32_t boff = rel * 2;
+                uint64_t um[2] = {0, 0};
+                bool has_act[2] = {true, true};
 #pragma unroll
                 for (uint32_t g = 0; g < 2; ++g) {
                     const uint32_t sp = rel + g * 64 + SPOS0;
@@ -278,17 +293,24 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                         dmin = min(dmin, min((int32_t)d1, (int32_t)d2));
                         *(uint16_t *)(glnk_b + boff + g * 128) = (uint16_t)lnk;
                         *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
-                        const uint64_t um = __ballot(ans > UNRES);
-                        if (lane == 0) um_s[(rel >> 6) + g] = um;
+                        um[g] = __ballot(ans > UNRES);
                     } else {
                         const uint32_t p = t0 + hidx + g * 64;
                         const bool valid = p >= l0 && p < q1, act = valid && p >= q0;
                         if (valid) dmin = min(dmin, min((int32_t)d1, (int32_t)d2));
                         if (valid) *(uint16_t *)(glnk_b + boff + g * 128) = (uint16_t)lnk;
                         if (act) *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
-                        const uint64_t am = __ballot(act), um = __ballot(act && ans > UNRES);
-                        if (am && lane == 0) um_s[(rel >> 6) + g] = um;
+                        um[g] = __ballot(act && ans > UNRES);
+                        has_act[g] = __ballot(act) != 0;
                     }
+                }
+                // the two ballot words of the wavefront's groups are neighbours (and 16-byte aligned: the host keeps lnk_base
+                // even): one store by one lane.  A word without an answered position is never read — and never written: behind
+                // the segment's last position it may be another segment's.
+                if (lane == 0) {
+                    if (has_act[0] && has_act[1]) *(ulonglong2 *)(um_s + (rel >> 6)) = make_ulonglong2(um[0], um[1]);
+                    else if (has_act[0]) um_s[rel >> 6] = um[0];
+                    else if (has_act[1]) um_s[(rel >> 6) + 1] = um[1];
                 }
             }
             sync(c0);
@@ -335,7 +357,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) {
                     const bool differ = ((q[s] ^ o[s]) & TAG_MASK) != 0;
-                    ad[s] = q[s] >> TAG_BITS;
+                    ad[s] = (q[s] >> TAG_BITS) + SEC_DELTA;
                     mk[s] = differ ? 0xFFFFFFFFu : 0u;
                     vl[s] = differ ? o[s] : 0u;
                 }
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
 namespace r7 {
 constexpr uint32_t SLAB_WORDS = 128;                       // 8192 positions per compaction workgroup
 constexpr uint32_t SLABS = SEG_POSITIONS / 64 / SLAB_WORDS;
-constexpr uint32_t THREADS = 256, WGS = 2;                 // resolver: 2 x 256 lanes per segment stride over its list
+constexpr uint32_t THREADS = 256, WGS = 2, NS = 4;         // resolver: 2 x 256 lanes per segment, NS walks each, stride over its list
 }  // namespace r7
 
 __global__ __launch_bounds__(r7::SLAB_WORDS) void lz77_compact7_kernel(
@@ -407,9 +429,10 @@ __global__ __launch_bounds__(r7::SLAB_WORDS) void lz77_compact7_kernel(
     }
 }
 
-// A lane strides over its segment's list and walks one entry after the other, on its own: every trip of the loop is ONE
-// memory round trip for every lane — the entry's position, or its answer-so-far and prefix, or a hop (the link of the position
-// reached and the dwords that hold its prefix, loaded together) — so that a lane with a long walk holds nobody up.
+// A lane strides over its segment's list with NS walks in flight at once, each on its own: every trip of the loop is ONE memory
+// round trip for every walk — the entry's position, or its answer-so-far and prefix, or a hop (the link of the position reached
+// and the dwords that hold its prefix, loaded together) — so that a long walk holds nobody up, and the kernel's time is the
+// round trips of its longest lane, not their sum over the entries.
 __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
     const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd, const uint16_t *__restrict__ glnk,
@@ -417,7 +440,6 @@ __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
     using namespace r7;
     const uint32_t seg = blockIdx.x / WGS, part = blockIdx.x % WGS;
     const uint32_t total = ucount[seg];
-    uint32_t i = part * THREADS + threadIdx.x;
     if (part * THREADS >= total) return;
     const SegDesc sg = segs[seg];
     const ChunkDesc ch = chunks[sg.chunk];
@@ -431,69 +453,96 @@ __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
     const gptr_u32 srcw = (gptr_u32)(a0 & ~3ull);
     const uint32_t shift = (uint32_t)(a0 & 3);
     const uint64_t lastm1 = ((in_bytes - ch.in_off + shift + 3) >> 2) - 1;
-    // lane state: 0 fetch the entry, 1 fetch its prefix and where its walk starts, 2 hop, 3 no more entries
-    uint32_t state = i < total ? 0u : 3u;
-    uint32_t p = 0, key = 0, r = 0, dist = 0;
-    bool first = false;
-    while (__ballot(state != 3u)) {
-        // ---- loads of this trip: only what the lane's state needs (a scattered load costs by its active lanes), all of them
+    constexpr uint32_t STRIDE = WGS * THREADS;             // walks j of all lanes: entries j * STRIDE + lane, + NS * STRIDE, ...
+    // walk state: 0 fetch the entry, 1 fetch its prefix and where its walk starts, 2 hop, 3 no more entries
+    uint32_t state[NS], i[NS], p[NS], key[NS], r[NS], dist[NS];
+    bool first[NS];
+#pragma unroll
+    for (uint32_t j = 0; j < NS; ++j) {
+        i[j] = part * THREADS + threadIdx.x + j * STRIDE;
+        state[j] = i[j] < total ? 0u : 3u;
+        p[j] = key[j] = r[j] = dist[j] = 0;
+        first[j] = false;
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (uint32_t j = 0; j < NS; ++j) any |= state[j] != 3u;
+        if (!__ballot(any)) break;
+        // ---- loads of this trip: only what a walk's state needs (a scattered load costs by its active lanes), all of them
         //      issued before the first is used
-        const bool s0 = state == 0, s1 = state == 1, s2 = state == 2;
-        const uint32_t pos = s1 ? p : r;                   // (state 2: the position reached)
-        const uint64_t wi = ((uint64_t)pos + shift) >> 2;
-        uint32_t e = 0, w0 = 0, w1 = 0, c = 0, l = 0;
-        if (s0) e = ulist_s[i];
-        if (s1 || s2) { w0 = srcw[min(wi, lastm1)]; w1 = srcw[min(wi + 1, lastm1)]; }
-        if (s1) c = cd_c[p];
-        if (s2) l = glnk_s[r - base];
-        // (the loaded values are pinned here: the compiler otherwise sinks a value's first use into the branch that loaded
-        //  it, and the trip becomes three round trips, one per state, instead of one)
-        asm volatile("" : "+v"(e), "+v"(w0), "+v"(w1), "+v"(c), "+v"(l));
-        const uint32_t k = __builtin_amdgcn_alignbyte(w1, w0, (pos + shift) & 3u) & 0xFFFFFFu;
+        uint32_t e[NS], w0[NS], w1[NS], c[NS], l[NS], pos[NS];
+#pragma unroll
+        for (uint32_t j = 0; j < NS; ++j) {
+            const bool s0 = state[j] == 0, s1 = state[j] == 1, s2 = state[j] == 2;
+            pos[j] = s1 ? p[j] : r[j];                       // (state 2: the position reached)
+            const uint64_t wi = ((uint64_t)pos[j] + shift) >> 2;
+            e[j] = w0[j] = w1[j] = c[j] = l[j] = 0;
+            if (s0) e[j] = ulist_s[i[j]];
+            if (s1 || s2) { w0[j] = srcw[min(wi, lastm1)]; w1[j] = srcw[min(wi + 1, lastm1)]; }
+            if (s1) c[j] = cd_c[p[j]];
+            if (s2) l[j] = glnk_s[r[j] - base];
+        }
+        // (the loaded values are pinned here: the compiler otherwise sinks a value's first use into the branch that loaded it,
+        //  and the trip becomes a round trip per state and walk instead of one)
+#pragma unroll
+        for (uint32_t j = 0; j < NS; ++j) asm volatile("" : "+v"(e[j]), "+v"(w0[j]), "+v"(w1[j]), "+v"(c[j]), "+v"(l[j]));
         // ---- uses
-        if (s0) { p = e; state = 1; }
-        else if (s1) {
-            key = k;
-            dist = c - m7::UNRES + 1;                      // d2: the position of `second`, known to carry another prefix
-            r = p - dist;
-            first = true;
-            state = 2;
-        } else if (s2) {
-            bool done = false;
-            uint32_t ans = 0;
-            if (!first && k == key) { done = true; ans = dist; }
-            else {
-                // (a link never reaches in front of l0, the first inserted position)
-                dist += l;
-                if (l == 0 || dist > window) done = true;             // default.rs:81 (inclusive window)
-                else r -= l;
-            }
-            first = false;
-            if (done) {
-                cd_c[p] = (uint16_t)ans;
-                i += WGS * THREADS;
-                state = i < total ? 0u : 3u;
+#pragma unroll
+        for (uint32_t j = 0; j < NS; ++j) {
+            const uint32_t k = __builtin_amdgcn_alignbyte(w1[j], w0[j], (pos[j] + shift) & 3u) & 0xFFFFFFu;
+            if (state[j] == 0) { p[j] = e[j]; state[j] = 1; }
+            else if (state[j] == 1) {
+                key[j] = k;
+                dist[j] = c[j] - m7::UNRES + 1;              // d2: the position of `second`, known to carry another prefix
+                r[j] = p[j] - dist[j];
+                first[j] = true;
+                state[j] = 2;
+            } else if (state[j] == 2) {
+                bool done = false;
+                uint32_t ans = 0;
+                if (!first[j] && k == key[j]) { done = true; ans = dist[j]; }
+                else {
+                    // (a link never reaches in front of l0, the first inserted position)
+                    dist[j] += l[j];
+                    if (l[j] == 0 || dist[j] > window) done = true;    // default.rs:81 (inclusive window)
+                    else r[j] -= l[j];
+                }
+                first[j] = false;
+                if (done) {
+                    cd_c[p[j]] = (uint16_t)ans;
+                    i[j] += NS * STRIDE;
+                    state[j] = i[j] < total ? 0u : 3u;
+                }
             }
         }
     }
 }
 
+// The candidate kernel for `nsegs` segments (the caller passes `segs` at the first of them)
 int launch_match7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint64_t *umask, uint32_t *ulist,
-                  uint32_t *ucount, uint32_t *flags, uint64_t *dbg) {
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint64_t *umask, uint32_t *flags, uint64_t *dbg) {
     if (nsegs == 0) return 0;
-    hipError_t e_ = hipMemsetAsync(ucount, 0, 4ull * nsegs, st);
-    if (e_ != hipSuccess) return (int)e_;
     if (dbg)
         hipLaunchKernelGGL(lz77_match7_kernel<true>, dim3(nsegs), dim3(m7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
                            cd, glnk, umask, flags, dbg);
     else
         hipLaunchKernelGGL(lz77_match7_kernel<false>, dim3(nsegs), dim3(m7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
                            cd, glnk, umask, flags, dbg);
-    if ((e_ = hipGetLastError()) != hipSuccess) return (int)e_;
+    const hipError_t e_ = hipGetLastError();
+    return e_ != hipSuccess ? (int)e_ : 0;
+}
+
+// ... and what it left open: ballot words → lists → walks.  ucount (one counter per segment, at the first of these segments)
+// must be zero.
+int launch_resolve7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
+                    uint32_t nsegs, uint32_t window, uint16_t *cd, const uint16_t *glnk, const uint64_t *umask, uint32_t *ulist,
+                    uint32_t *ucount) {
+    if (nsegs == 0) return 0;
     hipLaunchKernelGGL(lz77_compact7_kernel, dim3(nsegs * (r7::SLABS + 1)), dim3(r7::SLAB_WORDS), 0, st, chunks, segs, umask, ulist,
                        ucount);
-    if ((e_ = hipGetLastError()) != hipSuccess) return (int)e_;
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return (int)e_;
     hipLaunchKernelGGL(lz77_resolve7_kernel, dim3(nsegs * r7::WGS), dim3(r7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
                        cd, glnk, ulist, ucount);
     e_ = hipGetLastError();
