@@ -226,6 +226,7 @@ void Diag::read() {
     match_v1 = on("LFX_MATCH_V1");
     match_v5 = on("LFX_MATCH_V5");
     if (const char *mp = getenv("LFX_MATCH_PARTS")) match_parts = atoi(mp);
+    if (const char *rc7 = getenv("LFX_R7_CAP")) r7_cap = atoi(rc7);
     no_serial = on("LFX_NO_SERIAL");
     batch_serial = on("LFX_BATCH_SERIAL");
     no_markers = on("LFX_NO_MARKERS");
@@ -413,7 +414,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     if ((rc = c->d_segs.reserve(sizeof(SegDesc) * std::max<size_t>(segs.size(), 1)))) return rc;
     if ((rc = c->d_pwgs.reserve(sizeof(ParseWg) * std::max<size_t>(pwgs.size(), 1)))) return rc;
     if (!hc && (rc = c->d_cd.reserve(2 * n + 64))) return rc;                   // candidate distances, 16 bits per position
-    if (!hc && !match_v1 && (rc = c->d_glnk.reserve(136 * std::max<uint64_t>(lnk_units, 1)))) return rc;   // links (2 bytes) + lfx_match7's ballot words (8 bytes per 64)
+    if (!hc && !match_v1 && (rc = c->d_glnk.reserve(264 * std::max<uint64_t>(lnk_units, 1)))) return rc;   // lfx_match7: link records (4 bytes) + ballot words (8 bytes per 64); lfx_match5: links (2 bytes)
     if (!hc && !match_v1 && (rc = c->d_ucount.reserve(4 * std::max<size_t>(segs.size(), 1)))) return rc;   // lfx_match7: unresolved positions per segment
     if (!hc && match_v1 && (rc = c->d_md.reserve(4 * std::max<uint64_t>(n, 1)))) return rc;   // first-generation kernel: (length, distance) words
     if ((rc = c->d_codes.reserve(4 * std::max<uint64_t>(plan.n_codes_cap, 1)))) return rc;
@@ -493,8 +494,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             const uint32_t want_parts = (uint32_t)std::max(c->diag.match_parts, 1);
             const uint32_t parts = ns >= 2 * ncu ? std::min<uint32_t>(std::min<uint32_t>(4, want_parts), ns / ncu) : 1;
             const SegDesc *dsegs = (const SegDesc *)c->d_segs.p;
-            uint16_t *d_glnk = (uint16_t *)c->d_glnk.p;
-            uint64_t *d_umask = (uint64_t *)((uint8_t *)c->d_glnk.p + 128 * std::max<uint64_t>(lnk_units, 1));
+            uint32_t *d_glnk = (uint32_t *)c->d_glnk.p;
+            uint64_t *d_umask = (uint64_t *)((uint8_t *)c->d_glnk.p + 256 * std::max<uint64_t>(lnk_units, 1));
             uint32_t *d_ucount = (uint32_t *)c->d_ucount.p;
             HIP_TRY(hipMemsetAsync(d_ucount, 0, 4ull * std::max<uint32_t>(ns, 1), st));
             for (uint32_t k = 0; k < parts; k++) {
@@ -506,8 +507,8 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                     HIP_TRY(hipEventRecord(c->ev_part[k], st));
                     HIP_TRY(hipStreamWaitEvent(rs, c->ev_part[k], 0));
                 }
-                LAUNCH_TRY(launch_resolve7(rs, d_in, n, (const ChunkDesc *)c->d_chunks.p, dsegs + s0, s1 - s0, po.window_size, d_cd,
-                                           d_glnk, d_umask, (uint32_t *)c->d_stage.p, d_ucount + s0));
+                LAUNCH_TRY(launch_resolve7(rs, (const ChunkDesc *)c->d_chunks.p, dsegs + s0, s1 - s0, po.window_size, d_cd,
+                                           d_glnk, d_umask, (uint32_t *)c->d_stage.p, d_ucount + s0, (uint32_t)std::max(c->diag.r7_cap, 0)));
             }
             if (parts > 1) {
                 HIP_TRY(hipEventRecord(c->ev_res, c->side_stream));

@@ -25,6 +25,7 @@ struct Diag {
     bool debug = false;          // LFX_DEBUG: per-stage counters and cycle stamps on stderr
     bool match_v1 = false;       // LFX_MATCH_V1: first-generation match kernel (+ md → cd)
     bool match_v5 = false;       // LFX_MATCH_V5: lfx_match5.hip (round 4: hash heads, window ring, link ring)
+    int r7_cap = 0;              // LFX_R7_CAP: lfx_match7's resolver ends every walk after so many hops (WRONG answers: timing experiments only)
     int match_parts = 1;         // LFX_MATCH_PARTS: lfx_match7 in up to four launches, each part's resolver on the side stream
     bool no_serial = false;      // LFX_NO_SERIAL: the serial fallback of the single-stream decoder is an error
     bool batch_serial = false;   // LFX_BATCH_SERIAL: every stream of a batch through the serial kernel

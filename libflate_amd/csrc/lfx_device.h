@@ -48,13 +48,14 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
 // it leaves open.  glnk: scratch for the duplicate-collapsed link of every position of every segment (warm-up included),
 // regions by SegDesc::lnk_base
 int launch_match7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint64_t *umask /* 8 bytes per 64 link entries */,
-                  uint32_t *flags, uint64_t *dbg = nullptr);
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *glnk /* link | tag << 16 per link entry */,
+                  uint64_t *umask /* 8 bytes per 64 link entries */, uint32_t *flags, uint64_t *dbg = nullptr);
 // ... and the positions it leaves open (ballot words → a list per segment → chain walks through glnk): may run on another
 // stream, behind the candidate kernel of the same segments.  ucount: zeroed by the caller.
-int launch_resolve7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                    uint32_t nsegs, uint32_t window, uint16_t *cd, const uint16_t *glnk, const uint64_t *umask,
-                    uint32_t *ulist /* 4 bytes per input byte */, uint32_t *ucount /* 4 bytes per segment */);
+int launch_resolve7(hipStream_t st, const ChunkDesc *chunks, const SegDesc *segs, uint32_t nsegs, uint32_t window, uint16_t *cd,
+                    const uint32_t *glnk, const uint64_t *umask, uint32_t *ulist /* 4 bytes per input byte */,
+                    uint32_t *ucount /* 4 bytes per segment */,
+                    uint32_t hop_cap = 0 /* diagnostics (LFX_R7_CAP): end every walk after so many hops — wrong answers, timing only */);
 // lfx_match5.hip (round 4; LFX_MATCH_V5=1): hash heads + window ring + link ring, deep chain walks handed over to wave 0
 int launch_match5(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
                   uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint32_t *flags, uint64_t *dbg = nullptr);

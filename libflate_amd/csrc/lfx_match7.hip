@@ -29,8 +29,10 @@
 // as much as the second batch of exchanges in the same wavefront.)
 //
 // The same two values give every position its DUPLICATE-COLLAPSED LINK for free — the most recent position of the bucket
-// with ANOTHER prefix: o1 when the tags differ, the value read from `second` when they are equal — written to glnk[] (2 bytes
-// per position, as lfx_match5 did).  The unresolved positions are marked in one 64-bit word per 64 positions (a ballot);
+// with ANOTHER prefix: o1 when the tags differ, the value read from `second` when they are equal — written to glnk[] together
+// with the position's own tag (4 bytes per position: link | tag << 16).  A chain never leaves its bucket, so along a chain the
+// tag alone IS the prefix: the walk below compares tags and never reads the input (a hop is ONE scattered 4-byte load, not a
+// link and the bytes it leads to — the resolver's time is its scattered 64-byte sectors from HBM).  The unresolved positions are marked in one 64-bit word per 64 positions (a ballot);
 // lz77_compact7_kernel turns the words into a list per segment (in the parse stage's staging buffer, idle until then) and
 // lz77_resolve7_kernel walks the links for them through global memory: link, compare the 3 bytes, stop at the first exact hit
 // or beyond the window
@@ -149,7 +151,7 @@ template <bool DBG>
 __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
     const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd,
-    uint16_t *__restrict__ glnk, uint64_t *__restrict__ umask, uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg) {
+    uint32_t *__restrict__ glnk, uint64_t *__restrict__ umask, uint32_t *__restrict__ flags, uint64_t *__restrict__ dbg) {
     using namespace m7;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
     uint32_t *rqb = (uint32_t *)(smem + OFF_RQ);
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     } else if ((ROLE_IS_C >> wave) & 1) {
         // ================================================== C: the two exchanged values → answer, collapsed link
         const uint32_t hidx = ridx * 128 + lane;
-        // answers and links by one 32-bit byte offset per tile: glnk_s[p - base], cd_c[p] = (cd_c + base)[p - base]
+        // answers and links by one 32-bit byte offset per tile: cd_c[p] = (cd_c + base)[p - base] at boff, glnk_s[p - base] at 2 boff
         uint8_t *glnk_b = (uint8_t *)(glnk + (uint64_t)sg.lnk_base * 64u);
         uint8_t *cd_b = (uint8_t *)(cd + ch.in_off + base);
         uint64_t *um_s = umask + sg.lnk_base;
@@ -291,14 +293,14 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                     const uint32_t ans = d1 > window ? 0u : a1;
                     if (interior) {
                         dmin = min(dmin, min((int32_t)d1, (int32_t)d2));
-                        *(uint16_t *)(glnk_b + boff + g * 128) = (uint16_t)lnk;
+                        *(uint32_t *)(glnk_b + 2 * boff + g * 256) = lnk | (rq[g] << 16);   // (the request's low 16 bits: the tag and six bits of the bucket — inside a bucket as good as the tag)
                         *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
                         um[g] = __ballot(ans > UNRES);
                     } else {
                         const uint32_t p = t0 + hidx + g * 64;
                         const bool valid = p >= l0 && p < q1, act = valid && p >= q0;
                         if (valid) dmin = min(dmin, min((int32_t)d1, (int32_t)d2));
-                        if (valid) *(uint16_t *)(glnk_b + boff + g * 128) = (uint16_t)lnk;
+                        if (valid) *(uint32_t *)(glnk_b + 2 * boff + g * 256) = lnk | (rq[g] << 16);
                         if (act) *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
                         um[g] = __ballot(act && ans > UNRES);
                         has_act[g] = __ballot(act) != 0;
@@ -430,13 +432,14 @@ __global__ __launch_bounds__(r7::SLAB_WORDS) void lz77_compact7_kernel(
 }
 
 // A lane strides over its segment's list with NS walks in flight at once, each on its own: every trip of the loop is ONE memory
-// round trip for every walk — the entry's position, or its answer-so-far and prefix, or a hop (the link of the position reached
-// and the dwords that hold its prefix, loaded together) — so that a long walk holds nobody up, and the kernel's time is the
-// round trips of its longest lane, not their sum over the entries.
+// round trip for every walk — the entry's position, or its answer-so-far and its tag, or a hop (the record of the position
+// reached: its tag and its link) — so that a long walk holds nobody up, and the kernel's time is the round trips of its longest
+// lane, not their sum over the entries.  (What it costs is its scattered sectors from HBM: ending every walk after one hop —
+// LFX_R7_CAP=1, wrong answers — saves 0.07 of 0.24 ms.)
 __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
-    const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
-    const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd, const uint16_t *__restrict__ glnk,
-    const uint32_t *__restrict__ ulist, const uint32_t *__restrict__ ucount) {
+    const ChunkDesc *__restrict__ chunks, const SegDesc *__restrict__ segs, uint32_t window, uint16_t *__restrict__ cd,
+    const uint32_t *__restrict__ glnk, const uint32_t *__restrict__ ulist, const uint32_t *__restrict__ ucount,
+    uint32_t hop_cap /* diagnostics: 0 = none */) {
     using namespace r7;
     const uint32_t seg = blockIdx.x / WGS, part = blockIdx.x % WGS;
     const uint32_t total = ucount[seg];
@@ -447,21 +450,17 @@ __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
     const uint32_t l0 = q0 > MAX_WINDOW ? q0 - MAX_WINDOW : 0;
     const uint32_t base = l0 & ~3u;
     uint16_t *cd_c = cd + ch.in_off;
-    const uint16_t *glnk_s = glnk + (uint64_t)sg.lnk_base * 64u;
+    const uint32_t *glnk_s = glnk + (uint64_t)sg.lnk_base * 64u;
     const uint32_t *ulist_s = ulist + ch.in_off + sg.start;
-    const uint64_t a0 = (uint64_t)(in + ch.in_off);
-    const gptr_u32 srcw = (gptr_u32)(a0 & ~3ull);
-    const uint32_t shift = (uint32_t)(a0 & 3);
-    const uint64_t lastm1 = ((in_bytes - ch.in_off + shift + 3) >> 2) - 1;
     constexpr uint32_t STRIDE = WGS * THREADS;             // walks j of all lanes: entries j * STRIDE + lane, + NS * STRIDE, ...
-    // walk state: 0 fetch the entry, 1 fetch its prefix and where its walk starts, 2 hop, 3 no more entries
-    uint32_t state[NS], i[NS], p[NS], key[NS], r[NS], dist[NS];
+    // walk state: 0 fetch the entry, 1 fetch its tag and where its walk starts, 2 hop, 3 no more entries
+    uint32_t state[NS], i[NS], p[NS], tag[NS], r[NS], dist[NS], hops[NS];
     bool first[NS];
 #pragma unroll
     for (uint32_t j = 0; j < NS; ++j) {
         i[j] = part * THREADS + threadIdx.x + j * STRIDE;
         state[j] = i[j] < total ? 0u : 3u;
-        p[j] = key[j] = r[j] = dist[j] = 0;
+        p[j] = tag[j] = r[j] = dist[j] = hops[j] = 0;
         first[j] = false;
     }
     for (;;) {
@@ -471,42 +470,41 @@ __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
         if (!__ballot(any)) break;
         // ---- loads of this trip: only what a walk's state needs (a scattered load costs by its active lanes), all of them
         //      issued before the first is used
-        uint32_t e[NS], w0[NS], w1[NS], c[NS], l[NS], pos[NS];
+        uint32_t e[NS], c[NS], rec[NS];
 #pragma unroll
         for (uint32_t j = 0; j < NS; ++j) {
             const bool s0 = state[j] == 0, s1 = state[j] == 1, s2 = state[j] == 2;
-            pos[j] = s1 ? p[j] : r[j];                       // (state 2: the position reached)
-            const uint64_t wi = ((uint64_t)pos[j] + shift) >> 2;
-            e[j] = w0[j] = w1[j] = c[j] = l[j] = 0;
+            e[j] = c[j] = rec[j] = 0;
             if (s0) e[j] = ulist_s[i[j]];
-            if (s1 || s2) { w0[j] = srcw[min(wi, lastm1)]; w1[j] = srcw[min(wi + 1, lastm1)]; }
             if (s1) c[j] = cd_c[p[j]];
-            if (s2) l[j] = glnk_s[r[j] - base];
+            if (s1 || s2) rec[j] = glnk_s[(s1 ? p[j] : r[j]) - base];     // (state 2: the position reached)
         }
         // (the loaded values are pinned here: the compiler otherwise sinks a value's first use into the branch that loaded it,
         //  and the trip becomes a round trip per state and walk instead of one)
 #pragma unroll
-        for (uint32_t j = 0; j < NS; ++j) asm volatile("" : "+v"(e[j]), "+v"(w0[j]), "+v"(w1[j]), "+v"(c[j]), "+v"(l[j]));
+        for (uint32_t j = 0; j < NS; ++j) asm volatile("" : "+v"(e[j]), "+v"(c[j]), "+v"(rec[j]));
         // ---- uses
 #pragma unroll
         for (uint32_t j = 0; j < NS; ++j) {
-            const uint32_t k = __builtin_amdgcn_alignbyte(w1[j], w0[j], (pos[j] + shift) & 3u) & 0xFFFFFFu;
             if (state[j] == 0) { p[j] = e[j]; state[j] = 1; }
             else if (state[j] == 1) {
-                key[j] = k;
+                tag[j] = rec[j] >> 16;
                 dist[j] = c[j] - m7::UNRES + 1;              // d2: the position of `second`, known to carry another prefix
                 r[j] = p[j] - dist[j];
                 first[j] = true;
+                hops[j] = 0;
                 state[j] = 2;
             } else if (state[j] == 2) {
                 bool done = false;
                 uint32_t ans = 0;
-                if (!first[j] && k == key[j]) { done = true; ans = dist[j]; }
+                const uint32_t l = rec[j] & 0xFFFFu;
+                if (!first[j] && (rec[j] >> 16) == tag[j]) { done = true; ans = dist[j]; }
                 else {
                     // (a link never reaches in front of l0, the first inserted position)
-                    dist[j] += l[j];
-                    if (l[j] == 0 || dist[j] > window) done = true;    // default.rs:81 (inclusive window)
-                    else r[j] -= l[j];
+                    dist[j] += l;
+                    if (l == 0 || dist[j] > window) done = true;       // default.rs:81 (inclusive window)
+                    else r[j] -= l;
+                    if (hop_cap && ++hops[j] >= hop_cap) done = true;   // (LFX_R7_CAP: wrong answers, timing only)
                 }
                 first[j] = false;
                 if (done) {
@@ -521,7 +519,7 @@ __global__ __launch_bounds__(r7::THREADS) void lz77_resolve7_kernel(
 
 // The candidate kernel for `nsegs` segments (the caller passes `segs` at the first of them)
 int launch_match7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint16_t *glnk, uint64_t *umask, uint32_t *flags, uint64_t *dbg) {
+                  uint32_t nsegs, uint32_t window, uint16_t *cd, uint32_t *glnk, uint64_t *umask, uint32_t *flags, uint64_t *dbg) {
     if (nsegs == 0) return 0;
     if (dbg)
         hipLaunchKernelGGL(lz77_match7_kernel<true>, dim3(nsegs), dim3(m7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
@@ -535,16 +533,15 @@ int launch_match7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Ch
 
 // ... and what it left open: ballot words → lists → walks.  ucount (one counter per segment, at the first of these segments)
 // must be zero.
-int launch_resolve7(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, const SegDesc *segs,
-                    uint32_t nsegs, uint32_t window, uint16_t *cd, const uint16_t *glnk, const uint64_t *umask, uint32_t *ulist,
-                    uint32_t *ucount) {
+int launch_resolve7(hipStream_t st, const ChunkDesc *chunks, const SegDesc *segs, uint32_t nsegs, uint32_t window, uint16_t *cd,
+                    const uint32_t *glnk, const uint64_t *umask, uint32_t *ulist, uint32_t *ucount, uint32_t hop_cap) {
     if (nsegs == 0) return 0;
     hipLaunchKernelGGL(lz77_compact7_kernel, dim3(nsegs * (r7::SLABS + 1)), dim3(r7::SLAB_WORDS), 0, st, chunks, segs, umask, ulist,
                        ucount);
     hipError_t e_ = hipGetLastError();
     if (e_ != hipSuccess) return (int)e_;
-    hipLaunchKernelGGL(lz77_resolve7_kernel, dim3(nsegs * r7::WGS), dim3(r7::THREADS), 0, st, in, in_bytes, chunks, segs, window,
-                       cd, glnk, ulist, ucount);
+    hipLaunchKernelGGL(lz77_resolve7_kernel, dim3(nsegs * r7::WGS), dim3(r7::THREADS), 0, st, chunks, segs, window, cd, glnk, ulist,
+                       ucount, hop_cap);
     e_ = hipGetLastError();
     return e_ != hipSuccess ? (int)e_ : 0;
 }
