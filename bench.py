@@ -35,12 +35,44 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
 
 N_BYTES = 256 << 20
 WRITE = 8192
-HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy)
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec.  The peak a COPY reaches on the box at hand is measured in
+                           # every run (measure_copy_peak) and reported beside it: roofline.peak_measured / frac_measured
 
-# phase (HIP-event bracket in the library) -> the kernel that fills it
-PHASE_KERNEL = {"enc:lz77_match": "lz77_match5_kernel", "dec:lz77_copy": "blk_materialize2_kernel",
-                "dec:blk_scan": "blk_scan_kernel", "dec:blk_emit": "blk_emit_kernel", "enc:lz77_parse": "parse_walk_kernel"}
+# phase (HIP-event bracket in the library) -> the kernel that fills it (the match phase: the candidate kernel; its resolver
+# and compaction kernels are the rest of that bracket)
+PHASE_KERNEL = {"enc:lz77_match": "lz77_match7_kernel", "dec:lz77_copy": "blk_materialize2_kernel",
+                "dec:blk_scan": "blk_scan_kernel", "dec:blk_emit": "blk_emit_kernel", "enc:lz77_parse": "parse_walk_kernel",
+                "dec:find1": "find_blocks_stage1", "dec:find2": "find_blocks_stage2", "enc:pack": "pack_kernel",
+                "dec:batch_copy": "blk_materialize2_kernel"}
+# resident wavefronts per SIMD of those kernels (workgroup size x workgroups per CU / 4), for measure_bound
+PHASE_WAVES_PER_SIMD = {"enc:lz77_match": 4, "dec:lz77_copy": 4, "dec:blk_scan": 4, "dec:blk_emit": 4, "enc:lz77_parse": 2}
 CALIBRATION_KERNEL = "checksum_span_kernel"   # reads its input exactly once with wide coalesced loads
+
+
+def measure_copy_peak(torch, dev, nbytes=N_BYTES, reps=5):
+    """The HBM rate a plain device-to-device copy reaches on THIS box, now ("use the measured peak as the
+    denominator too"): bytes read + bytes written per second of the best of `reps` copies of `nbytes`."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    a.zero_()
+    best = None
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        b.copy_(a)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    del a, b
+    return 2.0 * nbytes / best / 1e9
+
+
+def dominant_phase(timing, skip=("upload", "start", "done")):
+    """(phase name, ms) of the longest kernel bracket of one library call's phase list"""
+    if not timing:
+        return None, None
+    ph = [(k, v) for k, v in timing["phases"] if k not in skip]
+    return max(ph, key=lambda kv: kv[1]) if ph else (None, None)
 
 
 def measure_traffic(kernel, n, schedule):
@@ -232,6 +264,37 @@ def oracle_worker(args):
     return t1 - t0, t2 - t1
 
 
+def sub_roofline(prefix, dom, algo_bytes):
+    """roofline record of a sub-configuration's dominant kernel: the longest HIP-event bracket of the call (one kernel, or
+    one kernel per round of a batch), its algorithmic bytes = the call's (input read + output written)"""
+    name, ms = dom
+    if not name or not ms:
+        return None
+    ach = algo_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": prefix + name, "kernel_name": PHASE_KERNEL.get(prefix + name), "achieved": round(ach, 2),
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+            "avg_launch_ms": round(ms, 4), "algorithmic_bytes": algo_bytes}
+
+
+def sub_pcie(ctx, _ffi, data, write):
+    """PCIe-inclusive figures (never `value`): lfx_encode_host / lfx_decode_host on host buffers — one H2D and one D2H copy
+    around the device path each.  One call each after a warm-up call; wall clock."""
+    opts, sched = _ffi.make_opts(mtime=0), _ffi.make_schedule(write)
+    buf = data.tobytes()
+    enc = ctx.encode_host(_ffi.GZIP, buf[:1 << 20], opts, sched)      # (warm-up: pinned staging, scratch)
+    t0 = time.perf_counter()
+    enc = ctx.encode_host(_ffi.GZIP, buf, opts, sched)
+    t1 = time.perf_counter()
+    rc, out, used, msg = ctx.decode_host(_ffi.GZIP, enc, cap=len(buf) + 64)
+    t2 = time.perf_counter()
+    ok = rc == 0 and used == len(enc) and out == buf
+    n = len(buf)
+    return {"workload": "lfx_encode_host + lfx_decode_host on host buffers (%d MiB in, %d B compressed): H2D + device path + D2H, "
+                        "pageable host memory, includes the ctypes buffer handling of this script" % (n >> 20, len(enc)),
+            "value": round(n / (t2 - t0) / 1e9, 3), "unit": "GB/s", "encode_ms": round((t1 - t0) * 1e3, 2),
+            "decode_ms": round((t2 - t1) * 1e3, 2), "round_trip_ok": ok}
+
+
 def sub_cfg3(ctx, torch, synth, _ffi, C, dev, reps=3):
     """BASELINE cfg3 as a sub-record: 4096 independent 64 KiB zlib streams decoded by ONE lfx_decode_batch_device call; wall
     clock around the blocking call, streams and outputs resident in HBM; GB/s of output bytes.  As SURVEY §8d asks, half of
@@ -291,6 +354,7 @@ def sub_cfg3(ctx, torch, synth, _ffi, C, dev, reps=3):
     status = np.zeros(count, dtype=np.int32)
     d_out = torch.zeros(count * size, dtype=torch.uint8, device=dev)
     best = None
+    dom = (None, None)
     for _ in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -298,10 +362,12 @@ def sub_cfg3(ctx, torch, synth, _ffi, C, dev, reps=3):
                                        d_out.data_ptr(), out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
                                        status.ctypes.data)
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        if best is None or dt < best:
+            best, dom = dt, dominant_phase(ctx.last_timing())
     ok = rc == 0 and not status.any() and bool((out_len == size).all()) and torch.equal(d_out, d_plain)
     comp = int(in_len.sum())
-    return {"workload": "cfg3: %d independent %d KiB zlib streams (half reference-format, half python-zlib level 6), one "
+    return {"roofline": sub_roofline("dec:", dom, comp + count * size),
+            "workload": "cfg3: %d independent %d KiB zlib streams (half reference-format, half python-zlib level 6), one "
                         "lfx_decode_batch_device call" % (count, size >> 10),
             "value": round(count * size / best / 1e9, 3), "unit": "GB/s of output", "ms": round(best * 1e3, 3),
             "compressed_bytes": comp, "round_trip_ok": ok,
@@ -323,19 +389,23 @@ def sub_cfg5(ctx, torch, synth, _ffi, C, dev, reps=2):
     d_out = torch.empty(bound, dtype=torch.uint8, device=dev)
     best = None
     m = 0
+    dom = (None, None)
     for _ in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         m = ctx.encode_device(_ffi.ZLIB, d_in.data_ptr(), n, d_out.data_ptr(), bound, opts, sched)
         dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
+        if best is None or dt < best:
+            best, dom = dt, dominant_phase(ctx.last_timing())
     d_dec = torch.empty(n, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rc, ol, used, msg = ctx.decode_device(_ffi.ZLIB, d_out.data_ptr(), m, d_dec.data_ptr(), n)
     tdec = time.perf_counter() - t0
+    dom_dec = dominant_phase(ctx.last_timing())
     ok = rc == 0 and ol == n and used == m and torch.equal(d_dec, d_in)
-    return {"workload": "cfg5: zlib::Encoder on LOWENT(1 GiB), 8192-byte writes", "value": round(n / best / 1e9, 3),
+    return {"roofline": sub_roofline("enc:", dom, n + m), "decode_roofline": sub_roofline("dec:", dom_dec, n + m),
+            "workload": "cfg5: zlib::Encoder on LOWENT(1 GiB), 8192-byte writes", "value": round(n / best / 1e9, 3),
             "unit": "GB/s of input", "ms": round(best * 1e3, 3), "compressed_bytes": int(m), "decode_ms": round(tdec * 1e3, 3),
             "round_trip_ok": ok, "hbm_frac_algorithmic": round((n + m) / best / 1e9 / HBM_PEAK_GBPS, 5)}
 
@@ -370,8 +440,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bytes", type=int, default=N_BYTES,
-                    help="uncompressed bytes PER RANK (weak scaling).  Default 256 MiB = the metric's configuration; the cfg4 "
-                         "shape (8-way sharded gzip encode of 8 GiB) is `--gpus 8 --bytes 1073741824`")
+                    help="uncompressed bytes PER RANK with --scaling weak (the default), of the WHOLE JOB with --scaling strong.  "
+                         "Default 256 MiB = the metric's configuration; the cfg4 shape (8-way sharded gzip encode of 8 GiB) is "
+                         "`--gpus 8 --bytes 1073741824` (and rides along as a sub-record of every --gpus 8 run)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank holds --bytes (256 MiB per GPU: the driver's scaling curve).  strong: --bytes is the "
+                         "whole job, split evenly over the ranks (BASELINE.json's metric read literally: 256 MiB at 1/2/4/8 GPUs; "
+                         "at 32 MiB per GPU the per-call fixed costs show)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes")
     ap.add_argument("--no-s1", action="store_true", help="skip the S1 sub-record")
@@ -425,7 +500,7 @@ def main():
     torch.cuda.set_device(local)
     ctx = libflate_amd.Context(local)
     ctx.enable_timing(True)
-    n = args.bytes
+    n = args.bytes if args.scaling == "weak" else max(args.bytes // world // 8192 * 8192, 8192)   # (whole writes per rank)
     data = synth.text(n, seed=synth.SEED_BASE + 2 + rank)
     d_in = torch.from_numpy(data).to(dev)
     L = _ffi.lib()
@@ -433,13 +508,14 @@ def main():
     class Run:
         """buffers + one step of the round trip for a write schedule"""
 
-        def __init__(self, schedule):
+        def __init__(self, schedule, n=n, d_in=d_in):
+            self.n, self.d_in = n, d_in
             self.schedule = schedule
             self.write = WRITE if schedule == "S8K" else 0       # 0 = one write_all
             self.opts, self.sched = _ffi.make_opts(mtime=0), _ffi.make_schedule(self.write)
-            self.bound = L.lfx_encode_bound(n, C.byref(self.opts), C.byref(self.sched)) & ~3
+            self.bound = L.lfx_encode_bound(self.n, C.byref(self.opts), C.byref(self.sched)) & ~3
             self.d_out = torch.empty(self.bound, dtype=torch.uint8, device=dev)
-            self.d_dec = torch.empty(n, dtype=torch.uint8, device=dev)
+            self.d_dec = torch.empty(self.n, dtype=torch.uint8, device=dev)
             self.hdr_len = L.lfx_container_header_len(_ffi.GZIP, C.byref(self.opts))
             self.phase_acc = {}
             self.member_len = 0
@@ -462,6 +538,7 @@ def main():
 
         def step(self, record=False):
             """→ (t_enc, t_dec, compressed bytes of this rank)"""
+            n, d_in = self.n, self.d_in
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if not sharded_path:
@@ -530,8 +607,9 @@ def main():
 
         def timed(self, steps, warmup, record=True):
             _, _, m = self.step()
-            if not torch.equal(self.d_dec, d_in):
+            if not torch.equal(self.d_dec, self.d_in):
                 raise RuntimeError("round trip mismatch")
+            self.step_s = []
             for _ in range(warmup):
                 self.step()
             if dist:
@@ -543,6 +621,7 @@ def main():
                 a, b, m = self.step(record=record)
                 enc_t += a
                 dec_t += b
+                self.step_s.append(a + b)
             torch.cuda.synchronize()
             if dist:
                 dist.barrier()
@@ -569,6 +648,26 @@ def main():
         member = run.d_member[:run.member_len].cpu().numpy().tobytes()
         whole = b"".join(synth.text(n, seed=synth.SEED_BASE + 2 + r).tobytes() for r in range(world))
         assert zlib.decompress(member, 31) == whole, "the concatenated member does not inflate to the ranks' input"
+    # ---- BASELINE cfg4 (8-way sharded gzip encode of 8 GiB, CRC-32 combine over RCCL) as a sub-record of every 8-rank run:
+    #      1 GiB per rank through the same sharded step (all ranks take part; LFX_BENCH_CFG4_BYTES sizes the self-test)
+    cfg4 = None
+    n4 = int(os.environ.get("LFX_BENCH_CFG4_BYTES", str(1 << 30)))
+    if sharded_path and (world == 8 or "LFX_BENCH_CFG4_BYTES" in os.environ) and not args.no_subs and n4 != n:
+        try:
+            d_in4 = torch.from_numpy(synth.text(n4, seed=synth.SEED_BASE + 40 + rank)).to(dev)
+            r4 = Run(args.schedule, n4, d_in4)
+            k4 = 2
+            e4, en4, de4, m4 = r4.timed(k4, 1, record=False)
+            cfg4 = {"workload": "cfg4: %d-way sharded gzip encode (+ N-GPU decode) of %d MiB of TEXT, %d MiB per rank, one member, "
+                                "CRC-32 combine and concatenation over %s" % (world, (n4 * world) >> 20, n4 >> 20,
+                                                                              "gloo (one-GPU self-test)" if one_gpu_test else "RCCL / xGMI"),
+                    "value": round(n4 * world / (e4 / k4) / 1e9, 4), "unit": "GB/s", "ms_per_step": round(e4 / k4 * 1e3, 3),
+                    "encode_GBps": round(n4 * world * k4 / en4 / 1e9, 4), "decode_GBps": round(n4 * world * k4 / de4 / 1e9, 4),
+                    "steps": k4, "member_bytes": int(r4.member_len) if rank == 0 else None}
+            del r4, d_in4
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001  (a sub-record must not take the metric down — but every rank must agree)
+            cfg4 = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -576,6 +675,13 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     total_bytes = n * world
+    steps_sorted = sorted(run.step_s)
+    median_s = steps_sorted[len(steps_sorted) // 2] if steps_sorted else None     # (this rank's encode + decode calls of one step)
+    peak_measured = None
+    try:
+        peak_measured = measure_copy_peak(torch, dev, min(n, N_BYTES))
+    except Exception:   # noqa: BLE001
+        pass
     value = total_bytes / (elapsed / args.steps) / 1e9
     # ---- roofline of the dominant kernel phase (HIP events on the context's stream, inside the timed region)
     avg = {k: sum(v) / len(v) for k, v in run.phase_acc.items()}
@@ -588,6 +694,9 @@ def main():
         ach = algo_bytes / (avg[dom] * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dom, "kernel_name": PHASE_KERNEL.get(dom), "achieved": round(ach, 2),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                "peak_measured": round(peak_measured, 1) if peak_measured else None,
+                "frac_measured": round(ach / peak_measured, 5) if peak_measured else None,
+                "peak_measured_how": "device-to-device copy of %d MiB in this run: bytes read + written per second" % (min(n, N_BYTES) >> 20),
                 "avg_launch_ms": round(avg[dom], 4), "algorithmic_bytes": algo_bytes}
         if under_profiler():
             roof["traffic_error"] = "not measured: this run is itself under a profiler"
@@ -600,11 +709,12 @@ def main():
             else:
                 roof["traffic_error"] = (t or {}).get("error", "unknown")
             # what the dominant kernel is actually bound by: the HBM figures above are the contract's
-            if dom == "enc:lz77_match":
-                roof["bound_detail"] = measure_bound(PHASE_KERNEL[dom], n, args.schedule, waves_per_simd=4)   # 16-wave workgroup, one per CU
+            if dom in PHASE_WAVES_PER_SIMD:
+                roof["bound_detail"] = measure_bound(PHASE_KERNEL[dom], n, args.schedule, waves_per_simd=PHASE_WAVES_PER_SIMD[dom])
     whole_ach = 2.0 * algo_bytes * world / (elapsed / args.steps) / 1e9
     whole = {"achieved": round(whole_ach, 2), "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
              "frac": round(whole_ach / (HBM_PEAK_GBPS * world), 5), "algorithmic_bytes_per_step": 2 * algo_bytes * world,
+             "frac_measured": round(whole_ach / (peak_measured * world), 5) if peak_measured else None,
              "traffic": step_traffic,
              "traffic_over_algorithmic": round(step_traffic / (2.0 * algo_bytes), 2) if step_traffic else None}
     # ---- the other write schedule of SURVEY cfg2 in the same run (fewer steps: it is a sub-record, not the metric)
@@ -628,6 +738,12 @@ def main():
             except Exception as e:      # noqa: BLE001  (a sub-record must not take the metric down)
                 subs[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
+    pcie = None
+    if world == 1 and not sharded_path and not args.no_subs:
+        try:
+            pcie = sub_pcie(ctx, _ffi, data, run.write)
+        except Exception as e:      # noqa: BLE001
+            pcie = {"error": "%s: %s" % (type(e).__name__, e)}
     cpu = None
     if not args.no_cpu_baseline and world == 1 and not sharded_path:
         import multiprocessing as mp
@@ -673,7 +789,9 @@ def main():
     line = {
         "metric": "gzip encode+decode throughput on 256 MiB synthetic text per GPU (uncompressed bytes through the round trip)",
         "value": round(value, 4), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "ms_per_step_median": round(median_s * 1e3, 3) if median_s else None,
+        "value_median": round(total_bytes / median_s / 1e9, 4) if median_s else None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": "cfg2: gzip::Encoder (DefaultLz77Encoder, default options, mtime=0) + gzip::Decoder on "
                                "TEXT(%d B) per GPU, write schedule %s" % (n, "S8K (8192-byte writes)" if args.schedule == "S8K" else "S1 (one write_all)"),
@@ -688,6 +806,8 @@ def main():
         "phases_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
         "roofline": roof, "whole_path": whole, "schedule_S1" if args.schedule == "S8K" else "schedule_S8K": s1,
         "other_configs": subs,
+        "pcie_inclusive": pcie,
+        "cfg4": cfg4,
         "cpu_baseline": cpu,
     }
     # The JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, whose buffer (when stdout is

@@ -22,10 +22,11 @@ def test_usable_cores_and_profiler_detection(monkeypatch):
 def test_phase_kernel_table_names_existing_kernels():
     import bench
     src = ""
-    for f in ("lfx_match3.hip", "lfx_match5.hip", "lfx_parse2.hip", "lfx_encode_kernels.hip", "lfx_inflate_fast.hip", "lfx_decode_kernels.hip"):
+    for f in ("lfx_match7.hip", "lfx_match5.hip", "lfx_parse2.hip", "lfx_encode_kernels.hip", "lfx_inflate_fast.hip", "lfx_decode_kernels.hip"):
         src += open(os.path.join(ROOT, "libflate_amd", "csrc", f)).read()
     for phase, kernel in bench.PHASE_KERNEL.items():
         assert "void %s(" % kernel in src, (phase, kernel)    # a renamed kernel must not silently lose its traffic figure
+    assert set(bench.PHASE_WAVES_PER_SIMD) <= set(bench.PHASE_KERNEL)
     assert "void %s(" % bench.CALIBRATION_KERNEL in src
 
 

@@ -21,6 +21,7 @@ def test_no_serialized_loads_in_the_data_loops():
                                  "window_rank_map_kernel", "window_ranks_kernel", "sym_substitute_kernel", "blk_scan_kernel",
                                  "blk_emit_kernel", "find_blocks_stage2"),
         "lfx_decode_kernels.hip": ("find_blocks_stage1",),
+        "lfx_match7.hip": ("lz77_match7_kernel", "lz77_compact7_kernel", "lz77_resolve7_kernel"),
         "lfx_encode_kernels.hip": ("checksum_span_kernel", "checksum_ranges_kernel", "histogram_kernel", "huffman_kernel"),
     }
     for fname, kernels in watched.items():
