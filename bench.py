@@ -553,54 +553,34 @@ def main():
                 if record:
                     self.acc_timing("dec:")
                 return t1 - t0, t2 - t1, m
-            info = _ffi.ShardInfo()
-            self.check(L.lfx_encode_shard_prepare(ctx.handle, _ffi.GZIP, C.byref(self.opts), C.byref(self.sched),
-                                                  d_in.data_ptr(), n, int(rank == 0), int(rank == world - 1),
-                                                  C.byref(info)), "shard_prepare")
-            mine = torch.tensor([info.total_bits, info.n_bytes, info.crc32, info.adler32], dtype=torch.int64, device=dev)
-            if one_gpu_test:
-                parts = [torch.empty(4, dtype=torch.int64) for _ in range(world)]
-                dist.all_gather(parts, mine.cpu())
-                allv = torch.cat(parts)
-            else:
-                allv = torch.empty(world * 4, dtype=torch.int64, device=dev)
-                dist.all_gather_into_tensor(allv, mine)    # RCCL over xGMI: 32 B per rank
-            infos = [tuple(int(x) for x in row) for row in allv.view(world, 4).cpu().tolist()]
-            start_bits, combined, total_n = sharded.layout(infos, self.hdr_len, _ffi.GZIP)
-            m = C.c_uint64(0)
-            self.check(L.lfx_encode_shard_emit(ctx.handle, start_bits[rank], combined, total_n, self.d_out.data_ptr(),
-                                               self.bound, C.byref(m)), "shard_emit")
+            # ---- the library's own N-GPU driver (lfx_sharded_encode_begin: prepare → 32-byte all-gather → emit at the rank's
+            #      bit offset → the shards start travelling to rank 0, all transfers posted at once); the collectives are this
+            #      script's torch.distributed calls behind an lfx_comm (libflate_amd/sharded.py: RCCL over xGMI, or gloo in the
+            #      one-GPU self-test)
+            gh, part = sharded.encode_begin(ctx, rank, world, _ffi.GZIP, self.opts, self.sched, d_in, n, self.d_out, self.bound,
+                                            self.d_member, self.bound * world if rank == 0 else 0, self.staging,
+                                            dist if world > 1 else None)
+            m = C.c_uint64(part.part_len)
+            combined, total_n = part.check, part.total_n
             if record:
                 self.acc_timing("enc:")
-            # ---- stream concatenation on the writer rank: every rank's emitted byte count, then the shard bytes
-            lens_t = torch.tensor([m.value], dtype=torch.int64, device="cpu" if one_gpu_test else dev)
-            if world > 1:
-                all_lens = [torch.empty_like(lens_t) for _ in range(world)]
-                dist.all_gather(all_lens, lens_t)
-                part_lens = [int(x.item()) for x in all_lens]
-            else:
-                part_lens = [m.value]
-            # the transfers are posted now and run (RCCL's stream, xGMI) while this rank decodes its own shard: the
-            # decode reads the local shard, not the member
-            gh = sharded.gather_begin(ctx, rank, world, self.d_out, m.value, start_bits, part_lens,
-                                      self.d_member, self.bound * world if rank == 0 else 0, dist, self.staging)
             t1 = time.perf_counter()
-            # ---- N-GPU decode of the ONE member, no bit offset from the encoder: every rank holds a byte range of the member
-            #      (here: the bytes it emitted — [start_bit // 8, next start_bit // 8] — the cut a consumer reading the member
-            #      in parallel would also know), finds and scans the blocks that start in it, the ranks all-gather their
-            #      candidate tuples (56 bytes each over RCCL), walk the same chain and materialise their own blocks;
-            #      arbitrary byte cuts: tests/test_gpu_round3.py::test_member_decode_on_virtual_ranks
-            lo = start_bits[rank] // 8 if rank else 0
-            hi = start_bits[rank + 1] // 8 if rank + 1 < world else lo + m.value
+            # ---- N-GPU decode of the ONE member, no bit offset from the encoder (lfx_sharded_decode): every rank holds a byte
+            #      range of the member (here: the bytes it emitted — the cut a consumer reading the member in parallel would also
+            #      know), finds and scans the blocks that start in it, the ranks all-gather their candidate tuples (56 bytes each
+            #      over RCCL), walk the same chain and materialise their own blocks; the transfers of the concatenation run
+            #      meanwhile.  Arbitrary byte cuts: tests/test_gpu_round3.py::test_member_decode_on_virtual_ranks
+            lo = part.start_bit // 8 if rank else 0
+            hi = part.end_bit // 8 if rank + 1 < world else lo + m.value
             ol, base, total_out, crc_all, _ad = sharded.decode_member_ranks(ctx, rank, world, self.d_out, m.value, lo, hi,
-                                                                            8 * self.hdr_len, self.d_dec, n, dist, small_group,
-                                                                            member_len=start_bits[-1] // 8 + part_lens[-1])
+                                                                            8 * self.hdr_len, self.d_dec, n, dist if world > 1 else None,
+                                                                            small_group, member_len=part.member_len)
             if ol != n or base != rank * n or total_out != total_n or crc_all != combined:
                 raise RuntimeError("member decode: slice %d bytes at %d of %d, crc %08x vs %08x" % (ol, base, total_out, crc_all, combined))
             t2 = time.perf_counter()
             if record:
                 self.acc_timing("dec:")
-            self.member_len = sharded.gather_finish(gh)      # (the member is complete on rank 0 when the step ends)
+            self.member_len = sharded.encode_finish(gh)      # (the member is complete on rank 0 when the step ends)
             torch.cuda.synchronize()
             t3 = time.perf_counter()
             return (t1 - t0) + (t3 - t2), t2 - t1, m.value

@@ -102,7 +102,10 @@ int lfx_encode_device(lfx_ctx *c, int format, const lfx_encode_opts *o, const lf
 /* `count` independent streams in one call (BASELINE.json configs[2] needs thousands of 64 KiB streams): stream i is what
  * lfx_encode_device makes of d_in[in_off[i] .. +in_len[i]) with the same options and the schedule applied to it alone, and
  * lies at d_out[out_off[i] .. +out_len[i]) (out_off 4-byte aligned, out_cap[i] >= lfx_encode_bound(in_len[i])).  Offsets and
- * lengths are HOST arrays.  A stream that does not fit its capacity voids the call (LFX_E_NOSPACE, status[i] says which). */
+ * lengths are HOST arrays.  The output ranges [out_off[i], out_off[i] + out_cap[i]) must not overlap (LFX_E_ARG); the whole
+ * span from the lowest out_off to the highest out_off + out_cap is zero-filled first — gaps between the ranges included, and
+ * also when the call then fails.  A stream that does not fit its capacity voids the call: LFX_E_NOSPACE, status[i] =
+ * LFX_E_NOSPACE for exactly the streams that were too small (0 for those that would have fit), every out_len[i] = 0. */
 int lfx_encode_batch_device(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s, uint32_t count,
                             const void *d_in, const uint64_t *in_off, const uint64_t *in_len, void *d_out,
                             const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status);
@@ -207,6 +210,74 @@ int lfx_decode_range_finish(lfx_ctx *c, const void *d_maps, uint32_t rank, uint3
  * rank order. */
 int lfx_shard_place_device(lfx_ctx *c, void *d_member, uint64_t cap, const void *d_part, uint64_t part_len,
                            uint64_t start_bit, int is_first);
+/* ---- the N-GPU drivers (round 5): the sequencing of the steps above, with the caller's collectives -----------------------
+ * One rank per GPU, one lfx_ctx per rank.  The reference has ONE encoder with ONE running checksum (gzip::Encoder::finish,
+ * src/gzip.rs:858-868; src/checksum.rs:22-33); here the ranks' block ranges, bit offsets and partial checksums are exchanged
+ * through an lfx_comm — four callbacks the caller implements over whatever moves bytes between its ranks (torch.distributed
+ * in libflate_amd/sharded.py, MPI, ...), or lfx_comm_rccl() for RCCL over xGMI.  Every callback returns 0 on success.
+ *   allgather: every rank contributes `bytes` HOST bytes; recv (world * bytes, rank order) is complete on return.
+ *   isend / irecv: post a transfer of a DEVICE buffer (they may return before it completes; RCCL groups them);
+ *   wait: everything this rank posted is complete.
+ * A failure on one rank travels with the next collective and comes back from the same call on EVERY rank. */
+typedef struct lfx_comm {
+    void *user;
+    uint32_t rank, world;
+    int (*allgather)(void *user, const void *send, void *recv, uint64_t bytes);
+    int (*isend)(void *user, const void *d_buf, uint64_t bytes, uint32_t to_rank);
+    int (*irecv)(void *user, void *d_buf, uint64_t bytes, uint32_t from_rank);
+    int (*wait)(void *user);
+} lfx_comm;
+/* RCCL binding: `nccl_comm` is an ncclComm_t, `hip_stream` the hipStream_t its collectives run on.  librccl is loaded at run
+ * time (LFX_E_UNSUPPORTED when it is not there): liblfx.so does not link it. */
+int lfx_comm_rccl(void *nccl_comm, void *hip_stream, uint32_t rank, uint32_t world, lfx_comm *out);
+void lfx_comm_rccl_free(lfx_comm *cm);
+
+/* Sharded encode of ONE member: rank r holds the r-th slice of the input (whole blocks: n a multiple of the block size on
+ * every rank but the last).  begin(): prepare → all-gather of the 32-byte shard infos → emit at the rank's bit offset →
+ * the shards start travelling to rank 0 (all transfers posted at once; d_staging on rank 0 holds the shards of ranks 1.. side
+ * by side, 256-byte aligned).  Between begin and finish the caller may use its own shard (d_part).  finish(): waits, places the
+ * shards in d_member (rank 0; the byte two shards share is OR-ed) and frees the state.  → the member equals what ONE
+ * encoder emits for the concatenated input. */
+typedef struct lfx_sharded_enc lfx_sharded_enc;
+typedef struct lfx_sharded_part {
+    uint64_t start_bit;   /* of this rank's first DEFLATE bit inside the member */
+    uint64_t end_bit;     /* the bit behind this rank's last one = the next rank's start_bit */
+    uint64_t part_len;    /* bytes emitted into d_part (d_part[0] is byte start_bit / 8 of the member) */
+    uint64_t member_len;  /* bytes of the whole member */
+    uint64_t total_n;     /* uncompressed bytes of the whole member */
+    uint32_t check;       /* combined CRC-32 (gzip) / Adler-32 (zlib) of the whole input */
+    uint32_t _pad;
+} lfx_sharded_part;
+int lfx_sharded_encode_begin(lfx_ctx *c, const lfx_comm *cm, int format, const lfx_encode_opts *o, const lfx_schedule *s,
+                             const void *d_in, uint64_t n, void *d_part, uint64_t part_cap, void *d_member /* rank 0 */,
+                             uint64_t member_cap, void *d_staging /* rank 0 */, uint64_t staging_cap, lfx_sharded_enc **state,
+                             lfx_sharded_part *out);
+int lfx_sharded_encode_finish(lfx_ctx *c, const lfx_comm *cm, lfx_sharded_enc *state, uint64_t *member_len /* rank 0 */);
+
+/* N-GPU decode of ONE member cut by compressed bytes (steps 1-6 above): rank r holds d_part = member bytes [lo_byte, hold_hi)
+ * (lfx_sharded_byte_range: an equal share plus a tail of one maximal block) and gets its slice of the output in d_out.
+ * first_bit: the member's first DEFLATE bit (behind the container header); member_len: 0 if unknown.  Collectives: the
+ * candidate tuples, the slices' (status, length, checksums), and — only for members whose blocks read earlier blocks — the
+ * ranks' 64 KiB index maps. */
+typedef struct lfx_sharded_slice {
+    uint64_t out_len, out_base;   /* this rank's slice: bytes, and where it lies in the member's output */
+    uint64_t total_out;           /* bytes of the whole member's output */
+    uint32_t crc32, adler32;      /* of the whole member's output (compare with the trailer) */
+} lfx_sharded_slice;
+void lfx_sharded_byte_range(uint64_t first_byte, uint64_t member_len, uint32_t rank, uint32_t world, uint64_t *lo_byte,
+                            uint64_t *hi_byte, uint64_t *hold_hi);
+int lfx_sharded_decode(lfx_ctx *c, const lfx_comm *cm, const void *d_part, uint64_t n_part, uint64_t lo_byte, uint64_t hi_byte,
+                       uint64_t first_bit, uint64_t member_len, void *d_out, uint64_t cap, lfx_sharded_slice *out);
+/* the exchange steps of the two drivers on their own (host memory + the comm; no device): the layout of the ranks' bit ranges
+ * and the combined trailer checksum; the all-gather of candidate tuples (*all: lfx_sharded_free); the fold of the slices'
+ * checksums.  `status`: this rank's error so far — a non-zero status of ANY rank is returned on EVERY rank. */
+int lfx_sharded_layout(const lfx_comm *cm, const lfx_shard_info *mine, uint64_t header_len, int format,
+                       uint64_t *start_bits /* world + 1 entries */, uint32_t *check, uint64_t *total_n);
+int lfx_sharded_gather_tuples(const lfx_comm *cm, const lfx_blk_tuple *mine, uint32_t count, int status, lfx_blk_tuple **all,
+                              uint32_t *n_all, uint32_t *failed_rank);
+int lfx_sharded_fold(const lfx_comm *cm, int status, uint32_t state, uint64_t len, uint32_t crc32, uint32_t adler32,
+                     uint32_t *any_state, uint32_t *crc_all, uint32_t *adler_all, uint64_t *total, uint32_t *failed_rank);
+void lfx_sharded_free(void *p);
 uint32_t lfx_crc32_combine(uint32_t crc1, uint32_t crc2, uint64_t len2);
 uint32_t lfx_adler32_combine(uint32_t ad1, uint32_t ad2, uint64_t len2);
 uint64_t lfx_container_header_len(int format, const lfx_encode_opts *o);

@@ -29,6 +29,8 @@ EXPORTS = [
     "lfx_decoder_consumed", "lfx_decoder_buffered", "lfx_decoder_surplus", "lfx_decoder_header", "lfx_decoder_last_error", "lfx_decoder_free", "lfx_lz77_new",
     "lfx_lz77_encode", "lfx_lz77_flush", "lfx_lz77_window_size", "lfx_lz77_compression_level",
     "lfx_lz77_free", "lfx_ctx_last_timing", "lfx_ctx_enable_timing", "lfx_version",
+    "lfx_comm_rccl", "lfx_comm_rccl_free", "lfx_sharded_encode_begin", "lfx_sharded_encode_finish", "lfx_sharded_byte_range",
+    "lfx_sharded_decode", "lfx_sharded_layout", "lfx_sharded_gather_tuples", "lfx_sharded_fold", "lfx_sharded_free",
 ]
 
 
@@ -57,6 +59,27 @@ class BlkTuple(C.Structure):
 
 class ShardInfo(C.Structure):
     _fields_ = [("total_bits", C.c_uint64), ("n_bytes", C.c_uint64), ("crc32", C.c_uint32),
+                ("adler32", C.c_uint32)]
+
+
+# lfx_comm: the caller's collectives (include/lfx.h); every callback returns 0 on success
+COMM_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+COMM_P2P = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32)
+COMM_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class Comm(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("allgather", COMM_ALLGATHER),
+                ("isend", COMM_P2P), ("irecv", COMM_P2P), ("wait", COMM_WAIT)]
+
+
+class ShardedPart(C.Structure):
+    _fields_ = [("start_bit", C.c_uint64), ("end_bit", C.c_uint64), ("part_len", C.c_uint64), ("member_len", C.c_uint64), ("total_n", C.c_uint64),
+                ("check", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class ShardedSlice(C.Structure):
+    _fields_ = [("out_len", C.c_uint64), ("out_base", C.c_uint64), ("total_out", C.c_uint64), ("crc32", C.c_uint32),
                 ("adler32", C.c_uint32)]
 
 
@@ -178,6 +201,22 @@ def lib():
     L.lfx_ctx_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.lfx_ctx_enable_timing.argtypes = [vp, i32]
     L.lfx_version.restype = u32
+    L.lfx_comm_rccl.argtypes = [vp, vp, u32, u32, C.POINTER(Comm)]
+    L.lfx_comm_rccl_free.argtypes = [C.POINTER(Comm)]
+    L.lfx_comm_rccl_free.restype = None
+    L.lfx_sharded_encode_begin.argtypes = [vp, C.POINTER(Comm), i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), vp, u64, vp, u64,
+                                           vp, u64, vp, u64, C.POINTER(vp), C.POINTER(ShardedPart)]
+    L.lfx_sharded_encode_finish.argtypes = [vp, C.POINTER(Comm), vp, C.POINTER(u64)]
+    L.lfx_sharded_byte_range.argtypes = [u64, u64, u32, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.lfx_sharded_byte_range.restype = None
+    L.lfx_sharded_decode.argtypes = [vp, C.POINTER(Comm), vp, u64, u64, u64, u64, u64, vp, u64, C.POINTER(ShardedSlice)]
+    L.lfx_sharded_layout.argtypes = [C.POINTER(Comm), C.POINTER(ShardInfo), u64, i32, C.POINTER(u64), C.POINTER(u32), C.POINTER(u64)]
+    L.lfx_sharded_gather_tuples.argtypes = [C.POINTER(Comm), C.POINTER(BlkTuple), u32, i32, C.POINTER(C.POINTER(BlkTuple)),
+                                            C.POINTER(u32), C.POINTER(u32)]
+    L.lfx_sharded_fold.argtypes = [C.POINTER(Comm), i32, u32, u64, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32),
+                                   C.POINTER(u64), C.POINTER(u32)]
+    L.lfx_sharded_free.argtypes = [vp]
+    L.lfx_sharded_free.restype = None
     # debug hooks (host execution of host/device-shared code; used by the CPU test-suite only)
     L.lfx_debug_huff_block.argtypes = [vp, u32, vp, vp, vp, C.POINTER(u32), C.POINTER(u64)]
     L.lfx_debug_plan.argtypes = [i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), u64, vp, C.c_size_t,

@@ -764,6 +764,17 @@ extern "C" int lfx_encode_batch_device(lfx_ctx *cc, int format, const lfx_encode
         out_lo = std::min(out_lo, out_off[i]);
         out_hi = std::max(out_hi, out_off[i] + out_cap[i]);
     }
+    {
+        // the streams are OR-ed into their ranges (pack kernel): two streams in one range would garble each other silently
+        std::vector<uint32_t> order(count);
+        for (uint32_t i = 0; i < count; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return out_off[a] < out_off[b]; });
+        for (uint32_t k = 0; k + 1 < count; k++)
+            if (out_off[order[k]] + out_cap[order[k]] > out_off[order[k + 1]]) {
+                c->set_error("the output ranges of two streams overlap");
+                return LFX_E_ARG;
+            }
+    }
     const uint32_t nblocks = (uint32_t)plan.blocks.size();
     // per-stream scratch: descriptors, checksums, end bits, status, lengths (+ the header bytes)
     const size_t sz_streams = sizeof(BatchStream) * count;
@@ -807,10 +818,13 @@ extern "C" int lfx_encode_batch_device(lfx_ctx *cc, int format, const lfx_encode
         break;
     }
     for (uint32_t i = 0; i < count; i++) {
-        if (status) status[i] = res.status ? (h_status[i] ? h_status[i] : LFX_E_NOSPACE) : LFX_OK;
+        if (status) status[i] = res.status ? h_status[i] : LFX_OK;     // (a voided call: non-zero for exactly the streams that were too small)
         if (out_len) out_len[i] = res.status ? 0 : h_len[i];
     }
-    if (res.status) { c->set_error("output capacity of a stream too small (status[] says which): nothing was written"); return LFX_E_NOSPACE; }
+    if (res.status) {
+        c->set_error("output capacity of a stream too small (status[] says which): the call is void, the output span holds no stream");
+        return LFX_E_NOSPACE;
+    }
     return LFX_OK;
 }
 
@@ -1070,6 +1084,8 @@ static int enc_run_codes(lfx_encoder *e) {
 
 // closed blocks of the codes mode are encoded once this many code words wait (about 8 MiB of text)
 static const uint64_t ENC_BATCH_CODES = 2ull << 20;
+// closed blocks (either mode) are encoded once this many raw bytes wait
+static const uint64_t ENC_BATCH_BYTES = 8ull << 20;
 
 extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, size_t n_codes, const uint8_t *raw, size_t n_raw,
                                        int end_block) {
@@ -1093,7 +1109,9 @@ extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, si
         e->closed_codes += e->open_codes + 1;
         e->open_codes = 0;
         if (end_block == 2) e->final_closed = true;
-        else if (e->closed_codes >= ENC_BATCH_CODES) {
+        else if (e->closed_codes >= ENC_BATCH_CODES || e->pending.size() >= ENC_BATCH_BYTES) {
+            // (the byte threshold: a well-compressing Lz77Encode — 258-byte matches — closes 2 M code words only after half a
+            //  gigabyte of raw bytes; the reference emits every block as it closes)
             int rc = enc_run_codes(e);
             if (rc) { e->failed = true; return rc; }
         }
@@ -1132,7 +1150,6 @@ extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encod
 // reference itself would be holding (encode.rs:386-426) — stay in `pending`.  8 MiB keeps what the encoder buffers within
 // eight default blocks (the reference emits per block, encode.rs:277-286) at a third of the one-shot call's throughput:
 // a batch is one GPU pass with ~0.4 ms of fixed latency.
-static const uint64_t ENC_BATCH_BYTES = 8ull << 20;
 
 extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n) {
     if (!e || e->finished) return -(int64_t)LFX_E_ARG;

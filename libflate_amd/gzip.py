@@ -66,8 +66,19 @@ class EncodeOptions(_deflate.EncodeOptions):
         self._kw.setdefault("mtime", 0)
 
     def header(self, header):  # gzip.rs:717-720
-        self._kw.update(header)
-        self._kw["lz77_level"] = 0       # the header REPLACES the one with_lz77 made: HeaderBuilder's level is Unknown (gzip.rs:157,684)
+        """`header`: what HeaderBuilder.finish() returns, or the dict a Decoder's header() returns (gzip.rs:959).  The header
+        REPLACES the one the options held, its compression level included: the XFL byte written is the header's
+        own — Unknown for a builder's header (gzip.rs:157), Fastest / Slowest kept for one cloned from a decoder."""
+        h = dict(header)
+        if "modification_time" in h:        # a decoder's header: the reference's field names
+            h = {k: v for k, v in {"mtime": h["modification_time"], "os": h.get("os", 3), "is_text": int(bool(h.get("is_text"))),
+                                   "hcrc": int(bool(h.get("is_verified"))), "extra": h.get("extra_field"),
+                                   "filename": h.get("filename"), "comment": h.get("comment"), "xfl": h.get("xfl", 0)}.items()
+                 if v is not None}
+        xfl = h.pop("xfl", 0)
+        self._kw.update(h)
+        # (lz77_level = 1 + libflate_lz77::CompressionLevel: Fast → XFL 4, Best → XFL 2, Balance → XFL 0, gzip.rs:84-92)
+        self._kw["lz77_level"] = {4: 1 + 1, 2: 1 + 3}.get(xfl, 1 + 2)
         return self
 
 

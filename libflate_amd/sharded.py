@@ -1,18 +1,128 @@
-"""Sharded encode, host side: layout of the ranks' bit ranges inside ONE member, the combined
-trailer checksum, and the concatenation of the shards on the writer rank.
+"""N-GPU encode / decode of ONE member, host side — a thin caller of the library's own drivers.
 
-The data path has no collective: every rank encodes its own blocks; the ranks exchange 32 bytes each
-(`lfx_shard_info`, one all-gather over RCCL / xGMI), emit at their global bit offset, and the shard bytes travel
-once to the writer rank (point-to-point over xGMI), where `lfx_shard_place_device` puts them in place — the byte at a
-shard boundary is shared by two shards and is OR-ed."""
+Until round 4 this module WAS the driver (layout, concatenation, the member decode with its retries and its window hand-over);
+since round 5 that sequencing lives in the C ABI (include/lfx.h: lfx_sharded_encode_begin / _finish, lfx_sharded_decode and
+their exchange steps lfx_sharded_layout / _gather_tuples / _fold; libflate_amd/csrc/lfx_sharded.cpp), so that a Rust or C
+caller has the same path.  What is left here: an `lfx_comm` whose four callbacks run over torch.distributed (RCCL on GPUs,
+gloo in CPU rigs), and the functions the tests and bench.py call, now forwarding to the library.
+
+The data path has no collective: every rank encodes its own blocks; the ranks exchange 32 bytes each (`lfx_shard_info`, one
+all-gather over RCCL / xGMI), emit at their global bit offset, and the shard bytes travel once to the writer rank
+(point-to-point over xGMI), where `lfx_shard_place_device` puts them in place — the byte at a shard boundary is shared by two
+shards and is OR-ed."""
 import ctypes as C
 
 from . import _ffi
 
+RANGE_TAIL = 4 << 20      # bytes of the right neighbour's range a rank also holds (lfx_sharded_byte_range applies it)
 
+
+class TorchComm:
+    """lfx_comm over torch.distributed.  allgather moves HOST bytes (through the device on RCCL: its collectives take
+    device tensors); isend / irecv post transfers of DEVICE buffers, all of them started together by wait()'s batch
+    (on RCCL the shards then arrive over different xGMI links concurrently) — with gloo (CPU rigs, the one-GPU self-test
+    of bench.py) they hop through host tensors."""
+
+    def __init__(self, dist, rank, world, device=None, group=None):
+        import torch
+        self.torch, self.dist, self.rank, self.world, self.group = torch, dist, rank, world, group
+        self.host = dist is None or dist.get_backend() == "gloo"
+        self.device = device if device is not None else "cpu"
+        self.ops, self.keep, self.copies = [], [], []
+        self._cbs = (_ffi.COMM_ALLGATHER(self._allgather), _ffi.COMM_P2P(self._isend), _ffi.COMM_P2P(self._irecv),
+                     _ffi.COMM_WAIT(self._wait))
+        self.c = _ffi.Comm(None, rank, world, *self._cbs)
+        self.error = None
+
+    def _wrap(self, ptr, n):
+        return (C.c_uint8 * n).from_address(ptr)
+
+    def _allgather(self, _user, send, recv, nbytes):
+        try:
+            torch = self.torch
+            mine = torch.frombuffer(bytearray(self._wrap(send, nbytes)), dtype=torch.uint8)
+            dev = "cpu" if self.host else self.device
+            parts = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine.to(dev), group=self.group)
+            out = torch.cat([p.cpu() for p in parts]).numpy().tobytes()
+            C.memmove(recv, out, len(out))
+            return 0
+        except Exception as e:  # noqa: BLE001  (an exception must not cross the C frame)
+            self.error = e
+            return 1
+
+    def _dev_tensor(self, ptr, n):
+        """a uint8 tensor over n bytes of device memory at `ptr` (no copy; the caller keeps the allocation alive)"""
+        torch = self.torch
+
+        class _Ext:       # __cuda_array_interface__: the way to hand torch a raw device pointer
+            pass
+        e = _Ext()
+        e.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+        return torch.as_tensor(e, device=self.device)
+
+    def _isend(self, _user, d_buf, nbytes, to):
+        try:
+            t = self._dev_tensor(d_buf, nbytes)
+            if self.host:
+                t = t.cpu()
+            self.keep.append(t)
+            self.ops.append(self.dist.P2POp(self.dist.isend, t, to))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
+
+    def _irecv(self, _user, d_buf, nbytes, frm):
+        try:
+            dst = self._dev_tensor(d_buf, nbytes)
+            if self.host:
+                h = self.torch.empty(nbytes, dtype=self.torch.uint8)
+                self.copies.append((dst, h))
+                self.ops.append(self.dist.P2POp(self.dist.irecv, h, frm))
+            else:
+                self.keep.append(dst)
+                self.ops.append(self.dist.P2POp(self.dist.irecv, dst, frm))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
+
+    def _wait(self, _user):
+        try:
+            if self.ops:
+                for w in self.dist.batch_isend_irecv(self.ops):
+                    w.wait()
+            for dst, h in self.copies:
+                dst.copy_(h)
+            if not self.host and self.torch.cuda.is_available():
+                # (wait() orders the RCCL stream before torch's current stream, not before the context's own stream on
+                #  which the placement kernels run: block the host until the shards have landed)
+                self.torch.cuda.synchronize()
+            self.ops, self.keep, self.copies = [], [], []
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
+
+
+def _comm(dist, rank, world, device=None, group=None):
+    if dist is None or world == 1:
+        return TorchComm(None, rank, world, device) if world == 1 else None
+    return TorchComm(dist, rank, world, device, group)
+
+
+def _raise(rc, ctx, cm, what):
+    if cm is not None and cm.error is not None:
+        raise cm.error
+    raise _ffi.LfxError(rc, "%s: %s" % (what, ctx.last_error() if ctx is not None else ""))
+
+
+# ------------------------------------------------------------------------------------------------ exchange steps
 def layout(infos, header_len, fmt):
-    """infos: list of (total_bits, n_bytes, crc32, adler32) in rank order (non-last shards end on a
-    block boundary; the last holds BFINAL).  → (start_bits, combined_check, total_n)."""
+    """infos: list of (total_bits, n_bytes, crc32, adler32) in rank order (non-last shards end on a block boundary; the last
+    holds BFINAL) → (start_bits, combined_check, total_n).  The same arithmetic as lfx_sharded_layout, on a list the caller
+    already gathered (tests; bench.py's first rounds)."""
     L = _ffi.lib()
     start_bits, bit = [], 8 * header_len
     for tb, _n, _c, _a in infos:
@@ -25,6 +135,19 @@ def layout(infos, header_len, fmt):
         total += n
     check = crc if fmt == _ffi.GZIP else adler
     return start_bits, check, total
+
+
+def layout_exchange(info, header_len, fmt, rank, world, dist=None, group=None):
+    """lfx_sharded_layout: all-gather of the ranks' shard infos (32 bytes each, the ONE collective on the encode's data path)
+    → (start_bits of every rank + the end bit, combined check, total uncompressed bytes).  info: (bits, bytes, crc, adler)."""
+    cm = _comm(dist, rank, world, group=group)
+    mine = _ffi.ShardInfo(*info)
+    sb = (C.c_uint64 * (world + 1))()
+    check, total = C.c_uint32(0), C.c_uint64(0)
+    rc = _ffi.lib().lfx_sharded_layout(C.byref(cm.c), C.byref(mine), header_len, fmt, sb, C.byref(check), C.byref(total))
+    if rc:
+        _raise(rc, None, cm, "lfx_sharded_layout")
+    return list(sb), check.value, total.value
 
 
 def assemble(parts, start_bits):
@@ -43,92 +166,46 @@ def assemble(parts, start_bits):
 
 def member_bytes(start_bits, part_lens):
     """size of the assembled member given every rank's emitted byte count"""
-    last = len(start_bits) - 1
+    last = len(part_lens) - 1
     return (start_bits[last] // 8 if last else 0) + part_lens[last]
 
 
-def gather_begin(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
-    """Start concatenating the shards on rank 0 (the writer) and return a handle for gather_finish().  d_part / d_member /
-    staging are torch uint8 tensors on the rank's device; `dist` is torch.distributed (None for world == 1).
-    Point-to-point transfers, ALL posted at once (one batch_isend_irecv: on RCCL the shards arrive over different xGMI
-    links concurrently — the links are point-to-point, a rank-by-rank receive would use one of seven at a time);
-    `staging` must hold the shards of ranks 1..world-1 side by side (256-byte aligned).  Between begin and finish the
-    caller is free to do other work on its own shard (the transfers run on RCCL's stream)."""
-    L = _ffi.lib()
-
-    def place(src_tensor, r):
-        rc = L.lfx_shard_place_device(ctx.handle, d_member.data_ptr(), cap, src_tensor.data_ptr(), part_lens[r],
-                                      start_bits[r], int(r == 0))
-        if rc:
-            raise _ffi.LfxError(rc, ctx.last_error())
-
-    h = {"rank": rank, "world": world, "works": [], "pending": [], "place": place, "host_hop": False,
-         "len": member_bytes(start_bits, part_lens) if rank == 0 else 0}
-    if world == 1 or dist is None:
-        place(d_part, 0)
-        return h
-    import torch
-    host_hop = h["host_hop"] = dist.get_backend() == "gloo"          # (CPU test rigs: gloo moves host tensors)
-    if rank == 0:
-        place(d_part, 0)
-        ops, off = [], 0
-        for r in range(1, world):
-            need = (part_lens[r] + 255) & ~255
-            if off + need > staging.numel():
-                raise ValueError("staging holds %d bytes, the shards of ranks 1..%d need more" % (staging.numel(), world - 1))
-            buf = staging[off:off + part_lens[r]]
-            off += need
-            host = None
-            if host_hop and buf.device.type != "cpu":
-                host = torch.empty(part_lens[r], dtype=torch.uint8)
-            ops.append(dist.P2POp(dist.irecv, host if host is not None else buf, r))
-            h["pending"].append((r, buf, host))
-        h["works"] = dist.batch_isend_irecv(ops)
-        return h
-    send = d_part[:part_len]
-    if host_hop and send.device.type != "cpu":
-        send = send.cpu()
-    h["keep"] = send
-    h["works"] = dist.batch_isend_irecv([dist.P2POp(dist.isend, send, 0)])
-    return h
+# ------------------------------------------------------------------------------------------------ sharded encode
+def encode_begin(ctx, rank, world, fmt, opts, sched, d_in, n, d_part, part_cap, d_member=None, member_cap=0, staging=None,
+                 dist=None, group=None):
+    """lfx_sharded_encode_begin on torch uint8 device tensors → (handle, ShardedPart).  The shards travel to rank 0 (posted,
+    not awaited); encode_finish() completes the member.  Between the two the caller may work on its own shard (d_part)."""
+    cm = _comm(dist, rank, world, d_part.device, group)
+    st = C.c_void_p(None)
+    part = _ffi.ShardedPart()
+    rc = _ffi.lib().lfx_sharded_encode_begin(ctx.handle, C.byref(cm.c), fmt, C.byref(opts), C.byref(sched), d_in.data_ptr(), n,
+                                             d_part.data_ptr(), part_cap, d_member.data_ptr() if d_member is not None else None,
+                                             member_cap, staging.data_ptr() if staging is not None else None,
+                                             staging.numel() if staging is not None else 0, C.byref(st), C.byref(part))
+    if rc:
+        _raise(rc, ctx, cm, "lfx_sharded_encode_begin")
+    return {"cm": cm, "state": st, "ctx": ctx}, part
 
 
-def gather_finish(h):
-    """Wait for the transfers of gather_begin(); rank 0 places the received shards.  → member length on rank 0, else 0."""
-    for w in h["works"]:
-        w.wait()
-    if h["pending"]:
-        import torch
-        if not h["host_hop"] and torch.cuda.is_available():
-            # (wait() orders the RCCL stream before torch's current stream, not before the context's own stream on
-            #  which the placement kernels run: block the host until the shards have landed)
-            torch.cuda.synchronize()
-        for r, buf, host in h["pending"]:
-            if host is not None:
-                buf.copy_(host)
-            h["place"](buf, r)
-    return h["len"]
+def encode_finish(h):
+    """→ member length on rank 0, else 0"""
+    ml = C.c_uint64(0)
+    rc = _ffi.lib().lfx_sharded_encode_finish(h["ctx"].handle, C.byref(h["cm"].c), h["state"], C.byref(ml))
+    if rc:
+        _raise(rc, h["ctx"], h["cm"], "lfx_sharded_encode_finish")
+    return ml.value
 
 
-def gather_member(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist=None, staging=None):
-    """gather_begin() + gather_finish()."""
-    return gather_finish(gather_begin(ctx, rank, world, d_part, part_len, start_bits, part_lens, d_member, cap, dist, staging))
-
-
-# ------------------------------------------------------------------------------------------------
-# N-GPU decode of ONE member without the encoder's layout (include/lfx.h: lfx_decode_range_scan / lfx_decode_chain /
-# lfx_decode_range_emit).  The member is cut by compressed BYTES; the only collective is one all-gather of the ranks'
-# candidate tuples (56 bytes each) and one of their slice checksums.
-RANGE_TAIL = 4 << 20      # bytes of the right neighbour's range a rank also holds: a block that starts in a rank's range
-                          # is scanned to its end (reference-made blocks: <= ~1.1 MB of stream)
-
-
+# ------------------------------------------------------------------------------------------------ member decode by byte ranges
 def byte_ranges(first_byte, member_len, world):
-    """Equal byte ranges of the DEFLATE part [first_byte, member_len) (the trailer's few bytes ride along in the last
-    one) → list of (lo, hi); a rank holds [lo, min(hi + RANGE_TAIL, member_len))."""
-    span = member_len - first_byte
-    cuts = [first_byte + span * r // world for r in range(world)] + [member_len]
-    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+    """Equal byte ranges of the DEFLATE part [first_byte, member_len) (the trailer's few bytes ride along in the last one) →
+    list of (lo, hi); a rank holds [lo, min(hi + RANGE_TAIL, member_len)) (lfx_sharded_byte_range)."""
+    out = []
+    for r in range(world):
+        lo, hi, hold = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _ffi.lib().lfx_sharded_byte_range(first_byte, member_len, r, world, C.byref(lo), C.byref(hi), C.byref(hold))
+        out.append((lo.value, hi.value))
+    return out
 
 
 def final_from(member_len):
@@ -199,115 +276,54 @@ def fold_checks(parts):
     return crc, ad
 
 
-def gather_tuples(tuples, cnt, world, dist, device="cpu", group=None, status=0):
-    """step 2: all-gather of the ranks' candidate tuples (variable counts: the counts first, then rows padded to the
-    longest) → (ctypes array of all tuples in rank order, their number).  `status`: this rank's error code of step 1 —
-    it rides with the counts, and a failure on ANY rank is raised on EVERY rank after the collective (a rank
-    that raises before a collective leaves the others waiting in it)."""
-    if dist is None or world == 1:
-        if status:
-            raise _ffi.LfxError(status, "range scan failed")
-        return tuples, cnt
-    import torch
-    tsz = C.sizeof(_ffi.BlkTuple)
-    dev = "cpu" if dist.get_backend() == "gloo" else device
-    counts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([cnt, status], dtype=torch.int64, device=dev), group=group)
-    counts = [[int(v) for v in x.cpu().tolist()] for x in counts]
-    bad = [(r, st) for r, (_, st) in enumerate(counts) if st]
-    if bad:
-        raise _ffi.LfxError(bad[0][1], "range scan failed on rank %d: decode the member on one GPU" % bad[0][0])
-    counts = [c0 for c0, _ in counts]
-    width = max(max(counts), 1) * tsz
-    mine = torch.zeros(width, dtype=torch.uint8)
-    if cnt:
-        mine[:cnt * tsz] = torch.frombuffer(bytearray(C.string_at(tuples, cnt * tsz)), dtype=torch.uint8)
-    mine = mine.to(dev)
-    gathered = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)         # RCCL over xGMI: a few KB per rank
-    n_all = sum(counts)
-    all_t = (_ffi.BlkTuple * max(n_all, 1))()
-    at = 0
-    for r in range(world):
-        raw = gathered[r][:counts[r] * tsz].cpu().numpy().tobytes()
-        C.memmove(C.byref(all_t, at * tsz), raw, len(raw))
-        at += counts[r]
-    return all_t, n_all
+def fold_exchange(rank, world, dist, status, state, length, crc, adler, group=None):
+    """lfx_sharded_fold: all-gather of (status, state, length, crc32, adler32) → (any rank in state 1?, crc32, adler32, total
+    length) of the concatenation; a non-zero status of ANY rank raises on EVERY rank."""
+    cm = _comm(dist, rank, world, group=group)
+    anyst, c_all, a_all, tot, bad = C.c_uint32(0), C.c_uint32(0), C.c_uint32(1), C.c_uint64(0), C.c_uint32(0)
+    rc = _ffi.lib().lfx_sharded_fold(C.byref(cm.c), status, state, length, crc, adler, C.byref(anyst), C.byref(c_all),
+                                     C.byref(a_all), C.byref(tot), C.byref(bad))
+    if rc:
+        if cm.error is not None:
+            raise cm.error
+        raise _ffi.LfxError(rc, "slice decode failed on rank %d: decode the member on one GPU" % bad.value)
+    return anyst.value, c_all.value, a_all.value, tot.value
+
+
+def gather_tuples(tuples, cnt, world, dist, device="cpu", group=None, status=0, rank=None):
+    """step 2 (lfx_sharded_gather_tuples): all-gather of the ranks' candidate tuples (variable counts: the counts first, then
+    rows padded to the longest) → (ctypes array of all tuples in rank order, their number).  `status`: this rank's error code
+    of step 1 — it rides with the counts, and a failure on ANY rank is raised on EVERY rank after the collective (a
+    rank that raises before a collective leaves the others waiting in it)."""
+    if rank is None:
+        rank = dist.get_rank() if dist is not None and world > 1 else 0
+    cm = _comm(dist, rank, world, device, group)
+    allp = C.POINTER(_ffi.BlkTuple)()
+    n_all, bad = C.c_uint32(0), C.c_uint32(0)
+    rc = _ffi.lib().lfx_sharded_gather_tuples(C.byref(cm.c), tuples, cnt, status, C.byref(allp), C.byref(n_all), C.byref(bad))
+    if rc:
+        if cm.error is not None:
+            raise cm.error
+        raise _ffi.LfxError(rc, "range scan failed on rank %d: decode the member on one GPU" % bad.value)
+    out = (_ffi.BlkTuple * max(n_all.value, 1))()
+    if n_all.value:
+        C.memmove(out, allp, n_all.value * C.sizeof(_ffi.BlkTuple))
+    _ffi.lib().lfx_sharded_free(allp)
+    return out, n_all.value
 
 
 def decode_member_ranks(ctx, rank, world, d_part, n_part, lo, hi, first_bit, d_out, cap, dist=None, group=None, member_len=None):
-    """One rank's side of the N-GPU decode over torch.distributed (RCCL on GPUs, gloo in CPU rigs): scan → all-gather of
-    the tuples → chain → emit → [window hand-over: all-gather of the ranks' 64 KiB index maps, only for members whose blocks
-    read earlier blocks] → all-gather of (length, crc, adler).  d_part / d_out: torch uint8 tensors on the rank's
-    device; `group`: a process group of its own for these small collectives, so that they do not queue behind bulk
-    transfers posted on the default group (bench.py: the member's concatenation is in flight).  Every failure is carried
-    through the next collective and raised on ALL ranks.  → (bytes of this rank's slice, its offset in the member's
-    output, total output bytes, crc32, adler32 of the whole member's output)."""
-    import torch
-    # `member_len` (bytes of the whole member, when the caller knows it): the finder looks for the BFINAL header only near
-    # the member's end; if the chain then breaks (a last block that starts earlier) every rank scans again without the rule
-    ffb = final_from(member_len) if member_len else 0
-    while True:
-        status = 0
-        tuples, cnt = None, 0
-        try:
-            tuples, cnt = range_scan(ctx, rank, d_part.data_ptr(), n_part, lo, hi, first_bit if rank == 0 else None, final_from_bit=ffb)
-        except _ffi.LfxError as e:
-            status = e.status or _ffi.E_UNSUPPORTED
-        all_t, n_all = gather_tuples(tuples, cnt, world, dist, d_part.device, group, status)
-        try:
-            chain, nch, total = chain_of(all_t, n_all, first_bit)        # (deterministic: breaks on every rank alike)
-            break
-        except _ffi.LfxError:
-            if not ffb:
-                raise
-            ffb = 0
-    ol = base = state = 0
-    crc, ad = 0, 1
-    try:
-        ol, base, state = range_emit(ctx, rank, d_part.data_ptr(), n_part, lo, all_t, chain, nch, d_out.data_ptr(), cap)
-        if state == 0:
-            crc, ad = range_finish(ctx, rank)
-    except _ffi.LfxError as e:
-        status = e.status or _ffi.E_UNSUPPORTED
-    if dist is None or world == 1:
-        if status:
-            raise _ffi.LfxError(status, ctx.last_error())
-        if state:
-            crc, ad = range_finish(ctx, rank)
-        return ol, base, total, crc, ad
-    host = dist.get_backend() == "gloo"
-    dev = "cpu" if host else d_part.device
-
-    def gather5(vals):
-        mine = torch.tensor(vals, dtype=torch.int64, device=dev)
-        parts = [torch.empty(len(vals), dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        return [[int(v) for v in p.cpu().tolist()] for p in parts]
-
-    rows = gather5([status, state, ol, crc, ad])
-    bad = [(r, row[0]) for r, row in enumerate(rows) if row[0]]
-    if bad:
-        raise _ffi.LfxError(bad[0][1], "slice decode failed on rank %d: decode the member on one GPU" % bad[0][0])
-    if any(row[1] for row in rows):
-        # ---- window hand-over (another encoder's member): every rank's slice as one index map, all-gathered
-        d_map = torch.empty(32768, dtype=torch.int16, device=d_part.device)
-        try:
-            range_map(ctx, d_map.data_ptr())
-        except _ffi.LfxError as e:
-            status = e.status or _ffi.E_UNSUPPORTED
-        mine = d_map.cpu() if host else d_map
-        maps = [torch.empty(32768, dtype=torch.int16, device=dev) for _ in range(world)]
-        dist.all_gather(maps, mine, group=group)                 # RCCL over xGMI: 64 KiB per rank
-        d_maps = torch.stack(maps).to(d_part.device).contiguous()
-        try:
-            if not status:
-                crc, ad = range_finish(ctx, rank, d_maps.data_ptr())
-        except _ffi.LfxError as e:
-            status = e.status or _ffi.E_UNSUPPORTED
-        rows = gather5([status, 0, ol, crc, ad])
-        bad = [(r, row[0]) for r, row in enumerate(rows) if row[0]]
-        if bad:
-            raise _ffi.LfxError(bad[0][1], "window hand-over failed on rank %d" % bad[0][0])
-    crc_all, ad_all = fold_checks([(row[2], row[3], row[4]) for row in rows])
-    return ol, base, total, crc_all, ad_all
+    """One rank's side of the N-GPU decode (lfx_sharded_decode) over torch.distributed: scan → all-gather of the tuples → chain
+    → emit → [window hand-over: all-gather of the ranks' 64 KiB index maps, only for members whose blocks read earlier blocks]
+    → all-gather of (status, length, crc, adler).  d_part / d_out: torch uint8 tensors on the rank's device; `group`: a process
+    group of its own for these small collectives, so that they do not queue behind bulk transfers posted on the default group
+    (bench.py: the member's concatenation is in flight).  Every failure is carried through the next collective and comes back
+    on ALL ranks.  → (bytes of this rank's slice, its offset in the member's output, total output bytes, crc32, adler32 of the
+    whole member's output)."""
+    cm = _comm(dist, rank, world, d_part.device, group)
+    sl = _ffi.ShardedSlice()
+    rc = _ffi.lib().lfx_sharded_decode(ctx.handle, C.byref(cm.c), d_part.data_ptr(), n_part, lo, hi, first_bit, member_len or 0,
+                                       d_out.data_ptr(), cap, C.byref(sl))
+    if rc:
+        _raise(rc, ctx, cm, "lfx_sharded_decode")
+    return sl.out_len, sl.out_base, sl.total_out, sl.crc32, sl.adler32

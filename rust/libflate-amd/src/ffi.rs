@@ -7,6 +7,12 @@ pub const LFX_DEFLATE: c_int = 0;
 pub const LFX_ZLIB: c_int = 1;
 pub const LFX_GZIP: c_int = 2;
 
+// lfx.h: LFX_LEVEL_* (libflate_lz77::CompressionLevel; lfx_encode_opts::lz77_level = 1 + level)
+pub const LFX_LEVEL_NONE: c_int = 0;
+pub const LFX_LEVEL_FAST: c_int = 1;
+pub const LFX_LEVEL_BALANCE: c_int = 2;
+pub const LFX_LEVEL_BEST: c_int = 3;
+
 pub const LFX_OK: c_int = 0;
 pub const LFX_E_INVALID_DATA: c_int = 1;
 pub const LFX_E_UNEXPECTED_EOF: c_int = 2;
@@ -74,7 +80,41 @@ pub type lfx_flush_cb = extern "C" fn(user: *mut c_void) -> c_int;
 pub type lfx_read_cb = extern "C" fn(user: *mut c_void, p: *mut u8, cap: usize) -> i64;
 pub type lfx_sink_cb = extern "C" fn(user: *mut c_void, codes: *const u32, n: usize);
 
+// ---- the N-GPU drivers (include/lfx.h, round 5): the caller's collectives as four callbacks
+#[repr(C)]
+pub struct lfx_comm {
+    pub user: *mut c_void,
+    pub rank: u32,
+    pub world: u32,
+    pub allgather: Option<extern "C" fn(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes: u64) -> c_int>,
+    pub isend: Option<extern "C" fn(user: *mut c_void, d_buf: *const c_void, bytes: u64, to_rank: u32) -> c_int>,
+    pub irecv: Option<extern "C" fn(user: *mut c_void, d_buf: *mut c_void, bytes: u64, from_rank: u32) -> c_int>,
+    pub wait: Option<extern "C" fn(user: *mut c_void) -> c_int>,
+}
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct lfx_sharded_part { pub start_bit: u64, pub end_bit: u64, pub part_len: u64, pub member_len: u64, pub total_n: u64, pub check: u32, pub _pad: u32 }
+#[repr(C)]
+#[derive(Default, Clone, Copy, Debug)]
+pub struct lfx_sharded_slice { pub out_len: u64, pub out_base: u64, pub total_out: u64, pub crc32: u32, pub adler32: u32 }
+#[repr(C)]
+pub struct lfx_sharded_enc { _private: [u8; 0] }
+#[repr(C)]
+pub struct lfx_schedule { pub kind: c_int, pub fixed_write: u64, pub writes: *const u64, pub n_writes: usize }
+
 extern "C" {
+    pub fn lfx_comm_rccl(nccl_comm: *mut c_void, hip_stream: *mut c_void, rank: u32, world: u32, out: *mut lfx_comm) -> c_int;
+    pub fn lfx_comm_rccl_free(cm: *mut lfx_comm);
+    pub fn lfx_sharded_encode_begin(c: *mut lfx_ctx, cm: *const lfx_comm, format: c_int, o: *const lfx_encode_opts, s: *const lfx_schedule,
+                                    d_in: *const c_void, n: u64, d_part: *mut c_void, part_cap: u64, d_member: *mut c_void, member_cap: u64,
+                                    d_staging: *mut c_void, staging_cap: u64, state: *mut *mut lfx_sharded_enc, out: *mut lfx_sharded_part) -> c_int;
+    pub fn lfx_sharded_encode_finish(c: *mut lfx_ctx, cm: *const lfx_comm, state: *mut lfx_sharded_enc, member_len: *mut u64) -> c_int;
+    pub fn lfx_sharded_byte_range(first_byte: u64, member_len: u64, rank: u32, world: u32, lo: *mut u64, hi: *mut u64, hold_hi: *mut u64);
+    pub fn lfx_sharded_decode(c: *mut lfx_ctx, cm: *const lfx_comm, d_part: *const c_void, n_part: u64, lo_byte: u64, hi_byte: u64,
+                              first_bit: u64, member_len: u64, d_out: *mut c_void, cap: u64, out: *mut lfx_sharded_slice) -> c_int;
+    pub fn lfx_container_header_len(format: c_int, o: *const lfx_encode_opts) -> u64;
+    pub fn lfx_encode_bound(n: u64, o: *const lfx_encode_opts, s: *const lfx_schedule) -> u64;
+
     pub fn lfx_version() -> u32;
     pub fn lfx_device_count() -> c_int;
     pub fn lfx_encode_opts_default(o: *mut lfx_encode_opts);

@@ -108,20 +108,34 @@ where
     E: GpuLz77,
 {
     inner: crate::deflate::EncodeOptions<E>,
-    header: Header,
-    level_from_lz77: bool,      // the header still is the one with_lz77 made (its XFL follows E::compression_level, gzip.rs:684)
+    header: Header,             // its compression_level IS the XFL byte the encoder writes (gzip.rs:84-92,368-389)
+}
+/// gzip.rs:84-92: `From<lz77::CompressionLevel> for CompressionLevel`
+fn level_of(l: crate::lz77::CompressionLevel) -> CompressionLevel {
+    match l {
+        crate::lz77::CompressionLevel::Fast => CompressionLevel::Fastest,
+        crate::lz77::CompressionLevel::Best => CompressionLevel::Slowest,
+        _ => CompressionLevel::Unknown,
+    }
 }
 impl Default for EncodeOptions<DefaultLz77Encoder> {
     fn default() -> Self { Self::new() }
 }
 impl EncodeOptions<DefaultLz77Encoder> {
-    pub fn new() -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::new(), header: HeaderBuilder::new().finish(), level_from_lz77: true } }
+    pub fn new() -> Self { Self::with_lz77(DefaultLz77Encoder::new()) }
 }
 impl<E: GpuLz77> EncodeOptions<E> {
     /// gzip.rs:667-672
-    pub fn with_lz77(lz77: E) -> Self { EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), header: HeaderBuilder::new().finish(), level_from_lz77: true } }
-    pub fn no_compression(mut self) -> Self { self.inner = self.inner.no_compression(); self.level_from_lz77 = false; self }
-    pub fn header(mut self, header: Header) -> Self { self.header = header; self.level_from_lz77 = false; self }
+    pub fn with_lz77(lz77: E) -> Self {
+        let mut header = HeaderBuilder::new().finish();
+        header.compression_level = level_of(lz77.compression_level());      // gzip.rs:684
+        EncodeOptions { inner: crate::deflate::EncodeOptions::with_lz77(lz77), header }
+    }
+    /// gzip.rs:700-705: stored blocks; the header's level goes back to Unknown
+    pub fn no_compression(mut self) -> Self { self.inner = self.inner.no_compression(); self.header.compression_level = CompressionLevel::Unknown; self }
+    /// gzip.rs:717-720: the header REPLACES the one the options held — its own compression_level included (a header cloned
+    /// from a Decoder keeps its Fastest / Slowest)
+    pub fn header(mut self, header: Header) -> Self { self.header = header; self }
     pub fn block_size(mut self, size: usize) -> Self { self.inner = self.inner.block_size(size); self }
     pub fn fixed_huffman_codes(mut self) -> Self { self.inner = self.inner.fixed_huffman_codes(); self }
 }
@@ -142,9 +156,13 @@ impl<W: io::Write, E: GpuLz77> Encoder<W, E> {
         o.os = h.os.0;
         o.is_text = h.is_text as u8;
         o.hcrc = h.is_verified as u8;
-        // XFL comes from the header the options hold: with_lz77 sets it from E::compression_level (gzip.rs:684), header()
-        // replaces it with the builder's Unknown (gzip.rs:157,717-720), no_compression() resets it (gzip.rs:703)
-        if !options.level_from_lz77 { o.lz77_level = 0; }
+        // XFL is the level of the header the options hold (gzip.rs:368-389): with_lz77 set it from E::compression_level
+        // (gzip.rs:684), header() replaced it with that header's own, no_compression() reset it (gzip.rs:703)
+        o.lz77_level = 1 + match h.compression_level {
+            CompressionLevel::Fastest => ffi::LFX_LEVEL_FAST,
+            CompressionLevel::Slowest => ffi::LFX_LEVEL_BEST,
+            CompressionLevel::Unknown => ffi::LFX_LEVEL_BALANCE,
+        } as u8;
         if let Some(ref e) = extra { o.extra = e.as_ptr(); o.extra_len = e.len() as u32; }
         if let Some(ref f) = h.filename { o.filename = f.as_ptr(); }
         if let Some(ref c) = h.comment { o.comment = c.as_ptr(); }

@@ -14,6 +14,7 @@ pub mod deflate;
 pub mod gzip;
 pub mod lz77;
 pub mod non_blocking;
+pub mod sharded;
 pub mod zlib;
 
 use std::ffi::CStr;

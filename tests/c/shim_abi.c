@@ -6,6 +6,8 @@
  *
  * Without a GPU: checks that construction fails loudly with LFX_E_DEVICE (exit 0, prints "no device").
  * With a GPU: runs the vectors (exit 0 and "shim abi ok", or exit 1 with the failing check). */
+#define _GNU_SOURCE   /* RTLD_DEFAULT */
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -55,6 +57,18 @@ static int read_all(lfx_decoder *d, unsigned char *out, size_t cap, size_t *got,
         if (r == 0) return 0;
         *got += (size_t)r;
     }
+}
+
+/* device buffers for the sharded drivers: the HIP runtime liblfx.so already brought into the process */
+typedef int (*hip_malloc_t)(void **, size_t);
+typedef int (*hip_free_t)(void *);
+typedef int (*hip_memcpy_t)(void *, const void *, size_t, int);
+static hip_malloc_t p_hipMalloc; static hip_free_t p_hipFree; static hip_memcpy_t p_hipMemcpy;
+static int hip_bind(void) {
+    p_hipMalloc = (hip_malloc_t)dlsym(RTLD_DEFAULT, "hipMalloc");
+    p_hipFree = (hip_free_t)dlsym(RTLD_DEFAULT, "hipFree");
+    p_hipMemcpy = (hip_memcpy_t)dlsym(RTLD_DEFAULT, "hipMemcpy");
+    return p_hipMalloc && p_hipFree && p_hipMemcpy;
 }
 
 static const unsigned char HELLO[] = "Hello World!";
@@ -210,6 +224,56 @@ int main(void) {
         CHECK(lfx_lz77_flush(z, on_codes, &cs) == LFX_OK);
         CHECK(cs.n == 2 && cs.w[0] == (97u << 16) && cs.w[1] == ((4u << 16) | 1u));
         lfx_lz77_free(z);
+    }
+    /* ---- the N-GPU drivers at world size 1 (rust/libflate-amd/src/sharded.rs): the sharded encode must give the bytes ONE
+     *      encoder gives (src/gzip.rs:858-868: one trailer from one checksum), the member decode by byte ranges must give the
+     *      input back with the trailer's CRC-32 */
+    {
+        CHECK(hip_bind());
+        const size_t n = 3u << 20;
+        lfx_encode_opts o;
+        lfx_encode_opts_default(&o);
+        o.mtime = 7;
+        lfx_schedule sc = {LFX_SCHED_FIXED, 8192, NULL, 0};
+        const uint64_t bound = lfx_encode_bound(n, &o, &sc) & ~3ull;
+        CHECK(bound > n / 2);
+        unsigned char *in = malloc(n), *one = malloc(bound), *mem = malloc(bound), *back = malloc(n);
+        CHECK(in && one && mem && back);
+        unsigned x = 12345;
+        for (size_t i = 0; i < n; i++) {                          /* text-like: words of a small vocabulary */
+            x = x * 1664525u + 1013904223u;
+            in[i] = (i % 7 == 6) ? ' ' : (unsigned char)('a' + ((x >> 24) % 9) + ((i / 4096) % 3));
+        }
+        uint64_t one_len = 0;
+        CHECK(lfx_encode_host(c, LFX_GZIP, &o, &sc, in, n, one, bound, &one_len) == LFX_OK);
+        void *d_in, *d_part, *d_member, *d_out;
+        CHECK(!p_hipMalloc(&d_in, n) && !p_hipMalloc(&d_part, bound) && !p_hipMalloc(&d_member, bound) && !p_hipMalloc(&d_out, n));
+        CHECK(!p_hipMemcpy(d_in, in, n, 1 /* hipMemcpyHostToDevice */));
+        lfx_comm cm = {NULL, 0, 1, NULL, NULL, NULL, NULL};
+        lfx_sharded_enc *stt = NULL;
+        lfx_sharded_part part;
+        CHECK(lfx_sharded_encode_begin(c, &cm, LFX_GZIP, &o, &sc, d_in, n, d_part, bound, d_member, bound, NULL, 0, &stt, &part) == LFX_OK);
+        CHECK(stt && part.start_bit == 8 * lfx_container_header_len(LFX_GZIP, &o) && part.total_n == n && part.member_len == one_len);
+        uint64_t mlen = 0;
+        CHECK(lfx_sharded_encode_finish(c, &cm, stt, &mlen) == LFX_OK && mlen == one_len);
+        CHECK(!p_hipMemcpy(mem, d_member, mlen, 2 /* hipMemcpyDeviceToHost */) && !memcmp(mem, one, mlen));
+        uint64_t lo, hi, hold;
+        lfx_sharded_byte_range(10, mlen, 0, 1, &lo, &hi, &hold);
+        CHECK(lo == 10 && hi == mlen && hold == mlen);
+        lfx_sharded_slice sl;
+        CHECK(lfx_sharded_decode(c, &cm, d_member, mlen, 0, mlen, part.start_bit, mlen, d_out, n, &sl) == LFX_OK);
+        CHECK(sl.out_len == n && sl.out_base == 0 && sl.total_out == n && sl.crc32 == part.check);
+        CHECK(!p_hipMemcpy(back, d_out, n, 2) && !memcmp(back, in, n));
+        uint32_t tr;
+        memcpy(&tr, mem + mlen - 8, 4);
+        CHECK(tr == sl.crc32);
+        /* the RCCL binding refuses a null communicator; freeing an unbound comm is a no-op */
+        lfx_comm rc;
+        memset(&rc, 0, sizeof rc);
+        CHECK(lfx_comm_rccl(NULL, NULL, 0, 1, &rc) == LFX_E_ARG);
+        lfx_comm_rccl_free(&rc);
+        p_hipFree(d_in); p_hipFree(d_part); p_hipFree(d_member); p_hipFree(d_out);
+        free(in); free(one); free(mem); free(back);
     }
     lfx_ctx_free(c);
     printf("shim abi ok\n");

@@ -83,7 +83,7 @@ def _shim_binary():
     exe = os.path.join(ROOT, "tests", "c", "shim_abi")
     libdir = os.path.join(ROOT, "libflate_amd")
     if not os.path.exists(exe) or os.path.getmtime(src) > os.path.getmtime(exe):
-        subprocess.check_call(["gcc", "-O1", "-Wall", "-o", exe, src, "-L" + libdir, "-llfx", "-Wl,-rpath," + libdir])
+        subprocess.check_call(["gcc", "-O1", "-Wall", "-o", exe, src, "-L" + libdir, "-llfx", "-ldl", "-Wl,-rpath," + libdir])
     return exe
 
 

@@ -234,6 +234,7 @@ def test_encode_batch_vs_oracle(env, oracle):
                                        in_len.ctypes.data, d_out.data_ptr(), out_off.ctypes.data, small.ctypes.data, out_len.ctypes.data,
                                        status.ctypes.data)
         assert rc == ffi.E_NOSPACE and status[5] == ffi.E_NOSPACE and not out_len.any()
+        assert status[4] == 0 and status[6] == 0        # (only the stream that was too small is named)
 
 
 # ------------------------------------------------------------------ D-6: mid-size members (a few ordinary blocks)

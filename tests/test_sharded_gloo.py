@@ -40,14 +40,19 @@ def _worker(rank, world, port, q):
         blocks = oracle.scan_blocks(full)
         last = rank == world - 1
         bits = blocks[-1][1] if last else blocks[-2][1]            # end bit of the last kept block
-        mine = torch.tensor([bits, n, oracle.crc32(data), oracle.adler32(data)], dtype=torch.int64)
-        allv = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(allv, mine)                                 # the only collective on this path
-        infos = [tuple(int(x) for x in t) for t in allv]
         opts = _ffi.make_opts(mtime=0)
         import ctypes as C
         hdr_len = _ffi.lib().lfx_container_header_len(_ffi.GZIP, C.byref(opts))
-        start_bits, check, total_n = sharded.layout(infos, hdr_len, _ffi.GZIP)
+        # the only collective on this path, through the LIBRARY's driver (lfx_sharded_layout) with gloo behind its lfx_comm
+        start_bits, check, total_n = sharded.layout_exchange((bits, n, oracle.crc32(data), oracle.adler32(data)), hdr_len, _ffi.GZIP,
+                                                              rank, world, dist)
+        assert len(start_bits) == world + 1 and start_bits[0] == 8 * hdr_len
+        # ... and the same arithmetic on a list gathered by hand
+        mine = torch.tensor([bits, n, oracle.crc32(data), oracle.adler32(data)], dtype=torch.int64)
+        allv = [torch.zeros(4, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        sb2, check2, total2 = sharded.layout([tuple(int(x) for x in t) for t in allv], hdr_len, _ffi.GZIP)
+        assert (sb2, check2, total2) == (start_bits[:world], check, total_n)
         # stand-in for lfx_encode_shard_emit: place my bits at start_bits[rank] (bit-granular shift)
         val = int.from_bytes(full, "little") & ((1 << bits) - 1)
         sb = start_bits[rank]
@@ -141,11 +146,10 @@ def _decode_worker(rank, world, port, q):
         off = sum(b[4] for b in blocks if hdr * 8 + b[0] < lo * 8)
         ln = sum(b[4] for b in mine)
         sl = data[off:off + ln]
-        part = torch.tensor([ln, oracle.crc32(sl), oracle.adler32(sl)], dtype=torch.int64)
-        parts = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(parts, part)
-        crc, ad = sharded.fold_checks([tuple(int(v) for v in p.tolist()) for p in parts])
+        # the slices' checksums folded by the library's driver step (lfx_sharded_fold) over gloo
+        any_state, crc, ad, tot = sharded.fold_exchange(rank, world, dist, 0, 0, ln, oracle.crc32(sl), oracle.adler32(sl))
         ok = got == want and total == len(data) and crc == oracle.crc32(data) and ad == oracle.adler32(data)
+        ok = ok and any_state == 0 and tot == len(data)
         ok = ok and crc == int.from_bytes(member[-8:-4], "little")
         if rank == 0:
             q.put(("ok", ok, nch, len(blocks), n_all))
