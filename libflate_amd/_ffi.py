@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liblfx.so")
+SO_PATH = os.environ.get("LFX_SO") or os.path.join(_HERE, "liblfx.so")     # (LFX_SO: a development build, tools/exp)
 
 DEFLATE, ZLIB, GZIP = 0, 1, 2
 OK, E_INVALID_DATA, E_UNEXPECTED_EOF, E_IO, E_OOM, E_DEVICE, E_ARG, E_NOSPACE, E_UNSUPPORTED, E_WOULD_BLOCK = range(10)

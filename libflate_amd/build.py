@@ -21,15 +21,18 @@ def _stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
+def build(force=False, verbose=False, defs=(), so=None, tag=""):
+    """defs / so / tag: development builds with extra -D macros into a library of another name (tools/exp: kernel variants
+    side by side in one GPU call, selected by LFX_SO); the product build takes none of them."""
+    so = so or SO
+    if not force and not defs and not _stale():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(CSRC, src.rsplit(".", 1)[0] + tag + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall",
-               "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", obj]
+               "-Wno-unused-result", "-c", os.path.join(CSRC, src), "-o", obj] + ["-D" + d for d in defs]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x")
             cmd.insert(2, "hip")
@@ -37,11 +40,11 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return SO
+    return so
 
 
 if __name__ == "__main__":

@@ -577,7 +577,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 if (c->diag.free_shift >= 0) free_shift = (uint32_t)c->diag.free_shift;
                 LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                            (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
-                                           c->d_dec_tabs.p, free_shift));
+                                           c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne));
                 c->phase("blk_emit");
                 // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
                 // the marker path, which may cut anywhere
@@ -1127,7 +1127,7 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
     uint32_t free_shift = 15;   // marker units as on one GPU: two resident per CU, as large as that allows
     while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
     LAUNCH_TRY(launch_blk_emit(st, d_in, n_part, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (uint32_t *)c->d_codes.p, d_flags,
-                               (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, free_shift));
+                               (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne));
     c->phase("blk_emit");
     // small blocks smell of another encoder: look at the flags before materialising (as inflate_member does); the reference's
     // 1 MiB blocks are materialised at once and the flags read afterwards

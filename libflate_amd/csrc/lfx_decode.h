@@ -126,7 +126,9 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
                     uint32_t *job_flags = nullptr,   // job_flags[j] = 1: block j reads bytes in front of itself
                     const void *tabs = nullptr,      // tables from launch_blk_scan, indexed by BlkEmit::cand
-                    uint32_t free_shift = 17);       // marker units: 2^free_shift output bytes each (>= 15)
+                    uint32_t free_shift = 17,        // marker units: 2^free_shift output bytes each (>= 15)
+                    bool large_blocks = false);      // the kernel instance whose lanes read their bits through LDS rings (round 5): one
+                                                     // workgroup per CU, faster per symbol — for blocks of tens of thousands of codes
 int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg);

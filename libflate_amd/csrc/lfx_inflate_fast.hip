@@ -254,7 +254,8 @@ __device__ __noinline__ uint32_t long_lookup(const uint16_t *count, const uint16
     return info[s] | w;
 }
 
-// Hot bit source of lane_decode: 64-bit window `buf` (nb valid bits), a FIFO of up to five dwords in
+// Bit source of lane_decode_fifo (rounds 1-4; still the scan kernel's and the batch path's: 64 vector registers, two
+// workgroups per CU): 64-bit window `buf` (nb valid bits), a FIFO of up to five dwords in
 // registers (q0 first) and four more dwords in flight (x0..x3).  The in-flight dwords are merged into
 // the FIFO only between symbols, *before* the next four loads are issued, so the loads write straight
 // into dead registers and the only wait for them sits one reload period (~8 symbols) later.
@@ -313,6 +314,124 @@ struct FastBits {
     __device__ __forceinline__ void reload() { take(); issue(); }
 };
 
+// Hot bit source of lane_decode (round 5): the lane's next dwords of the stream in a RING IN LDS — eight dwords per lane plus
+// copies of slots 0..2 behind slot 7, so that FOUR consecutive dwords are two ds_read2_b32 at any position — and four more
+// dwords in flight in registers (x0..x3).  A symbol's bits are `v_alignbit(hi, lo, position)` on a register window of four
+// dwords: no 64-bit shift (a quarter of the vector rate), no register FIFO to shuffle (five v_cndmask per appended dword).
+// The literal/length code with its extra bits (<= 20 bits) and the distance code with its extra bits (<= 28) each fit one
+// 32-bit window, and a symbol's two windows lie inside the four dwords read at the PREVIOUS symbol's distance position: the
+// ring read for the next symbol is issued one symbol ahead, off the critical path.  What that path is made of — measured,
+// profiles/r05_pmc_counters.csv: a wavefront of the two Huffman kernels waits 68 % of its cycles, an LDS round trip costs it
+// about 240 cycles with sixteen wavefronts on the CU, the vector unit is 32 % busy — is the number of DEPENDENT LDS round trips
+// per symbol: two (the literal/length table, the distance table).  And a 128-byte line of the stream is fetched once per
+// sixteen-byte piece by the ONE lane that decodes it, not reloaded around the L2 (blk_emit: 1.8 GB of fabric traffic for a
+// 130 MB stream until round 4).
+#ifndef LFX_RING_DW
+#define LFX_RING_DW 16        // dwords of a lane's ring
+#endif
+#ifndef LFX_RING_FILL
+#define LFX_RING_FILL 8       // dwords per refill (in flight in registers meanwhile)
+#endif
+#ifndef LFX_RING_PIPE
+#define LFX_RING_PIPE 1       // 1: a four-dword register window, the ring read issued a symbol ahead; 0: two ring reads per symbol
+#endif
+constexpr uint32_t RING_DW = LFX_RING_DW, RING_FILL = LFX_RING_FILL, RING_DUP = LFX_RING_PIPE ? 3 : 1;
+constexpr uint32_t RING_STRIDE = RING_DW + RING_DUP + ((RING_DW + RING_DUP) % 2 == 0 ? 1 : 0);   // (odd stride: the lanes' slots k fall into different banks)
+constexpr uint32_t RING_AHEAD = LFX_RING_PIPE ? 5 : 3;        // dwords from rel / 32 on that a symbol may read
+static_assert(RING_FILL == 4 || RING_FILL == 8, "register sets below");
+static_assert(RING_DW % RING_FILL == 0 && RING_DW >= RING_FILL + RING_AHEAD && RING_DUP <= RING_FILL, "ring geometry");
+struct RingBits {
+    gptr_u32 w;
+    uint64_t wlast, widx;           // last readable dword, next dword to fetch
+    uint32_t *ring;                 // this lane's RING_STRIDE dwords of LDS
+    uint32_t rel, off0;             // bit position since the first ring dword; its value at init (used = rel - off0)
+    uint32_t filled;                // dwords written to the ring since init (a multiple of RING_FILL)
+    uint64_t r01, r23;              // (LFX_RING_PIPE) the register window: ring dwords rb .. rb + 3, loaded by inline asm
+    uint32_t rb;
+    uint32_t x[RING_FILL];
+    __device__ __forceinline__ uint32_t ld(uint64_t i) const { return w[i < wlast ? i : wlast]; }   // (clamped: callers stop by bit position)
+    __device__ __forceinline__ void init(const uint8_t *base, uint64_t nbytes, uint64_t bitpos, uint32_t *lds_ring) {
+        const uint64_t a = (uint64_t)base;
+        w = (gptr_u32)(a & ~3ull);
+        wlast = ((a & 3) + nbytes + 3) / 4;
+        wlast = wlast ? wlast - 1 : 0;
+        const uint64_t abs = bitpos + (a & 3) * 8;
+        widx = abs >> 5;
+        ring = lds_ring;
+        uint32_t f[RING_DW];
+#pragma unroll
+        for (uint32_t k = 0; k < RING_DW; ++k) f[k] = ld(widx + k);
+        // (the ring's dwords are pinned before the in-flight loads are issued: the compiler otherwise issues THESE loads last,
+        //  and their first use waits for the prefetch as well)
+#pragma unroll
+        for (uint32_t k = 0; k < RING_DW; ++k) asm volatile("" : "+v"(f[k]));
+#pragma unroll
+        for (uint32_t k = 0; k < RING_FILL; ++k) x[k] = ld(widx + RING_DW + k);
+        widx += RING_DW + RING_FILL;
+#pragma unroll
+        for (uint32_t k = 0; k < RING_DW; ++k) ring[k] = f[k];
+#pragma unroll
+        for (uint32_t k = 0; k < RING_DUP; ++k) ring[RING_DW + k] = f[k];
+        filled = RING_DW;
+        rel = off0 = (uint32_t)abs & 31;
+        r01 = (uint64_t)f[0] | (uint64_t)f[1] << 32; r23 = (uint64_t)f[2] | (uint64_t)f[3] << 32; rb = 0;
+    }
+    __device__ __forceinline__ uint32_t used() const { return rel - off0; }
+    // a whole symbol can be decoded at `rel`: every dword it may read is in the ring
+    __device__ __forceinline__ bool room() const { return (rel >> 5) + RING_AHEAD <= filled; }
+    // the 32 bits at position `at`
+    // (LFX_RING_PIPE: the compiler must not see the window's LDS loads — it sinks a load it sees to its first use, an iteration
+    //  later, and the look-ahead is gone — so they are inline asm, and an explicit wait that names the registers sits in front
+    //  of their first use; by then the distance-table read issued behind them has been waited for: the wait is free)
+    __device__ __forceinline__ uint32_t window_lit(uint32_t at) {
+        if (LFX_RING_PIPE) {                                                  // at / 32 - rb in {0, 1}
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r01), "+v"(r23));
+            const uint32_t r0 = (uint32_t)r01, r1 = (uint32_t)(r01 >> 32), r2 = (uint32_t)r23;
+            const bool o = (at >> 5) != rb;
+            return __builtin_amdgcn_alignbit(o ? r2 : r1, o ? r1 : r0, at);  // (the shift is at mod 32)
+        }
+        const uint32_t *p = ring + ((at >> 5) & (RING_DW - 1));
+        return __builtin_amdgcn_alignbit(p[1], p[0], at);
+    }
+    __device__ __forceinline__ uint32_t window_dist(uint32_t at) {
+        if (LFX_RING_PIPE) {                                                  // at / 32 - rb in {0, 1, 2}
+            const uint32_t r0 = (uint32_t)r01, r1 = (uint32_t)(r01 >> 32), r2 = (uint32_t)r23, r3 = (uint32_t)(r23 >> 32);
+            const uint32_t o = (at >> 5) - rb;
+            const uint32_t lo = o == 0 ? r0 : o == 1 ? r1 : r2, hi = o == 0 ? r1 : o == 1 ? r2 : r3;
+            const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, at);
+            // the register window of the NEXT symbol (it starts at at .. at + 28): issued here, used an iteration later
+            rb = at >> 5;
+            const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(ring + (rb & (RING_DW - 1)));
+            asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %2 offset0:2 offset1:3"
+                         : "=&v"(r01), "=&v"(r23) : "v"(a) : "memory");
+            return v;
+        }
+        const uint32_t *p = ring + ((at >> 5) & (RING_DW - 1));
+        return __builtin_amdgcn_alignbit(p[1], p[0], at);
+    }
+    // reload in two halves, so that the caller's code stores go between them: the wait for the in-flight dwords then sits in
+    // FRONT of the stores (vmcnt counts loads and stores alike, in order: behind them it waits for their acknowledgements too).
+    // take(): only when !room() — every later read of the ring starts at rel / 32 >= filled - RING_AHEAD + 1, so the RING_FILL
+    // oldest dwords are free
+    __device__ __forceinline__ void take() {
+        const uint32_t slot = filled & (RING_DW - 1);                   // a multiple of RING_FILL
+        uint32_t *p = ring + slot;
+#pragma unroll
+        for (uint32_t k = 0; k < RING_FILL; ++k) p[k] = x[k];
+        if (slot == 0) {
+#pragma unroll
+            for (uint32_t k = 0; k < RING_DUP; ++k) ring[RING_DW + k] = x[k];
+        }
+        filled += RING_FILL;
+        __builtin_amdgcn_sched_barrier(0);       // keep the caller's stores and the loads of issue() below the writes above
+    }
+    __device__ __forceinline__ void issue() {
+#pragma unroll
+        for (uint32_t k = 0; k < RING_FILL; ++k) x[k] = ld(widx + k);
+        widx += RING_FILL;
+    }
+};
+
 constexpr uint32_t EMIT_STAGE = 8;             // code words staged per lane (two workgroups' staging must fit one CU)
 constexpr uint32_t EMIT_STRIDE = EMIT_STAGE + 1;   // row stride in dwords (odd: conflict-free across lanes)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -323,8 +442,9 @@ struct __attribute__((packed, aligned(4))) U32x4 { u32x4 v; };   // 16-byte stor
 // EMIT also tracks the earliest cut of the slice: (cut_code, cut_out) = first code / byte such that no later
 // code OF THIS SLICE reads a byte produced before it.  A back-reference that reads below the current
 // candidate kills it and every later one up to itself, so the candidate moves to just behind it.
+// the symbol loop over the register FIFO (FastBits)
 template <bool EMIT>
-__device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
+__device__ __forceinline__ int lane_decode_fifo(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
                                            uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
                                            int64_t &reach, uint64_t &endpos, uint32_t &cut_code, uint32_t &cut_out,
                                            uint32_t *stage = nullptr) {
@@ -415,6 +535,101 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
     }
     nout += no;
     endpos = start + b.used;
+    return ret;
+}
+
+// the symbol loop over the LDS ring (RingBits)
+template <bool EMIT>
+__device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
+                                           uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
+                                           int64_t &reach, uint64_t &endpos, uint32_t &cut_code, uint32_t &cut_out,
+                                           uint32_t *ring, uint32_t *stage = nullptr) {
+    // EMIT: code words are staged in this lane's LDS row (EMIT_STAGE entries) and written out as runs of
+    // 16-byte stores whenever the wavefront pauses to refill its bit rings — a lane's 4-byte stores, each
+    // to a cache line of its own, cost ~6x their size in HBM traffic (partial-line evictions).
+    RingBits b;
+    uint32_t staged = 0;
+    b.init(in, nbytes, start, ring);
+    const uint64_t span = limit > start ? limit - start : 0;
+    const uint32_t lim = span > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)span;
+    const uint32_t rlim = lim + b.off0;          // used < lim  <=>  rel < rlim
+    int ret = 0;
+    uint32_t no = 0;   // bytes produced by this call (added to nout at the end)
+    int32_t reach_rel = INT32_MAX;   // EMIT: smallest (bytes produced by this call) - distance over the matches
+    while (b.rel < rlim && ret == 0) {
+        // ONE divergent region per symbol: the loop runs on the lanes that still take a symbol, and EndOfBlock or an
+        // undecodable code end a lane by predication (zero-length skips, nothing staged, nothing counted) instead of by
+        // breaks — every break cost the loop an exec-mask save / merge of its own.
+        bool act = b.room() && (!EMIT || staged < EMIT_STAGE);      // (b.rel < rlim holds here)
+        while (act) {
+            const uint32_t w1 = b.window_lit(b.rel);
+            uint32_t e = T.lit[w1 & ((1u << LIT_BITS) - 1)];
+            if (__builtin_expect((e & 15) == 0, 0))
+                e = e == E_LONG ? long_lookup(T.lit_count, T.lit_sorted, T.lit_info, 286, (uint64_t)w1) : 0;
+            const bool bad1 = e == 0;
+            const uint32_t kind = (e >> 4) & 3;
+            const bool eob = kind == K_EOB;              // (an entry 0 has kind 0: never EndOfBlock)
+            // Literals and matches share one straight-line path (a literal is a symbol without extra bits and
+            // without a distance): nearly every wavefront iteration holds both kinds, and a divergent branch
+            // costs exec-mask round trips and a register copy per live value.  A literal lane also looks up a
+            // distance entry; it is harmless and ignored.
+            const bool is_match = kind == K_LEN;
+            const uint32_t wl = e & 15, eb = (e >> 6) & 31;      // (EndOfBlock carries no extra bits; entry 0: wl = eb = 0)
+            const uint32_t val = (e >> 16) + __builtin_amdgcn_ubfe(w1, wl, eb);   // byte, or length
+            const uint32_t at2 = b.rel + wl + eb;
+            const uint32_t w2 = b.window_dist(at2);
+            uint32_t d = T.dist[w2 & ((1u << DIST_BITS) - 1)];
+            if (__builtin_expect(is_match && (d & 15) == 0, 0))
+                d = d == E_LONG ? long_lookup(T.dist_count, T.dist_sorted, T.dist_info, 30, (uint64_t)w2) : 0;
+            const bool bad2 = is_match && d == 0;
+            const bool ok = !(bad1 || eob || bad2);
+            const bool okm = ok && is_match;
+            const uint32_t dw = d & 15, db = (d >> 6) & 31;
+            const uint32_t distance = (d >> 16) + __builtin_amdgcn_ubfe(w2, dw, db);
+            b.rel = at2 + (okm ? dw + db : 0u);
+            ret = (bad1 || bad2) ? 2 : eob ? 1 : 0;
+            if (EMIT) {
+                stage[staged] = (val << 16) | (is_match ? distance : 0u);    // (a slot behind the last code is never flushed)
+                staged += ok ? 1u : 0u;
+                const int32_t rel = (int32_t)no - (int32_t)distance;          // first byte a match reads
+                reach_rel = okm && rel < reach_rel ? rel : reach_rel;
+                const bool cut = okm && rel < (int32_t)cut_out;
+                cut_code = cut ? ncodes + 1 : cut_code;
+                cut_out = cut ? no + val : cut_out;
+            }
+            ncodes += ok ? 1u : 0u;
+            no += ok ? (is_match ? val : 1u) : 0u;
+            act = ok && b.room() && b.rel < rlim && (!EMIT || staged < EMIT_STAGE);
+        }
+        const bool refill = ret == 0 && b.rel < rlim && !b.room();
+        if (refill) b.take();
+        if (EMIT) {
+            uint32_t *dst = codes + (ncodes - staged);
+            for (uint32_t j = 0; j < EMIT_STAGE; j += 4) {
+                if (__ballot(j < staged) == 0) break;
+                if (j < staged) {
+                    const uint32_t c0 = stage[j], c1 = stage[j + 1], c2 = stage[j + 2], c3 = stage[j + 3];
+                    if (j + 4 <= staged) {
+                        U32x4 q;
+                        q.v = u32x4{c0, c1, c2, c3};
+                        *(U32x4 *)(dst + j) = q;
+                    } else {
+                        dst[j] = c0;
+                        if (j + 1 < staged) dst[j + 1] = c1;
+                        if (j + 2 < staged) dst[j + 2] = c2;
+                    }
+                }
+            }
+            staged = 0;
+        }
+        if (refill) b.issue();
+    }
+    if (EMIT && reach_rel != INT32_MAX) {
+        const int64_t r = (int64_t)nout + (int64_t)reach_rel;
+        reach = r < reach ? r : reach;
+    }
+    nout += no;
+    endpos = start + b.used();
     return ret;
 }
 
@@ -626,7 +841,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
             uint32_t wn = 0, wcc = 0, wco = 0;
             uint64_t wo = 0, at = 0;
             int64_t wr = 0;
-            const int r = lane_decode<false>(T, in, nbytes, job.warm_bit, job.lo_bit, wn, wo, nullptr, wr, at, wcc, wco);
+            const int r = lane_decode_fifo<false>(T, in, nbytes, job.warm_bit, job.lo_bit, wn, wo, nullptr, wr, at, wcc, wco);
             hdr64[0] = at;
             hdr[2] = r != 0;          // EndOfBlock or an undecodable code before the piece: the block ended earlier
         }
@@ -671,25 +886,25 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
                 int r = 0;
                 bool reuse = false;
                 if (have_cp && st < cp_pos) {
-                    r = lane_decode<false>(T, in, nbytes, st, cp_pos, nc, no, nullptr, dummy, at, cc, co);
+                    r = lane_decode_fifo<false>(T, in, nbytes, st, cp_pos, nc, no, nullptr, dummy, at, cc, co);
                     reuse = r == 0 && at == cp_pos;
                     if (!reuse) have_cp = false;
                 } else {
                     have_cp = false;
                     const uint64_t cpl = st + CP_BITS < lim ? st + CP_BITS : lim;
-                    r = lane_decode<false>(T, in, nbytes, st, cpl, nc, no, nullptr, dummy, at, cc, co);
+                    r = lane_decode_fifo<false>(T, in, nbytes, st, cpl, nc, no, nullptr, dummy, at, cc, co);
                     if (r == 0 && at < lim) {
                         have_cp = true;
                         cp_pos = at;
                         rest_nc = 0; rest_no = 0;
-                        const int rr = lane_decode<false>(T, in, nbytes, at, lim, rest_nc, rest_no, nullptr, dummy, rest_exit, cc, co);
+                        const int rr = lane_decode_fifo<false>(T, in, nbytes, at, lim, rest_nc, rest_no, nullptr, dummy, rest_exit, cc, co);
                         rest_flag = rr == 1 ? 1 : rr == 2 ? 2 : 0;
                         reuse = true;
                     }
                 }
                 if (reuse) { nc += rest_nc; no += rest_no; exitpos = rest_exit; flag = rest_flag; }
                 else {
-                    if (r == 0 && at < lim) r = lane_decode<false>(T, in, nbytes, at, lim, nc, no, nullptr, dummy, at, cc, co);
+                    if (r == 0 && at < lim) r = lane_decode_fifo<false>(T, in, nbytes, at, lim, nc, no, nullptr, dummy, at, cc, co);
                     exitpos = at;
                     flag = r == 1 ? 1 : r == 2 ? 2 : 0;
                 }
@@ -766,7 +981,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
 // default.rs:73) so that K3 can materialise them concurrently.
 constexpr uint32_t MAX_UNITS = 8;
 
-__global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+// RING: the lanes' bits come through LDS rings (RingBits: one workgroup per CU — the single-stream path, whose blocks are
+// large); else through the register FIFO (FastBits: two workgroups per CU — the batch path's thousands of small blocks)
+template <bool RING>
+__global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkEmit *__restrict__ jobs,
                                                                 const BlkLanes *__restrict__ lanes,
                                                                 uint32_t *__restrict__ codes,
@@ -779,6 +997,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
     extern __shared__ uint32_t emit_stage[];   // SCAN_THREADS rows of EMIT_STRIDE dwords
+    __shared__ uint32_t s_ring[RING ? SCAN_THREADS * RING_STRIDE : 1];      // the lanes' bit rings (lane_decode)
     const uint32_t tid = threadIdx.x;
     const BlkEmit job = jobs[blockIdx.x];
     BlkUnits *U = &units[blockIdx.x];
@@ -812,8 +1031,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_emit_kernel(const uint8_t
         uint32_t nc = 0, cc = 0, co = 0;
         const uint64_t out0 = L->out_off[tid];   // bytes of this block produced before my slice
         uint64_t no = out0, endpos;
-        lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
-                          emit_stage + tid * EMIT_STRIDE);
+        if (RING)
+            lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
+                              s_ring + tid * RING_STRIDE, emit_stage + tid * EMIT_STRIDE);
+        else
+            lane_decode_fifo<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
+                                   emit_stage + tid * EMIT_STRIDE);
         if (reach < -(int64_t)job.hist) {         // a back-reference reaches in front of the member's first byte
             atomicOr(&flags[0], 1u);              // ... summary, and per job (batch decode)
             if (job_flags) job_flags[blockIdx.x] = 1u;
@@ -1789,7 +2012,7 @@ int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
 }
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
-                    uint32_t *job_flags, const void *tabs, uint32_t free_shift) {
+                    uint32_t *job_flags, const void *tabs, uint32_t free_shift, bool large_blocks) {
     if (!njobs) return 0;
     constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
     // (a function attribute is per device: one flag per device ordinal)
@@ -1797,11 +2020,20 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     if (!attr_set[dev_ & 63]) {
-        (void)hipFuncSetAttribute((const void *)blk_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        (void)hipFuncSetAttribute((const void *)blk_emit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        (void)hipFuncSetAttribute((const void *)blk_emit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
         attr_set[dev_ & 63] = true;
     }
-    hipLaunchKernelGGL(blk_emit_kernel, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes, flags, units,
-                       unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags, (const FastTabs *)tabs);
+    // large blocks (a stream's own 1 MiB blocks, pieces): the LDS-ring bit source, one workgroup per CU; many small blocks
+    // (the batch path, another encoder's 30 KB blocks): the register FIFO, two workgroups per CU
+    if (large_blocks)
+        hipLaunchKernelGGL(blk_emit_kernel<true>, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes,
+                           codes, flags, units, unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags,
+                           (const FastTabs *)tabs);
+    else
+        hipLaunchKernelGGL(blk_emit_kernel<false>, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes,
+                           flags, units, unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags,
+                           (const FastTabs *)tabs);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -5,7 +5,7 @@ oracle's byte for byte (DefaultLz77Encoder::flush default.rs:69-109 … Encoder:
 returns the input for our stream AND for a python-zlib stream of the same bytes (foreign block structure, back-references
 across blocks: decode.rs:112-164, lib.rs:149-242).
 
-LFX_FUZZ=<n> sets the number of cases (default 24: a few seconds), LFX_FUZZ_SEED the seed, LFX_FUZZ_MINLOG2 / LFX_FUZZ_MAXLOG2 the
+LFX_FUZZ=<n> sets the number of cases (default 120: about half a minute), LFX_FUZZ_SEED the seed, LFX_FUZZ_MINLOG2 / LFX_FUZZ_MAXLOG2 the
 size range (default 6 … 23).  The round's soaks: profiles/r04_fuzz.txt."""
 import ctypes as C
 import os
@@ -52,7 +52,7 @@ def _data(rng, synth, n, kind):
 def test_random_round_trips(env, oracle):
     import torch
     lfx, ctx, ffi, synth = env
-    cases = int(os.environ.get("LFX_FUZZ", "24"))
+    cases = int(os.environ.get("LFX_FUZZ", "120"))
     rng = np.random.default_rng(int(os.environ.get("LFX_FUZZ_SEED", "20260927")))
     fmts = ((ffi.GZIP, oracle.GZIP, 31), (ffi.ZLIB, oracle.ZLIB, 15), (ffi.DEFLATE, oracle.DEFLATE, -15))
     lo2, hi2 = float(os.environ.get("LFX_FUZZ_MINLOG2", "6")), float(os.environ.get("LFX_FUZZ_MAXLOG2", "23"))
