@@ -70,6 +70,17 @@ constexpr uint64_t ROLE_IDX = 0x6564325104321000ull;     // index of the wavefro
 constexpr uint32_t ROLE_IS_P = 0x227Cu;                   // waves 2 3 4 5 6 9 13
 constexpr uint32_t ROLE_IS_C = 0xDD80u;                   // waves 7 8 10 11 12 14 15
 constexpr int AHEAD = 4;                       // register sets of the loading wavefronts = iterations between a load and its use
+// How the stages of the pipeline wait for each other.  1 (the default): one workgroup barrier per tile — every wavefront waits
+// for the slowest of the sixteen, every tile: a quarter of the kernel's time is that wait.  0 (measured, round 5, not kept): every
+// stage publishes how far it is in an LDS counter of its own and waits only for what it reads or overwrites (the rings are
+// three to four tiles deep, so a slow tile of one stage is absorbed) — bit-exact, and SLOWER: 1.00 against 0.89 ms for the
+// match stage at 256 MiB.  A wait that is already satisfied still costs the LDS round trip of its poll (about 250 cycles with
+// sixteen wavefronts on the CU), one or two per stage and tile on the two exchange wavefronts that ARE the critical path;
+// the hardware barrier costs no LDS access at all.
+#ifndef LFX_M7_BARRIER
+#define LFX_M7_BARRIER 1
+#endif
+constexpr uint32_t NP = 7, NC = 7;             // loading / storing helper wavefronts
 constexpr uint32_t BUCKET_BITS = 14, TAG_BITS = 24 - BUCKET_BITS;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr uint32_t KEY_MULT = 0x00374ADDu;     // odd, 24 bits: k → k·M mod 2^24 is a bijection (chosen on text)
@@ -81,12 +92,13 @@ constexpr uint32_t UNRES = 0x8000u;            // cd value UNRES + (d2 − 1), d
 // SEC_DELTA further (two tables, not pairs: an exchange's 64 random buckets then spread over all 32 banks).  A lane without a
 // position exchanges on a slot of its own in dummy 1 (and, SEC_DELTA further, in dummy 2): no exchange wavefront ever tests
 // for validity.
-constexpr uint32_t OFF_DUMMY = 0;                                   // 64 dwords
-constexpr uint32_t OFF_TAB = 256;                                   // head: 16 Ki dwords
-constexpr uint32_t OFF_DUMMY2 = OFF_TAB + (4u << BUCKET_BITS);      // 64 dwords
-constexpr uint32_t OFF_SEC = OFF_DUMMY2 + 256;                      // second: 16 Ki dwords
+constexpr uint32_t OFF_DUMMY = 0;                                   // 32 dwords (lanes l and l + 32 share one: ordered like any bucket)
+constexpr uint32_t OFF_TAB = 128;                                   // head: 16 Ki dwords
+constexpr uint32_t OFF_DUMMY2 = OFF_TAB + (4u << BUCKET_BITS);      // 32 dwords
+constexpr uint32_t OFF_SEC = OFF_DUMMY2 + 128;                      // second: 16 Ki dwords
 constexpr uint32_t SEC_DELTA = OFF_SEC - OFF_TAB;
-constexpr uint32_t OFF_RQ = OFF_SEC + (4u << BUCKET_BITS);          // 4 tiles of requests
+constexpr uint32_t OFF_CTL = OFF_SEC + (4u << BUCKET_BITS);         // progress counters of the four stages (LFX_M7_BARRIER=0)
+constexpr uint32_t OFF_RQ = OFF_CTL + 64;                           // 4 tiles of requests
 constexpr uint32_t OFF_R1 = OFF_RQ + 4 * TILE * 4;                  // 3 tiles: what the exchange on head returned
 constexpr uint32_t OFF_R2 = OFF_R1 + 3 * TILE * 4;                  // 2 tiles: what the exchange on second returned
 constexpr uint32_t LDS_BYTES = OFF_R2 + 2 * TILE * 4;
@@ -95,10 +107,25 @@ static_assert(OFF_DUMMY + SEC_DELTA == OFF_DUMMY2, "a dummy request's second ent
 static_assert(LDS_BYTES < (1u << (32 - TAG_BITS)), "LDS addresses fit the request");
 static_assert(SEG_POSITIONS + MAX_WINDOW + SPOS0 + 8 * TILE < (1u << (32 - TAG_BITS)), "segment-relative positions fit the entry");
 static_assert(KEY_MULT < (1u << 24) && (KEY_MULT & 1), "24-bit multiplication, bijective");
-static_assert(NG == 14, "operand lists below: two batches of seven");
+static_assert(NG == 14 && NP + NC == NG, "operand lists below: two batches of seven; two groups per helper wavefront");
 static_assert(TILE % 4 == 0, "a lane's byte phase is the same in every tile");
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// progress counters in LDS (byte address `a`).  A wavefront's LDS instructions execute in order, so a counter written behind a
+// stage's data is seen only when the data is; a reader that has seen the counter reads the data behind it.
+__device__ __forceinline__ void ctr_set(uint32_t a, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+// until the `n` counters from `a` on (one per wavefront of a stage: each is written by its own wavefront only — a sum would not
+// say that the slowest of them has arrived) are all >= v: lane l reads counter l, one LDS read per poll
+__device__ __forceinline__ void ctr_wait(uint32_t a, uint32_t n, int v) {
+    const uint32_t l = threadIdx.x & 63;
+    const uint32_t mine = a + (l < n ? l : 0u) * 4;
+    for (;;) {
+        int got;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(mine) : "memory");
+        if (__ballot(got - v < 0) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 
 // seven exchanges on the head entries, in order; NO wait (lds_wait14 below orders every use of the results)
 __device__ __forceinline__ void xchg7(uint32_t (&old)[14], const uint32_t (&addr)[14], const uint32_t (&val)[14], const int o) {
@@ -190,10 +217,20 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     lds_barrier();
 
     uint64_t cy_work = 0, cy_wait = 0;
+    // barrier mode: one barrier per iteration.  counter mode: wait_for() in front of a stage, done() behind it
+    // counters: [0, 7) the P wavefronts, [7] X1, [8, 15) the C wavefronts, [15] X2 — each the number of tiles its wavefront has finished
+    const uint32_t c_p = lds0 + OFF_CTL, c_x1 = c_p + 4 * NP, c_c = c_p + 32, c_x2 = c_c + 4 * NC;
     auto sync = [&](uint64_t c0) {
+        if (!LFX_M7_BARRIER) { if (DBG) cy_work += clock64() - c0; return; }
         const uint64_t c1 = DBG ? clock64() : 0;
         lds_barrier();
         if (DBG) { cy_work += c1 - c0; cy_wait += clock64() - c1; }
+    };
+    auto wait_for = [&](uint32_t ctr, uint32_t nctr, int v) {
+        if (LFX_M7_BARRIER || v <= 0) return;
+        const uint64_t c0 = DBG ? clock64() : 0;
+        ctr_wait(ctr, nctr, v);
+        if (DBG) { const uint64_t d = clock64() - c0; cy_wait += d; cy_work -= d; }
     };
     if (wave < 2) __builtin_amdgcn_s_setprio(3);
 
@@ -210,7 +247,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
         const uint32_t sh8 = (base + hidx + shift) & 3u;      // byte phase inside the dword pair (TILE and 64 are multiples of 4)
         // last dword of the CHUNK (every valid position's pair ends at or in front of it: p + 2 < n)
         const uint32_t last_off = (uint32_t)min((((uint64_t)n + shift + 3) >> 2 << 2) - 4, (uint64_t)0xFFFFFFFCu);
-        const uint32_t dummy = (lds0 + OFF_DUMMY + lane * 4) << TAG_BITS;
+        const uint32_t dummy = (lds0 + OFF_DUMMY + (lane & 31) * 4) << TAG_BITS;
         const uint32_t tab = lds0 + OFF_TAB;
         auto ldw = [&](uint32_t off) { return *(gptr_u32)(srcb + off); };
         // the loads rotate through AHEAD register sets (an iteration consumes the set that was loaded AHEAD iterations ago and
@@ -220,6 +257,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
             const uint64_t c0 = DBG ? clock64() : 0;
             const int tp = i + 1;
             if (tp >= 0 && tp < ntiles) {
+                wait_for(c_c, NC, tp - 3);                                // the slot's last readers: C(tp - 4), all of its wavefronts
                 const uint32_t t0 = base + (uint32_t)tp * TILE;           // first position of the tile
                 const bool interior = t0 >= l0 && t0 + TILE <= q1;        // every position takes part
                 uint32_t *rq = rqb + (uint32_t)(tp & 3) * TILE + hidx;
@@ -236,6 +274,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                     }
                     rq[g * 64] = r;
                 }
+                if (!LFX_M7_BARRIER) ctr_set(c_p + 4 * ridx, tp + 1);
             }
             // ---- loads of tile i+1+AHEAD, into the registers P just consumed (unconditional; clamped where the chunk ends)
             {
@@ -264,6 +303,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
             const uint64_t c0 = DBG ? clock64() : 0;
             const int tc = i - 2;
             if (tc >= 0 && tc < ntiles) {
+                wait_for(c_x2, 1, tc + 1);                                // X2(tc) (and with it X1(tc), P(tc))
                 const uint32_t t0 = base + (uint32_t)tc * TILE;
                 const bool interior = t0 >= q0 && t0 + TILE <= q1;        // every position is answered
                 uint32_t rq[2], o1[2], o2[2];
@@ -272,6 +312,11 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                     rq[g] = rqb[(uint32_t)(tc & 3) * TILE + hidx + g * 64];
                     o1[g] = r1b[(uint32_t)(tc % 3) * TILE + hidx + g * 64];
                     o2[g] = r2b[(uint32_t)(tc & 1) * TILE + hidx + g * 64];
+                }
+                if (!LFX_M7_BARRIER) {
+                    // (the three slots are free once the values are in registers: the wait names them, the add sits behind it)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq[0]), "+v"(rq[1]), "+v"(o1[0]), "+v"(o1[1]), "+v"(o2[0]), "+v"(o2[1]));
+                    ctr_set(c_c + 4 * ridx, tc + 1);
                 }
                 const uint32_t rel = (uint32_t)tc * TILE + hidx;          // p - base of the first group
                 const uint32_t boff = rel * 2;
@@ -324,6 +369,8 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
         for (int i = i_first; i < i_end; ++i) {
             const uint64_t c0 = DBG ? clock64() : 0;
             if (i >= 0 && i < ntiles) {
+                wait_for(c_p, NP, i + 1);                                 // P(i), all of its wavefronts
+                wait_for(c_c, NC, i - 2);                                 // the r1 slot's last readers: C(i - 3)
                 const uint32_t *rq = rqb + (uint32_t)(i & 3) * TILE + lane;
                 uint32_t *r1 = r1b + (uint32_t)(i % 3) * TILE + lane;
                 const uint32_t ent0 = ((uint32_t)i * TILE + lane + SPOS0) << TAG_BITS;
@@ -340,6 +387,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                 lds_wait14(od);
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) r1[s * 64] = od[s];
+                if (!LFX_M7_BARRIER) ctr_set(c_x1, i + 1);
             }
             sync(c0);
         }
@@ -350,6 +398,8 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
             const uint64_t c0 = DBG ? clock64() : 0;
             const int t2 = i - 1;
             if (t2 >= 0 && t2 < ntiles) {
+                wait_for(c_x1, 1, t2 + 1);                                // X1(t2)
+                wait_for(c_c, NC, t2 - 1);                                // the r2 slot's readers: C(t2 - 2)
                 const uint32_t *rq = rqb + (uint32_t)(t2 & 3) * TILE + lane;
                 const uint32_t *r1 = r1b + (uint32_t)(t2 % 3) * TILE + lane;
                 uint32_t *r2 = r2b + (uint32_t)(t2 & 1) * TILE + lane;
@@ -368,6 +418,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                 lds_wait14(od);
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) r2[s * 64] = od[s];
+                if (!LFX_M7_BARRIER) ctr_set(c_x2, t2 + 1);
             }
             sync(c0);
         }
