@@ -49,6 +49,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "lfx_common.h"
 #include "lfx_device.h"
 
@@ -81,6 +83,15 @@ constexpr int AHEAD = 4;                       // register sets of the loading w
 #define LFX_M7_BARRIER 1
 #endif
 constexpr uint32_t NP = 7, NC = 7;             // loading / storing helper wavefronts
+// RUNS (zero-filled and constant regions, BASELINE cfg5's LOWENT: every position repeats the prefix of the one in front of it).
+// The lanes of an exchange that hit the same dword are served one after the other — a run is sixty-four of them, on both
+// tables (cfg5's match stage took 8.3 ms per GiB against 2.6 for a text).  But a position that repeats its predecessor's prefix
+// needs no table at all: its head answer IS the predecessor, and `second` is for it what it was for the run's first lane.  So
+// the P stage marks such lanes in the request (bit 30: same prefix as the lane below, bit 31: the lane above continues), only
+// a run's first lane (the true exchange) and last lane (its entry must stay in `head`) touch the table, the others exchange
+// on dummies, and X2 hands the run's first lane's `second` to the rest by one ds_bpermute.  A tile without a marked lane (nine
+// in ten of a text's) takes the paths without any of this: the test is the OR of the tile's fourteen requests.
+constexpr uint32_t RQ_SAME_PREV = 1u << 30, RQ_NEXT_SAME = 1u << 31, RQ_ADDR_BITS = 18;
 constexpr uint32_t BUCKET_BITS = 14, TAG_BITS = 24 - BUCKET_BITS;
 constexpr uint32_t TAG_MASK = (1u << TAG_BITS) - 1;
 constexpr uint32_t KEY_MULT = 0x00374ADDu;     // odd, 24 bits: k → k·M mod 2^24 is a bijection (chosen on text)
@@ -104,7 +115,7 @@ constexpr uint32_t OFF_R2 = OFF_R1 + 3 * TILE * 4;                  // 2 tiles: 
 constexpr uint32_t LDS_BYTES = OFF_R2 + 2 * TILE * 4;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(OFF_DUMMY + SEC_DELTA == OFF_DUMMY2, "a dummy request's second entry is a dummy too");
-static_assert(LDS_BYTES < (1u << (32 - TAG_BITS)), "LDS addresses fit the request");
+static_assert(LDS_BYTES < (1u << RQ_ADDR_BITS) && TAG_BITS + RQ_ADDR_BITS <= 30, "LDS addresses fit the request, below its two run bits");
 static_assert(SEG_POSITIONS + MAX_WINDOW + SPOS0 + 8 * TILE < (1u << (32 - TAG_BITS)), "segment-relative positions fit the entry");
 static_assert(KEY_MULT < (1u << 24) && (KEY_MULT & 1), "24-bit multiplication, bijective");
 static_assert(NG == 14 && NP + NC == NG, "operand lists below: two batches of seven; two groups per helper wavefront");
@@ -209,10 +220,28 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     const int n_iter = (ntiles + 2 - i_first + AHEAD - 1) / AHEAD * AHEAD;   // (stages are predicated: extra iterations do nothing)
     const int i_end = i_first + n_iter;
 
-    // ---- prologue: empty tables
+    // ---- prologue: empty tables; and a sample of the segment — 4 KiB from its first answered position on: a dword of four
+    //      equal bytes in one of sixteen or more means constant regions (zero-filled pages, BASELINE cfg5's LOWENT: 95 % of the
+    //      positions repeat their predecessor's prefix; a text: 1 in 6000).  A wrong guess costs time, never the answer.
     {
         uint4 *t4 = (uint4 *)smem;
         for (uint32_t i = tid; i < (OFF_RQ >> 4); i += THREADS) t4[i] = make_uint4(0, 0, 0, 0);
+    }
+    lds_barrier();
+    bool runs_mode;
+    {
+        const uint64_t a0 = (uint64_t)(in + ch.in_off);
+        const uint32_t shift = (uint32_t)(a0 & 3);
+        const uint32_t last_off = (uint32_t)min((((uint64_t)n + shift + 3) >> 2 << 2) - 4, (uint64_t)0xFFFFFFFCu);
+        const uint32_t off = min(((q0 + shift) & ~3u) + tid * 4, last_off);      // (chunk-relative, as the P wavefronts' loads)
+        const uint32_t v = *(gptr_u32)((gptr_u8)(a0 & ~3ull) + off);
+        const uint64_t eq = __ballot(((v ^ (v >> 8)) & 0xFFFFFFu) == 0);
+        uint32_t *cnt = (uint32_t *)(smem + OFF_CTL) + 15;                      // (no room for __syncthreads_count's own LDS)
+        if (lane == 0) atomicAdd(cnt, (uint32_t)__popcll(eq));
+        lds_barrier();
+        runs_mode = *cnt >= THREADS / 16;
+        lds_barrier();
+        if (tid == 0) *cnt = 0;
     }
     lds_barrier();
 
@@ -220,6 +249,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     // barrier mode: one barrier per iteration.  counter mode: wait_for() in front of a stage, done() behind it
     // counters: [0, 7) the P wavefronts, [7] X1, [8, 15) the C wavefronts, [15] X2 — each the number of tiles its wavefront has finished
     const uint32_t c_p = lds0 + OFF_CTL, c_x1 = c_p + 4 * NP, c_c = c_p + 32, c_x2 = c_c + 4 * NC;
+
     auto sync = [&](uint64_t c0) {
         if (!LFX_M7_BARRIER) { if (DBG) cy_work += clock64() - c0; return; }
         const uint64_t c1 = DBG ? clock64() : 0;
@@ -234,6 +264,10 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     };
     if (wave < 2) __builtin_amdgcn_s_setprio(3);
 
+    // The whole pipeline, in two instances: RUNS marks and short-cuts repeated prefixes (see RQ_SAME_PREV), the other knows nothing
+    // of them — and is correct on any data, only slower on runs.  A workgroup picks one for its segment from a sample (below).
+    auto pipeline = [&](auto runs_tag) {
+    constexpr bool RUNS = decltype(runs_tag)::value;
     const uint32_t ridx = (uint32_t)(ROLE_IDX >> (4 * wave)) & 15u;   // which pair of groups a P / C wavefront takes
     if ((ROLE_IS_P >> wave) & 1) {
         // ================================================== P: bytes → prefix → (bucket, tag) → request
@@ -271,6 +305,14 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                     if (!interior) {
                         const uint32_t p = t0 + hidx + g * 64;
                         r = (p >= l0 && p < q1) ? r : dummy;
+                    }
+                    // runs: the lane below / above asks for the same bucket and tag — four equal bytes in a row, so a prefix of
+                    // three equal bytes comes first (a text: one wavefront in sixteen holds such a lane; the others skip the shuffles)
+                    if (RUNS && __ballot(((key ^ (key >> 8)) & 0xFFFFu) == 0)) {
+                        const uint32_t below = (uint32_t)__shfl_up((int)r, 1), above = (uint32_t)__shfl_down((int)r, 1);
+                        // (a dummy request never equals its neighbour's: lanes l and l + 32 share a dummy)
+                        const bool sp = lane > 0 && below == r && r != dummy, ns = lane < 63 && above == r && r != dummy;
+                        r |= (sp ? RQ_SAME_PREV : 0u) | (ns ? RQ_NEXT_SAME : 0u);
                     }
                     rq[g * 64] = r;
                 }
@@ -377,14 +419,26 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                 uint32_t q[NG], ad[NG], vl[NG], od[NG];
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) q[s] = rq[s * 64];
+                constexpr bool runs = RUNS;
+                const uint32_t dummy_a = lds0 + OFF_DUMMY + (lane & 31) * 4;
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) {
-                    ad[s] = q[s] >> TAG_BITS;
+                    ad[s] = __builtin_amdgcn_ubfe(q[s], TAG_BITS, RQ_ADDR_BITS);
                     vl[s] = (q[s] & TAG_MASK) | (ent0 + ((s * 64u) << TAG_BITS));
+                }
+                if constexpr (runs) {
+                    // the middle of a run touches no table: only its first lane (the true exchange) and its last (its entry stays)
+#pragma unroll
+                    for (uint32_t s = 0; s < NG; ++s) ad[s] = (q[s] >> 30) == 3u ? dummy_a : ad[s];
                 }
                 xchg7(od, ad, vl, 0);
                 xchg7(od, ad, vl, 7);
                 lds_wait14(od);
+                if constexpr (runs) {
+                    // ... and what a lane behind a run's first would have received: the entry of the position in front of it
+#pragma unroll
+                    for (uint32_t s = 0; s < NG; ++s) od[s] = (q[s] & RQ_SAME_PREV) ? vl[s] - (1u << TAG_BITS) : od[s];
+                }
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) r1[s * 64] = od[s];
                 if (!LFX_M7_BARRIER) ctr_set(c_x1, i + 1);
@@ -406,16 +460,35 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                 uint32_t q[NG], o[NG], ad[NG], mk[NG], vl[NG], od[NG];
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) { q[s] = rq[s * 64]; o[s] = r1[s * 64]; }
+                constexpr bool runs = RUNS;
+                const uint32_t dummy_a = lds0 + OFF_DUMMY2 + (lane & 31) * 4;
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) {
-                    const bool differ = ((q[s] ^ o[s]) & TAG_MASK) != 0;
-                    ad[s] = (q[s] >> TAG_BITS) + SEC_DELTA;
+                    const bool differ = ((q[s] ^ o[s]) & TAG_MASK) != 0;       // (never for a lane behind a run's first)
+                    ad[s] = __builtin_amdgcn_ubfe(q[s], TAG_BITS, RQ_ADDR_BITS) + SEC_DELTA;
                     mk[s] = differ ? 0xFFFFFFFFu : 0u;
                     vl[s] = differ ? o[s] : 0u;
+                }
+                if constexpr (runs) {
+#pragma unroll
+                    for (uint32_t s = 0; s < NG; ++s) ad[s] = (q[s] & RQ_SAME_PREV) ? dummy_a : ad[s];
                 }
                 mskor7(od, ad, mk, vl, 0);
                 mskor7(od, ad, mk, vl, 7);
                 lds_wait14(od);
+                if constexpr (runs) {
+                    // `second` behind a lane's action: its old head where it wrote, what it read otherwise; a lane behind a run's
+                    // first takes the first's (nothing between them touches the bucket)
+#pragma unroll
+                    for (uint32_t s = 0; s < NG; ++s) {
+                        const bool sp = (q[s] & RQ_SAME_PREV) != 0;
+                        const uint64_t heads = __ballot(!sp) & ((2ull << lane) - 1ull);      // (lane 0 never is behind a first)
+                        const uint32_t h = 63u - (uint32_t)__builtin_clzll(heads);
+                        const uint32_t behind = mk[s] ? o[s] : od[s];
+                        const uint32_t fromhead = (uint32_t)__shfl((int)behind, (int)h);
+                        od[s] = sp ? fromhead : od[s];
+                    }
+                }
 #pragma unroll
                 for (uint32_t s = 0; s < NG; ++s) r2[s * 64] = od[s];
                 if (!LFX_M7_BARRIER) ctr_set(c_x2, t2 + 1);
@@ -423,6 +496,8 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
             sync(c0);
         }
     }
+    };
+    if (runs_mode) pipeline(std::true_type{}); else pipeline(std::false_type{});
     if (DBG && dbg && blockIdx.x == 0 && lane == 0) {
         uint64_t *d = dbg + wave * 8;
         d[0] = cy_work; d[1] = cy_wait; d[2] = 0; d[3] = 0; d[4] = 0; d[5] = (uint64_t)ntiles; d[6] = 0; d[7] = 0;
