@@ -1300,6 +1300,11 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
         //      ring (its own slot when there is nothing to fetch) and stores (to the dump when it lies behind the tile).
         uint32_t pp[PASSES][4];
         bool pend = false;
+        // (two instances: a tile cut by its BYTES — tot > TILE, six codes of 258 instead of 256 codes — is made of long
+        //  matches, and long matches at short distances are what runs turn into: cfg5's LOWENT is half runs of 64 .. 4096
+        //  equal bytes, a chain 1536 deep for the jumping below, eleven rounds per tile.  A tile of text never comes here.)
+        auto round0 = [&](auto periodic_tag) {
+        constexpr bool PERIODIC = decltype(periodic_tag)::value;
 #pragma unroll
         for (uint32_t ps = 0; ps < PASSES; ++ps) {
             const uint32_t b = ps * 4 * THREADS + 4 * tid;
@@ -1320,10 +1325,24 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
                     const uint32_t t = m2_wrap<RING>(tr + bi);
                     const bool in = bi < total;
                     lit[q] = d == 0;
-                    fin[q] = lit[q] || d > bi;
-                    src[q] = (d > bi && in) ? m2_back<RING>(t, d) : t;
+                    // the byte this one copies: bi - d — or, PERIODIC, the byte of the match's first period it repeats
+                    // (offset mod distance): a match that overlaps itself is then one step deep instead of length /
+                    // distance.  off < 258 and d <= off here: the float quotient is exact or one too small.
+                    uint32_t tgt = bi, tt = t;
+                    if constexpr (PERIODIC) {
+                        const uint32_t s0 = xc.x - (xc.y >> 16);                // the match's first byte (tile offset)
+                        const uint32_t off = bi - s0;
+                        if (d != 0 && off >= d) {
+                            uint32_t r = off - d * (uint32_t)((float)off * __builtin_amdgcn_rcpf((float)d));
+                            r = r >= d ? r - d : r;
+                            tgt = s0 + r;
+                            tt = m2_wrap<RING>(tr + tgt);
+                        }
+                    }
+                    fin[q] = lit[q] || d > tgt;
+                    src[q] = (d > tgt && in) ? m2_back<RING>(tt, d) : t;
                     dst[q] = in ? t : RING + (tid & 63u);
-                    pp[ps][q] = (fin[q] || !in) ? M2_DONE : bi - d;
+                    pp[ps][q] = (fin[q] || !in) ? M2_DONE : tgt - d;
                     cwq[q] = xc.x;                                  // end offset now, code word's literal below
                     src[q] |= xc.y & 0xFFFF0000u;                   // (ring indices are below 2^16: the value rides along)
                 }
@@ -1336,6 +1355,8 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
             }
             *(uint64_t *)&P[b] = (uint64_t)pp[ps][0] | (uint64_t)pp[ps][1] << 16 | (uint64_t)pp[ps][2] << 32 | (uint64_t)pp[ps][3] << 48;
         }
+        };
+        if (tot > TILE) round0(std::true_type{}); else round0(std::false_type{});
         // ---- rounds of pointer jumping.  Per byte: load the target's state, then the target's byte (in this order: a
         //      target seen resolved has its byte in the ring), store the byte, then the state.  A byte fetched from an
         //      unresolved target is garbage in a slot nobody reads yet.

@@ -424,3 +424,16 @@ def test_incremental_planner_equals_one_shot(ffi):
             got_c, got_b = ch[:4 * nc.value].reshape(-1, 4), bl[:6 * nb.value].reshape(-1, 6)
             assert got_c.shape == want_c.shape and (got_c == want_c).all(), (trial, every, kw)
             assert got_b.shape == want_b.shape and (got_b == want_b).all(), (trial, every, kw)
+
+
+def test_gzip_options_header_carries_the_level(ffi):
+    """gzip::EncodeOptions::header (gzip.rs:717-720) replaces the header the options held, compression level included:
+    a header cloned from a decoder keeps its XFL (4 Fastest, 2 Slowest, gzip.rs:84-92), a builder's is Unknown."""
+    from libflate_amd import gzip
+    cloned = dict(modification_time=5, os=3, is_text=False, is_verified=False, extra_field=None, filename=b"a", comment=None)
+    for xfl, level in ((4, 2), (2, 4), (0, 3), (7, 3)):
+        o = gzip.EncodeOptions().header(dict(cloned, xfl=xfl))
+        assert o._kw["lz77_level"] == level and o._kw["mtime"] == 5 and o._kw["filename"] == b"a"
+        assert "comment" not in o._kw and "extra" not in o._kw
+    o = gzip.EncodeOptions().header(gzip.HeaderBuilder().modification_time(9).finish())
+    assert o._kw["lz77_level"] == 3 and o._kw["mtime"] == 9
