@@ -1170,7 +1170,8 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
 template <uint32_t THREADS>
 struct M2 {
     static constexpr uint32_t WAVES = THREADS / 64;
-    static constexpr uint32_t TILE = 6 * THREADS;                           // bytes one tile may produce
+    static constexpr uint32_t NC = 2 * THREADS;                             // codes a tile looks at (two per lane)
+    static constexpr uint32_t TILE = 4 * THREADS;                           // bytes one tile may produce (four per lane)
     static constexpr uint32_t RING = 32768 + TILE;                          // the DEFLATE window + the tile in flight
     static constexpr uint32_t PASSES = (TILE + 4 * THREADS - 1) / (4 * THREADS);
     static_assert(RING % 4 == 0 && TILE >= 258 && TILE < 0xFFFFu && RING + 64 < 65536, "tile");
@@ -1198,7 +1199,7 @@ struct M2Lds {
     using G = M2<THREADS>;
     static constexpr uint32_t RING_BYTES = ((G::RING + 64) * (uint32_t)sizeof(elem_t) + 15u) & ~15u;
     static constexpr uint32_t P_BYTES = G::PASSES * 4 * THREADS * 2;
-    static constexpr uint32_t XC_BYTES = (THREADS + 4) * 8;
+    static constexpr uint32_t XC_BYTES = (G::NC + 4) * 8;
     static constexpr uint32_t SW_BYTES = 2 * G::WAVES * 4, SANY_BYTES = 2 * G::WAVES * 4;
     static constexpr uint32_t BYTES = RING_BYTES + P_BYTES + XC_BYTES + SW_BYTES + SANY_BYTES;
 };
@@ -1211,12 +1212,13 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     using elem_t = typename std::conditional<SYM, uint16_t, uint8_t>::type;
     using G = M2<THREADS>;
     using LD = M2Lds<SYM, THREADS>;
-    constexpr uint32_t WAVES = G::WAVES, TILE = G::TILE, RING = G::RING, PASSES = G::PASSES;
+    constexpr uint32_t WAVES = G::WAVES, TILE = G::TILE, RING = G::RING, PASSES = G::PASSES, NC = G::NC;
     constexpr uint32_t EPD = 4 / sizeof(elem_t);                                // elements per dword (flush granule)
     elem_t *ring;             // RING + 64 (+ a dump for the stores of idle bytes)
     uint16_t *P;              // PASSES * 4 * THREADS
-    // per code of the tile: x = inclusive end offset, y = code word; four sentinels behind the last (never passed)
-    uint2 *XC;                // THREADS + 4
+    // per code of the window (the NC codes from `base` on): x = its end offset (inclusive prefix sum of the lengths), y = the
+    // code word; four sentinels behind the last (never passed)
+    uint2 *XC;                // NC + 4
     uint32_t *s_w;            // 2 * WAVES
     uint32_t (*s_any)[WAVES]; // [2][WAVES]
     if constexpr (DYN) {
@@ -1229,7 +1231,7 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     } else {
         __shared__ __attribute__((aligned(16))) elem_t ring_s[RING + 64];
         __shared__ __attribute__((aligned(8))) uint16_t P_s[PASSES * 4 * THREADS];
-        __shared__ __attribute__((aligned(8))) uint2 XC_s[THREADS + 4];
+        __shared__ __attribute__((aligned(16))) uint2 XC_s[G::NC + 4];
         __shared__ uint32_t s_w_s[2 * WAVES];
         __shared__ uint32_t s_any_s[2][WAVES];
         ring = ring_s; P = P_s; XC = XC_s; s_w = s_w_s; s_any = s_any_s;
@@ -1259,50 +1261,58 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     const uint32_t shift = (uint32_t)((gbase - hist) & (EPD - 1)) + hist;       // < RING
     for (uint32_t k = tid; k < hist; k += THREADS)
         ring[shift - hist + k] = SYM ? (elem_t)(256 + k) : (elem_t)o[(int64_t)k - (int64_t)hist];
-    if (tid < 4) XC[THREADS + tid] = make_uint2(0xFFFFFFFFu, 0u);
+    if (tid < 4) XC[NC + tid] = make_uint2(0xFFFFFFFFu, 0u);
     uint64_t produced = 0, flushed = 0;
     uint32_t tr = shift;                       // ring index of the tile's first byte
     uint32_t fr = shift;                       // ring index of byte `flushed`
     uint32_t base = 0, ntiles = 0, nrounds = 0;
-    uint32_t c_cur = tid < n ? cp[tid] : 0;
+    // Round 5: a tile looks at TWO codes per lane (window positions 2 tid, 2 tid + 1) and takes as many as give four bytes per
+    // lane.  (One code per lane and six bytes: a text's 256 codes are 640 bytes, the byte-level work below ran with three
+    // lanes of eight idle.)
+    uint32_t cw0 = 2 * tid < n ? cp[2 * tid] : 0u, cw1 = 2 * tid + 1 < n ? cp[2 * tid + 1] : 0u;
     const uint64_t t0 = dbg ? clock64() : 0;
     uint32_t par = 0;
     while (base < n) {
         ntiles++;
-        const uint32_t i = base + tid;
-        const uint32_t c_pref = (uint64_t)i + THREADS < n ? cp[i + THREADS] : 0;   // assuming the whole tile is taken
-        const uint32_t c = c_cur;
-        const uint32_t mylen = i < n ? ((c & 0xFFFFu) ? c >> 16 : 1u) : 0u;
-        uint32_t x = wave_inclusive_sum(mylen);
+        const uint32_t i = base + 2 * tid;
+        const uint32_t len0 = i < n ? ((cw0 & 0xFFFFu) ? cw0 >> 16 : 1u) : 0u;
+        const uint32_t len1 = i + 1 < n ? ((cw1 & 0xFFFFu) ? cw1 >> 16 : 1u) : 0u;
+        uint32_t x = wave_inclusive_sum(len0 + len1);
         if (lane == 63) s_w[wave] = x;
         __syncthreads();       // (also: the previous tile's flush has read the ring before this tile writes it)
-        uint32_t tot = 0;
+        uint32_t tot = 0, cum[WAVES];          // cum[j]: end offset of wavefront j's last code = X[128 j + 127]
 #pragma unroll
         for (uint32_t j = 0; j < WAVES; ++j) {
             const uint32_t wj = s_w[j];
             x += j < wave ? wj : 0u;
             tot += wj;
+            cum[j] = tot;
         }
-        XC[tid] = make_uint2(x, c);
+        *(uint4 *)&XC[2 * tid] = make_uint4(x - len1, cw0, x, cw1);
         if (tot > TILE) {   // (uniform) only the codes whose output fits are taken; a code is at most 258 bytes
-            const uint32_t cnt = (uint32_t)__popcll(__ballot(x <= TILE));
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(x - len1 <= TILE)) + (uint32_t)__popcll(__ballot(x <= TILE));
             if (lane == 0) s_w[WAVES + wave] = cnt;
         }
         __syncthreads();
-        uint32_t take = THREADS, total = tot;
+        uint32_t take = NC, total = tot;
         if (tot > TILE) {
             take = 0;
 #pragma unroll
             for (uint32_t j = 0; j < WAVES; ++j) take += s_w[WAVES + j];
             total = XC[take - 1].x;
         }
+        // the codes that move into the window behind the taken ones (stored at the tile's end: the round trip hides behind it)
+        const uint32_t r0 = base + NC + tid, r1 = r0 + THREADS;
+        const uint32_t rf0 = (tid < take && r0 < n) ? cp[r0] : 0u;
+        const uint32_t rf1 = (tid + THREADS < take && r1 < n) ? cp[r1] : 0u;
         // ---- round 0: bytes -> owner code -> literal / final source / pointer.  Branch-free: every byte loads from the
         //      ring (its own slot when there is nothing to fetch) and stores (to the dump when it lies behind the tile).
         uint32_t pp[PASSES][4];
         bool pend = false;
-        // (two instances: a tile cut by its BYTES — tot > TILE, six codes of 258 instead of 256 codes — is made of long
-        //  matches, and long matches at short distances are what runs turn into: cfg5's LOWENT is half runs of 64 .. 4096
-        //  equal bytes, a chain 1536 deep for the jumping below, eleven rounds per tile.  A tile of text never comes here.)
+        // (two instances: a tile whose codes are more than eight bytes long on average is made of long matches, and long
+        //  matches at short distances are what runs turn into: cfg5's LOWENT is half runs of 64 .. 4096 equal bytes, a chain
+        //  as deep as the tile for the jumping below, eleven rounds per tile.  A tile of text — 2.5 bytes per code — never
+        //  comes here.)
         auto round0 = [&](auto periodic_tag) {
         constexpr bool PERIODIC = decltype(periodic_tag)::value;
 #pragma unroll
@@ -1312,8 +1322,12 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
             for (uint32_t q = 0; q < 4; ++q) pp[ps][q] = M2_DONE;
             if (ps == 0 || __ballot(b < total)) {   // (pass 1 and later: whole wavefronts skip)
                 uint32_t k = 0;   // smallest k with X[k] > b  (zero-length slots behind the last code are never chosen)
+                // the search's first levels — which wavefront's 128 codes — from the totals every lane holds in registers
+                // (two dependent LDS round trips less per tile)
 #pragma unroll
-                for (uint32_t step = THREADS / 2; step; step >>= 1) k += XC[k + step - 1].x <= b ? step : 0u;
+                for (uint32_t j = 0; j + 1 < WAVES; ++j) k += cum[j] <= b ? 128u : 0u;
+#pragma unroll
+                for (uint32_t step = 64; step; step >>= 1) k += XC[k + step - 1].x <= b ? step : 0u;
                 uint32_t src[4], dst[4], cwq[4];
                 bool lit[4], fin[4];
 #pragma unroll
@@ -1356,7 +1370,7 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
             *(uint64_t *)&P[b] = (uint64_t)pp[ps][0] | (uint64_t)pp[ps][1] << 16 | (uint64_t)pp[ps][2] << 32 | (uint64_t)pp[ps][3] << 48;
         }
         };
-        if (tot > TILE) round0(std::true_type{}); else round0(std::false_type{});
+        if (take * 8 < total) round0(std::true_type{}); else round0(std::false_type{});
         // ---- rounds of pointer jumping.  Per byte: load the target's state, then the target's byte (in this order: a
         //      target seen resolved has its byte in the ring), store the byte, then the state.  A byte fetched from an
         //      unresolved target is garbage in a slot nobody reads yet.
@@ -1422,17 +1436,16 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
         }
         produced = upto;
         tr = m2_wrap<RING>(tr + total);
-        if (take == THREADS) c_cur = c_pref;
-        else {
-            // Only some of the tile's codes were taken (data made of long matches: 1536 bytes are six codes of 258).  The
-            // window of codes moves by `take`: its tail is still in XC, the head of the prefetched codes follows it — through
-            // LDS (P is dead between tiles).  Round 4: a reload from global memory stood here, one exposed round trip per
-            // tile; cfg5's 1 GiB of LOWENT took 7.9 ms in this kernel.
+        // the window moves by `take`: its tail is still in XC, the codes just loaded follow it — through LDS (P is dead between
+        // tiles)
+        if (base < n) {
             uint32_t *scratch = (uint32_t *)P;
-            scratch[tid] = c_pref;
+            scratch[tid] = rf0;
+            scratch[tid + THREADS] = rf1;
             __syncthreads();
-            const uint32_t j = tid + take;
-            c_cur = j < THREADS ? XC[j].y : scratch[j - THREADS];
+            const uint32_t j0 = 2 * tid + take, j1 = j0 + 1;
+            cw0 = j0 < NC ? XC[j0].y : scratch[j0 - NC];
+            cw1 = j1 < NC ? XC[j1].y : scratch[j1 - NC];
         }
     }
     if (!SYM && dbg && tid == 0) {
