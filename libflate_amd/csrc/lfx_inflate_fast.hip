@@ -1181,6 +1181,10 @@ constexpr uint32_t M2_WIDE_THREADS = 1024;                // direct path of a st
 constexpr uint32_t M2_FEW_JOBS = 4;
 constexpr uint32_t M2_SYM_THREADS = 256;                  // marker path
 constexpr uint32_t M2_DONE = 0xFFFFu;
+#ifndef LFX_M2_PRIO_TILES
+#define LFX_M2_PRIO_TILES 8
+#endif
+constexpr uint32_t M2_PRIO_TILES = LFX_M2_PRIO_TILES;   // tiles per priority step (a power of two)
 
 template <uint32_t RING> __device__ __forceinline__ uint32_t m2_wrap(uint32_t x) { return min(x, x - RING); }   // x in [0, 2 RING)
 template <uint32_t RING> __device__ __forceinline__ uint32_t m2_back(uint32_t idx, uint32_t d) {                 // idx, d < RING
@@ -1273,6 +1277,18 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     const uint64_t t0 = dbg ? clock64() : 0;
     uint32_t par = 0;
     while (base < n) {
+        // Wavefront priority rotates with the tile count, a quarter turn per unit index: the units that share a CU — four,
+        // one of each launch quarter, of equal work and all resident from the start — were served oldest first, the oldest
+        // left after 1.49 M cycles, the youngest after 2.02 M, and the CU ran with three, two, one unit for the last quarter
+        // of the kernel (LFX_DEBUG K3 lines, round 5).
+        if ((ntiles & (M2_PRIO_TILES - 1)) == 0) {
+            switch (((ntiles / M2_PRIO_TILES) + u) & 3u) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         ntiles++;
         const uint32_t i = base + 2 * tid;
         const uint32_t len0 = i < n ? ((cw0 & 0xFFFFu) ? cw0 >> 16 : 1u) : 0u;
