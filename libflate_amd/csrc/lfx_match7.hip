@@ -71,6 +71,13 @@ constexpr uint32_t TILE = NG * 64;             // 896 positions per barrier
 constexpr uint64_t ROLE_IDX = 0x6564325104321000ull;     // index of the wavefront among those of its role (a nibble each)
 constexpr uint32_t ROLE_IS_P = 0x227Cu;                   // waves 2 3 4 5 6 9 13
 constexpr uint32_t ROLE_IS_C = 0xDD80u;                   // waves 7 8 10 11 12 14 15
+// Wavefront priorities (s_setprio, two bits per wavefront): the exchange wavefronts 3, the C wavefronts 2, the P wavefronts 0.
+// Every wavefront has to reach the tile's barrier; the C wavefronts are the ones that arrive last (LFX_DEBUG: work 250 .. 300 K
+// cycles of 411 K against 120 .. 200 K for a P wavefront), and on a SIMD they share with P wavefronts they now issue first:
+// the kernel 0.66 -> 0.60 ms.  (Measured, tools/exp/r5_prio.sh: C at 3 or 1, P at 1, X1 at 0..2 — all between the two.)
+#ifndef LFX_M7_PRIO
+#define LFX_M7_PRIO 0xa2a2800fu
+#endif
 constexpr int AHEAD = 4;                       // register sets of the loading wavefronts = iterations between a load and its use
 // How the stages of the pipeline wait for each other.  1 (the default): one workgroup barrier per tile — every wavefront waits
 // for the slowest of the sixteen, every tile: a quarter of the kernel's time is that wait.  0 (measured, round 5, not kept): every
@@ -268,6 +275,12 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
     // of them — and is correct on any data, only slower on runs.  A workgroup picks one for its segment from a sample (below).
     auto pipeline = [&](auto runs_tag) {
     constexpr bool RUNS = decltype(runs_tag)::value;
+    switch ((LFX_M7_PRIO >> (2 * wave)) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
     const uint32_t ridx = (uint32_t)(ROLE_IDX >> (4 * wave)) & 15u;   // which pair of groups a P / C wavefront takes
     if ((ROLE_IS_P >> wave) & 1) {
         // ================================================== P: bytes → prefix → (bucket, tag) → request
