@@ -443,6 +443,24 @@ struct __attribute__((packed, aligned(4))) U32x4 { u32x4 v; };   // 16-byte stor
 // code OF THIS SLICE reads a byte produced before it.  A back-reference that reads below the current
 // candidate kills it and every later one up to itself, so the candidate moves to just behind it.
 // the symbol loop over the register FIFO (FastBits)
+#ifndef LFX_DEC_PRIO
+#define LFX_DEC_PRIO 1
+#endif
+// Wavefront priority that rotates with a trip count (round 5).  The wavefronts of a workgroup — and the workgroups of a CU —
+// that do equal work from the same start were served oldest first: in the symbol kernels the first wavefront left its decode
+// after 783 K cycles and waited 297 K at the barrier for the last one (LFX_DEBUG, K2 lines), a SIMD running with three, two,
+// one wavefront towards the end.  The four wavefronts that share a SIMD (w, w+4, w+8, w+12 or 4s .. 4s+3, either way) hold
+// four different priorities at any trip, each one every priority in turn.
+__device__ __forceinline__ void rotate_prio(uint32_t trip) {
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    switch ((trip + w + (w >> 2)) & 3u) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 template <bool EMIT>
 __device__ __forceinline__ int lane_decode_fifo(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
                                            uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
@@ -459,7 +477,9 @@ __device__ __forceinline__ int lane_decode_fifo(const FastTabs &T, const uint8_t
     int ret = 0;
     uint32_t no = 0;   // bytes produced by this call (added to nout at the end)
     int32_t reach_rel = INT32_MAX;   // EMIT: smallest (bytes produced by this call) - distance over the matches
+    uint32_t trip = 0;
     while (b.used < lim && ret == 0) {
+        if (LFX_DEC_PRIO) rotate_prio(trip++);
         // each symbol takes at most two dwords from the FIFO.
         // ONE divergent region per symbol: the loop runs on the lanes that still take a symbol, and EndOfBlock or an
         // undecodable code end a lane by predication (zero-length skips, nothing staged, nothing counted) instead of by
@@ -556,7 +576,9 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
     int ret = 0;
     uint32_t no = 0;   // bytes produced by this call (added to nout at the end)
     int32_t reach_rel = INT32_MAX;   // EMIT: smallest (bytes produced by this call) - distance over the matches
+    uint32_t trip = 0;
     while (b.rel < rlim && ret == 0) {
+        if (LFX_DEC_PRIO) rotate_prio(trip++);
         // ONE divergent region per symbol: the loop runs on the lanes that still take a symbol, and EndOfBlock or an
         // undecodable code end a lane by predication (zero-length skips, nothing staged, nothing counted) instead of by
         // breaks — every break cost the loop an exec-mask save / merge of its own.
