@@ -494,26 +494,51 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
 // ------------------------------------------------------------------------------------------------
 // block finder, stage 1: every bit offset of the stream is tested for "dynamic block header with a
 // complete code-length code".  A workgroup stages 4 KiB (+16 bytes) of the stream in LDS with coalesced
-// dword loads; every lane then tests the bit offsets of four dwords.  The Kraft sum of the (at most 19)
-// 3-bit code-length-code widths comes from a 512-entry table of 3-field sums.
+// dword loads.  Round 5: two steps per 256 dwords.  (a) A lane takes one dword, a 3-operation mask gives its offsets whose
+// BTYPE reads 2 (and whose BFINAL is clear, outside the stream's tail) — an eighth of them, four per dword on average and
+// nine in the worst lane of a wavefront — and the lane appends them to a list in LDS.  (b) The list is tested DENSELY, one
+// entry per lane: HLIT / HDIST ranges, then the Kraft sum of the (at most 19) 3-bit code-length-code widths from a
+// 4096-entry table of 4-field sums.  (Rounds 1-4 ran the test inside the per-lane loop over the mask: the loop's trip count
+// is the wavefront's maximum, so more than half of the lanes idled through a 70-instruction body.)
 // Survivors are collected per workgroup in LDS and appended with ONE atomic per workgroup to one of
 // FIND_SHARDS counters (a single device-scope counter serialises at ~11 ns per atomic).
 constexpr uint32_t FIND_DWORDS = 1024;   // dwords (4 KiB of stream) per workgroup
 constexpr uint32_t FIND_WL = 512;        // survivors a workgroup can hold (expected: ~30)
+constexpr uint32_t FIND_LIST = 4096;     // offsets of 256 dwords that pass the mask: no two adjacent ones can (bit 1 clear, bit 2 set)
+// Kraft contribution (128 >> l, 0 for l = 0) of four 3-bit fields | number of nonzero fields << 12
+struct FindLut { uint16_t v[4096]; };
+constexpr FindLut make_find_lut() {
+    FindLut t{};
+    for (uint32_t i = 0; i < 4096; ++i) {
+        uint32_t k = 0, u = 0;
+        for (int f = 0; f < 4; ++f) { const uint32_t l = (i >> (3 * f)) & 7; if (l) { k += 128u >> l; u++; } }
+        t.v[i] = (uint16_t)(k | (u << 12));
+    }
+    return t;
+}
+__device__ const FindLut g_find_lut = make_find_lut();
+
+__device__ __forceinline__ uint32_t find_wave_inclusive_sum(uint32_t x) {        // (row shifts and broadcasts, no LDS traffic)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+
 __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                           uint64_t first_byte, uint32_t *__restrict__ count,
                                                           uint64_t *__restrict__ cand, uint32_t shard_cap,
                                                           uint64_t final_from_bit) {
-    __shared__ uint32_t sd[FIND_DWORDS + 4];
+    __shared__ __attribute__((aligned(16))) uint32_t sd[FIND_DWORDS + 4];
+    __shared__ __attribute__((aligned(16))) uint16_t lut[4096];
+    __shared__ uint16_t list[FIND_LIST];
     __shared__ uint64_t wl[FIND_WL];
-    __shared__ uint32_t wn, wbase;
+    __shared__ uint32_t wn, wbase, s_wtot[4];
     if (threadIdx.x == 0) wn = 0;
-    __shared__ uint16_t lut[512];   // kraft contribution (128 >> l, 0 for l = 0) of three fields | used << 12
-    for (uint32_t i = threadIdx.x; i < 512; i += 256) {
-        uint32_t k = 0, u = 0;
-        for (int f = 0; f < 3; ++f) { const uint32_t l = (i >> (3 * f)) & 7; if (l) { k += 128u >> l; u++; } }
-        lut[i] = (uint16_t)(k | (u << 12));
-    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t a = (uint64_t)in;
     gptr_u32 w = (gptr_u32)(a & ~3ull);
     const uint64_t shift = a & 3;                      // stream byte b lives at aligned byte b + shift
@@ -524,39 +549,59 @@ __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restr
         // the staging loads are issued together (clamped addresses): a loop of dependent load → store pairs made every
         // workgroup wait five HBM round trips before its first test
         uint32_t v[5];
+        const uint4 *gl = (const uint4 *)g_find_lut.v;
+        const uint4 l0 = gl[tid], l1 = gl[tid + 256];
 #pragma unroll
-        for (uint32_t k = 0; k < 5; ++k) { const uint64_t idx = w0 + threadIdx.x + 256 * k; v[k] = w[idx < wlast ? idx : wlast]; }
+        for (uint32_t k = 0; k < 5; ++k) { const uint64_t idx = w0 + tid + 256 * k; v[k] = w[idx < wlast ? idx : wlast]; }
 #pragma unroll
-        for (uint32_t k = 0; k < 5; ++k) { const uint32_t i = threadIdx.x + 256 * k; if (i < FIND_DWORDS + 4) sd[i] = v[k]; }
+        for (uint32_t k = 0; k < 5; ++k) { const uint32_t i = tid + 256 * k; if (i < FIND_DWORDS + 4) sd[i] = v[k]; }
+        ((uint4 *)lut)[tid] = l0;
+        ((uint4 *)lut)[tid + 256] = l1;
     }
     __syncthreads();
     const uint64_t stream_bits = nbytes * 8, lo_bit = first_byte * 8;
-    for (uint32_t t = threadIdx.x; t < FIND_DWORDS; t += 256) {
-        // my dword = aligned dword w0 + t ; its bit 0 is stream bit (4*(w0+t) - shift) * 8
-        const uint64_t dword_bit0 = (4 * (w0 + t) - shift) * 8;    // "negative" only for the first dword when shift > 0
-        const uint32_t d0 = sd[t], d1 = sd[t + 1], d2 = sd[t + 2], d3 = sd[t + 3];
-        const uint64_t lo = (uint64_t)d0 | (uint64_t)d1 << 32, hi = (uint64_t)d2 | (uint64_t)d3 << 32;
+    for (uint32_t t0 = 0; t0 < FIND_DWORDS; t0 += 256) {
+        // ---- (a) my dword = aligned dword w0 + t; its bit 0 is stream bit (4*(w0+t) - shift) * 8
+        const uint32_t t = t0 + tid;
+        const uint32_t d0 = sd[t], d1 = sd[t + 1];
         // offsets whose BTYPE field (bits 1..2) reads 2: bit 1 clear, bit 2 set — a quarter of them.  A header with
         // BFINAL set is wanted only near the end of the stream (final_from_bit, see launch_find_stage1): elsewhere the
         // offsets with bit 0 set are dropped too, which halves the candidates of both stages.
+        const uint64_t dword_bit0 = (4 * (w0 + t) - shift) * 8;    // "negative" only for the first dword when shift > 0
         const uint32_t allow_final = dword_bit0 + 32 > final_from_bit ? ~0u : 0u;
+        const uint64_t lo = (uint64_t)d0 | (uint64_t)d1 << 32;
         uint32_t pm = (uint32_t)(~(lo >> 1) & (lo >> 2)) & (~d0 | allow_final);
+        const uint32_t cnt = (uint32_t)__popc(pm);
+        const uint32_t incl = find_wave_inclusive_sum(cnt);
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();                                     // (also: the previous trip's list has been read)
+        uint32_t pos = incl - cnt, total = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) { const uint32_t wj = s_wtot[j]; pos += j < wave ? wj : 0u; total += wj; }
         while (pm) {
             const uint32_t ph = (uint32_t)__builtin_ctz(pm);
             pm &= pm - 1;
-            const uint64_t v = ph ? (lo >> ph) | (hi << (64 - ph)) : lo;   // 64 bits from this offset
-            const uint32_t hlit = (v >> 3) & 31, hdist = (v >> 8) & 31, hclen = (v >> 13) & 15;
+            list[pos++] = (uint16_t)(t << 5 | ph);
+        }
+        __syncthreads();
+        // ---- (b) one list entry per lane: 96 bits of the stream from the offset on
+        for (uint32_t i = tid; i < total; i += 256) {
+            const uint32_t e = list[i], te = e >> 5, ph = e & 31;
+            const uint32_t e0 = sd[te], e1 = sd[te + 1], e2 = sd[te + 2], e3 = sd[te + 3];
+            const uint32_t x0 = __builtin_amdgcn_alignbit(e1, e0, ph), x1 = __builtin_amdgcn_alignbit(e2, e1, ph),
+                           x2 = __builtin_amdgcn_alignbit(e3, e2, ph);
+            const uint32_t hlit = (x0 >> 3) & 31, hdist = (x0 >> 8) & 31, hclen = (x0 >> 13) & 15;
             if (hlit > 29 || hdist > 29) continue;
-            // the (hclen + 4) 3-bit fields start at bit 17
-            const uint64_t v2 = hi >> ph;                                    // bits 64.. of the window
-            const uint64_t f = (v >> 17) | (v2 << 47);                       // fields 0..20 (63 bits)
-            const uint32_t nf = hclen + 4;
-            const uint64_t fm = f & ((1ull << (3 * nf)) - 1);
-            uint32_t acc = 0;
-#pragma unroll
-            for (int g = 0; g < 7; ++g) acc += lut[(uint32_t)(fm >> (9 * g)) & 511];
+            // the (hclen + 4) 3-bit fields start at bit 17: 57 bits at most
+            const uint32_t nb = 3 * (hclen + 4);
+            uint32_t f0 = __builtin_amdgcn_alignbit(x1, x0, 17), f1 = __builtin_amdgcn_alignbit(x2, x1, 17);
+            const uint32_t m0 = nb >= 32 ? ~0u : (1u << nb) - 1u, m1 = nb > 32 ? (1u << (nb - 32)) - 1u : 0u;
+            f0 &= m0;
+            f1 &= m1;
+            const uint32_t acc = (uint32_t)lut[f0 & 4095] + lut[(f0 >> 12) & 4095] + lut[__builtin_amdgcn_alignbit(f1, f0, 24) & 4095] +
+                                 lut[(f1 >> 4) & 4095] + lut[(f1 >> 16) & 4095];
             if ((acc & 0xFFF) != 128 || (acc >> 12) < 2) continue;           // complete code-length code
-            const uint64_t bit = dword_bit0 + ph;
+            const uint64_t bit = (4 * (w0 + te) - shift) * 8 + ph;
             if ((int64_t)bit < (int64_t)lo_bit || bit + 96 > stream_bits) continue;
             const uint32_t slot = atomicAdd(&wn, 1u);
             if (slot < FIND_WL) wl[slot] = bit;
