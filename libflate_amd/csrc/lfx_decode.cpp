@@ -162,8 +162,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // stage 2 takes the survivor counts from the device (persistent grid): no host round trip between the stages; the
             // counts, the overflow marker, the number of results and the first results come back in ONE round trip
             LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
-                                          (uint32_t)std::max(c->n_cu, 1)));
-            uint32_t hc[66];
+                                          (uint32_t)std::max(c->n_cu, 1), c->diag.debug ? (uint64_t *)(d_count + 104) : nullptr));
+            uint32_t hc[128];
             constexpr uint32_t HEAD_N = 1024;      // (results that come back with the counts; a stream has a few hundred)
             const uint32_t head_n = std::min<uint32_t>(HEAD_N, final_cap);
             std::vector<uint64_t> cand(head_n);
@@ -173,6 +173,14 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             overflow = hc[FIND_SHARDS] != 0;
             n1 = 0;
             for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (hc[k] > shard_cap) overflow = true; n1 += hc[k]; }
+            if (c->diag.debug) {
+                uint64_t d[7];
+                memcpy(d, hc + 104, sizeof d);
+                fprintf(stderr, "[lfx] finder stage 2: batches=%llu cycles per batch: stage+fields=%llu table=%llu walk=%llu; steps per batch=%.1f "
+                        "restagings=%llu; wavefront lives (sum)=%llu\n", (unsigned long long)d[5], (unsigned long long)(d[0] / (d[5] ? d[5] : 1)),
+                        (unsigned long long)(d[1] / (d[5] ? d[5] : 1)), (unsigned long long)(d[2] / (d[5] ? d[5] : 1)),
+                        (double)d[3] / (double)(d[5] ? d[5] : 1), (unsigned long long)d[4], (unsigned long long)d[6]);
+            }
             starts.clear();
             starts.push_back(first_bit);  // the first block's start is known
             if (overflow) return LFX_OK;

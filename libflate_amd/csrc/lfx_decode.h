@@ -169,7 +169,8 @@ int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint6
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
                        uint32_t shard_cap, const uint32_t *count /* device: stage 1's FIND_SHARDS + 1 words */,
                        uint32_t *work /* device, zero: the batch counter of the persistent grid */,
-                       uint32_t *final_count, uint64_t *final_list, uint32_t final_cap, uint32_t n_cu);
+                       uint32_t *final_count, uint64_t *final_list, uint32_t final_cap, uint32_t n_cu,
+                       uint64_t *dbg = nullptr /* device, zero: seven counters (LFX_DEBUG) */);
 int launch_verify_trailers(hipStream_t st, int format, uint32_t count, const uint8_t *in,
                            const DecStream *streams, const DecHeader *hdrs, InflateResult *results,
                            const uint32_t *crc, const uint32_t *adler, uint64_t *consumed);

@@ -32,6 +32,10 @@ __constant__ uint16_t f_dist_base[30] = {1,    2,    3,    4,    5,    7,    9, 
 __constant__ uint8_t f_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2,  3,  3,  4,  4,  5,  5,  6,
                                          6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t f_clen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+constexpr uint32_t f_clen_order_c(uint32_t k) {
+    constexpr uint8_t o[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    return o[k];
+}
 // BITWIDTH_CODE_ORDER (symbol.rs:16-18) without a memory lookup: 5 bits per entry
 __device__ __forceinline__ uint32_t clen_order(uint32_t k) {
     // entries 0..11 in lo, 12..18 in hi
@@ -1891,14 +1895,22 @@ __device__ __forceinline__ void clen_table_build(uint8_t *tab, uint32_t lane, ui
         if (w) tab[r * 64 + lane] = (uint8_t)(s | w << 5);
     }
     // ... and is replicated upward: entry i + 2^k (i < 2^k) decodes like entry i iff that code is at most k bits wide
-    // (otherwise bit k belongs to the code and i + 2^k is a base entry of its own).  127 uniform steps instead of one
-    // divergent fill loop per symbol; the code is complete (stage 1), so every entry ends up written.
-#pragma unroll 1
-    for (uint32_t k = 0; k < 7; ++k)
-        for (uint32_t i = 0; i < (1u << k); ++i) {
-            const uint8_t e = tab[i * 64 + lane];
-            if ((uint32_t)(e >> 5) <= k) tab[(i + (1u << k)) * 64 + lane] = e;
+    // (otherwise bit k belongs to the code and i + 2^k is a base entry of its own); the code is complete (stage 1), so every
+    // entry ends up written.  Uniform steps instead of one divergent fill loop per symbol — and (round 5) a level's reads in
+    // batches of sixteen before its writes: one read and one conditional write per step were 127 dependent LDS round trips.
+#pragma unroll
+    for (uint32_t k = 0; k < 7; ++k) {
+#pragma unroll
+        for (uint32_t i0 = 0; i0 < (1u << k); i0 += 16) {
+            uint8_t e[16];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j)
+                if (i0 + j < (1u << k)) e[j] = tab[(i0 + j) * 64 + lane];
+#pragma unroll
+            for (uint32_t j = 0; j < 16; ++j)
+                if (i0 + j < (1u << k) && (uint32_t)(e[j] >> 5) <= k) tab[(i0 + j + (1u << k)) * 64 + lane] = e[j];
         }
+    }
 }
 
 // block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
@@ -2010,6 +2022,124 @@ __device__ __forceinline__ bool stage2_check(const uint8_t *__restrict__ in, uin
     return good;
 }
 
+// The same check for a wavefront whose candidates all lie at least 6000 bits in front of the stream's end (a header is at
+// most 17 + 19*3 + 320*(7+7) = 4554 bits long: no bounds checks), round 5: the lanes' bits come from LDS.  Every lane
+// stages FIND2_HB dwords of the stream from its candidate on with all loads in flight (hbuf: dword k of lane l at k * 64 + l),
+// takes the header's fixed fields from them by funnel shifts, and walks on them; a lane that uses its dwords up makes
+// every lane still walking stage again from where it stands (a few times per batch).  Rounds 3-4 topped the window up from global memory inside the walk: one dependent, uncoalesced load and
+// its wait per step of the wavefront — the stage's time was that latency, about 200 times per batch, and the generic bit
+// reader's in front of it.
+#ifndef LFX_FIND2_HB
+#define LFX_FIND2_HB 16
+#endif
+constexpr uint32_t FIND2_HB = LFX_FIND2_HB;   // dwords of the stream a lane stages at a time (stage2_check_staged)
+__device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ in, uint64_t cand_bit, bool valid,
+                                                    uint8_t *cl_tab, uint32_t *hbuf, uint64_t *dbg) {
+    const uint32_t lane = threadIdx.x;
+    const uint64_t t0 = dbg ? clock64() : 0;
+    const uint64_t a = (uint64_t)in;
+    const uint64_t abs0 = cand_bit + (a & 3) * 8;
+    gptr_u32 w = (gptr_u32)(a & ~3ull);
+    uint64_t gd = abs0 >> 5;                         // dword of the stream that hbuf[0] holds
+    const uint32_t off = (uint32_t)abs0 & 31;
+    auto stage = [&](bool need) {
+        uint32_t v[FIND2_HB];
+#pragma unroll
+        for (uint32_t k = 0; k < FIND2_HB; ++k) v[k] = need ? w[gd + k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < FIND2_HB; ++k)
+            if (need) hbuf[k * 64 + lane] = v[k];
+    };
+    stage(valid);
+    const uint32_t e0 = hbuf[lane], e1 = hbuf[64 + lane], e2 = hbuf[128 + lane], e3 = hbuf[192 + lane];
+    const uint32_t x0 = __builtin_amdgcn_alignbit(e1, e0, off), x1 = __builtin_amdgcn_alignbit(e2, e1, off),
+                   x2 = __builtin_amdgcn_alignbit(e3, e2, off);
+    const uint32_t nl = ((x0 >> 3) & 31) + 257, nd = ((x0 >> 8) & 31) + 1, nc = ((x0 >> 13) & 15) + 4;
+    const uint32_t f0 = __builtin_amdgcn_alignbit(x1, x0, 17), f1 = __builtin_amdgcn_alignbit(x2, x1, 17);   // the 3-bit widths
+    uint64_t clw = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 19; ++k) {
+        const uint32_t fw = 3 * k + 3 <= 32 ? f0 >> (3 * k) : 3 * k >= 32 ? f1 >> (3 * k - 32) : __builtin_amdgcn_alignbit(f1, f0, 3 * k);
+        clw |= (uint64_t)(k < nc ? fw & 7u : 0u) << (3 * f_clen_order_c(k));
+    }
+    const uint64_t t1 = dbg ? clock64() : 0;
+    clen_table_build(cl_tab, lane, clw);
+    const uint64_t t2 = dbg ? clock64() : 0;
+    uint32_t steps = 0, restaged = 0;
+    uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
+    const uint32_t total = nl + nd;
+    bool good = valid;
+    // the window behind the fixed fields: 32 bits from bit `o` of the dword pair (cur, nxt) by ONE funnel shift — a step takes at
+    // most 7 + 7 bits.  (A 64-bit register window cost three 64-bit shifts per step, quarter-rate instructions: a sixth of the
+    // loop's issue time.)
+    const uint32_t bp = off + 17 + 3 * nc;             // (at most 31 + 17 + 57: dwords 0 .. 3)
+    uint32_t di = (bp >> 5) + 2;                       // next dword of hbuf to take
+    uint32_t cur = hbuf[(bp >> 5) * 64 + lane], nxt = hbuf[((bp >> 5) + 1) * 64 + lane];
+    uint32_t o = bp & 31;
+    bool run = good && have < total;
+    while (__ballot(run)) {
+        ++steps;
+        if (__ballot(run && di >= FIND2_HB)) {         // (uniform, rare) a lane's dwords are used up
+            ++restaged;
+            gd += di;
+            di = run ? 0u : di;
+            gd -= di;                                  // (a lane that has stopped keeps its place: it is not staged)
+            stage(run);
+        }
+        const uint32_t win = __builtin_amdgcn_alignbit(nxt, cur, o);
+        const uint32_t e = cl_tab[(win & 127) * 64 + lane];
+        const uint32_t ahead = hbuf[min(di, FIND2_HB - 1) * 64 + lane];      // (the dword behind nxt, taken when o passes 32)
+        const uint32_t sym = e & 31, used = e >> 5;
+        // repeat codes 16 / 17 / 18: extra bits 2 / 3 / 7, base count 3 / 3 / 11 (packed nibble tables)
+        const uint32_t k4 = (sym > 15 ? sym - 15 : 0) * 4;
+        const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
+        uint32_t rep = basex + __builtin_amdgcn_ubfe(win, used, nbx);
+        uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
+        uint32_t adv = used + nbx;
+        bool bad = run && ((sym == 16 && have == 0) || have + rep > total);
+        rep = run ? rep : 0u;
+        val = run ? val : 0u;
+        adv = run ? adv : 0u;
+        o += adv;
+        const bool pass = o >= 32;
+        cur = pass ? nxt : cur;
+        nxt = pass ? ahead : nxt;
+        di += pass ? 1u : 0u;
+        o &= 31u;
+        // [have, have+rep) split at the literal / distance boundary
+        const uint32_t nlit_part = have < nl ? min(rep, nl - have) : 0u;
+        const uint32_t ndist_part = rep - nlit_part;
+        const uint32_t wgt = val ? 32768u >> val : 0u;
+        kl += __umul24(nlit_part, wgt);
+        kd += __umul24(ndist_part, wgt);
+        nlit += val ? nlit_part : 0u;
+        ndist += val ? ndist_part : 0u;
+        eob_len = (val && have <= 256 && 256 < have + rep) ? val : eob_len;
+        bad |= kl > 32768u || kd > 32768u;                       // over-subscribed
+        // the literal / length widths are complete once `have` passes HLIT+257
+        bad |= have + rep >= nl && have < nl && !(kl == 32768u || (nlit == 1 && kl == 16384u));
+        have += rep;
+        last = val;
+        good = good && !bad;
+        run = good && have < total;
+    }
+    if (good) {
+        if (eob_len == 0) good = false;
+        if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
+        if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
+    }
+    if (dbg && lane == 0) {   // LFX_DEBUG: cycles of staging + fields, table, walk; steps, restagings, batches
+        const uint64_t t3 = clock64();
+        atomicAdd((unsigned long long *)&dbg[0], (unsigned long long)(t1 - t0));
+        atomicAdd((unsigned long long *)&dbg[1], (unsigned long long)(t2 - t1));
+        atomicAdd((unsigned long long *)&dbg[2], (unsigned long long)(t3 - t2));
+        atomicAdd((unsigned long long *)&dbg[3], (unsigned long long)steps);
+        atomicAdd((unsigned long long *)&dbg[4], (unsigned long long)restaged);
+        atomicAdd((unsigned long long *)&dbg[5], 1ull);
+    }
+    return good;
+}
+
 // Persistent grid (round 3): the number of survivors is only known on the device, so a fixed number of one-wavefront
 // workgroups fetch batches of 64 survivors from a device counter until the lists are exhausted — stage 1 and stage 2 run
 // back to back without the host reading the counts in between (it reads them, the overflow marker and the result list
@@ -2018,34 +2148,46 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
                                                          const uint64_t *__restrict__ cand, uint32_t shard_cap,
                                                          const uint32_t *__restrict__ count, uint32_t *__restrict__ work,
                                                          uint32_t *__restrict__ final_count,
-                                                         uint64_t *__restrict__ final_list, uint32_t final_cap) {
+                                                         uint64_t *__restrict__ final_list, uint32_t final_cap,
+                                                         uint64_t *__restrict__ dbg) {
     __shared__ uint8_t cl_tab[128 * 64];
-    __shared__ uint32_t s_pre[FIND_SHARDS + 1], s_base;
-    if (threadIdx.x == 0) {
-        uint32_t off = 0;
-        for (uint32_t k = 0; k < FIND_SHARDS; ++k) { s_pre[k] = off; off += min(count[k], shard_cap); }   // (an overflow is the host's to report)
-        s_pre[FIND_SHARDS] = off;
+    __shared__ uint32_t hbuf[FIND2_HB * 64];
+    const uint64_t tk0 = dbg ? clock64() : 0;
+    __shared__ uint32_t s_pre[FIND_SHARDS + 1];
+    {
+        // exclusive prefix of the shard counts, a lane per shard
+        const uint32_t cnt = threadIdx.x < FIND_SHARDS ? min(count[threadIdx.x], shard_cap) : 0u;   // (an overflow is the host's to report)
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        if (threadIdx.x < FIND_SHARDS) s_pre[threadIdx.x] = incl - cnt;
+        if (threadIdx.x == FIND_SHARDS) s_pre[FIND_SHARDS] = incl;
     }
     __syncthreads();
     const uint32_t n1 = s_pre[FIND_SHARDS];
-    for (;;) {
-        if (threadIdx.x == 0) s_base = atomicAdd(work, 64u);
-        __syncthreads();
-        const uint32_t base = s_base;
-        if (base >= n1) break;
+    // Batches of 64 survivors: a wavefront's first one by its index, the later ones from a device counter — asked for a batch
+    // ahead.  (Rounds 3-4 fetched every batch, the first included, from the counter and waited for it: the grid's first atomics,
+    // thousands on one address at about 11 ns each, arrived together — LFX_DEBUG: the wavefronts' lives summed to 1.6 times their
+    // batches' cycles.  A fixed deal by stride alone loses a third to rounding: 2.4 batches per wavefront are three rounds.)
+    __shared__ uint32_t s_base;
+    uint32_t base = blockIdx.x * 64u;
+    while (base < n1) {
+        if (threadIdx.x == 0) s_base = gridDim.x * 64u + atomicAdd(work, 64u);      // the batch behind this one
         const uint32_t gi = base + threadIdx.x;
         const bool valid = gi < n1;
         uint32_t shard = 0;
         for (uint32_t k = 1; k < FIND_SHARDS; ++k) shard += gi >= s_pre[k];
         const uint64_t i = (uint64_t)shard * shard_cap + (gi - s_pre[shard]);
         const uint64_t cand_bit = valid ? cand[i] : 0;
-        const bool good = stage2_check(in, nbytes, cand_bit, valid, cl_tab);
+        const bool lean = __ballot(cand_bit + 6000 > nbytes * 8) == 0;   // (uniform; see stage2_check_staged)
+        const bool good = lean ? stage2_check_staged(in, cand_bit, valid, cl_tab, hbuf, dbg) : stage2_check(in, nbytes, cand_bit, valid, cl_tab);
         if (good) {
             const uint32_t slot = atomicAdd(final_count, 1u);   // a few hundred per stream
             if (slot < final_cap) final_list[slot] = cand_bit;
         }
-        __syncthreads();      // (s_base and the per-lane tables are reused)
+        __syncthreads();      // (the per-lane tables are reused)
+        base = s_base;
+        __syncthreads();
     }
+    if (dbg && threadIdx.x == 0) atomicAdd((unsigned long long *)&dbg[6], (unsigned long long)(clock64() - tk0));   // a wavefront's life
 }
 
 // marker path, pass 1, second generation: the byte kernel's tiles on 16-bit symbols (75 KB of LDS: two units per CU,
@@ -2232,10 +2374,11 @@ int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *un
 }
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
                        uint32_t shard_cap, const uint32_t *count, uint32_t *work, uint32_t *final_count, uint64_t *final_list,
-                       uint32_t final_cap, uint32_t n_cu) {
-    // (sixteen one-wavefront workgroups per CU: 8 KB of LDS each)
-    hipLaunchKernelGGL(find_blocks_stage2, dim3(16u * (n_cu ? n_cu : 256u)), dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work,
-                       final_count, final_list, final_cap);
+                       uint32_t final_cap, uint32_t n_cu, uint64_t *dbg) {
+    // (one-wavefront workgroups, 8 KB + 256 bytes per staged dword of LDS each: as many as fit a CU's 160 KB)
+    constexpr uint32_t per_cu = (160u * 1024u) / (8192u + 256u * FIND2_HB + 256u);
+    hipLaunchKernelGGL(find_blocks_stage2, dim3(per_cu * (n_cu ? n_cu : 256u)), dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work,
+                       final_count, final_list, final_cap, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
