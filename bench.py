@@ -410,6 +410,12 @@ def sub_cfg5(ctx, torch, synth, _ffi, C, dev, reps=2):
             "round_trip_ok": ok, "hbm_frac_algorithmic": round((n + m) / best / 1e9 / HBM_PEAK_GBPS, 5)}
 
 
+def strong_share(total_bytes, world):
+    """--scaling strong: a rank's share of the job — whole blocks, since a shard boundary has to be a block boundary
+    (deflate/encode.rs:12, DEFAULT_BLOCK_SIZE = 1 MiB; 8192-byte writes divide it)."""
+    return max(total_bytes // world // (1 << 20) * (1 << 20), 1 << 20)
+
+
 def launch_plan(gpus, env, device_count, argv):
     """Decide how `bench.py --gpus N` runs.  → ("inline", None) when this process IS the job (N = 1, or a launcher
     already set WORLD_SIZE: the driver's `python -m torch.distributed.run ... bench.py --gpus N`), ("spawn", cmd) when
@@ -500,7 +506,7 @@ def main():
     torch.cuda.set_device(local)
     ctx = libflate_amd.Context(local)
     ctx.enable_timing(True)
-    n = args.bytes if args.scaling == "weak" else max(args.bytes // world // 8192 * 8192, 8192)   # (whole writes per rank)
+    n = args.bytes if args.scaling == "weak" else strong_share(args.bytes, world)
     data = synth.text(n, seed=synth.SEED_BASE + 2 + rank)
     d_in = torch.from_numpy(data).to(dev)
     L = _ffi.lib()

@@ -47,3 +47,11 @@ def test_gpus_flag_launches_the_ranks_itself():
         bench.launch_plan(8, {}, 1, [])
     mode, cmd = bench.launch_plan(3, {"LFX_BENCH_ONE_GPU": "1"}, 1, ["--gpus", "3"])    # ... unless it is the one-GPU self-test
     assert mode == "spawn" and cmd[cmd.index("--nproc-per-node") + 1] == "3"
+
+
+def test_strong_scaling_share_is_whole_blocks():
+    import bench
+    for total in (256 << 20, 1 << 30, 100 << 20):
+        for world in (1, 2, 3, 4, 7, 8):
+            n = bench.strong_share(total, world)
+            assert n % (1 << 20) == 0 and n >= 1 << 20 and n * world <= max(total, world << 20)

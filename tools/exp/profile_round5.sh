@@ -31,5 +31,5 @@ timeout 300 python bench.py --schedule S1 --no-traffic --no-cpu-baseline --no-s1
 LFX_FUZZ=500 timeout 900 python -m pytest tests/test_gpu_fuzz.py -q -m gpu 2>&1 | tail -2 | grep -v amdgpu > $O/r05_fuzz.txt; cat $O/r05_fuzz.txt
 timeout 400 python tools/exp/m5_stress.py 1000 2>&1 | tail -1 >> $O/r05_fuzz.txt; tail -1 $O/r05_fuzz.txt
 LFX_BENCH_FORCE_SHARDED=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-subs --no-cpu-baseline --no-s1 --no-traffic 2>/dev/null | tail -1 > $O/r05_bench_force_sharded_world1.txt; cut -c1-160 $O/r05_bench_force_sharded_world1.txt
-LFX_BENCH_ONE_GPU=1 LFX_BENCH_CFG4_BYTES=134217728 timeout 900 python bench.py --gpus 3 --steps 3 --warmup 1 --bytes 67108864 --no-cpu-baseline --no-s1 --no-traffic 2>/dev/null | tail -1 > $O/r05_bench_one_gpu_3ranks.txt; cut -c1-160 $O/r05_bench_one_gpu_3ranks.txt
-LFX_BENCH_ONE_GPU=1 timeout 900 python bench.py --gpus 3 --steps 3 --warmup 1 --scaling strong --no-subs --no-cpu-baseline --no-s1 --no-traffic 2>/dev/null | tail -1 > $O/r05_bench_one_gpu_3ranks_strong.txt; cut -c1-160 $O/r05_bench_one_gpu_3ranks_strong.txt
+LFX_BENCH_ONE_GPU=1 LFX_BENCH_CFG4_BYTES=134217728 timeout 900 python bench.py --gpus 3 --steps 3 --warmup 1 --bytes 67108864 --no-cpu-baseline --no-s1 --no-traffic 2>/dev/null | grep "^{" | tail -1 > $O/r05_bench_one_gpu_3ranks.txt; cut -c1-160 $O/r05_bench_one_gpu_3ranks.txt
+LFX_BENCH_ONE_GPU=1 timeout 900 python bench.py --gpus 3 --steps 3 --warmup 1 --scaling strong --no-subs --no-cpu-baseline --no-s1 --no-traffic 2>/dev/null | grep "^{" | tail -1 > $O/r05_bench_one_gpu_3ranks_strong.txt; cut -c1-160 $O/r05_bench_one_gpu_3ranks_strong.txt
