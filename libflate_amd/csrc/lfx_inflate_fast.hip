@@ -660,6 +660,18 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
 }
 
 // ------------------------------------------------------------------------------------------------
+// inclusive prefix sum over the wavefront: four row shifts and two row broadcasts, no LDS traffic
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 → rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 → rows 2, 3
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------
 // header parse (lane 0, plain byte loads — ~300 short steps per block) + tables
 struct HdrBits {
     LaneBits b;       // register bit buffer + prefetched dwords (no per-call memory latency)
@@ -762,30 +774,81 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
             const uint32_t sym = cc.decode(tid, used);
             cl_tab[tid] = sym == 99 ? 0xFF : (uint8_t)(sym | used << 5);
         }
+        // Round 5: the code-length sequence (HLIT + 257 + HDIST + 1 widths, up to 320 symbols of 1 .. 14 bits) is decoded by
+        // wavefront 0 a WINDOW of 64 bit offsets at a time: lane i decodes the symbol that would start at offset i, a scalar walk
+        // (one v_readlane per symbol) marks the offsets the true chain visits, and everything else — output positions (prefix sum
+        // of the repeat counts), "previous width" for symbol 16 (the last marked lane in front that is not a 16), the
+        // checks, the stores — is data-parallel over the marked lanes: about eleven symbols per window.  Rounds 1-4 walked the
+        // sequence on ONE lane, a dependent LDS lookup and a 64-bit window update per symbol: 57 us per block, which is most of a
+        // small block's scan (cfg3: 4096 streams of 64 KiB) and all of a small stream's.
+        // (a header is at most 4554 bits long: far from the end of the stream no step needs a bounds check — the window form;
+        //  near the end: lane 0, every step checked)
+        __shared__ uint32_t hbits[160];
+        const uint64_t hpos = hdr64[0];
+        const uint64_t a = (uint64_t)in;
+        const uint64_t habs = hpos + (a & 3) * 8;
+        const bool lean = hpos + 6000 <= nbytes * 8;
+        if (lean && tid < 160) hbits[tid] = ((gptr_u32)(a & ~3ull))[(habs >> 5) + tid];      // (6000 bits = 187 dwords are there)
         __syncthreads();
-        if (tid == 0) {
+        if (lean && tid < 64) {
+            const uint32_t lane = tid;
+            const uint32_t total = hdr[3] + hdr[4];
+            uint32_t rel = (uint32_t)habs & 31, have = 0, last = 0, bad = 0;
+            bool done = false;
+            while (!done && !bad) {
+                const uint32_t b = rel + lane;
+                const uint32_t w = __builtin_amdgcn_alignbit(hbits[(b >> 5) + 1], hbits[b >> 5], b & 31);
+                const uint32_t e = cl_tab[w & 127];
+                const uint32_t sym = e & 31, used = e >> 5;
+                const uint32_t k4 = (sym - 16u < 3u ? sym - 15 : 0) * 4;   // repeat codes 16 / 17 / 18
+                const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
+                const uint32_t rep = basex + __builtin_amdgcn_ubfe(w, used, nbx);
+                const uint32_t nxt = lane + used + nbx;
+                // the offsets of this window the chain visits
+                uint64_t M = 0;
+                uint32_t i = 0;
+                while (i < 64) {
+                    M |= 1ull << i;
+                    i = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)i);
+                }
+                const bool on = (M >> lane) & 1ull;
+                const uint32_t repm = on ? rep : 0u;
+                const uint32_t incl = wave_inclusive_sum(repm);
+                const uint32_t at = have + incl - repm;                    // widths in front of this symbol
+                const bool real = on && at < total;                        // (a marked lane behind the last width is data already)
+                const uint64_t R = __ballot(real);
+                if (__ballot(real && (e == 0xFF || (sym == 16 && at == 0) || at + rep > total))) { bad = 1; break; }
+                // symbol 16 repeats the previous width: that of the last real lane in front that is not a 16 (17 / 18 leave 0)
+                const uint64_t D = __ballot(real && sym != 16);
+                const uint64_t Dlt = D & ((1ull << lane) - 1ull);
+                const uint32_t own = sym < 16 ? sym : 0u;
+                const uint32_t from = Dlt ? 63u - (uint32_t)__builtin_clzll(Dlt) : 0u;
+                const uint32_t prev = (uint32_t)__shfl((int)own, (int)from);
+                const uint32_t val = sym == 16 ? (Dlt ? prev : last) : own;
+                if (real && val)
+                    for (uint32_t k = 0; k < rep; ++k) lens[at + k] = (uint8_t)val;      // (rep <= 6 here: zeros are not written)
+                if (R) {
+                    const uint32_t lr = 63u - (uint32_t)__builtin_clzll(R);            // the window's last real symbol
+                    have = (uint32_t)__builtin_amdgcn_readlane((int)(at + rep), (int)lr);
+                    last = (uint32_t)__builtin_amdgcn_readlane((int)val, (int)lr);
+                }
+                // the first marked lane that is not real any more is where the header ends; else the chain's exit from the window
+                const uint64_t E = M & ~R;
+                if (have >= total) {
+                    done = true;
+                    rel += E ? (uint32_t)__builtin_ctzll(E) : i;
+                } else rel += i;
+            }
+            if (lane == 0) {
+                hdr[2] = bad;
+                hdr64[0] = ((habs >> 5) << 5) + rel - (a & 3) * 8;
+            }
+        }
+        if (!lean && tid == 0) {
             HdrBits hb;
             hb.init(in, nbytes, hdr64[0]);
             const uint32_t nl = hdr[3], nd = hdr[4], total = nl + nd;
             uint32_t have = 0, last = 0, bad = 0;
-            // (a header is at most 4554 bits long: far from the end of the stream no step needs a bounds check)
-            const bool lean = hdr64[0] + 6000 <= hb.nbits;
-            while (lean && have < total) {
-                hb.b.refill();
-                const uint32_t e = cl_tab[(uint32_t)hb.b.buf & 127];
-                const uint32_t sym = e & 31, used = e >> 5;
-                const uint32_t k4 = (sym - 16u < 3u ? sym - 15 : 0) * 4;   // repeat codes 16 / 17 / 18
-                const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
-                const uint32_t rep = basex + (((uint32_t)(hb.b.buf >> used)) & ((1u << nbx) - 1));
-                const uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
-                hb.b.buf >>= used + nbx;
-                hb.b.nb -= used + nbx;
-                hb.b.pos += used + nbx;
-                if (e == 0xFF || (sym == 16 && have == 0) || have + rep > total) { bad = 1; break; }
-                if (val) for (uint32_t k = 0; k < rep; ++k) lens[have + k] = (uint8_t)val;
-                have += rep;
-                last = val;
-            }
             while (!bad && have < total) {
                 if (hb.b.pos >= hb.nbits) { bad = 1; break; }
                 hb.b.refill();
@@ -1159,17 +1222,6 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(co
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// inclusive prefix sum over the wavefront: four row shifts and two row broadcasts, no LDS traffic
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 → rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 → rows 2, 3
-    return x;
-}
 
 
 // ------------------------------------------------------------------------------------------------
