@@ -79,3 +79,53 @@ def test_long_matches_at_short_distances_decode(ctx, ffi, oracle, synth):
     z = zlib.compress(lo, 9)
     st, out, used, _ = ctx.decode_host(ffi.ZLIB, z)
     assert (st, used) == (0, len(z)) and out == lo
+
+
+def test_block_headers_of_many_shapes_decode(ctx, ffi, synth):
+    """The code-length sequence of a dynamic block header (decode.rs:166-223 / symbol.rs:245-331: symbols 0-15 literal widths, 16
+    repeat the previous width 3-6 times, 17 / 18 runs of zeros) is decoded 64 bit offsets at a time (parse_header, round 5): a
+    repeat whose previous width lies in the window before, runs of zeros across the literal / distance boundary, alphabets of
+    two symbols and of 286.  Streams of another encoder (python-zlib: every strategy, small memLevel = many blocks), single
+    stream and batch path, against the bytes that went in."""
+    import zlib
+    rng = np.random.default_rng(23)
+    text = synth.text(1 << 19).tobytes()
+    inputs = {
+        "text": text,
+        "two symbols": rng.integers(0, 2, 200000, dtype=np.uint8).tobytes(),
+        "sparse alphabet": bytes(rng.choice(np.array([0, 7, 64, 200, 255], dtype=np.uint8), 200000)),
+        "all byte values, flat": rng.integers(0, 256, 150000, dtype=np.uint8).tobytes(),
+        "all byte values, skewed": bytes(np.minimum(rng.geometric(0.03, 200000), 255).astype(np.uint8)),
+        "ramp": bytes(range(256)) * 400,
+        "text + zeros": text[:100000] + bytes(50000) + text[100000:150000],
+    }
+    streams = []
+    for name, data in inputs.items():
+        for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE):
+            for mem in (1, 8):
+                for level in (1, 6, 9):
+                    co = zlib.compressobj(level, zlib.DEFLATED, 15, mem, strategy)
+                    streams.append((name, strategy, mem, level, co.compress(data) + co.flush(), data))
+    for name, strategy, mem, level, z, data in streams:
+        st, out, used, msg = ctx.decode_host(ffi.ZLIB, z)
+        assert (st, used) == (0, len(z)) and out == data, (name, strategy, mem, level, msg)
+    # the batch path (blocks of many streams per launch): every fourth stream
+    import torch
+    sub = streams[::4]
+    zs, ds = [t[4] for t in sub], [t[5] for t in sub]
+    in_len = np.array([len(z) for z in zs], dtype=np.uint64)
+    in_off = (np.cumsum(in_len) - in_len).astype(np.uint64)
+    out_cap = np.array([len(d) for d in ds], dtype=np.uint64)
+    out_off = (np.cumsum(out_cap) - out_cap).astype(np.uint64)
+    d_in = torch.frombuffer(bytearray(b"".join(zs)), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(int(out_cap.sum()), dtype=torch.uint8, device="cuda")
+    out_len = np.zeros(len(sub), dtype=np.uint64)
+    status = np.zeros(len(sub), dtype=np.int32)
+    torch.cuda.synchronize()
+    rc = ffi.lib().lfx_decode_batch_device(ctx.handle, ffi.ZLIB, len(sub), d_in.data_ptr(), in_off.ctypes.data, in_len.ctypes.data,
+                                           d_out.data_ptr(), out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data,
+                                           status.ctypes.data)
+    assert rc == 0 and not status.any(), (rc, status.nonzero())
+    host = d_out.cpu().numpy().tobytes()
+    for i, (name, strategy, mem, level, z, data) in enumerate(sub):
+        assert host[int(out_off[i]):int(out_off[i]) + int(out_len[i])] == data, (name, strategy, mem, level)
