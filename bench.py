@@ -43,7 +43,7 @@ HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec.  The peak a
 PHASE_KERNEL = {"enc:lz77_match": "lz77_match7_kernel", "dec:lz77_copy": "blk_materialize2_kernel",
                 "dec:blk_scan": "blk_scan_kernel", "dec:blk_emit": "blk_emit_kernel", "enc:lz77_parse": "parse_walk_kernel",
                 "dec:find1": "find_blocks_stage1", "dec:find2": "find_blocks_stage2", "enc:pack": "pack_kernel",
-                "dec:batch_copy": "blk_materialize2_kernel"}
+                "dec:batch_copy": "blk_materialize2_kernel", "dec:fast": "blk_scan_kernel"}
 # resident wavefronts per SIMD of those kernels (workgroup size x workgroups per CU / 4), for measure_bound
 PHASE_WAVES_PER_SIMD = {"enc:lz77_match": 4, "dec:lz77_copy": 4, "dec:blk_scan": 4, "dec:blk_emit": 4, "enc:lz77_parse": 2}
 CALIBRATION_KERNEL = "checksum_span_kernel"   # reads its input exactly once with wide coalesced loads
@@ -71,8 +71,11 @@ def dominant_phase(timing, skip=("upload", "start", "done")):
     """(phase name, ms) of the longest kernel bracket of one library call's phase list"""
     if not timing:
         return None, None
-    ph = [(k, v) for k, v in timing["phases"] if k not in skip]
-    return max(ph, key=lambda kv: kv[1]) if ph else (None, None)
+    tot = {}
+    for k, v in timing["phases"]:          # (a batch call brackets the kernels of each of its rounds: same names, summed)
+        if k not in skip:
+            tot[k] = tot.get(k, 0.0) + v
+    return max(tot.items(), key=lambda kv: kv[1]) if tot else (None, None)
 
 
 def measure_traffic(kernel, n, schedule):

@@ -1303,6 +1303,9 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
         HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
         LAUNCH_TRY(launch_blk_scan(st, d_in, n_in, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
                                    (BlkLanes *)c->d_dec_cand.p, c->d_dec_tabs.p));
+        // (phase brackets of the first rounds only: the timer holds sixteen, and "fast" / "inflate" / "verify" close the call)
+        const bool stamp = c->n_ev + 6 < 17;
+        if (stamp) c->phase("blk_scan");
         std::vector<BlkInfo> bi(nj);
         HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1341,8 +1344,10 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
             const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
             LAUNCH_TRY(launch_blk_emit(st, d_in, n_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p, (uint32_t *)c->d_codes.p,
                                        d_flags, (BlkUnits *)c->d_hist.p, unit_target, d_jf, c->d_dec_tabs.p));
+            if (stamp) c->phase("blk_emit");
             LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p,
                                               (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, nullptr));
+            if (stamp) c->phase("lz77_copy");
             HIP_TRY(hipMemcpyAsync(jf.data(), d_jf, 4ull * ne, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }

@@ -25,6 +25,10 @@ cd $R
 cd /tmp; rm -rf /tmp/kt_r5c5
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_r5c5 -- python $R/tools/exp/cfg5_run.py > $O/r05_cfg5_phases.json 2>/dev/null
 python $R/tools/prof_summary.py /tmp/kt_r5c5 "rocprofv3 --kernel-trace --stats -- python tools/exp/cfg5_run.py (zlib encode + decode of 1 GiB LOWENT, 8192-byte writes)" 2>/dev/null | grep -v "at::native\|elementwise" > $O/r05_cfg5_kernel_stats.csv; head -6 $O/r05_cfg5_kernel_stats.csv | cut -c1-150
+# cfg3 (4096 x 64 KiB): kernel stats of one batch encode + four batch decodes
+cd /tmp; rm -rf /tmp/kt_c3
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kt_c3 -- python $R/tools/exp/cfg3_run.py 2>/dev/null | tail -2 > $O/r05_cfg3_phases.json
+python $R/tools/prof_summary.py /tmp/kt_c3 "rocprofv3 --kernel-trace --stats -- python tools/exp/cfg3_run.py (4096 x 64 KiB zlib streams: one batch encode of 2048, four batch decodes of 4096)" 2>/dev/null | grep -v "at::native\|elementwise" > $O/r05_cfg3_kernel_stats.csv; head -5 $O/r05_cfg3_kernel_stats.csv | cut -c1-150
 cd $R
 timeout 300 python tools/bench_small.py 8192 65536 262144 1048576 4194304 16777216 33554432 67108864 100663296 134217728 > $O/r05_small_sizes.json 2>/dev/null; cut -c1-300 $O/r05_small_sizes.json
 timeout 300 python bench.py --schedule S1 --no-traffic --no-cpu-baseline --no-s1 --no-subs --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/r05_bench_s1.json; cut -c1-200 $O/r05_bench_s1.json
