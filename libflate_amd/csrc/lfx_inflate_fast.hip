@@ -1468,15 +1468,13 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
         // ---- rounds of pointer jumping.  Per byte: load the target's state, then the target's byte (in this order: a
         //      target seen resolved has its byte in the ring), store the byte, then the state.  A byte fetched from an
         //      unresolved target is garbage in a slot nobody reads yet.
-        for (;;) {
-            const uint64_t bal = __ballot(pend);
-            if (lane == 0) s_any[par][wave] = bal != 0;
-            __syncthreads();
-            uint32_t any = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < WAVES; ++j) any |= s_any[par][j];
-            par ^= 1;
-            if (!any) break;
+        //      Round 5: the rounds are a WAVEFRONT's own loop.  The order above is all that in-place jumping needs between
+        //      wavefronts — a reader that sees a state resolved finds the byte, one that sees a pointer follows it — so
+        //      nothing has to hold the wavefronts in step: one barrier behind round 0 (P is rewritten whole there: no state of
+        //      the tile before survives it), one when a wavefront's own bytes are all final (the flush reads across
+        //      wavefronts).  Rounds 2-4 put a barrier and an exchange of "anyone pending" between all rounds: 3.9 per tile.
+        __syncthreads();
+        while (__ballot(pend)) {
             nrounds++;
             if (pend) {
 #pragma unroll
@@ -1507,6 +1505,7 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
                 for (uint32_t ps = 0; ps < PASSES; ++ps) pend |= (pp[ps][0] & pp[ps][1] & pp[ps][2] & pp[ps][3]) != M2_DONE;
             }
         }
+        __syncthreads();
         // ---- flush: whole dwords; what is left over waits for the next tile
         const uint64_t upto = produced + total;
         base += take;
