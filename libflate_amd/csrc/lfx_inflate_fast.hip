@@ -450,6 +450,9 @@ struct __attribute__((packed, aligned(4))) U32x4 { u32x4 v; };   // 16-byte stor
 #ifndef LFX_DEC_PRIO
 #define LFX_DEC_PRIO 1
 #endif
+#ifndef LFX_SCAN_CP_BITS
+#define LFX_SCAN_CP_BITS 768      // head of a slice: what a corrected start decodes again (blk_scan_kernel)
+#endif
 // Wavefront priority that rotates with a trip count (round 5).  The wavefronts of a workgroup — and the workgroups of a CU —
 // that do equal work from the same start were served oldest first: in the symbol kernels the first wavefront left its decode
 // after 783 K cycles and waited 297 K at the barrier for the last one (LFX_DEBUG, K2 lines), a SIMD running with three, two,
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
     // [checkpoint, bound).  A corrected start (round 2+) only re-decodes the head: when it lands exactly on
     // the checkpoint — a speculative decode is in step after a few symbols — the rest is bit for bit the
     // decode already done, so its counts are reused.
-    constexpr uint64_t CP_BITS = 768;
+    constexpr uint64_t CP_BITS = LFX_SCAN_CP_BITS;
     uint32_t nc = 0, flag = 4;
     uint64_t no = 0, exitpos = ~0ull;
     uint64_t decoded_from = ~0ull, cp_pos = 0, rest_no = 0, rest_exit = 0;
@@ -1282,8 +1285,8 @@ struct M2Lds {
     static constexpr uint32_t RING_BYTES = ((G::RING + 64) * (uint32_t)sizeof(elem_t) + 15u) & ~15u;
     static constexpr uint32_t P_BYTES = G::PASSES * 4 * THREADS * 2;
     static constexpr uint32_t XC_BYTES = (G::NC + 4) * 8;
-    static constexpr uint32_t SW_BYTES = 2 * G::WAVES * 4, SANY_BYTES = 2 * G::WAVES * 4;
-    static constexpr uint32_t BYTES = RING_BYTES + P_BYTES + XC_BYTES + SW_BYTES + SANY_BYTES;
+    static constexpr uint32_t SW_BYTES = 2 * G::WAVES * 4;
+    static constexpr uint32_t BYTES = RING_BYTES + P_BYTES + XC_BYTES + SW_BYTES;
 };
 template <bool SYM, uint32_t THREADS, bool DYN = false>
 __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in, const BlkEmit *__restrict__ jobs,
@@ -1302,21 +1305,18 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     // code word; four sentinels behind the last (never passed)
     uint2 *XC;                // NC + 4
     uint32_t *s_w;            // 2 * WAVES
-    uint32_t (*s_any)[WAVES]; // [2][WAVES]
     if constexpr (DYN) {
         extern __shared__ __attribute__((aligned(16))) uint8_t m2_dyn[];
         ring = (elem_t *)m2_dyn;
         P = (uint16_t *)(m2_dyn + LD::RING_BYTES);
         XC = (uint2 *)(m2_dyn + LD::RING_BYTES + LD::P_BYTES);
         s_w = (uint32_t *)(m2_dyn + LD::RING_BYTES + LD::P_BYTES + LD::XC_BYTES);
-        s_any = (uint32_t (*)[WAVES])(m2_dyn + LD::RING_BYTES + LD::P_BYTES + LD::XC_BYTES + LD::SW_BYTES);
     } else {
         __shared__ __attribute__((aligned(16))) elem_t ring_s[RING + 64];
         __shared__ __attribute__((aligned(8))) uint16_t P_s[PASSES * 4 * THREADS];
         __shared__ __attribute__((aligned(16))) uint2 XC_s[G::NC + 4];
         __shared__ uint32_t s_w_s[2 * WAVES];
-        __shared__ uint32_t s_any_s[2][WAVES];
-        ring = ring_s; P = P_s; XC = XC_s; s_w = s_w_s; s_any = s_any_s;
+        ring = ring_s; P = P_s; XC = XC_s; s_w = s_w_s;
     }
     const uint32_t bidx = blockIdx.x % njobs, u = blockIdx.x / njobs;   // unit-major (XCD balance, see K3)
     const BlkEmit job = jobs[bidx];
@@ -1353,7 +1353,6 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
     // lanes of eight idle.)
     uint32_t cw0 = 2 * tid < n ? cp[2 * tid] : 0u, cw1 = 2 * tid + 1 < n ? cp[2 * tid + 1] : 0u;
     const uint64_t t0 = dbg ? clock64() : 0;
-    uint32_t par = 0;
     while (base < n) {
         // Wavefront priority rotates with the tile count, a quarter turn per unit index: the units that share a CU — four,
         // one of each launch quarter, of equal work and all resident from the start — were served oldest first, the oldest
