@@ -1394,10 +1394,14 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
             for (uint32_t j = 0; j < WAVES; ++j) take += s_w[WAVES + j];
             total = XC[take - 1].x;
         }
-        // the codes that move into the window behind the taken ones (stored at the tile's end: the round trip hides behind it)
-        const uint32_t r0 = base + NC + tid, r1 = r0 + THREADS;
-        const uint32_t rf0 = (tid < take && r0 < n) ? cp[r0] : 0u;
-        const uint32_t rf1 = (tid + THREADS < take && r1 < n) ? cp[r1] : 0u;
+        // The window moves by `take`: this lane's next two codes are the ones `take` further on — still in XC, or behind the
+        // window: those are loaded now, by the lane that will hold them (the round trip hides behind the tile's work; an
+        // exchange through LDS and its barrier stood here).
+        // (predicated loads, picked against XC only at the tile's end: with the choice up here the wait for them stood in
+        //  front of round 0)
+        const uint32_t j0 = 2 * tid + take, j1 = j0 + 1;
+        const uint32_t rf0 = (j0 >= NC && base + j0 < n) ? cp[base + j0] : 0u;
+        const uint32_t rf1 = (j1 >= NC && base + j1 < n) ? cp[base + j1] : 0u;
         // ---- round 0: bytes -> owner code -> literal / final source / pointer.  Branch-free: every byte loads from the
         //      ring (its own slot when there is nothing to fetch) and stores (to the dump when it lies behind the tile).
         uint32_t pp[PASSES][4];
@@ -1528,17 +1532,8 @@ __device__ __forceinline__ void materialize2_body(const uint8_t *__restrict__ in
         }
         produced = upto;
         tr = m2_wrap<RING>(tr + total);
-        // the window moves by `take`: its tail is still in XC, the codes just loaded follow it — through LDS (P is dead between
-        // tiles)
-        if (base < n) {
-            uint32_t *scratch = (uint32_t *)P;
-            scratch[tid] = rf0;
-            scratch[tid + THREADS] = rf1;
-            __syncthreads();
-            const uint32_t j0 = 2 * tid + take, j1 = j0 + 1;
-            cw0 = j0 < NC ? XC[j0].y : scratch[j0 - NC];
-            cw1 = j1 < NC ? XC[j1].y : scratch[j1 - NC];
-        }
+        cw0 = j0 < NC ? XC[j0].y : rf0;
+        cw1 = j1 < NC ? XC[j1].y : rf1;
     }
     if (!SYM && dbg && tid == 0) {
         uint64_t *d = dbg + ((uint64_t)bidx * MAX_UNITS + u) * 8;
