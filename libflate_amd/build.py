@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblfx.so")
 SOURCES = ["lfx_encode_kernels.hip", "lfx_match7.hip", "lfx_match5.hip", "lfx_parse2.hip", "lfx_decode_kernels.hip", "lfx_inflate_fast.hip", "lfx_api.cpp", "lfx_decode.cpp", "lfx_sharded.cpp"]
-HEADERS = ["lfx_common.h", "lfx_container.h", "lfx_device.h", "lfx_decode.h", "lfx_huff.h", "lfx_plan.h", "lfx_ctx.h",
+HEADERS = ["lfx_common.h", "lfx_container.h", "lfx_device.h", "lfx_decode.h", "lfx_huff.h", "lfx_plan.h", "lfx_ctx.h", "lfx_abi_guard.h",
            os.path.join("..", "..", "include", "lfx.h"), os.path.join("..", "..", "include", "lfx_testhooks.h")]
 
 

@@ -18,6 +18,7 @@
 #include "lfx_device.h"
 #include "lfx_huff.h"
 #include "lfx_plan.h"
+#include "lfx_abi_guard.h"
 
 using namespace lfx;
 
@@ -254,7 +255,7 @@ extern "C" int lfx_device_count(void) {
     return n;
 }
 
-extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) {
+extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) try {
     int st = LFX_OK;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) {
@@ -293,7 +294,7 @@ extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) {
     }
     if (status) *status = st;
     return reinterpret_cast<lfx_ctx *>(c);
-}
+} LFX_ABI_CATCH_NEW
 extern "C" void lfx_ctx_free(lfx_ctx *cc) {
     if (!cc) return;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
@@ -319,7 +320,7 @@ extern "C" void lfx_ctx_set_stream(lfx_ctx *cc, void *s) {
     c->stream = s ? (hipStream_t)s : c->own_stream;
 }
 extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on != 0; }
-extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) {
+extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) try {
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     memset(t, 0, sizeof *t);
@@ -332,7 +333,7 @@ extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) {
         snprintf(t->phase_name[i], sizeof t->phase_name[i], "%s", c->ev_name[i + 1]);
     }
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------
 // encode core
@@ -674,7 +675,7 @@ static bool match_violation(Ctx *c, const EncodeResult &res) {
 }
 
 extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
-                                 const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len) {
+                                 const void *d_in, uint64_t n, void *d_out, uint64_t cap, uint64_t *out_len) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -719,7 +720,7 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
     if (rc) return rc;
     if (out_len) *out_len = res.out_bytes;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 // ---- batch encode: `count` independent streams in ONE launch set (thousands of small streams).
 // Every stream is what lfx_encode_device would make of its bytes alone (same options, the schedule applied to each
@@ -727,7 +728,7 @@ extern "C" int lfx_encode_device(lfx_ctx *cc, int format, const lfx_encode_opts 
 // thousands of chunks at once instead of one launch set per 64 KiB.
 extern "C" int lfx_encode_batch_device(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s, uint32_t count,
                                        const void *d_in, const uint64_t *in_off, const uint64_t *in_len, void *d_out,
-                                       const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status) {
+                                       const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -826,10 +827,10 @@ extern "C" int lfx_encode_batch_device(lfx_ctx *cc, int format, const lfx_encode
         return LFX_E_NOSPACE;
     }
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
-                               const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len) {
+                               const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -847,12 +848,12 @@ extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o
     HIP_TRY(hipMemcpy(out, c->d_io_out.p, len, hipMemcpyDeviceToHost));
     if (out_len) *out_len = len;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 // ---- sharded encode -------------------------------------------------------------------------
 extern "C" int lfx_encode_shard_prepare(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                                         const void *d_in, uint64_t n, int is_first, int is_last,
-                                        lfx_shard_info *info) {
+                                        lfx_shard_info *info) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -905,10 +906,10 @@ extern "C" int lfx_encode_shard_prepare(lfx_ctx *cc, int format, const lfx_encod
     info->crc32 = r.crc32;
     info->adler32 = r.adler32;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" int lfx_encode_shard_emit(lfx_ctx *cc, uint64_t start_bit, uint32_t combined_check, uint64_t total_n,
-                                     void *d_out, uint64_t cap, uint64_t *out_len) {
+                                     void *d_out, uint64_t cap, uint64_t *out_len) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -920,10 +921,10 @@ extern "C" int lfx_encode_shard_emit(lfx_ctx *cc, uint64_t start_bit, uint32_t c
     if (rc) return rc;
     if (out_len) *out_len = c->shard_last ? res.out_bytes : (res.end_bit + 7) / 8;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" int lfx_shard_place_device(lfx_ctx *cc, void *d_member, uint64_t cap, const void *d_part, uint64_t part_len,
-                                      uint64_t start_bit, int is_first) {
+                                      uint64_t start_bit, int is_first) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -942,7 +943,7 @@ extern "C" int lfx_shard_place_device(lfx_ctx *cc, void *d_member, uint64_t cap,
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------
 // stream encoder: io::Write shaped
@@ -1088,7 +1089,7 @@ static const uint64_t ENC_BATCH_CODES = 2ull << 20;
 static const uint64_t ENC_BATCH_BYTES = 8ull << 20;
 
 extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, size_t n_codes, const uint8_t *raw, size_t n_raw,
-                                       int end_block) {
+                                       int end_block) try {
     if (!e || e->finished || e->final_closed || end_block < 0 || end_block > 2 || (n_codes && !codes) || (n_raw && !raw)) return LFX_E_ARG;
     if (e->failed) return LFX_E_IO;
     // stored blocks never run an Lz77Encode (RawBuf, encode.rs:348-383); bytes and codes cannot be mixed on one encoder
@@ -1117,10 +1118,10 @@ extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, si
         }
     }
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encode_opts *o, lfx_write_cb w,
-                                        lfx_flush_cb f, void *user, int *status) {
+                                        lfx_flush_cb f, void *user, int *status) try {
     if (!cc || !w) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
     lfx_encode_opts d = norm_opts(o);
     int rc = check_opts(d);
@@ -1144,14 +1145,14 @@ extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encod
     if (rc) { if (status) *status = rc; delete e->pl; delete e; return nullptr; }
     if (status) *status = LFX_OK;
     return e;
-}
+} LFX_ABI_CATCH_NEW
 
 // closed blocks are encoded — and handed to the sink — once this much input is waiting; the open block's bytes — all the
 // reference itself would be holding (encode.rs:386-426) — stay in `pending`.  8 MiB keeps what the encoder buffers within
 // eight default blocks (the reference emits per block, encode.rs:277-286) at a third of the one-shot call's throughput:
 // a batch is one GPU pass with ~0.4 ms of fixed latency.
 
-extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n) {
+extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n) try {
     if (!e || e->finished) return -(int64_t)LFX_E_ARG;
     if (e->failed) return -(int64_t)LFX_E_IO;
     if (e->mode == 2) { e->err = "lfx_encoder_write on an encoder that takes code words"; return -(int64_t)LFX_E_ARG; }
@@ -1164,9 +1165,9 @@ extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n)
         if (rc) { e->failed = true; return -(int64_t)rc; }
     }
     return (int64_t)n;  // encode.rs:243: always consumes everything
-}
+} LFX_ABI_CATCH_NEG
 
-extern "C" int lfx_encoder_flush(lfx_encoder *e) {
+extern "C" int lfx_encoder_flush(lfx_encoder *e) try {
     if (!e || e->finished) return LFX_E_ARG;
     if (e->failed) return LFX_E_IO;
     int rc;
@@ -1184,9 +1185,9 @@ extern "C" int lfx_encoder_flush(lfx_encoder *e) {
     if (rc) { e->failed = true; return rc; }
     if (e->f && e->f(e->user) != 0) { e->failed = true; e->err = "flush callback failed"; return LFX_E_IO; }
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
-extern "C" int lfx_encoder_finish(lfx_encoder *e) {
+extern "C" int lfx_encoder_finish(lfx_encoder *e) try {
     if (!e || e->finished) return LFX_E_ARG;
     if (e->failed) return LFX_E_IO;
     if (e->mode == 2 && !e->final_closed) { e->err = "close the final block first (end_block = 2)"; return LFX_E_ARG; }
@@ -1209,7 +1210,7 @@ extern "C" int lfx_encoder_finish(lfx_encoder *e) {
     if (rc) return rc;
     if (e->f && e->f(e->user) != 0) { e->err = "flush callback failed"; return LFX_E_IO; }
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 extern "C" const char *lfx_encoder_last_error(const lfx_encoder *e) { return e ? e->err.c_str() : "null"; }
 extern "C" void lfx_encoder_free(lfx_encoder *e) {
     if (!e) return;
@@ -1229,7 +1230,7 @@ struct lfx_lz77 {
     DevBuf d_in;
     std::vector<uint32_t> host_codes;
 };
-extern "C" lfx_lz77 *lfx_lz77_new(lfx_ctx *cc, uint32_t window_size, uint32_t max_length, int *status) {
+extern "C" lfx_lz77 *lfx_lz77_new(lfx_ctx *cc, uint32_t window_size, uint32_t max_length, int *status) try {
     if (!cc) { if (status) *status = LFX_E_DEVICE; return nullptr; }
     if (max_length < 3) { if (status) *status = LFX_E_ARG; return nullptr; }
     lfx_lz77 *z = new lfx_lz77();
@@ -1238,8 +1239,8 @@ extern "C" lfx_lz77 *lfx_lz77_new(lfx_ctx *cc, uint32_t window_size, uint32_t ma
     z->max_len = std::min(max_length, MAX_LENGTH);
     if (status) *status = LFX_OK;
     return z;
-}
-extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
+} LFX_ABI_CATCH_NEW
+extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) try {
     // DefaultLz77Encoder::flush default.rs:69-109 — one chunk through match + parse
     Ctx *c = z->c;
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1279,12 +1280,12 @@ extern "C" int lfx_lz77_flush(lfx_lz77 *z, lfx_sink_cb sink, void *user) {
     z->buf.clear();  // default.rs:108
     if (sink && nc) sink(user, z->host_codes.data(), nc);
     return LFX_OK;
-}
-extern "C" int lfx_lz77_encode(lfx_lz77 *z, const uint8_t *buf, size_t len, lfx_sink_cb sink, void *user) {
+} LFX_ABI_CATCH
+extern "C" int lfx_lz77_encode(lfx_lz77 *z, const uint8_t *buf, size_t len, lfx_sink_cb sink, void *user) try {
     z->buf.insert(z->buf.end(), buf, buf + len);                     // default.rs:64
     if (z->buf.size() >= (size_t)z->window * 8) return lfx_lz77_flush(z, sink, user);  // default.rs:65-67
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 extern "C" uint32_t lfx_lz77_window_size(const lfx_lz77 *z) { return z->window; }
 extern "C" int lfx_lz77_compression_level(const lfx_lz77 *) { return LFX_LEVEL_BALANCE; }
 extern "C" void lfx_lz77_free(lfx_lz77 *z) {
@@ -1298,7 +1299,7 @@ extern "C" void lfx_lz77_free(lfx_lz77 *z) {
 // test hooks (include/lfx_testhooks.h) for the CPU test-suite: run the SAME host/device-shared code on the host.
 // Not a product path (no compression work can be reached through them).
 extern "C" int lfx_debug_huff_block(const uint32_t *hist320, uint32_t type, uint32_t *lit288, uint32_t *dist32,
-                                    uint32_t *hdr160, uint32_t *hdr_bits, uint64_t *body_bits) {
+                                    uint32_t *hdr160, uint32_t *hdr_bits, uint64_t *body_bits) try {
     static HuffScratch S;
     static BlockCodes bc;
     memset(&bc, 0, sizeof bc);
@@ -1309,11 +1310,11 @@ extern "C" int lfx_debug_huff_block(const uint32_t *hist320, uint32_t type, uint
     *hdr_bits = bc.hdr_bits;
     *body_bits = bc.body_bits;
     return 0;
-}
+} LFX_ABI_CATCH
 extern "C" int lfx_debug_plan(int format, const lfx_encode_opts *o, const lfx_schedule *s, uint64_t n,
                               uint64_t *chunk_out /* in_off,len,block,flags per chunk */, size_t max_chunks,
                               size_t *n_chunks, uint64_t *block_out /* type,final,first,n,in_off,in_len */,
-                              size_t max_blocks, size_t *n_blocks) {
+                              size_t max_blocks, size_t *n_blocks) try {
     lfx_encode_opts d = norm_opts(o);
     if (check_opts(d)) return LFX_E_ARG;
     Planner pl(plan_opts(format, d));
@@ -1331,12 +1332,12 @@ extern "C" int lfx_debug_plan(int format, const lfx_encode_opts *o, const lfx_sc
         block_out[6 * i + 4] = p.blocks[i].in_off; block_out[6 * i + 5] = p.blocks[i].in_len;
     }
     return 0;
-}
+} LFX_ABI_CATCH
 // the same plan, but collected the way the stream encoder does: closed blocks are taken out after every
 // `take_every`-th event and the remainder is rebased; the pieces are stitched back together here
 extern "C" int lfx_debug_plan_incremental(int format, const lfx_encode_opts *o, const lfx_schedule *s, uint64_t n,
                                           uint32_t take_every, uint64_t *chunk_out, size_t max_chunks, size_t *n_chunks,
-                                          uint64_t *block_out, size_t max_blocks, size_t *n_blocks) {
+                                          uint64_t *block_out, size_t max_blocks, size_t *n_blocks) try {
     lfx_encode_opts d = norm_opts(o);
     if (check_opts(d) || !s || s->kind != LFX_SCHED_LIST) return LFX_E_ARG;
     Planner pl(plan_opts(format, d));
@@ -1374,7 +1375,7 @@ extern "C" int lfx_debug_plan_incremental(int format, const lfx_encode_opts *o, 
         block_out[6 * i + 4] = blocks[i].in_off; block_out[6 * i + 5] = blocks[i].in_len;
     }
     return 0;
-}
+} LFX_ABI_CATCH
 extern "C" void lfx_debug_symbols(uint32_t length, uint32_t distance, uint32_t *out6) {
     out6[0] = len_symbol(length, out6[1], out6[2]);
     out6[3] = dist_symbol(distance, out6[4], out6[5]);

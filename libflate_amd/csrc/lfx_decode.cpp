@@ -21,6 +21,7 @@
 static_assert(offsetof(lfx::DecStream, out_off) == 16 && sizeof(lfx::DecStream) % 8 == 0, "checksum_ranges stride");
 static_assert(offsetof(lfx::InflateResult, out_len) == 8 && sizeof(lfx::InflateResult) % 8 == 0, "checksum_ranges stride");
 #include "lfx_device.h"
+#include "lfx_abi_guard.h"
 
 using namespace lfx;
 
@@ -903,7 +904,7 @@ int decode_stream(Ctx *c, int format, uint32_t flags, const uint8_t *d_in, uint6
 }  // namespace
 
 extern "C" int lfx_decode_device(lfx_ctx *cc, int format, uint32_t flags, const void *d_in, uint64_t n,
-                                 void *d_out, uint64_t cap, uint64_t *out_len, uint64_t *consumed) {
+                                 void *d_out, uint64_t cap, uint64_t *out_len, uint64_t *consumed) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -916,11 +917,11 @@ extern "C" int lfx_decode_device(lfx_ctx *cc, int format, uint32_t flags, const 
     if (consumed) *consumed = oc.consumed;
     if (oc.status != LFX_OK) c->set_error(oc.msg);
     return oc.status;
-}
+} LFX_ABI_CATCH
 
 extern "C" int lfx_decode_shard_device(lfx_ctx *cc, const void *d_in, uint64_t n, uint64_t start_bit,
                                        uint64_t total_bits, int is_last, void *d_out, uint64_t cap,
-                                       uint64_t *out_len) {
+                                       uint64_t *out_len) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -934,7 +935,7 @@ extern "C" int lfx_decode_shard_device(lfx_ctx *cc, const void *d_in, uint64_t n
     if (out_len) *out_len = mr.out_len;
     if (mr.status != LFX_OK) c->set_error(mr.msg);
     return mr.status;
-}
+} LFX_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------
 // N-GPU decode of ONE member without the encoder's help: the member is cut by compressed BYTES;
@@ -946,7 +947,7 @@ static_assert(sizeof(lfx_blk_tuple) == 56, "tuple layout (all-gathered as raw by
 
 extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t n_part, uint64_t lo_byte, uint64_t hi_byte,
                                      uint64_t first_bit, uint64_t final_from_bit, uint32_t rank, lfx_blk_tuple *tuples, uint32_t cap,
-                                     uint32_t *count) {
+                                     uint32_t *count) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1057,10 +1058,10 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
     c->phase("blk_scan");
     *count = nc;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" int lfx_decode_chain(const lfx_blk_tuple *all, uint32_t n_all, uint64_t first_bit, uint32_t *chain, uint32_t cap,
-                                uint32_t *n_chain, uint64_t *total_out) {
+                                uint32_t *n_chain, uint64_t *total_out) try {
     if (!all || !chain || !n_chain) return LFX_E_ARG;
     // the true block list: from the known first block, every block starts where the one before it ended; false candidates
     // (inside a block) are never reached.  Deterministic: every rank computes the same list from the same table.
@@ -1085,11 +1086,11 @@ extern "C" int lfx_decode_chain(const lfx_blk_tuple *all, uint32_t n_all, uint64
     *n_chain = k;
     if (total_out) *total_out = total;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t n_part, uint64_t lo_byte, const lfx_blk_tuple *all,
                                      const uint32_t *chain, uint32_t n_chain, uint32_t rank, void *d_out_, uint64_t cap,
-                                     uint64_t *out_len, uint64_t *out_base, uint32_t *state) {
+                                     uint64_t *out_len, uint64_t *out_base, uint32_t *state) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1187,9 +1188,9 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
         if (state) *state = 1;
     }
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
-extern "C" int lfx_decode_range_map(lfx_ctx *cc, void *d_map) {
+extern "C" int lfx_decode_range_map(lfx_ctx *cc, void *d_map) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1202,9 +1203,9 @@ extern "C" int lfx_decode_range_map(lfx_ctx *cc, void *d_map) {
     } else LAUNCH_TRY(launch_bytes_to_map(c->stream, c->range.d_out, c->range.total, (uint16_t *)d_map));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
-extern "C" int lfx_decode_range_finish(lfx_ctx *cc, const void *d_maps, uint32_t rank, uint32_t *crc32, uint32_t *adler32) {
+extern "C" int lfx_decode_range_finish(lfx_ctx *cc, const void *d_maps, uint32_t rank, uint32_t *crc32, uint32_t *adler32) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1250,10 +1251,10 @@ extern "C" int lfx_decode_range_finish(lfx_ctx *cc, const void *d_maps, uint32_t
     } else HIP_TRY(hipStreamSynchronize(st));
     c->phase("checksum");
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const void *in, uint64_t n, void *out,
-                               uint64_t cap, uint64_t *out_len, uint64_t *consumed) {
+                               uint64_t cap, uint64_t *out_len, uint64_t *consumed) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1268,7 +1269,7 @@ extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const vo
     if (ol) HIP_TRY(hipMemcpy(out, c->d_io_out.p, ol, hipMemcpyDeviceToHost));
     if (out_len) *out_len = ol;
     return rc;
-}
+} LFX_ABI_CATCH
 
 // Batch fast path: every stream's blocks go through the lane-parallel kernels, one block per stream and
 // round (a block's start is only known once the block before it has been scanned; reference-made streams
@@ -1385,7 +1386,7 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
 extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, const void *d_in,
                                        const uint64_t *in_off, const uint64_t *in_len, void *d_out,
                                        const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len,
-                                       int32_t *status) {
+                                       int32_t *status) try {
     if (!cc) return LFX_E_DEVICE;
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -1471,7 +1472,7 @@ extern "C" int lfx_decode_batch_device(lfx_ctx *cc, int format, uint32_t count, 
         if (s != LFX_OK && worst == LFX_OK) { worst = s; c->set_error(format_error(res[i].err, res[i].a0, res[i].a1)); }
     }
     return LFX_OK;  // per-stream results are in status[]
-}
+} LFX_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------
 // stream decoder: io::Read shaped ({deflate,zlib,gzip}::Decoder, gzip::MultiDecoder, src/non_blocking/*).
@@ -1765,7 +1766,7 @@ int dec_body(lfx_decoder *d) {
 
 }  // namespace
 
-extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags, lfx_read_cb r, void *user, int *status) {
+extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags, lfx_read_cb r, void *user, int *status) try {
     if (!cc || !r || format < 0 || format > 2) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
     lfx_decoder *d = new lfx_decoder();
     d->c = reinterpret_cast<Ctx *>(cc);
@@ -1787,9 +1788,9 @@ extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags,
     }
     if (status) *status = LFX_OK;
     return d;
-}
+} LFX_ABI_CATCH_NEW
 
-extern "C" int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap) {
+extern "C" int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap) try {
     if (!d) return -(int64_t)LFX_E_ARG;
     if (cap == 0) return 0;  // never latches end-of-stream (gzip.rs:1025-1027, zlib.rs:383-385)
     for (;;) {
@@ -1838,16 +1839,16 @@ extern "C" int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap) {
             }
         }
     }
-}
-extern "C" int lfx_decoder_unread(lfx_decoder *d, const uint8_t **p, size_t *n) {
+} LFX_ABI_CATCH_NEG
+extern "C" int lfx_decoder_unread(lfx_decoder *d, const uint8_t **p, size_t *n) try {
     if (!d) return LFX_E_ARG;
     // data decoded but not handed out: the rest of completed blocks + the partial block (decode.rs:68-73)
     const uint64_t start = std::min<uint64_t>(d->cursor, d->out.size());
     *p = d->out.data() + start;
     *n = d->out.size() - start;
     return LFX_OK;
-}
-extern "C" int lfx_decoder_surplus(lfx_decoder *d, const uint8_t **p, size_t *n) {
+} LFX_ABI_CATCH
+extern "C" int lfx_decoder_surplus(lfx_decoder *d, const uint8_t **p, size_t *n) try {
     if (!d) return LFX_E_ARG;
     // input pulled from the reader that lies behind the last finished member (only meaningful between members /
     // at the end: while a member is being collected `in` holds that member's bytes)
@@ -1856,8 +1857,8 @@ extern "C" int lfx_decoder_surplus(lfx_decoder *d, const uint8_t **p, size_t *n)
     *p = d->in.data();
     *n = settled ? d->in.size() : 0;
     return LFX_OK;
-}
-extern "C" int lfx_decoder_header(lfx_decoder *d, lfx_header *h) {
+} LFX_ABI_CATCH
+extern "C" int lfx_decoder_header(lfx_decoder *d, lfx_header *h) try {
     if (!d || !h) return LFX_E_ARG;
     memset(h, 0, sizeof *h);
     if (!d->have_header) {
@@ -1883,7 +1884,7 @@ extern "C" int lfx_decoder_header(lfx_decoder *d, lfx_header *h) {
         h->zlib_level = (uint32_t)f.flg >> 6;                        // CompressionLevel (zlib.rs:28-58)
     }
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 extern "C" uint64_t lfx_decoder_consumed(const lfx_decoder *d) { return d ? d->consumed_total : 0; }
 extern "C" uint64_t lfx_decoder_buffered(const lfx_decoder *d) {
     return d ? (uint64_t)(d->in.size() + d->out.size() + d->hist.size() + d->chunk.size()) : 0;

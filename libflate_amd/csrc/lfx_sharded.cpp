@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/lfx.h"
+#include "lfx_abi_guard.h"
 
 namespace {
 
@@ -47,7 +48,7 @@ uint64_t final_from(uint64_t member_len) {
 
 // ------------------------------------------------------------------------------------------------ exchange steps (host + comm)
 extern "C" int lfx_sharded_layout(const lfx_comm *cm, const lfx_shard_info *mine, uint64_t header_len, int format,
-                                  uint64_t *start_bits /* world + 1 */, uint32_t *check, uint64_t *total_n) {
+                                  uint64_t *start_bits /* world + 1 */, uint32_t *check, uint64_t *total_n) try {
     if (!cm || !mine || !start_bits || cm->world == 0 || cm->rank >= cm->world || (cm->world > 1 && !cm->allgather)) return LFX_E_ARG;
     const uint64_t row[4] = {mine->total_bits, mine->n_bytes, mine->crc32, mine->adler32};
     std::vector<uint64_t> all;
@@ -66,13 +67,13 @@ extern "C" int lfx_sharded_layout(const lfx_comm *cm, const lfx_shard_info *mine
     if (check) *check = format == LFX_GZIP ? crc : adler;
     if (total_n) *total_n = total;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 // all-gather of the ranks' candidate tuples (variable counts: the counts first, then rows padded to the longest).  `status`:
 // this rank's error code of the scan — it rides with the counts, and a failure on ANY rank comes back on EVERY rank
 // (a rank that left before a collective kept the others waiting in it).  *all is malloc'ed (lfx_sharded_free).
 extern "C" int lfx_sharded_gather_tuples(const lfx_comm *cm, const lfx_blk_tuple *mine, uint32_t count, int status,
-                                         lfx_blk_tuple **all, uint32_t *n_all, uint32_t *failed_rank) {
+                                         lfx_blk_tuple **all, uint32_t *n_all, uint32_t *failed_rank) try {
     if (!cm || !all || !n_all || (count && !mine) || cm->world == 0) return LFX_E_ARG;
     *all = nullptr;
     *n_all = 0;
@@ -104,13 +105,13 @@ extern "C" int lfx_sharded_gather_tuples(const lfx_comm *cm, const lfx_blk_tuple
     *all = out;
     *n_all = (uint32_t)total;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" void lfx_sharded_free(void *p) { free(p); }
 
 // (length, crc32, adler32) of every rank's slice → the checksums of the concatenation; `status` as above
 extern "C" int lfx_sharded_fold(const lfx_comm *cm, int status, uint32_t state, uint64_t len, uint32_t crc32, uint32_t adler32,
-                                uint32_t *any_state, uint32_t *crc_all, uint32_t *adler_all, uint64_t *total, uint32_t *failed_rank) {
+                                uint32_t *any_state, uint32_t *crc_all, uint32_t *adler_all, uint64_t *total, uint32_t *failed_rank) try {
     if (!cm || cm->world == 0) return LFX_E_ARG;
     const uint64_t row[5] = {(uint64_t)(int64_t)status, state, len, crc32, adler32};
     std::vector<uint64_t> all;
@@ -132,7 +133,7 @@ extern "C" int lfx_sharded_fold(const lfx_comm *cm, int status, uint32_t state, 
     if (adler_all) *adler_all = ad;
     if (total) *total = tot;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------ encode: prepare → layout → emit → gather
 struct lfx_sharded_enc {
@@ -147,7 +148,7 @@ struct lfx_sharded_enc {
 extern "C" int lfx_sharded_encode_begin(lfx_ctx *c, const lfx_comm *cm, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                                         const void *d_in, uint64_t n, void *d_part, uint64_t part_cap, void *d_member,
                                         uint64_t member_cap, void *d_staging, uint64_t staging_cap, lfx_sharded_enc **state,
-                                        lfx_sharded_part *out) {
+                                        lfx_sharded_part *out) try {
     if (!c) return LFX_E_DEVICE;
     if (!cm || !state || !out || cm->world == 0 || cm->rank >= cm->world) return LFX_E_ARG;
     if (cm->world > 1 && (!cm->allgather || !cm->isend || !cm->irecv || !cm->wait)) return LFX_E_ARG;
@@ -205,9 +206,9 @@ extern "C" int lfx_sharded_encode_begin(lfx_ctx *c, const lfx_comm *cm, int form
     st->posted = world > 1;
     *state = st.release();
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
-extern "C" int lfx_sharded_encode_finish(lfx_ctx *c, const lfx_comm *cm, lfx_sharded_enc *st, uint64_t *member_len) {
+extern "C" int lfx_sharded_encode_finish(lfx_ctx *c, const lfx_comm *cm, lfx_sharded_enc *st, uint64_t *member_len) try {
     if (!c || !cm || !st) { delete st; return LFX_E_ARG; }
     int rc = LFX_OK;
     if (st->posted && cm->wait(cm->user)) rc = LFX_E_IO;
@@ -216,7 +217,7 @@ extern "C" int lfx_sharded_encode_finish(lfx_ctx *c, const lfx_comm *cm, lfx_sha
     if (member_len) *member_len = cm->rank == 0 ? st->member_len : 0;
     delete st;
     return rc;
-}
+} LFX_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------ decode of ONE member by byte ranges
 extern "C" void lfx_sharded_byte_range(uint64_t first_byte, uint64_t member_len, uint32_t rank, uint32_t world, uint64_t *lo,
@@ -230,7 +231,7 @@ extern "C" void lfx_sharded_byte_range(uint64_t first_byte, uint64_t member_len,
 
 extern "C" int lfx_sharded_decode(lfx_ctx *c, const lfx_comm *cm, const void *d_part, uint64_t n_part, uint64_t lo_byte,
                                   uint64_t hi_byte, uint64_t first_bit, uint64_t member_len, void *d_out, uint64_t cap,
-                                  lfx_sharded_slice *out) {
+                                  lfx_sharded_slice *out) try {
     if (!c) return LFX_E_DEVICE;
     if (!cm || !out || cm->world == 0 || cm->rank >= cm->world || (cm->world > 1 && !cm->allgather)) return LFX_E_ARG;
     const uint32_t rank = cm->rank, world = cm->world;
@@ -297,7 +298,7 @@ extern "C" int lfx_sharded_decode(lfx_ctx *c, const lfx_comm *cm, const void *d_
     out->crc32 = crc_all;
     out->adler32 = ad_all;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------------ RCCL binding (optional, run-time)
 namespace {
@@ -354,7 +355,7 @@ int rccl_wait(void *user) {
 }
 }  // namespace
 
-extern "C" int lfx_comm_rccl(void *nccl_comm, void *hip_stream, uint32_t rank, uint32_t world, lfx_comm *out) {
+extern "C" int lfx_comm_rccl(void *nccl_comm, void *hip_stream, uint32_t rank, uint32_t world, lfx_comm *out) try {
     if (!nccl_comm || !out || world == 0 || rank >= world) return LFX_E_ARG;
     Rccl api;
     for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"})
@@ -375,7 +376,7 @@ extern "C" int lfx_comm_rccl(void *nccl_comm, void *hip_stream, uint32_t rank, u
     out->irecv = rccl_irecv;
     out->wait = rccl_wait;
     return LFX_OK;
-}
+} LFX_ABI_CATCH
 
 extern "C" void lfx_comm_rccl_free(lfx_comm *cm) {
     if (!cm || !cm->user) return;
