@@ -1232,22 +1232,24 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(co
 //
 // (The first-generation kernel — removed in round 3 — gave a unit to ONE wavefront: lanes = codes, back-references that
 // read bytes of their own batch executed one after the other, and with a single wavefront per SIMD every instruction's
-// latency was exposed: 3360 cycles per batch of 64 codes = 234 bytes.)  Here a tile of 256 codes (<= M2_TILE bytes) is
-// expanded to bytes: every lane owns four output bytes, finds the code that covers them (binary search in the codes'
-// end offsets), and
+// latency was exposed: 3360 cycles per batch of 64 codes = 234 bytes.)  Here a tile — a window of 512 codes, of which as
+// many are taken as give four bytes per lane (round 5; rounds 2-4: 256 codes and up to six bytes per lane) — is
+// expanded to bytes: every lane owns four output bytes, finds the code that covers them (the wavefronts' totals in registers
+// pick the wavefront's 128 codes, a binary search in their end offsets the code), and
 //   * a literal, or a byte whose source lies in front of the tile (final, in the ring), is written at once;
-//   * a byte whose source lies inside the tile gets a POINTER to it: P[i] = i - distance.  Rounds of pointer jumping
-//     (P[i] = P[P[i]] until the target is resolved) settle these in log2(chain depth) rounds — the overlapping
+//   * a byte whose source lies inside the tile gets a POINTER to it: P[i] = i - distance — or, in tiles of long matches, to
+//     the byte of the match's first period it repeats (a match that overlaps itself is then one step deep).  Pointer
+//     jumping (P[i] = P[P[i]] until the target is resolved) settles these in log2(chain depth) steps — the overlapping
 //     forward copy of rle_decode (libflate_lz77/src/lib.rs:186-190) is just a chain of depth length / distance.
-// In-place jumping is safe without a second buffer: every value a reader can observe in P[j] is either "resolved" —
-// and then the byte is already in the ring, because the LDS executes a wavefront's instructions in order — or an
-// earlier byte with the same content.
-// Four units per CU (39.7 KB of LDS each), 16 wavefronts per CU instead of 4.
+// In-place jumping is safe without a second buffer and without holding the wavefronts in step (round 5: each wavefront jumps
+// in its own loop): every value a reader can observe in P[j] is either "resolved" — and then the byte is already in the
+// ring, because the LDS executes a wavefront's instructions in order — or an earlier byte with the same content.
+// Four units per CU (40.1 KB of LDS each), 16 wavefronts per CU instead of 4; their priorities rotate (M2_PRIO_TILES).
 // Geometry by workgroup size.  Measured on the 256 MiB corpus (round 3, units = the 1024 LZ77 chunks): 256 lanes, four
 // units per CU: 1.03 ms; 512 lanes (tiles of 512 codes, three units per CU): 1.11 ms; 1024 lanes (two units): 1.47 ms.
 // Larger tiles amortise the per-tile latencies (barriers, the owner search, the pointer rounds) and still lose: the
-// kernel is bound by its VALU instruction count — about 250 per wavefront and tile of 256 codes = 640 bytes, four
-// cycles each on a SIMD — not by those latencies, and the wider search and the second pass add instructions.
+// kernel is bound by its VALU instruction count per byte slot and by its barriers (four per tile since round 5), not by
+// those latencies.  Round 5: 1.00 -> 0.68 ms.
 template <uint32_t THREADS>
 struct M2 {
     static constexpr uint32_t WAVES = THREADS / 64;
