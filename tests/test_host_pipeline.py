@@ -437,3 +437,52 @@ def test_gzip_options_header_carries_the_level(ffi):
         assert "comment" not in o._kw and "extra" not in o._kw
     o = gzip.EncodeOptions().header(gzip.HeaderBuilder().modification_time(9).finish())
     assert o._kw["lz77_level"] == 3 and o._kw["mtime"] == 9
+
+
+def test_header_window_model_equals_serial_walk():
+    """parse_header's decode of the code-length sequence by windows of 64 bit offsets (round 5) against the one-symbol-at-a-time
+    walk of the reference (decode.rs:166-223, symbol.rs:245-331), as CPU models (tools/hdr_model.py): random complete
+    code-length codes, random width sequences with runs (symbols 16 / 17 / 18 across window borders, a 16 whose previous width
+    lies one or two windows back), clean and with flipped bits."""
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hdr_model as hm
+    rng = random.Random(5)
+    checked = damaged = 0
+    for trial in range(400):
+        # a complete code over the 19 code-length symbols: widths from a random binary tree (Kraft sum 1)
+        leaves = [0]
+        while len(leaves) < rng.randint(2, 19):
+            k = rng.randrange(len(leaves))
+            if leaves[k] >= 7:
+                continue
+            d = leaves.pop(k)
+            leaves += [d + 1, d + 1]
+        syms = rng.sample(range(19), len(leaves))
+        cl = [0] * 19
+        for s, w in zip(syms, leaves):
+            cl[s] = w
+        if min(leaves) == 0:
+            continue
+        tab = hm.build_table(cl)
+        usable = [s for s in range(16) if cl[s]]
+        if not usable:
+            continue
+        total = rng.randint(258, 316)
+        lengths, style = [], rng.random()
+        while len(lengths) < total:
+            v = rng.choice(usable)
+            lengths += [v] * (rng.randint(1, 40) if style < 0.5 else rng.randint(1, 3))
+        lengths = lengths[:total]
+        bits = hm.encode_lengths(lengths, cl, rng) + [rng.randint(0, 1) for _ in range(200)]
+        a, b = hm.serial(bits, tab, total), hm.windowed(bits, tab, total)
+        assert a is not None and a[0] == lengths and a == b, trial
+        checked += 1
+        for _ in range(3):                       # damage: the two walks have to agree on the verdict and, when clean, on the widths
+            hurt = list(bits)
+            hurt[rng.randrange(len(bits) - 200)] ^= 1
+            a, b = hm.serial(hurt, tab, total), hm.windowed(hurt, tab, total)
+            assert a == b, trial
+            damaged += a is None
+    assert checked > 300 and damaged > 50
