@@ -486,3 +486,21 @@ def test_header_window_model_equals_serial_walk():
             assert a == b, trial
             damaged += a is None
     assert checked > 300 and damaged > 50
+
+
+def test_periodic_source_quotient_is_exact_or_one_short():
+    """K3's tiles of long matches take a self-overlapping match's byte from `offset mod distance` of its first period
+    (materialize2_body, PERIODIC; rle_decode, libflate_lz77 lib.rs:186-190), the remainder by a float multiply with v_rcp_f32
+    and ONE fix-up: r = off - d * uint(float(off) * rcp(d)); if r >= d: r -= d.  v_rcp_f32 is good to one ulp: for every
+    distance and offset that can occur (d <= off < 258) and the reciprocal one ulp low, exact-rounded and one ulp high, the
+    truncated quotient is exact or one short — never above, never two short."""
+    d = np.arange(1, 258, dtype=np.float32)[:, None]
+    off = np.arange(0, 258, dtype=np.float32)[None, :]
+    exact = (np.float32(1.0) / d).astype(np.float32)
+    for rcp in (np.nextafter(exact, np.float32(0)), exact, np.nextafter(exact, np.float32(2))):
+        q = (off * rcp).astype(np.float32).astype(np.int64)           # (float multiply rounded to nearest, then truncated)
+        di, oi = d.astype(np.int64), off.astype(np.int64)
+        r = oi - di * q
+        r = np.where(r >= di, r - di, r)
+        live = oi >= di                                               # (the kernel takes this path only for off >= d)
+        assert ((r == oi % di) | ~live).all()
