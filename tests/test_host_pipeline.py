@@ -504,3 +504,22 @@ def test_periodic_source_quotient_is_exact_or_one_short():
         r = np.where(r >= di, r - di, r)
         live = oi >= di                                               # (the kernel takes this path only for off >= d)
         assert ((r == oi % di) | ~live).all()
+
+
+def test_bucket_lru_formulation_is_exact(tmp_path):
+    """The candidate stage's formulation (lfx_match7.hip): per bucket the most recent entry and the most recent
+    entry with ANOTHER tag, bucket + tag = the 24-bit prefix under a bijection, the rest by a walk over duplicate-collapsed
+    links — against the exact "most recent earlier occurrence of the three bytes inside the window" (libflate_lz77
+    default.rs:76-87), as a CPU model with the kernel's own key multiplier: text, LOWENT, random bytes (55 % of the positions
+    go to the walk), a three-letter alphabet, nibbles.  The model exits non-zero on the first wrong answer."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = str(tmp_path / "lru_model")
+    subprocess.run([gcc, "-O2", "-o", exe, os.path.join(root, "tools", "exp", "lru_model.c"), os.path.join(root, "tools", "synth.c"), "-lm"],
+                   check=True, capture_output=True, timeout=120)
+    for kind in range(5):
+        r = subprocess.run([exe, str(kind), "2", "6"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "WRONG=0" in r.stdout, (kind, r.stdout, r.stderr)

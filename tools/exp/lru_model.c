@@ -2,7 +2,8 @@
  * duplicate-collapsed links, against the exact "most recent earlier occurrence of the 3-byte prefix inside the window"
  * (libflate_lz77/src/default.rs:76-87).  Prints, per kind of data and per candidate key mix, the share of positions whose head
  * entry carries another tag, the share left unresolved after two levels, the resolver's hops — and WRONG must be 0.
- *   gcc -O2 -o lru_model tools/exp/lru_model.c tools/synth.c -lm && ./lru_model 0    (0 text, 1 lowent, 2 random, 3 "abc", 4 nibbles)
+ *   gcc -O2 -o lru_model tools/exp/lru_model.c tools/synth.c -lm && ./lru_model 0 [MiB [mix]]   (0 text, 1 lowent, 2 random,
+ *   3 "abc", 4 nibbles; mix 6 = the kernel's multiplier; exit status 1 when any answer is wrong)
  * Not product code, not the oracle: a design worksheet. */
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,11 +22,14 @@ static uint32_t mix(uint32_t k,int mode){
    case 3: { uint32_t x=k; x^=x>>9; x=(x*0x2C1B3C6Du)&0xFFFFFF; x^=x>>13; x=(x*0x297A2D39u)&0xFFFFFF; x^=x>>11; return x; }
    case 4: { uint32_t x=(k*0x00C5A3B5u)&0xFFFFFF; return x; }
    case 5: { uint32_t x=k^(k>>7); x=(x*0x9E3779B1u)&0xFFFFFF; return x; }
+   case 6: return (k*0x00374ADDu)&0xFFFFFF;           // the kernel's KEY_MULT (tools/exp/lru_mult.c picked it)
   }
   return k;
 }
 int main(int argc,char**argv){
-  size_t N = 16u<<20; int kind = argc>1?atoi(argv[1]):0;
+  size_t N = (size_t)(argc>2?atoi(argv[2]):16)<<20; int kind = argc>1?atoi(argv[1]):0;
+  const int only = argc>3?atoi(argv[3]):-1;          /* one key mix instead of all seven */
+  uint64_t wrong_all=0;
   uint8_t*buf=malloc(N+8);
   if(kind==1) lfx_synth_lowent(buf,N,0x5EED0005); else if(kind==0) lfx_synth_text(buf,N,0x5EED0002);
   else if(kind==2){ uint64_t s=88172645463325252ull; for(size_t i=0;i<N;i++){ s^=s<<13;s^=s>>7;s^=s<<17; buf[i]=s>>32; } }
@@ -35,7 +39,8 @@ int main(int argc,char**argv){
   int32_t *last = malloc(sizeof(int32_t)<<24);
   uint32_t *head=malloc(4<<BITS), *sec=malloc(4<<BITS);
   uint16_t *cd=malloc(2*CH), *cl=malloc(2*CH);
-  for(int mode=0;mode<6;mode++){
+  for(int mode=0;mode<7;mode++){
+  if(only>=0&&mode!=only) continue;
   uint64_t nAll=0, mism=0, unres=0, wrong=0, hops=0, maxh=0;
   for(size_t c0=0;c0+CH<=N;c0+=CH){
     uint8_t*b=buf+c0; size_t n=CH; size_t end=n-3;
@@ -65,5 +70,7 @@ int main(int argc,char**argv){
     }
   }
   printf("kind=%d mode=%d mismatch=%.4f unresolved=%.4f hops/unres=%.2f maxhops=%lu WRONG=%lu\n",kind,mode,(double)mism/nAll,(double)unres/nAll,unres?(double)hops/unres:0.0,maxh,wrong);
+  wrong_all+=wrong;
   }
+  return wrong_all!=0;
 }
