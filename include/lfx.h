@@ -109,7 +109,11 @@ int lfx_encode_device(lfx_ctx *c, int format, const lfx_encode_opts *o, const lf
 int lfx_encode_batch_device(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s, uint32_t count,
                             const void *d_in, const uint64_t *in_off, const uint64_t *in_len, void *d_out,
                             const uint64_t *out_off, const uint64_t *out_cap, uint64_t *out_len, int32_t *status);
-/* same, host buffers (stages through HBM; PCIe-inclusive) */
+/* same, host buffers (H2D + device path + D2H; PCIe-inclusive).  Round 6: page-locked buffers — lfx_host_alloc below, or the
+ * caller's own hipHostMalloc / hipHostRegister — are handed to the DMA engine as they are; pageable ones are staged through
+ * page-locked slabs by four copy threads (one thread's memcpy is slower than the link).  lfx_decode_host likewise. */
+void *lfx_host_alloc(size_t bytes);   /* page-locked host memory (NULL: none to be had); for buffers that cross PCIe often */
+void lfx_host_free(void *p);
 int lfx_encode_host(lfx_ctx *c, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                     const void *in, uint64_t n, void *out, uint64_t cap, uint64_t *out_len);
 
@@ -216,8 +220,11 @@ int lfx_shard_place_device(lfx_ctx *c, void *d_member, uint64_t cap, const void 
  * through an lfx_comm — four callbacks the caller implements over whatever moves bytes between its ranks (torch.distributed
  * in libflate_amd/sharded.py, MPI, ...), or lfx_comm_rccl() for RCCL over xGMI.  Every callback returns 0 on success.
  *   allgather: every rank contributes `bytes` HOST bytes; recv (world * bytes, rank order) is complete on return.
- *   isend / irecv: post a transfer of a DEVICE buffer (they may return before it completes; RCCL groups them);
- *   wait: everything this rank posted is complete.
+ *   isend / irecv: post a transfer of a DEVICE buffer (a binding may only collect them: RCCL groups them, torch batches them);
+ *   start (round 6; may be NULL when isend / irecv start their transfers themselves): everything posted so far begins to
+ *     move NOW and the call returns without waiting for it — lfx_sharded_encode_begin calls it last, so the shards travel
+ *     while the caller works between begin and finish;
+ *   wait: everything this rank posted is complete (transfers that were never started are started first).
  * A failure on one rank travels with the next collective and comes back from the same call on EVERY rank. */
 typedef struct lfx_comm {
     void *user;
@@ -226,9 +233,14 @@ typedef struct lfx_comm {
     int (*isend)(void *user, const void *d_buf, uint64_t bytes, uint32_t to_rank);
     int (*irecv)(void *user, void *d_buf, uint64_t bytes, uint32_t from_rank);
     int (*wait)(void *user);
+    int (*start)(void *user);
 } lfx_comm;
 /* RCCL binding: `nccl_comm` is an ncclComm_t, `hip_stream` the hipStream_t its collectives run on.  librccl is loaded at run
- * time (LFX_E_UNSUPPORTED when it is not there): liblfx.so does not link it. */
+ * time (LFX_E_UNSUPPORTED when it is not there): liblfx.so does not link it.  isend / irecv open ONE ncclGroup, start closes
+ * it (all transfers of the group begin together, one per xGMI link), wait synchronises the stream; an all-gather that finds a
+ * group open closes it first (a collective issued inside an open group would only be queued, and its result read too early).
+ * RCCL serialises the operations of one communicator: a caller that wants its small all-gathers (lfx_sharded_decode) not to
+ * queue behind shards in flight gives the two drivers two communicators. */
 int lfx_comm_rccl(void *nccl_comm, void *hip_stream, uint32_t rank, uint32_t world, lfx_comm *out);
 void lfx_comm_rccl_free(lfx_comm *cm);
 
@@ -392,6 +404,9 @@ typedef struct lfx_timing {
     char phase_name[16][24];
     int n_phases;
 } lfx_timing;
+/* encode passes this context ran on the fallback match kernel because the ordered-LDS-exchange assumption of the default one
+ *  was seen violated — 0 on every part measured so far; a non-zero value explains a 3x slower match stage */
+uint64_t lfx_ctx_match_fallbacks(const lfx_ctx *c);
 int lfx_ctx_last_timing(lfx_ctx *c, lfx_timing *t);
 void lfx_ctx_enable_timing(lfx_ctx *c, int on);
 uint32_t lfx_version(void);

@@ -31,6 +31,7 @@ EXPORTS = [
     "lfx_lz77_free", "lfx_ctx_last_timing", "lfx_ctx_enable_timing", "lfx_version",
     "lfx_comm_rccl", "lfx_comm_rccl_free", "lfx_sharded_encode_begin", "lfx_sharded_encode_finish", "lfx_sharded_byte_range",
     "lfx_sharded_decode", "lfx_sharded_layout", "lfx_sharded_gather_tuples", "lfx_sharded_fold", "lfx_sharded_free",
+    "lfx_host_alloc", "lfx_host_free", "lfx_ctx_match_fallbacks",
 ]
 
 
@@ -70,7 +71,7 @@ COMM_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 class Comm(C.Structure):
     _fields_ = [("user", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("allgather", COMM_ALLGATHER),
-                ("isend", COMM_P2P), ("irecv", COMM_P2P), ("wait", COMM_WAIT)]
+                ("isend", COMM_P2P), ("irecv", COMM_P2P), ("wait", COMM_WAIT), ("start", COMM_WAIT)]
 
 
 class ShardedPart(C.Structure):
@@ -143,10 +144,16 @@ def lib():
     L.lfx_encode_bound.argtypes = [u64, C.POINTER(EncodeOpts), C.POINTER(Schedule)]
     L.lfx_encode_device.argtypes = [vp, i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), vp, u64, vp, u64,
                                     C.POINTER(u64)]
-    L.lfx_encode_host.argtypes = [vp, i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), C.c_char_p, u64, vp,
+    # (host pointers as void*: bytes objects and raw addresses — numpy buffers, lfx_host_alloc blocks — both pass)
+    L.lfx_encode_host.argtypes = [vp, i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), vp, u64, vp,
                                   u64, C.POINTER(u64)]
+    L.lfx_host_alloc.restype = vp
+    L.lfx_host_alloc.argtypes = [C.c_size_t]
+    L.lfx_host_free.argtypes = [vp]
+    L.lfx_ctx_match_fallbacks.restype = u64
+    L.lfx_ctx_match_fallbacks.argtypes = [vp]
     L.lfx_decode_device.argtypes = [vp, i32, u32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]
-    L.lfx_decode_host.argtypes = [vp, i32, u32, C.c_char_p, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]
+    L.lfx_decode_host.argtypes = [vp, i32, u32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]
     L.lfx_decode_batch_device.argtypes = [vp, i32, u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lfx_encode_batch_device.argtypes = [vp, i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), u32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.lfx_encode_shard_prepare.argtypes = [vp, i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), vp, u64, i32,

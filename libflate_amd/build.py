@@ -9,8 +9,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "liblfx.so")
-SOURCES = ["lfx_encode_kernels.hip", "lfx_match7.hip", "lfx_match5.hip", "lfx_parse2.hip", "lfx_decode_kernels.hip", "lfx_inflate_fast.hip", "lfx_api.cpp", "lfx_decode.cpp", "lfx_sharded.cpp"]
-HEADERS = ["lfx_common.h", "lfx_container.h", "lfx_device.h", "lfx_decode.h", "lfx_huff.h", "lfx_plan.h", "lfx_ctx.h", "lfx_abi_guard.h",
+SOURCES = ["lfx_encode_kernels.hip", "lfx_match7.hip", "lfx_match5.hip", "lfx_parse2.hip", "lfx_decode_kernels.hip", "lfx_inflate_fast.hip", "lfx_api.cpp", "lfx_decode.cpp", "lfx_sharded.cpp", "lfx_hostio.cpp"]
+HEADERS = ["lfx_common.h", "lfx_container.h", "lfx_device.h", "lfx_decode.h", "lfx_huff.h", "lfx_plan.h", "lfx_ctx.h", "lfx_abi_guard.h", "lfx_hostio.h",
            os.path.join("..", "..", "include", "lfx.h"), os.path.join("..", "..", "include", "lfx_testhooks.h")]
 
 
@@ -25,8 +25,8 @@ def build(force=False, verbose=False, defs=(), so=None, tag=""):
     """defs / so / tag: development builds with extra -D macros into a library of another name (tools/exp: kernel variants
     side by side in one GPU call, selected by LFX_SO); the product build takes none of them."""
     so = so or SO
-    if not force and not defs and not _stale():
-        return SO
+    if not force and not defs and not _stale() and os.path.exists(so):
+        return so
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for src in SOURCES:

@@ -44,6 +44,28 @@ class Context:
                 "phases": [(bytes(t.phase_name[i]).split(b"\0")[0].decode(), t.phase_ms[i])
                            for i in range(t.n_phases)]}
 
+    def match_fallbacks(self):
+        """encode passes that ran on the fallback match kernel (lfx_ctx_match_fallbacks): 0 unless the default kernel's
+        hardware assumption was seen violated on this part"""
+        return int(_ffi.lib().lfx_ctx_match_fallbacks(self._h))
+
+    # ---- one-shot calls on raw HOST pointers (ints: numpy buffers, lfx_host_alloc blocks) — no Python-side copies --------
+    def encode_host_ptr(self, fmt, in_ptr, n, out_ptr, cap, opts=None, schedule=None):
+        out_len = C.c_uint64(0)
+        rc = _ffi.lib().lfx_encode_host(self._h, fmt, C.byref(opts) if opts is not None else None,
+                                        C.byref(schedule) if schedule is not None else None, in_ptr, n, out_ptr, cap, C.byref(out_len))
+        if rc:
+            raise (_ffi.DeviceError if rc == _ffi.E_DEVICE else _ffi.LfxError)(rc, self.last_error())
+        return out_len.value
+
+    def decode_host_ptr(self, fmt, in_ptr, n, out_ptr, cap, flags=0):
+        """→ (status, out_len, consumed, message)"""
+        out_len, consumed = C.c_uint64(0), C.c_uint64(0)
+        rc = _ffi.lib().lfx_decode_host(self._h, fmt, flags, in_ptr, n, out_ptr, cap, C.byref(out_len), C.byref(consumed))
+        if rc in (_ffi.E_DEVICE, _ffi.E_OOM, _ffi.E_ARG):
+            raise (_ffi.DeviceError if rc == _ffi.E_DEVICE else _ffi.LfxError)(rc, self.last_error())
+        return rc, out_len.value, consumed.value, self.last_error() if rc else ""
+
     # ---- one-shot calls on raw device pointers (ints) -------------------------------------------
     def encode_device(self, fmt, d_in, n, d_out, cap, opts=None, schedule=None):
         out_len = C.c_uint64(0)

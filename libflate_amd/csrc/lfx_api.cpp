@@ -108,9 +108,12 @@ static PlanOpts plan_opts(int format, const lfx_encode_opts &o) {
 static void gzip_header(const lfx_encode_opts &o, bool with_hcrc, std::vector<uint8_t> &b) {
     uint8_t flg = (uint8_t)((o.is_text ? 1 : 0) | (with_hcrc ? 2 : 0) | (o.extra ? 4 : 0) |
                             (o.filename ? 8 : 0) | (o.comment ? 16 : 0));
-    // XFL: DefaultLz77Encoder → Balance → Unknown(0); NoCompression → None → Unknown(0); a caller's E: Fast → Fastest(4),
-    // Best → Slowest(2) (gzip.rs:84-92,684); no_compression() resets it to Unknown (gzip.rs:703)
-    const uint8_t xfl = o.no_compression ? 0 : o.lz77_level == 1 + LFX_LEVEL_FAST ? 4 : o.lz77_level == 1 + LFX_LEVEL_BEST ? 2 : 0;
+    // XFL is the level of the header the options hold when the encoder is made (gzip.rs:368-389): DefaultLz77Encoder →
+    // Balance → Unknown(0); NoCompression → None → Unknown(0); a caller's E: Fast → Fastest(4), Best → Slowest(2)
+    // (gzip.rs:84-92,684).  no_compression() resets it to Unknown WHEN IT IS CALLED (gzip.rs:703) and a later header(h)
+    // replaces it again (gzip.rs:717-720): the option builders above this ABI apply both in call order and pass the result in
+    // lz77_level — it is not overridden here (no_compression().header(h with Fastest) writes XFL 4).
+    const uint8_t xfl = o.lz77_level == 1 + LFX_LEVEL_FAST ? 4 : o.lz77_level == 1 + LFX_LEVEL_BEST ? 2 : 0;
     const uint8_t h[10] = {31, 139, 8, flg, (uint8_t)o.mtime, (uint8_t)(o.mtime >> 8),
                            (uint8_t)(o.mtime >> 16), (uint8_t)(o.mtime >> 24), xfl, o.os};
     b.insert(b.end(), h, h + 10);
@@ -236,6 +239,7 @@ void Diag::read() {
     window_chain = on("LFX_WINDOW_CHAIN");
     if (const char *fs = getenv("LFX_FREE_SHIFT")) free_shift = atoi(fs);
     if (const char *pm = getenv("LFX_POCR_MAX")) pocr_max = atoi(pm);
+    if (const char *eb = getenv("LFX_ENC_BATCH_MB")) enc_batch_mb = atoi(eb);
 }
 
 void Ctx::phase(const char *name) {
@@ -303,6 +307,7 @@ extern "C" void lfx_ctx_free(lfx_ctx *cc) {
     for (DevBuf *b : c->all_bufs()) b->release();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    c->hostio.release();
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_zero) (void)hipEventDestroy(c->ev_zero);
@@ -318,6 +323,9 @@ extern "C" const char *lfx_ctx_last_error(const lfx_ctx *cc) {
 extern "C" void lfx_ctx_set_stream(lfx_ctx *cc, void *s) {
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     c->stream = s ? (hipStream_t)s : c->own_stream;
+}
+extern "C" uint64_t lfx_ctx_match_fallbacks(const lfx_ctx *cc) {
+    return cc ? reinterpret_cast<const Ctx *>(cc)->match_fallbacks : 0;
 }
 extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on != 0; }
 extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) try {
@@ -356,6 +364,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     const uint32_t nchunks = (uint32_t)plan.chunks.size(), nblocks = (uint32_t)plan.blocks.size();
     // ---- which candidate stage: lfx_match3.hip unless it once reported a lane-order violation (or LFX_MATCH_V1 is set)
     const bool match_v1 = c->force_match_v1 || c->diag.match_v1;
+    if (c->force_match_v1 && !hc) c->match_fallbacks++;      // (a silent fallback must be visible)
     // A segment is one workgroup's serial walk (plus a 32 KiB warm-up when it does not start a chunk).  Small
     // inputs are cut finer so that the GPU still fills: halve the segment length until there are >= 512 of them
     // (never below 32 Ki positions: the warm-up would dominate).
@@ -840,12 +849,14 @@ extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o
     int rc;
     if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
     if ((rc = c->d_io_out.reserve(bound))) return rc;
-    if (n) HIP_TRY(hipMemcpyAsync(c->d_io_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    // H2D / D2H at link rate (lfx_hostio.h): page-locked buffers (lfx_host_alloc) go to the DMA engine as they are, pageable
+    // ones through page-locked slabs filled by a few threads
+    if ((rc = host_to_device(c, c->d_io_in.p, in, n, c->stream))) { c->set_error("host to device copy failed"); return rc; }
     uint64_t len = 0;
     rc = lfx_encode_device(cc, format, o, s, c->d_io_in.p, n, c->d_io_out.p, bound & ~3ull, &len);
     if (rc) return rc;
     if (len > cap) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
-    HIP_TRY(hipMemcpy(out, c->d_io_out.p, len, hipMemcpyDeviceToHost));
+    if ((rc = device_to_host(c, out, c->d_io_out.p, len, c->stream))) { c->set_error("device to host copy failed"); return rc; }
     if (out_len) *out_len = len;
     return LFX_OK;
 } LFX_ABI_CATCH
@@ -957,7 +968,9 @@ struct lfx_encoder {
     lfx_write_cb w;
     lfx_flush_cb f;
     void *user;
-    std::vector<uint8_t> pending;       // input bytes not yet encoded: the planner's byte 0 is pending[0]
+    PinVec pending;                     // input bytes not yet encoded: the planner's byte 0 is pending[0].  Page-locked (lfx_hostio.h):
+                                        // the batch's H2D copy is one DMA transfer straight out of it
+    PinVec h_out;                       // a batch's output lands here (page-locked) and goes to the sink from here: no copy between
     Planner *pl = nullptr;              // incremental write-schedule state (chunks / blocks of `pending`)
     uint64_t total_in = 0, encoded_in = 0;
     uint32_t crc = 0, adler = 1;        // running container checksum (combined per batch)
@@ -1013,12 +1026,13 @@ static int enc_run(lfx_encoder *e, bool final) {
     if (e->format == LFX_ZLIB) e->adler = e->encoded_in == 0 ? res.adler32 : lfx_adler32_combine(e->adler, res.adler32, n);
     e->encoded_in += n;
     const uint64_t whole = final ? (res.end_bit + 7) / 8 : res.end_bit / 8;
-    std::vector<uint8_t> host(whole + 1);
-    if (hipMemcpy(host.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
+    e->h_out.resize(whole + 1);
+    if (hipMemcpyAsync(e->h_out.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return LFX_E_DEVICE;
     e->carry_bits = final ? 0 : (uint32_t)(res.end_bit & 7);
-    e->carry = e->carry_bits ? host[whole] : 0;
+    e->carry = e->carry_bits ? e->h_out[whole] : 0;
     e->pending.erase(e->pending.begin(), e->pending.begin() + (std::ptrdiff_t)n);
-    return enc_emit_bytes(e, host.data(), whole);
+    return enc_emit_bytes(e, e->h_out.data(), whole);
 }
 
 // codes mode: encode every closed block (CompressBuf::flush from the histogram on, encode.rs:416-425)
@@ -1072,21 +1086,23 @@ static int enc_run_codes(lfx_encoder *e) {
         e->encoded_in += n;
     }
     const uint64_t whole = e->final_closed ? (res.end_bit + 7) / 8 : res.end_bit / 8;
-    std::vector<uint8_t> host(whole + 1);
-    if (hipMemcpy(host.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost) != hipSuccess) return LFX_E_DEVICE;
+    e->h_out.resize(whole + 1);
+    if (hipMemcpyAsync(e->h_out.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return LFX_E_DEVICE;
     e->carry_bits = e->final_closed ? 0 : (uint32_t)(res.end_bit & 7);
-    e->carry = e->carry_bits ? host[whole] : 0;
+    e->carry = e->carry_bits ? e->h_out[whole] : 0;
     e->pending.clear();
     e->codes.erase(e->codes.begin(), e->codes.begin() + (std::ptrdiff_t)e->closed_codes);
     e->closed_codes = 0;
     e->cblocks.clear();
-    return enc_emit_bytes(e, host.data(), whole);
+    return enc_emit_bytes(e, e->h_out.data(), whole);
 }
 
 // closed blocks of the codes mode are encoded once this many code words wait (about 8 MiB of text)
 static const uint64_t ENC_BATCH_CODES = 2ull << 20;
 // closed blocks (either mode) are encoded once this many raw bytes wait
-static const uint64_t ENC_BATCH_BYTES = 8ull << 20;
+static const uint64_t ENC_BATCH_BYTES_DEFAULT = 8ull << 20;
+static uint64_t enc_batch_bytes(const lfx_encoder *e) { return e->c->diag.enc_batch_mb > 0 ? (uint64_t)e->c->diag.enc_batch_mb << 20 : ENC_BATCH_BYTES_DEFAULT; }
 
 extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, size_t n_codes, const uint8_t *raw, size_t n_raw,
                                        int end_block) try {
@@ -1110,7 +1126,7 @@ extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, si
         e->closed_codes += e->open_codes + 1;
         e->open_codes = 0;
         if (end_block == 2) e->final_closed = true;
-        else if (e->closed_codes >= ENC_BATCH_CODES || e->pending.size() >= ENC_BATCH_BYTES) {
+        else if (e->closed_codes >= ENC_BATCH_CODES || e->pending.size() >= enc_batch_bytes(e)) {
             // (the byte threshold: a well-compressing Lz77Encode — 258-byte matches — closes 2 M code words only after half a
             //  gigabyte of raw bytes; the reference emits every block as it closes)
             int rc = enc_run_codes(e);
@@ -1160,7 +1176,7 @@ extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n)
     e->pending.insert(e->pending.end(), p, p + n);
     e->pl->write(n);
     e->total_in += n;
-    if (e->pl->closed_bytes() >= ENC_BATCH_BYTES || (e->po.no_compression && e->pl->closed_blocks() >= 1024)) {
+    if (e->pl->closed_bytes() >= enc_batch_bytes(e) || (e->po.no_compression && e->pl->closed_blocks() >= 1024)) {
         int rc = enc_run(e, false);
         if (rc) { e->failed = true; return -(int64_t)rc; }
     }

@@ -8,6 +8,7 @@
 
 #include "lfx_common.h"
 #include "lfx_device.h"
+#include "lfx_hostio.h"
 
 namespace lfx {
 
@@ -34,6 +35,7 @@ struct Diag {
     bool no_final_cand = false;  // LFX_NO_FINAL_CAND: the finder reports no BFINAL header at all (the chain walk scans the last block on demand)
     bool window_chain = false;   // LFX_WINDOW_CHAIN
     int free_shift = -1;         // LFX_FREE_SHIFT
+    int enc_batch_mb = 0;        // LFX_ENC_BATCH_MB: the stream encoder encodes closed blocks once so many MiB wait (0: the default, 8)
     int pocr_max = 100;          // LFX_POCR_MAX: most candidate ranges the decoder scans in pieces at once
     void read();
 };
@@ -89,6 +91,8 @@ struct Ctx {
     const uint32_t *cur_tile_map = nullptr;   // tile → chunk table of the prepared encode (lives in d_chunkmap)
     const uint8_t *cur_in = nullptr;
     bool force_match_v1 = false;   // sticky: the second-generation match kernel reported a lane-order violation
+    uint64_t match_fallbacks = 0;  // encode passes this context ran on the fallback kernel because of it (lfx_ctx_match_fallbacks)
+    HostIo hostio;                 // copy streams and page-locked slabs for callers' pageable buffers (lfx_hostio.h), made on first use
     std::vector<uint8_t> shard_hdr;
     int shard_format = 0;
     bool shard_last = false;

@@ -1262,11 +1262,12 @@ extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const vo
     int rc;
     if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
     if ((rc = c->d_io_out.reserve(std::max<uint64_t>(cap, 4)))) return rc;
-    if (n) HIP_TRY(hipMemcpyAsync(c->d_io_in.p, in, n, hipMemcpyHostToDevice, c->stream));
+    // (lfx_hostio.h: page-locked buffers — lfx_host_alloc — go to the DMA engine as they are, pageable ones through slabs)
+    if (int hr = host_to_device(c, c->d_io_in.p, in, n, c->stream)) { c->set_error("host to device copy failed"); return hr; }
     uint64_t ol = 0;
     rc = lfx_decode_device(cc, format, flags, c->d_io_in.p, n, c->d_io_out.p, cap, &ol, consumed);
     if (rc == LFX_E_DEVICE || rc == LFX_E_OOM || rc == LFX_E_ARG) return rc;
-    if (ol) HIP_TRY(hipMemcpy(out, c->d_io_out.p, ol, hipMemcpyDeviceToHost));
+    if (ol) { if (int hr = device_to_host(c, out, c->d_io_out.p, ol, c->stream)) { c->set_error("device to host copy failed"); return hr; } }
     if (out_len) *out_len = ol;
     return rc;
 } LFX_ABI_CATCH
@@ -1491,8 +1492,9 @@ struct lfx_decoder {
     uint32_t flags;
     lfx_read_cb r;
     void *user;
-    std::vector<uint8_t> in;        // pulled from the reader and not yet consumed by a decoded window
-    std::vector<uint8_t> chunk;     // what one read callback fills
+    // (page-locked vectors, lfx_hostio.h: a window's H2D / D2H copies are DMA transfers straight out of / into them, and
+    //  resize() does not zero-fill what a copy overwrites)
+    PinVec in;                      // pulled from the reader and not yet consumed by a decoded window
     bool reader_eof = false;
     enum State { ST_HEADER, ST_BODY, ST_SERVE, ST_DONE, ST_FAILED } state = ST_HEADER;
     bool first_member = true;
@@ -1500,7 +1502,7 @@ struct lfx_decoder {
     ContainerFields hf{};
     std::vector<uint8_t> hdr_bytes;
     bool have_header = false;
-    std::vector<uint8_t> out;
+    PinVec out;
     uint64_t cursor = 0, serve_limit = 0;
     int pending_status = LFX_OK;    // reported once the bytes in front of it have been served
     uint64_t consumed_total = 0;    // reader bytes that belong to finished members
@@ -1525,11 +1527,12 @@ enum { PULL_OK = 0, PULL_EOF = 1, PULL_BLOCK = 2, PULL_ERR = 3 };
 int dec_pull(lfx_decoder *d, size_t want, size_t *got) {
     *got = 0;
     if (d->reader_eof) return PULL_EOF;
-    // (into a reusable chunk, then appended: growing `in` by `want` zero-filled bytes per callback made a reader that
-    //  hands over a few bytes at a time pay for 4 MiB of memset each time)
-    if (d->chunk.size() < want) d->chunk.resize(want);
-    const int64_t k = d->r(d->user, d->chunk.data(), want);
-    if (k > 0) d->in.insert(d->in.end(), d->chunk.begin(), d->chunk.begin() + (std::ptrdiff_t)std::min<int64_t>(k, (int64_t)want));
+    // (straight into the spare room behind `in` — page-locked, no zero fill, no second copy; the vector grows geometrically,
+    //  so a reader that hands over a few bytes at a time does not pay for `want` bytes each time)
+    const size_t old = d->in.size();
+    d->in.resize(old + want);
+    const int64_t k = d->r(d->user, d->in.data() + old, want);
+    d->in.resize(old + (k > 0 ? (size_t)std::min<int64_t>(k, (int64_t)want) : 0));
     if (k == -(int64_t)LFX_E_WOULD_BLOCK) return PULL_BLOCK;
     if (k < 0) return PULL_ERR;
     if (k == 0) { d->reader_eof = true; return PULL_EOF; }
@@ -1887,7 +1890,7 @@ extern "C" int lfx_decoder_header(lfx_decoder *d, lfx_header *h) try {
 } LFX_ABI_CATCH
 extern "C" uint64_t lfx_decoder_consumed(const lfx_decoder *d) { return d ? d->consumed_total : 0; }
 extern "C" uint64_t lfx_decoder_buffered(const lfx_decoder *d) {
-    return d ? (uint64_t)(d->in.size() + d->out.size() + d->hist.size() + d->chunk.size()) : 0;
+    return d ? (uint64_t)(d->in.size() + d->out.size() + d->hist.size()) : 0;
 }
 extern "C" const char *lfx_decoder_last_error(const lfx_decoder *d) { return d ? d->err.c_str() : "null"; }
 extern "C" void lfx_decoder_free(lfx_decoder *d) { delete d; }

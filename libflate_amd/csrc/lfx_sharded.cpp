@@ -33,7 +33,8 @@ constexpr uint64_t RANGE_TAIL = 4ull << 20;   // bytes of the right neighbour's 
 // every rank's row of `n` 64-bit values, rank order
 int gather_rows(const lfx_comm *cm, const uint64_t *mine, uint32_t n, std::vector<uint64_t> &all) {
     all.assign((size_t)cm->world * n, 0);
-    if (cm->world == 1) { std::copy(mine, mine + n, all.begin()); return LFX_OK; }
+    // (one rank without a collective: nothing to exchange; one rank WITH one — the RCCL binding on a one-GPU box — runs it)
+    if (cm->world == 1 && !cm->allgather) { std::copy(mine, mine + n, all.begin()); return LFX_OK; }
     return cm->allgather(cm->user, mine, all.data(), 8ull * n) ? LFX_E_IO : LFX_OK;
 }
 
@@ -93,7 +94,7 @@ extern "C" int lfx_sharded_gather_tuples(const lfx_comm *cm, const lfx_blk_tuple
     std::vector<lfx_blk_tuple> send(widest), recv((size_t)widest * cm->world);
     memset(send.data(), 0, send.size() * sizeof(lfx_blk_tuple));
     if (count) memcpy(send.data(), mine, (size_t)count * sizeof(lfx_blk_tuple));
-    if (cm->world == 1) recv = send;
+    if (cm->world == 1 && !cm->allgather) recv = send;
     else if (cm->allgather(cm->user, send.data(), recv.data(), widest * sizeof(lfx_blk_tuple))) return LFX_E_IO;
     lfx_blk_tuple *out = (lfx_blk_tuple *)malloc(std::max<uint64_t>(total, 1) * sizeof(lfx_blk_tuple));
     if (!out) return LFX_E_OOM;
@@ -173,14 +174,18 @@ extern "C" int lfx_sharded_encode_begin(lfx_ctx *c, const lfx_comm *cm, int form
     }
     if (!rc) rc = lfx_encode_shard_emit(c, st->start_bits[rank], check, total_n, d_part, part_cap, &part_len);
     // ---- every rank's emitted byte count (and status), then the shards travel to rank 0, all transfers posted at once: on
-    //      RCCL they arrive over different xGMI links concurrently (the links are point-to-point)
-    const uint64_t row[2] = {part_len, (uint64_t)(int64_t)rc};
+    //      RCCL they arrive over different xGMI links concurrently (the links are point-to-point).  Rank 0's capacities ride
+    //      in the same row: whether the member and the staging area are large enough is then decided by EVERY rank
+    //      from the same numbers — a rank 0 that found its buffers too small behind the last collective left ranks 1.. with
+    //      posted sends nobody receives, blocked in finish()
+    const uint64_t row[4] = {part_len, (uint64_t)(int64_t)rc, rank == 0 && d_member ? member_cap : 0,
+                             rank == 0 && d_staging ? staging_cap : 0};
     std::vector<uint64_t> lens;
-    if (int rc3 = gather_rows(cm, row, 2, lens)) return rc3;
+    if (int rc3 = gather_rows(cm, row, 4, lens)) return rc3;
     for (uint32_t r = 0; r < world; r++)
-        if ((int64_t)lens[2 * r + 1]) return (int)(int64_t)lens[2 * r + 1];
+        if ((int64_t)lens[4 * r + 1]) return (int)(int64_t)lens[4 * r + 1];
     st->part_lens.resize(world);
-    for (uint32_t r = 0; r < world; r++) st->part_lens[r] = lens[2 * r];
+    for (uint32_t r = 0; r < world; r++) st->part_lens[r] = lens[4 * r];
     out->start_bit = st->start_bits[rank];
     out->end_bit = st->start_bits[rank + 1];
     out->part_len = part_len;
@@ -188,21 +193,30 @@ extern "C" int lfx_sharded_encode_begin(lfx_ctx *c, const lfx_comm *cm, int form
     out->total_n = total_n;
     out->member_len = (world > 1 ? st->start_bits[world - 1] / 8 : 0) + st->part_lens[world - 1];
     st->member_len = out->member_len;
+    uint64_t staging_need = 0;
+    for (uint32_t r = 1; r < world; r++) staging_need += (st->part_lens[r] + 255) & ~255ull;
+    if (lens[2] < out->member_len || lens[3] < staging_need) return LFX_E_NOSPACE;      // (the same verdict on every rank)
+    // ---- from here on nothing may leave a peer waiting: the transfers are posted FIRST and started (lfx_comm.start: the
+    //      shards travel while the caller works between begin and finish — bench.py decodes meanwhile), and a failure behind
+    //      the posts still starts and completes them before it returns
+    int post = 0;
     if (rank == 0) {
-        if (!d_member || member_cap < out->member_len) return LFX_E_NOSPACE;
         st->d_member = d_member;
         st->member_cap = member_cap;
-        if ((rc = lfx_shard_place_device(c, d_member, member_cap, d_part, part_len, st->start_bits[0], 1))) return rc;
         uint64_t off = 0;
         for (uint32_t r = 1; r < world; r++) {
-            const uint64_t need = (st->part_lens[r] + 255) & ~255ull;
-            if (!d_staging || off + need > staging_cap) return LFX_E_NOSPACE;
             void *buf = (uint8_t *)d_staging + off;
-            off += need;
-            if (cm->irecv(cm->user, buf, st->part_lens[r], r)) return LFX_E_IO;
+            off += (st->part_lens[r] + 255) & ~255ull;
+            if (cm->irecv(cm->user, buf, st->part_lens[r], r)) post = LFX_E_IO;
             st->pending.push_back({r, buf, st->part_lens[r]});
         }
-    } else if (cm->isend(cm->user, d_part, part_len, 0)) return LFX_E_IO;
+    } else if (cm->isend(cm->user, d_part, part_len, 0)) post = LFX_E_IO;
+    if (world > 1 && cm->start && cm->start(cm->user)) post = LFX_E_IO;
+    if (!post && rank == 0) post = lfx_shard_place_device(c, d_member, member_cap, d_part, part_len, st->start_bits[0], 1);
+    if (post) {
+        if (world > 1) (void)cm->wait(cm->user);
+        return post;
+    }
     st->posted = world > 1;
     *state = st.release();
     return LFX_OK;
@@ -222,11 +236,17 @@ extern "C" int lfx_sharded_encode_finish(lfx_ctx *c, const lfx_comm *cm, lfx_sha
 // ------------------------------------------------------------------------------------------------ decode of ONE member by byte ranges
 extern "C" void lfx_sharded_byte_range(uint64_t first_byte, uint64_t member_len, uint32_t rank, uint32_t world, uint64_t *lo,
                                        uint64_t *hi, uint64_t *hold_hi) {
-    const uint64_t span = member_len - first_byte;
-    const uint64_t a = first_byte + span * rank / world, b = rank + 1 == world ? member_len : first_byte + span * (rank + 1) / world;
+    uint64_t a = 0, b = 0, h = 0;
+    if (world && rank < world && member_len >= first_byte) {      // (anything else: an empty range — ADVICE r5)
+        const uint64_t span = member_len - first_byte;
+        const auto cut = [&](uint32_t r) { return first_byte + (uint64_t)((unsigned __int128)span * r / world); };
+        a = cut(rank);
+        b = rank + 1 == world ? member_len : cut(rank + 1);
+        h = std::min(b + RANGE_TAIL, member_len);
+    }
     if (lo) *lo = a;
     if (hi) *hi = b;
-    if (hold_hi) *hold_hi = std::min(b + RANGE_TAIL, member_len);
+    if (hold_hi) *hold_hi = h;
 }
 
 extern "C" int lfx_sharded_decode(lfx_ctx *c, const lfx_comm *cm, const void *d_part, uint64_t n_part, uint64_t lo_byte,
@@ -281,7 +301,7 @@ extern "C" int lfx_sharded_decode(lfx_ctx *c, const lfx_comm *cm, const void *d_
         uint32_t dummy = 0;
         int rc = lfx_sharded_fold(cm, status, 0, 0, 0, 1, &dummy, nullptr, nullptr, nullptr, nullptr);
         if (!rc) {
-            if (world == 1) maps = mine;
+            if (world == 1 && !cm->allgather) maps = mine;
             else if (cm->allgather(cm->user, mine.data(), maps.data(), 65536)) rc = LFX_E_IO;
         }
         if (!rc && hipMemcpy(d_maps, maps.data(), maps.size(), hipMemcpyHostToDevice) != hipSuccess) rc = LFX_E_DEVICE;
@@ -321,12 +341,21 @@ struct RcclComm {
 };
 constexpr int NCCL_CHAR = 0;    // ncclInt8 / ncclChar
 
+int rccl_start(void *user) {
+    RcclComm *r = (RcclComm *)user;
+    if (r->in_group) { r->in_group = false; if (r->api.GroupEnd()) return 1; }    // (all transfers of the group start together)
+    return 0;
+}
 int rccl_allgather(void *user, const void *send, void *recv, uint64_t bytes) {
     RcclComm *r = (RcclComm *)user;
+    // (group state is per thread: a collective issued inside an open group is only queued — the copy back and the stream
+    //  synchronisation below would complete without it.  Posted transfers are started instead of being held back.)
+    if (rccl_start(user)) return 1;
     const uint64_t need = bytes * (r->world + 1);
     if (need > r->tmp_cap) {
-        if (r->d_tmp) (void)hipFree(r->d_tmp);
+        if (r->d_tmp) { if (hipStreamSynchronize(r->stream) != hipSuccess) return 1; (void)hipFree(r->d_tmp); }
         r->d_tmp = nullptr;
+        r->tmp_cap = 0;
         if (hipMalloc(&r->d_tmp, need) != hipSuccess) return 1;
         r->tmp_cap = need;
     }
@@ -350,7 +379,7 @@ int rccl_irecv(void *user, void *d_buf, uint64_t bytes, uint32_t from) {
 }
 int rccl_wait(void *user) {
     RcclComm *r = (RcclComm *)user;
-    if (r->in_group) { r->in_group = false; if (r->api.GroupEnd()) return 1; }    // (all transfers of the group start together)
+    if (rccl_start(user)) return 1;                  // (a caller that never called start)
     return hipStreamSynchronize(r->stream) == hipSuccess ? 0 : 1;
 }
 }  // namespace
@@ -375,6 +404,7 @@ extern "C" int lfx_comm_rccl(void *nccl_comm, void *hip_stream, uint32_t rank, u
     out->isend = rccl_isend;
     out->irecv = rccl_irecv;
     out->wait = rccl_wait;
+    out->start = rccl_start;
     return LFX_OK;
 } LFX_ABI_CATCH
 

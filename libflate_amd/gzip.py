@@ -65,6 +65,13 @@ class EncodeOptions(_deflate.EncodeOptions):
         super().__init__(lz77)
         self._kw.setdefault("mtime", 0)
 
+    def no_compression(self):  # gzip.rs:700-705
+        """stored blocks; the header's compression level goes back to Unknown at this point (gzip.rs:703) — a header()
+        call AFTER it brings its own level along again"""
+        super().no_compression()
+        self._kw["lz77_level"] = 1 + 2
+        return self
+
     def header(self, header):  # gzip.rs:717-720
         """`header`: what HeaderBuilder.finish() returns, or the dict a Decoder's header() returns (gzip.rs:959).  The header
         REPLACES the one the options held, its compression level included: the XFL byte written is the header's

@@ -19,20 +19,26 @@ RANGE_TAIL = 4 << 20      # bytes of the right neighbour's range a rank also hol
 
 class TorchComm:
     """lfx_comm over torch.distributed.  allgather moves HOST bytes (through the device on RCCL: its collectives take
-    device tensors); isend / irecv post transfers of DEVICE buffers, all of them started together by wait()'s batch
-    (on RCCL the shards then arrive over different xGMI links concurrently) — with gloo (CPU rigs, the one-GPU self-test
-    of bench.py) they hop through host tensors."""
+    device tensors); isend / irecv collect transfers of DEVICE buffers, start() launches all of them as ONE batch
+    (`batch_isend_irecv`: on RCCL the shards then arrive over different xGMI links concurrently) and returns at once —
+    lfx_sharded_encode_begin calls it last, so the shards are in flight while the caller decodes; wait() completes them.
+    With gloo (CPU rigs, the one-GPU self-test of bench.py) the buffers hop through host tensors.  A comm of ONE rank
+    without a process group has no callbacks at all (NULL: the drivers then exchange nothing)."""
 
     def __init__(self, dist, rank, world, device=None, group=None):
         import torch
         self.torch, self.dist, self.rank, self.world, self.group = torch, dist, rank, world, group
         self.host = dist is None or dist.get_backend() == "gloo"
         self.device = device if device is not None else "cpu"
-        self.ops, self.keep, self.copies = [], [], []
-        self._cbs = (_ffi.COMM_ALLGATHER(self._allgather), _ffi.COMM_P2P(self._isend), _ffi.COMM_P2P(self._irecv),
-                     _ffi.COMM_WAIT(self._wait))
-        self.c = _ffi.Comm(None, rank, world, *self._cbs)
+        self.ops, self.keep, self.copies, self.works = [], [], [], []
         self.error = None
+        if dist is None:
+            self._cbs = ()
+            self.c = _ffi.Comm(None, rank, world)
+            return
+        self._cbs = (_ffi.COMM_ALLGATHER(self._allgather), _ffi.COMM_P2P(self._isend), _ffi.COMM_P2P(self._irecv),
+                     _ffi.COMM_WAIT(self._wait), _ffi.COMM_WAIT(self._start))
+        self.c = _ffi.Comm(None, rank, world, *self._cbs)
 
     def _wrap(self, ptr, n):
         return (C.c_uint8 * n).from_address(ptr)
@@ -52,8 +58,11 @@ class TorchComm:
             return 1
 
     def _dev_tensor(self, ptr, n):
-        """a uint8 tensor over n bytes of device memory at `ptr` (no copy; the caller keeps the allocation alive)"""
+        """a uint8 tensor over n bytes of device memory at `ptr` (no copy; the caller keeps the allocation alive).  With
+        device "cpu" (the CPU rigs of tests/test_sharded_gloo.py) `ptr` is host memory."""
         torch = self.torch
+        if str(self.device) == "cpu":
+            return torch.frombuffer(self._wrap(ptr, n), dtype=torch.uint8)
 
         class _Ext:       # __cuda_array_interface__: the way to hand torch a raw device pointer
             pass
@@ -67,7 +76,7 @@ class TorchComm:
             if self.host:
                 t = t.cpu()
             self.keep.append(t)
-            self.ops.append(self.dist.P2POp(self.dist.isend, t, to))
+            self.ops.append(self.dist.P2POp(self.dist.isend, t, to, group=self.group))
             return 0
         except Exception as e:  # noqa: BLE001
             self.error = e
@@ -79,10 +88,21 @@ class TorchComm:
             if self.host:
                 h = self.torch.empty(nbytes, dtype=self.torch.uint8)
                 self.copies.append((dst, h))
-                self.ops.append(self.dist.P2POp(self.dist.irecv, h, frm))
+                self.ops.append(self.dist.P2POp(self.dist.irecv, h, frm, group=self.group))
             else:
                 self.keep.append(dst)
-                self.ops.append(self.dist.P2POp(self.dist.irecv, dst, frm))
+                self.ops.append(self.dist.P2POp(self.dist.irecv, dst, frm, group=self.group))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            self.error = e
+            return 1
+
+    def _start(self, _user):
+        """everything collected so far starts to move; returns without waiting"""
+        try:
+            if self.ops:
+                self.works += self.dist.batch_isend_irecv(self.ops)
+                self.ops = []
             return 0
         except Exception as e:  # noqa: BLE001
             self.error = e
@@ -90,16 +110,17 @@ class TorchComm:
 
     def _wait(self, _user):
         try:
-            if self.ops:
-                for w in self.dist.batch_isend_irecv(self.ops):
-                    w.wait()
+            if self._start(_user):
+                return 1
+            for w in self.works:
+                w.wait()
             for dst, h in self.copies:
                 dst.copy_(h)
             if not self.host and self.torch.cuda.is_available():
                 # (wait() orders the RCCL stream before torch's current stream, not before the context's own stream on
                 #  which the placement kernels run: block the host until the shards have landed)
                 self.torch.cuda.synchronize()
-            self.ops, self.keep, self.copies = [], [], []
+            self.works, self.keep, self.copies = [], [], []
             return 0
         except Exception as e:  # noqa: BLE001
             self.error = e
@@ -107,8 +128,10 @@ class TorchComm:
 
 
 def _comm(dist, rank, world, device=None, group=None):
-    if dist is None or world == 1:
-        return TorchComm(None, rank, world, device) if world == 1 else None
+    if dist is None and world > 1:
+        raise ValueError("a sharded call with world = %d needs a torch.distributed module (dist=None)" % world)
+    if world == 1:
+        return TorchComm(None, rank, world, device)
     return TorchComm(dist, rank, world, device, group)
 
 
@@ -173,8 +196,9 @@ def member_bytes(start_bits, part_lens):
 # ------------------------------------------------------------------------------------------------ sharded encode
 def encode_begin(ctx, rank, world, fmt, opts, sched, d_in, n, d_part, part_cap, d_member=None, member_cap=0, staging=None,
                  dist=None, group=None):
-    """lfx_sharded_encode_begin on torch uint8 device tensors → (handle, ShardedPart).  The shards travel to rank 0 (posted,
-    not awaited); encode_finish() completes the member.  Between the two the caller may work on its own shard (d_part)."""
+    """lfx_sharded_encode_begin on torch uint8 device tensors → (handle, ShardedPart).  The shards are travelling to rank 0
+    when this returns (posted AND started: lfx_comm.start, TorchComm._start); encode_finish() waits for them and completes
+    the member.  Between the two the caller may work on its own shard (d_part)."""
     cm = _comm(dist, rank, world, d_part.device, group)
     st = C.c_void_p(None)
     part = _ffi.ShardedPart()

@@ -80,7 +80,7 @@ pub type lfx_flush_cb = extern "C" fn(user: *mut c_void) -> c_int;
 pub type lfx_read_cb = extern "C" fn(user: *mut c_void, p: *mut u8, cap: usize) -> i64;
 pub type lfx_sink_cb = extern "C" fn(user: *mut c_void, codes: *const u32, n: usize);
 
-// ---- the N-GPU drivers (include/lfx.h, round 5): the caller's collectives as four callbacks
+// ---- the N-GPU drivers (include/lfx.h, round 5): the caller's collectives as callbacks (round 6: `start`)
 #[repr(C)]
 pub struct lfx_comm {
     pub user: *mut c_void,
@@ -90,6 +90,7 @@ pub struct lfx_comm {
     pub isend: Option<extern "C" fn(user: *mut c_void, d_buf: *const c_void, bytes: u64, to_rank: u32) -> c_int>,
     pub irecv: Option<extern "C" fn(user: *mut c_void, d_buf: *mut c_void, bytes: u64, from_rank: u32) -> c_int>,
     pub wait: Option<extern "C" fn(user: *mut c_void) -> c_int>,
+    pub start: Option<extern "C" fn(user: *mut c_void) -> c_int>,
 }
 #[repr(C)]
 #[derive(Default, Clone, Copy, Debug)]
@@ -121,6 +122,10 @@ extern "C" {
     pub fn lfx_ctx_new(device: c_int, status: *mut c_int) -> *mut lfx_ctx;
     pub fn lfx_ctx_free(c: *mut lfx_ctx);
     pub fn lfx_ctx_last_error(c: *const lfx_ctx) -> *const c_char;
+    pub fn lfx_ctx_match_fallbacks(c: *const lfx_ctx) -> u64;
+    /// page-locked host memory: buffers handed to lfx_encode_host / lfx_decode_host cross PCIe by DMA without staging
+    pub fn lfx_host_alloc(bytes: usize) -> *mut c_void;
+    pub fn lfx_host_free(p: *mut c_void);
 
     pub fn lfx_encoder_new(c: *mut lfx_ctx, format: c_int, o: *const lfx_encode_opts, w: lfx_write_cb,
                            f: Option<lfx_flush_cb>, user: *mut c_void, status: *mut c_int) -> *mut lfx_encoder;

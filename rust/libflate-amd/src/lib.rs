@@ -43,6 +43,33 @@ impl Context {
     pub(crate) fn last_error(&self) -> String {
         unsafe { CStr::from_ptr(ffi::lfx_ctx_last_error(self.0)).to_string_lossy().into_owned() }
     }
+    /// Encode passes this context ran on the fallback match kernel because the default kernel's hardware assumption
+    /// (ordered LDS exchanges) was seen violated: 0 on every part measured so far; a non-zero value
+    /// explains a three times slower match stage.
+    pub fn match_fallbacks(&self) -> u64 { unsafe { ffi::lfx_ctx_match_fallbacks(self.0) } }
+}
+
+/// Page-locked host memory (`lfx_host_alloc`): what a caller that moves large buffers through the one-shot host calls
+/// should hold them in — the DMA engine then reads / writes it directly (no staging copy, the transfer runs at link rate).
+/// Derefs to a byte slice.
+pub struct HostBuf { p: *mut u8, n: usize }
+unsafe impl Send for HostBuf {}
+impl HostBuf {
+    pub fn new(n: usize) -> io::Result<HostBuf> {
+        let p = unsafe { ffi::lfx_host_alloc(n.max(1)) } as *mut u8;
+        if p.is_null() { return Err(io::Error::new(io::ErrorKind::Other, "no page-locked memory to be had")); }
+        Ok(HostBuf { p, n })
+    }
+}
+impl Drop for HostBuf {
+    fn drop(&mut self) { unsafe { ffi::lfx_host_free(self.p as *mut c_void) } }
+}
+impl std::ops::Deref for HostBuf {
+    type Target = [u8];
+    fn deref(&self) -> &[u8] { unsafe { std::slice::from_raw_parts(self.p, self.n) } }
+}
+impl std::ops::DerefMut for HostBuf {
+    fn deref_mut(&mut self) -> &mut [u8] { unsafe { std::slice::from_raw_parts_mut(self.p, self.n) } }
 }
 
 /// The lazily created context of device 0 ("no hidden global state beyond lazily-created per-device

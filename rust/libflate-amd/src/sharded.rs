@@ -16,9 +16,12 @@ use crate::{ffi, Context};
 pub trait Collective {
     /// every rank contributes `send`; `recv` (world x send.len(), rank order) is complete on return
     fn allgather(&self, send: &[u8], recv: &mut [u8]) -> io::Result<()>;
-    /// post a transfer of `bytes` bytes of DEVICE memory (may return before it completes)
+    /// post a transfer of `bytes` bytes of DEVICE memory (may return before it completes; may only collect it)
     fn isend(&self, d_buf: *const c_void, bytes: u64, to_rank: u32) -> io::Result<()>;
     fn irecv(&self, d_buf: *mut c_void, bytes: u64, from_rank: u32) -> io::Result<()>;
+    /// everything posted so far begins to move now; returns without waiting (`encode_begin` calls it last, so the shards
+    /// travel while the caller works).  The default suits a collective whose `isend` / `irecv` start at once.
+    fn start(&self) -> io::Result<()> { Ok(()) }
     /// everything this rank posted is complete
     fn wait(&self) -> io::Result<()>;
 }
@@ -44,6 +47,10 @@ extern "C" fn tr_wait<C: Collective>(user: *mut c_void) -> c_int {
     let (c, _) = unsafe { &*(user as *const (&C, u32)) };
     c.wait().is_err() as c_int
 }
+extern "C" fn tr_start<C: Collective>(user: *mut c_void) -> c_int {
+    let (c, _) = unsafe { &*(user as *const (&C, u32)) };
+    c.start().is_err() as c_int
+}
 
 impl<'a> Comm<'a> {
     /// `slot` keeps the (collective, world) pair the callbacks read: it must live as long as the `Comm`
@@ -51,17 +58,17 @@ impl<'a> Comm<'a> {
         *slot = Some((c, world));
         let user = slot.as_ref().unwrap() as *const (&C, u32) as *mut c_void;
         Comm { raw: ffi::lfx_comm { user, rank, world, allgather: Some(tr_allgather::<C>), isend: Some(tr_isend::<C>),
-                                    irecv: Some(tr_irecv::<C>), wait: Some(tr_wait::<C>) }, rccl: false, _c: std::marker::PhantomData }
+                                    irecv: Some(tr_irecv::<C>), wait: Some(tr_wait::<C>), start: Some(tr_start::<C>) }, rccl: false, _c: std::marker::PhantomData }
     }
     /// one rank, no collective at all (world = 1)
     pub fn single() -> Comm<'static> {
-        Comm { raw: ffi::lfx_comm { user: std::ptr::null_mut(), rank: 0, world: 1, allgather: None, isend: None, irecv: None, wait: None },
+        Comm { raw: ffi::lfx_comm { user: std::ptr::null_mut(), rank: 0, world: 1, allgather: None, isend: None, irecv: None, wait: None, start: None },
                rccl: false, _c: std::marker::PhantomData }
     }
     /// RCCL over xGMI: `nccl_comm` is an `ncclComm_t`, `hip_stream` the `hipStream_t` its collectives run on
     /// (librccl is loaded at run time).
     pub fn rccl(nccl_comm: *mut c_void, hip_stream: *mut c_void, rank: u32, world: u32) -> io::Result<Comm<'static>> {
-        let mut raw = ffi::lfx_comm { user: std::ptr::null_mut(), rank, world, allgather: None, isend: None, irecv: None, wait: None };
+        let mut raw = ffi::lfx_comm { user: std::ptr::null_mut(), rank, world, allgather: None, isend: None, irecv: None, wait: None, start: None };
         let rc = unsafe { ffi::lfx_comm_rccl(nccl_comm, hip_stream, rank, world, &mut raw) };
         if rc != ffi::LFX_OK { return Err(io::Error::new(io::ErrorKind::Other, format!("RCCL is not available (status {})", rc))); }
         Ok(Comm { raw, rccl: true, _c: std::marker::PhantomData })
@@ -95,11 +102,23 @@ pub fn encode_begin<'a>(ctx: &'a Context, comm: &'a Comm<'a>, format: c_int, opt
 }
 impl<'a> EncodeInFlight<'a> {
     /// → the member's length on rank 0 (0 elsewhere)
-    pub fn finish(self) -> io::Result<u64> {
+    pub fn finish(mut self) -> io::Result<u64> {
         let mut len = 0u64;
-        let rc = unsafe { ffi::lfx_sharded_encode_finish(self.ctx.0, &self.comm.raw, self.state, &mut len) };
+        let state = std::mem::replace(&mut self.state, std::ptr::null_mut());      // (finish frees it: Drop must not)
+        let rc = unsafe { ffi::lfx_sharded_encode_finish(self.ctx.0, &self.comm.raw, state, &mut len) };
         if rc != ffi::LFX_OK { return Err(err(self.ctx, rc, "lfx_sharded_encode_finish")); }
         Ok(len)
+    }
+}
+/// Dropped without `finish` (an early return with `?`): the transfers this rank posted are still completed and the state is
+/// freed — the peers must not be left waiting in their own `finish`.
+impl<'a> Drop for EncodeInFlight<'a> {
+    fn drop(&mut self) {
+        if !self.state.is_null() {
+            let mut len = 0u64;
+            unsafe { ffi::lfx_sharded_encode_finish(self.ctx.0, &self.comm.raw, self.state, &mut len) };
+            self.state = std::ptr::null_mut();
+        }
     }
 }
 

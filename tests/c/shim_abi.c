@@ -246,10 +246,24 @@ int main(void) {
         }
         uint64_t one_len = 0;
         CHECK(lfx_encode_host(c, LFX_GZIP, &o, &sc, in, n, one, bound, &one_len) == LFX_OK);
+        /* page-locked buffers (lfx_host_alloc; rust: HostBuf) through the same call: the same bytes (3 MiB is above the size
+         * from which pageable memory is staged by the copy threads, so `one` above took that path and this one plain DMA) */
+        {
+            unsigned char *pin_in = lfx_host_alloc(n), *pin_out = lfx_host_alloc(bound);
+            CHECK(pin_in && pin_out);
+            memcpy(pin_in, in, n);
+            uint64_t pl = 0;
+            CHECK(lfx_encode_host(c, LFX_GZIP, &o, &sc, pin_in, n, pin_out, bound, &pl) == LFX_OK);
+            CHECK(pl == one_len && !memcmp(pin_out, one, one_len));
+            lfx_host_free(pin_in);
+            lfx_host_free(pin_out);
+            lfx_host_free(NULL);
+            CHECK(lfx_ctx_match_fallbacks(c) == 0);
+        }
         void *d_in, *d_part, *d_member, *d_out;
         CHECK(!p_hipMalloc(&d_in, n) && !p_hipMalloc(&d_part, bound) && !p_hipMalloc(&d_member, bound) && !p_hipMalloc(&d_out, n));
         CHECK(!p_hipMemcpy(d_in, in, n, 1 /* hipMemcpyHostToDevice */));
-        lfx_comm cm = {NULL, 0, 1, NULL, NULL, NULL, NULL};
+        lfx_comm cm = {NULL, 0, 1, NULL, NULL, NULL, NULL, NULL};
         lfx_sharded_enc *stt = NULL;
         lfx_sharded_part part;
         CHECK(lfx_sharded_encode_begin(c, &cm, LFX_GZIP, &o, &sc, d_in, n, d_part, bound, d_member, bound, NULL, 0, &stt, &part) == LFX_OK);
@@ -272,6 +286,72 @@ int main(void) {
         memset(&rc, 0, sizeof rc);
         CHECK(lfx_comm_rccl(NULL, NULL, 0, 1, &rc) == LFX_E_ARG);
         lfx_comm_rccl_free(&rc);
+        /* ---- the RCCL binding EXECUTED: a communicator of one rank on this GPU.  Every callback runs
+         *      on real RCCL: the all-gather; a self send + receive inside ONE group (legal in NCCL), started by `start` and
+         *      completed by `wait`; an all-gather issued while a group is still open (it has to close the group first — inside
+         *      it the collective would only be queued and `recv` read too early); then both drivers over this comm (at one
+         *      rank their all-gathers go through RCCL since round 6; the member must not change). */
+        void *rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!rccl) rccl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!rccl) rccl = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (rccl && !getenv("LFX_SHIM_NO_RCCL")) {
+            typedef struct { char internal[128]; } nccl_uid;
+            int (*p_uid)(nccl_uid *) = (int (*)(nccl_uid *))dlsym(rccl, "ncclGetUniqueId");
+            int (*p_init)(void **, int, nccl_uid, int) = (int (*)(void **, int, nccl_uid, int))dlsym(rccl, "ncclCommInitRank");
+            int (*p_destroy)(void *) = (int (*)(void *))dlsym(rccl, "ncclCommDestroy");
+            CHECK(p_uid && p_init && p_destroy);
+            nccl_uid uid;
+            void *ncomm = NULL;
+            CHECK(p_uid(&uid) == 0);
+            CHECK(p_init(&ncomm, 1, uid, 0) == 0 && ncomm);
+            CHECK(lfx_comm_rccl(ncomm, NULL /* the null stream */, 0, 1, &rc) == LFX_OK);
+            CHECK(rc.allgather && rc.isend && rc.irecv && rc.wait && rc.start && rc.world == 1 && rc.rank == 0);
+            unsigned char sendb[40], recvb[40];
+            for (int i = 0; i < 40; i++) sendb[i] = (unsigned char)(3 * i + 1);
+            memset(recvb, 0, sizeof recvb);
+            CHECK(rc.allgather(rc.user, sendb, recvb, 40) == 0 && !memcmp(sendb, recvb, 40));
+            const size_t tn = 3u << 20;                                   /* a shard-sized transfer to self */
+            void *d_a, *d_b;
+            CHECK(!p_hipMalloc(&d_a, tn) && !p_hipMalloc(&d_b, tn));
+            CHECK(!p_hipMemcpy(d_a, in, tn, 1) && !p_hipMemcpy(d_b, back, tn, 1));
+            CHECK(rc.irecv(rc.user, d_b, tn, 0) == 0 && rc.isend(rc.user, d_a, tn, 0) == 0);
+            CHECK(rc.start(rc.user) == 0);
+            CHECK(rc.wait(rc.user) == 0);
+            unsigned char *chk = malloc(tn);
+            CHECK(chk && !p_hipMemcpy(chk, d_b, tn, 2) && !memcmp(chk, in, tn));
+            /* posted but not started, then an all-gather: the group is closed first, the gather's result is real, and the
+             * posted transfer completes by wait() */
+            CHECK(!p_hipMemcpy(d_b, one, tn < one_len ? tn : one_len, 1));
+            CHECK(rc.irecv(rc.user, d_b, tn, 0) == 0 && rc.isend(rc.user, d_a, tn, 0) == 0);
+            memset(recvb, 0, sizeof recvb);
+            CHECK(rc.allgather(rc.user, sendb, recvb, 40) == 0 && !memcmp(sendb, recvb, 40));
+            CHECK(rc.wait(rc.user) == 0);
+            CHECK(!p_hipMemcpy(chk, d_b, tn, 2) && !memcmp(chk, in, tn));
+            free(chk);
+            p_hipFree(d_a); p_hipFree(d_b);
+            /* both drivers over the RCCL comm */
+            lfx_sharded_enc *st2 = NULL;
+            lfx_sharded_part part2;
+            CHECK(!p_hipMemcpy(d_member, back, 16, 1));
+            CHECK(lfx_sharded_encode_begin(c, &rc, LFX_GZIP, &o, &sc, d_in, n, d_part, bound, d_member, bound, NULL, 0, &st2, &part2) == LFX_OK);
+            CHECK(st2 && part2.member_len == one_len && part2.check == part.check);
+            uint64_t mlen2 = 0;
+            CHECK(lfx_sharded_encode_finish(c, &rc, st2, &mlen2) == LFX_OK && mlen2 == one_len);
+            CHECK(!p_hipMemcpy(mem, d_member, mlen2, 2) && !memcmp(mem, one, mlen2));
+            memset(&sl, 0, sizeof sl);
+            CHECK(lfx_sharded_decode(c, &rc, d_member, mlen2, 0, mlen2, part2.start_bit, mlen2, d_out, n, &sl) == LFX_OK);
+            CHECK(sl.out_len == n && sl.total_out == n && sl.crc32 == part.check);
+            CHECK(!p_hipMemcpy(back, d_out, n, 2) && !memcmp(back, in, n));
+            /* a member buffer that is too small is refused by the exchange itself (every rank the same verdict) */
+            st2 = NULL;
+            CHECK(lfx_sharded_encode_begin(c, &rc, LFX_GZIP, &o, &sc, d_in, n, d_part, bound, d_member, one_len - 1, NULL, 0, &st2, &part2) == LFX_E_NOSPACE);
+            CHECK(st2 == NULL);
+            lfx_comm_rccl_free(&rc);
+            CHECK(p_destroy(ncomm) == 0);
+            printf("rccl binding ok (1 rank: all-gather, grouped self send/recv, start/wait, both drivers)\n");
+        } else {
+            printf("rccl binding skipped (librccl not loadable)\n");
+        }
         p_hipFree(d_in); p_hipFree(d_part); p_hipFree(d_member); p_hipFree(d_out);
         free(in); free(one); free(mem); free(back);
     }

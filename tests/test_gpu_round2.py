@@ -442,3 +442,6 @@ def test_shim_abi_program(env):
     from test_abi import _shim_binary, _shim_env
     out = subprocess.run([_shim_binary()], env=_shim_env(), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "shim abi ok" in out.stdout, (out.stdout, out.stderr)
+    # round 6: lfx_comm_rccl EXECUTED on a one-rank RCCL communicator (all-gather, grouped self send / recv, start / wait,
+    # both drivers) — torch ships librccl, so "skipped" would mean the loader path is broken
+    assert "rccl binding ok" in out.stdout, (out.stdout, out.stderr)

@@ -1,0 +1,135 @@
+"""GPU: round-6 cases — the drop-in surface on HOST memory.
+
+* cfg1 as SURVEY.md §8d words it: `gzip.compress(TEXT(1 MiB), mtime=0)` made by python, decoded through the STREAM ABI with
+  8 KiB reads (lfx_decoder_read; the reference's `io::copy` out of a `gzip::Decoder`, src/gzip.rs:1018-1047,
+  examples/flate.rs:96-97) — and by the oracle on the CPU; both must give the input back.
+* lfx_encode_host / lfx_decode_host on pageable and on page-locked buffers (lfx_hostio.h): the bytes of the oracle at sizes
+  around the staging thresholds.
+* The io::copy protocol (8192-byte write() calls, examples/flate.rs:52) through the stream encoder with page-locked pending /
+  output buffers, at several batch sizes: the oracle's bytes for the same write schedule."""
+import ctypes as C
+import gzip as pygzip
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_parity import ctx, enc, ffi, lfx, synth  # noqa: F401  (fixtures)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_cfg1_python_gzip_1mib_stream_api_8k_reads(ctx, ffi, oracle, synth):
+    import stream_copy
+    data = synth.text(1 << 20, seed=synth.SEED_BASE + 1)
+    member = pygzip.compress(data.tobytes(), mtime=0)
+    # the oracle (CPU restatement of gzip::Decoder) ...
+    rc, out, used, _ = oracle.decode(oracle.GZIP, member)
+    assert rc == 0 and out == data.tobytes() and used == len(member)
+    # ... and the HIP path through the stream ABI, 8 KiB reads
+    src = np.frombuffer(member, dtype=np.uint8)
+    dec = np.zeros(data.size + 8192, dtype=np.uint8)
+    rc, ol, _t = stream_copy.decode(ctx, ffi.GZIP, src.ctypes.data, src.size, 8192, dec.ctypes.data, dec.size)
+    assert rc == 0 and ol == data.size and (dec[:ol] == data).all()
+    # the same member through read sizes that do not divide anything
+    for chunk in (1, 4093, 70001):
+        if chunk == 1:
+            small = pygzip.compress(data[:20000].tobytes(), mtime=0)
+            s2 = np.frombuffer(small, dtype=np.uint8)
+            rc, ol, _t = stream_copy.decode(ctx, ffi.GZIP, s2.ctypes.data, s2.size, 1, dec.ctypes.data, dec.size)
+            assert rc == 0 and ol == 20000 and (dec[:ol] == data[:20000]).all()
+        else:
+            rc, ol, _t = stream_copy.decode(ctx, ffi.GZIP, src.ctypes.data, src.size, chunk, dec.ctypes.data, dec.size)
+            assert rc == 0 and ol == data.size and (dec[:ol] == data).all()
+
+
+@pytest.mark.parametrize("n", [0, 1, 70000, (2 << 20) - 1, 2 << 20, (9 << 20) + 3, 40 << 20])
+def test_host_calls_pageable_and_pinned_vs_oracle(ctx, ffi, oracle, synth, n):
+    """H2D / D2H by copy threads through page-locked slabs (pageable memory, from 2 MiB on) and by plain DMA (page-locked
+    memory): same bytes either way, equal to the oracle's."""
+    L = ffi.lib()
+    data = synth.text(max(n, 1))[:n]
+    opts, sched = ffi.make_opts(mtime=3), ffi.make_schedule(8192)
+    want = oracle.encode(oracle.GZIP, data.tobytes(), write_size=8192, mtime=3)
+    bound = L.lfx_encode_bound(n, C.byref(opts), C.byref(sched))
+    out = np.zeros(bound, dtype=np.uint8)
+    back = np.zeros(max(n, 1), dtype=np.uint8)
+    m = ctx.encode_host_ptr(ffi.GZIP, data.ctypes.data if n else None, n, out.ctypes.data, bound, opts, sched)
+    assert out[:m].tobytes() == want
+    rc, ol, used, msg = ctx.decode_host_ptr(ffi.GZIP, out.ctypes.data, m, back.ctypes.data, n)
+    assert (rc, ol, used) == (0, n, m), msg
+    assert (back[:n] == data).all()
+    pin_in, pin_out, pin_back = L.lfx_host_alloc(max(n, 1)), L.lfx_host_alloc(bound), L.lfx_host_alloc(max(n, 1))
+    assert pin_in and pin_out and pin_back
+    try:
+        if n:
+            C.memmove(pin_in, data.ctypes.data, n)
+        m2 = ctx.encode_host_ptr(ffi.GZIP, pin_in, n, pin_out, bound, opts, sched)
+        assert m2 == m and C.string_at(pin_out, m2) == want
+        rc, ol, used, msg = ctx.decode_host_ptr(ffi.GZIP, pin_out, m2, pin_back, n)
+        assert (rc, ol, used) == (0, n, m), msg
+        assert C.string_at(pin_back, n) == data.tobytes()
+        # a truncated member from host memory: the reference's error kind, output so far delivered
+        if n >= 70000:
+            rc, ol, used, msg = ctx.decode_host_ptr(ffi.GZIP, pin_out, m2 - 9, pin_back, n)
+            assert rc == ffi.E_UNEXPECTED_EOF
+    finally:
+        for p in (pin_in, pin_out, pin_back):
+            L.lfx_host_free(p)
+    assert ctx.match_fallbacks() == 0
+
+
+def test_io_copy_protocol_through_the_stream_abi_vs_oracle(ffi, lfx, oracle, synth, monkeypatch):
+    """8192-byte write() calls into gzip::Encoder, 8192-byte read() calls out of gzip::Decoder (examples/flate.rs:52,96-97),
+    from C; the stream encoder's batches (page-locked pending buffer, DMA out of it, output handed to the sink from
+    page-locked staging) at three batch sizes — the write schedule, not the batching, decides the bytes."""
+    import stream_copy
+    n = 40 << 20
+    data = synth.text(n, seed=synth.SEED_BASE + 9)
+    want = oracle.encode(oracle.GZIP, data.tobytes(), write_size=8192, mtime=0)
+    opts = ffi.make_opts(mtime=0)
+    encb = np.zeros(n + n // 4 + 4096, dtype=np.uint8)
+    dec = np.zeros(n, dtype=np.uint8)
+    for batch_mb in (None, 1, 32):
+        if batch_mb is None:
+            monkeypatch.delenv("LFX_ENC_BATCH_MB", raising=False)
+        else:
+            monkeypatch.setenv("LFX_ENC_BATCH_MB", str(batch_mb))
+        c2 = lfx.Context(0)                       # (diagnostic switches are read when a context is made)
+        try:
+            rc, m, _t = stream_copy.encode(c2, ffi.GZIP, opts, data.ctypes.data, n, 8192, encb.ctypes.data, encb.size)
+            assert rc == 0 and encb[:m].tobytes() == want, (batch_mb, rc, m, len(want))
+            dec[:] = 0
+            rc, ol, _t = stream_copy.decode(c2, ffi.GZIP, encb.ctypes.data, m, 8192, dec.ctypes.data, n)
+            assert rc == 0 and ol == n and (dec == data).all(), batch_mb
+        finally:
+            c2.close()
+    # odd write sizes: another schedule, another stream — still the oracle's
+    for ws in (1000, 65537):
+        want2 = oracle.encode(oracle.ZLIB, data[:5 << 20].tobytes(), write_size=ws)
+        c2 = lfx.Context(0)
+        try:
+            rc, m, _t = stream_copy.encode(c2, ffi.ZLIB, None, data.ctypes.data, 5 << 20, ws, encb.ctypes.data, encb.size)
+            assert rc == 0 and encb[:m].tobytes() == want2, ws
+        finally:
+            c2.close()
+
+
+def test_gzip_no_compression_then_header_keeps_the_headers_level(ctx, lfx):
+    """EncodeOptions::no_compression() resets the header's level when it is called (gzip.rs:703), header(h)
+    afterwards replaces the header — level included (gzip.rs:717-720): XFL 4 survives in that order, not in the other."""
+    import io
+    cloned = dict(modification_time=5, os=3, is_text=False, is_verified=False, extra_field=None, filename=None, comment=None, xfl=4)
+    for opts, xfl in ((lfx.gzip.EncodeOptions().no_compression().header(cloned), 4),
+                      (lfx.gzip.EncodeOptions().header(cloned).no_compression(), 0)):
+        sink = io.BytesIO()
+        e = lfx.gzip.Encoder.with_options(sink, opts, context=ctx)
+        e.write(b"Hello World!")
+        e.finish()
+        b = sink.getvalue()
+        assert b[:4] == b"\x1f\x8b\x08\x00" and b[4:8] == (5).to_bytes(4, "little") and b[8] == xfl
+        assert pygzip.decompress(b) == b"Hello World!"

@@ -437,6 +437,11 @@ def test_gzip_options_header_carries_the_level(ffi):
         assert "comment" not in o._kw and "extra" not in o._kw
     o = gzip.EncodeOptions().header(gzip.HeaderBuilder().modification_time(9).finish())
     assert o._kw["lz77_level"] == 3 and o._kw["mtime"] == 9
+    # no_compression() resets the level when it is called (gzip.rs:703); header() afterwards replaces it again
+    # (gzip.rs:717-720) — call order decides, and the library writes what it is handed
+    a = gzip.EncodeOptions().header(dict(cloned, xfl=4)).no_compression()
+    b = gzip.EncodeOptions().no_compression().header(dict(cloned, xfl=4))
+    assert a._kw["lz77_level"] == 3 and b._kw["lz77_level"] == 2 and a._kw["no_compression"] == b._kw["no_compression"] == 1
 
 
 def test_header_window_model_equals_serial_walk():

@@ -216,3 +216,65 @@ def test_failure_on_one_rank_is_raised_on_all_ranks():
     for p in procs:
         p.join(timeout=60)
     assert res == ("ok", 2), res
+
+
+def _p2p_worker(rank, world, port, q):
+    """the comm's point-to-point half.  isend / irecv only COLLECT transfers; `start` launches them and
+    returns (the shards then travel while the caller decodes); an all-gather between start and wait must not disturb them;
+    wait completes.  Host memory stands in for device buffers (TorchComm with device "cpu"), driven through the C struct's
+    function pointers exactly as lfx_sharded_encode_begin / _finish drive them."""
+    try:
+        for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests")):
+            sys.path.insert(0, p)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import ctypes as C
+        import numpy as np
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from libflate_amd import sharded
+        cm = sharded.TorchComm(dist, rank, world, "cpu")
+        n = 1 << 20
+        ok = True
+        if rank == 0:
+            bufs = [np.zeros(n + r, dtype=np.uint8) for r in range(1, world)]
+            for r, b in zip(range(1, world), bufs):
+                ok &= cm.c.irecv(None, b.ctypes.data, b.size, r) == 0
+            ok &= len(cm.ops) == world - 1 and not cm.works          # collected, nothing moving yet
+        else:
+            mine = (np.arange(n + rank, dtype=np.uint32) * (rank + 7) & 0xFF).astype(np.uint8)
+            ok &= cm.c.isend(None, mine.ctypes.data, mine.size, 0) == 0
+            ok &= len(cm.ops) == 1 and not cm.works
+        ok &= cm.c.start(None) == 0
+        ok &= not cm.ops and len(cm.works) == (world - 1 if rank == 0 else 1)      # launched, not awaited
+        # a small all-gather while the transfers are in flight (what lfx_sharded_decode does between begin and finish)
+        send = (C.c_uint8 * 8)(*([rank + 1] * 8))
+        recv = (C.c_uint8 * (8 * world))()
+        ok &= cm.c.allgather(None, C.addressof(send), C.addressof(recv), 8) == 0
+        ok &= bytes(recv) == b"".join(bytes([r + 1] * 8) for r in range(world))
+        ok &= cm.c.wait(None) == 0 and not cm.works
+        if rank == 0:
+            for r, b in zip(range(1, world), bufs):
+                want = (np.arange(n + r, dtype=np.uint32) * (r + 7) & 0xFF).astype(np.uint8)
+                ok &= bool((b == want).all())
+            q.put(("ok", bool(ok), cm.error))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc()))
+        raise
+
+
+def test_comm_start_launches_posted_transfers_world3():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0] == "ok" and res[1], res
