@@ -348,16 +348,27 @@ def sub_stream_api(ctx, _ffi, data, enc_want=None, chunk=8192):
     rc, m, te = stream_copy.encode(ctx, _ffi.GZIP, opts, data.ctypes.data, n, chunk, enc.ctypes.data, enc.size)
     if rc:
         raise RuntimeError("stream encode failed: %d" % rc)
+    enc_gpu_s, enc_gpu_calls = stream_copy.last_split()
     rc, ol, td = stream_copy.decode(ctx, _ffi.GZIP, enc.ctypes.data, m, chunk, dec.ctypes.data, n)
     if rc:
         raise RuntimeError("stream decode failed: %d" % rc)
+    dec_gpu_s, dec_gpu_calls = stream_copy.last_split()
+    scratch = np.empty(n, dtype=np.uint8)
+    t_copy = min(stream_copy.memcpy_seconds(scratch.ctypes.data, data.ctypes.data, n, chunk) for _ in range(2))
     same = None if enc_want is None else bool(m == len(enc_want) and enc[:m].tobytes() == enc_want)
     return {"workload": "io::copy protocol on the stream ABI: lfx_encoder_write in %d-byte calls + lfx_decoder_read with %d-byte "
                         "reads over %d MiB of TEXT (gzip, default options), host memory, C driver tools/stream_copy.c" % (chunk, chunk, n >> 20),
             "value": round(n / (te + td) / 1e9, 3), "unit": "GB/s", "encode_GBps": round(n / te / 1e9, 3),
             "decode_GBps": round(n / td / 1e9, 3), "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
             "compressed_bytes": int(m), "round_trip_ok": bool(ol == n and (dec == data).all()),
-            "equals_one_shot_output": same}
+            "equals_one_shot_output": same,
+            # where the time goes: the calls that wait for GPU work (a write() that closes a batch and collects the one before,
+            # finish(); a read() that decodes the next window) against the protocol's own copying
+            "encode_ms_in_batch_calls": round(enc_gpu_s * 1e3, 2), "encode_batch_calls": enc_gpu_calls,
+            "decode_ms_in_window_calls": round(dec_gpu_s * 1e3, 2), "decode_window_calls": dec_gpu_calls,
+            "host_memcpy_ms": round(t_copy * 1e3, 2),
+            "host_memcpy_how": "one plain pass over the %d MiB in %d-byte memcpy calls on this host, one thread: what each of "
+                               "the protocol's four copies (into the encoder, sink, cursor, out of the decoder) costs at best" % (n >> 20, chunk)}
 
 
 def sub_raw_deflate(ctx, torch, _ffi, C, d_in, n, write, reps=3):

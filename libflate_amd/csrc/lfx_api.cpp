@@ -305,6 +305,9 @@ extern "C" void lfx_ctx_free(lfx_ctx *cc) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : c->all_bufs()) b->release();
+    for (DevBuf &b : c->dev_pool) b.release();
+    c->dev_pool.clear();
+    c->pin_pool.clear();
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_res) (void)hipHostFree(c->h_res);
     c->hostio.release();
@@ -623,11 +626,16 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     return LFX_OK;
 }
 
+int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, bool use_device_check, uint64_t total_n,
+                const uint8_t *prefix, uint32_t prefix_len, uint64_t start_bit, uint8_t *d_out, uint64_t cap,
+                EncodeResult *host_res, EncodeResult *async_slot = nullptr);
 // Stage B: offsets → pack → framing.  `prefix` bytes are placed at the start of d_out; the DEFLATE
 // bits start at bit `start_bit` of d_out (prefix may end with a partial byte).
 int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, bool use_device_check,
                 uint64_t total_n, const uint8_t *prefix, uint32_t prefix_len, uint64_t start_bit,
-                uint8_t *d_out, uint64_t cap, EncodeResult *host_res) {
+                uint8_t *d_out, uint64_t cap, EncodeResult *host_res, EncodeResult *async_slot) {
+    // async_slot (page-locked, the caller's own): the result is copied there and the call returns WITHOUT waiting — the
+    // stream encoder's batch in flight; the caller synchronises and reads the slot itself.  host_res is not touched then.
     (void)hipSetDevice(c->device);
     hipStream_t st = c->stream;
     if (((uintptr_t)d_out & 3) != 0) { c->set_error("output buffer must be 4-byte aligned"); return LFX_E_ARG; }
@@ -665,8 +673,9 @@ int encode_emit(Ctx *c, int format, bool with_trailer, uint32_t trailer_check, b
         HIP_TRY(hipMemcpyAsync((uint8_t *)dres + offsetof(EncodeResult, adler32), &trailer_check, 4, hipMemcpyHostToDevice, st));
     }
     LAUNCH_TRY(launch_trailer(st, with_trailer ? format : LFX_DEFLATE, (uint32_t)total_n, 0, dres, (uint32_t *)d_out));
-    HIP_TRY(hipMemcpyAsync(c->h_res, dres, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(async_slot ? (void *)async_slot : c->h_res, dres, sizeof(EncodeResult), hipMemcpyDeviceToHost, st));
     c->phase("frame");
+    if (async_slot) return LFX_OK;
     HIP_TRY(hipStreamSynchronize(st));
     *host_res = *(EncodeResult *)c->h_res;
     if (host_res->status != 0) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
@@ -971,6 +980,12 @@ struct lfx_encoder {
     PinVec pending;                     // input bytes not yet encoded: the planner's byte 0 is pending[0].  Page-locked (lfx_hostio.h):
                                         // the batch's H2D copy is one DMA transfer straight out of it
     PinVec h_out;                       // a batch's output lands here (page-locked) and goes to the sink from here: no copy between
+    // one batch in flight on the GPU (bytes mode; enc_launch / enc_collect)
+    PinVec inflight_buf, h_res;         // the batch's input bytes (DMA source until collected); result slot + the shared byte
+    bool inflight = false, inflight_final = false;
+    uint64_t inflight_n = 0, inflight_bound = 0;
+    Plan inflight_plan;
+    hipEvent_t ev_out = nullptr, ev_small = nullptr;
     Planner *pl = nullptr;              // incremental write-schedule state (chunks / blocks of `pending`)
     uint64_t total_in = 0, encoded_in = 0;
     uint32_t crc = 0, adler = 1;        // running container checksum (combined per batch)
@@ -996,43 +1011,108 @@ static int enc_emit_bytes(lfx_encoder *e, const uint8_t *p, size_t n) {
     return LFX_OK;
 }
 
-// Encode the closed blocks of `pending` (all of it when `final`, which first closes the stream) as one GPU batch and
-// hand the bytes to the sink; the open block's bytes stay pending.
-static int enc_run(lfx_encoder *e, bool final) {
+// ---- bytes mode: the closed blocks of `pending` as one GPU batch, ONE BATCH IN FLIGHT (round 6).
+// The write() that closes a batch starts it — H2D straight out of the page-locked pending buffer, match … pack — and returns;
+// the GPU works while the caller copies the next batch's bytes in (io::copy: 8192 at a time).  The NEXT batch's start (or
+// flush / finish) collects it: result, the partial last byte (the next batch's first bits share it), the bytes to the sink.
+// A failure of a batch therefore surfaces at the call that collects it — like an io::BufWriter's; the bytes and their
+// order are those of the synchronous form.
+struct EncCollected { uint64_t whole = 0; bool have = false; };
+
+// start the batch; nothing is waited for.  The batch's bytes move to `inflight_buf`, the open block's bytes stay pending.
+static int enc_launch(lfx_encoder *e, Plan &&plan, uint64_t n, bool final) {
     Ctx *c = e->c;
-    std::lock_guard<std::recursive_mutex> lock(c->mu);
-    (void)hipSetDevice(c->device);
-    if (final) e->pl->finish();
-    const uint64_t n = final ? e->pending.size() : e->pl->closed_bytes();
-    Plan plan = final ? std::move(e->pl->plan()) : e->pl->take_closed();
-    if (plan.blocks.empty()) return LFX_OK;
     int rc;
     if ((rc = e->d_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
     const uint64_t bound = n + n / 4 + 1024 * (uint64_t)plan.blocks.size() + 128;
     if ((rc = e->d_out.reserve(bound))) return rc;
-    if (n && hipMemcpyAsync(e->d_in.p, e->pending.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
-    EncodeResult res{};
-    uint8_t prefix[1] = {e->carry};
-    for (;;) {
-        if ((rc = encode_prepare(c, plan, e->po, (const uint8_t *)e->d_in.p, n, e->format == LFX_GZIP ? 1 : e->format == LFX_ZLIB ? 2 : 0))) { e->err = c->err; return rc; }
-        // the container trailer is written by the host here (the checksum spans batches)
-        rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits,
-                         (uint8_t *)e->d_out.p, bound & ~3ull, &res);
-        if (match_violation(c, res)) continue;
-        break;
-    }
+    if (e->h_res.size() < 256) e->h_res.resize(256);
+    // ping-pong: appends of later writes must not move (or free) memory a DMA transfer is still reading
+    e->inflight_buf.assign(e->pending.begin() + (std::ptrdiff_t)n, e->pending.end());
+    e->inflight_buf.swap(e->pending);              // pending = the open block's bytes, inflight_buf = the batch (its first n bytes)
+    if (n && hipMemcpyAsync(e->d_in.p, e->inflight_buf.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
+    const uint8_t prefix[1] = {e->carry};
+    if ((rc = encode_prepare(c, plan, e->po, (const uint8_t *)e->d_in.p, n, e->format == LFX_GZIP ? 1 : e->format == LFX_ZLIB ? 2 : 0))) { e->err = c->err; return rc; }
+    // the container trailer is written by the host (the checksum spans batches)
+    rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits, (uint8_t *)e->d_out.p,
+                     bound & ~3ull, nullptr, (EncodeResult *)e->h_res.data());
     if (rc) { e->err = c->err; return rc; }
+    e->inflight = true;
+    e->inflight_final = final;
+    e->inflight_n = n;
+    e->inflight_bound = bound;
+    e->inflight_plan = std::move(plan);
+    return LFX_OK;
+}
+
+// wait for the batch in flight, take its result and the byte the next batch shares with it, queue its bytes' way back
+// (into h_out; `*done` tells when they have arrived)
+static int enc_collect(lfx_encoder *e, EncCollected *out) {
+    Ctx *c = e->c;
+    out->have = false;
+    if (!e->inflight) return LFX_OK;
+    e->inflight = false;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return LFX_E_DEVICE;
+    EncodeResult res = *(const EncodeResult *)e->h_res.data();
+    const uint64_t n = e->inflight_n;
+    int rc = LFX_OK;
+    if (match_violation(c, res)) {
+        // (never observed) the batch's bytes are still in d_in: once more, on the fallback kernel, synchronously
+        const uint8_t prefix[1] = {e->carry};
+        if ((rc = encode_prepare(c, e->inflight_plan, e->po, (const uint8_t *)e->d_in.p, n, e->format == LFX_GZIP ? 1 : e->format == LFX_ZLIB ? 2 : 0))) { e->err = c->err; return rc; }
+        rc = encode_emit(c, LFX_DEFLATE, false, 0, true, 0, prefix, e->carry_bits ? 1 : 0, e->carry_bits, (uint8_t *)e->d_out.p,
+                         e->inflight_bound & ~3ull, &res);
+        if (rc) { e->err = c->err; return rc; }
+    }
+    if (res.status != 0) { c->set_error("output capacity too small"); e->err = c->err; return LFX_E_NOSPACE; }
     if (e->format == LFX_GZIP) e->crc = e->encoded_in == 0 ? res.crc32 : lfx_crc32_combine(e->crc, res.crc32, n);
     if (e->format == LFX_ZLIB) e->adler = e->encoded_in == 0 ? res.adler32 : lfx_adler32_combine(e->adler, res.adler32, n);
     e->encoded_in += n;
-    const uint64_t whole = final ? (res.end_bit + 7) / 8 : res.end_bit / 8;
+    const uint64_t whole = e->inflight_final ? (res.end_bit + 7) / 8 : res.end_bit / 8;
     e->h_out.resize(whole + 1);
-    if (hipMemcpyAsync(e->h_out.data(), e->d_out.p, whole + 1, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) return LFX_E_DEVICE;
-    e->carry_bits = final ? 0 : (uint32_t)(res.end_bit & 7);
-    e->carry = e->carry_bits ? e->h_out[whole] : 0;
-    e->pending.erase(e->pending.begin(), e->pending.begin() + (std::ptrdiff_t)n);
-    return enc_emit_bytes(e, e->h_out.data(), whole);
+    // the shared byte first (the next batch's launch needs it), then the bulk — which travels while that launch is prepared
+    uint8_t *slot = e->h_res.data() + 128;
+    if (hipMemcpyAsync(slot, (const uint8_t *)e->d_out.p + whole, 1, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipEventRecord(e->ev_small, c->stream) != hipSuccess ||
+        (whole && hipMemcpyAsync(e->h_out.data(), e->d_out.p, whole, hipMemcpyDeviceToHost, c->stream) != hipSuccess) ||
+        hipEventRecord(e->ev_out, c->stream) != hipSuccess || hipEventSynchronize(e->ev_small) != hipSuccess) return LFX_E_DEVICE;
+    e->carry_bits = e->inflight_final ? 0 : (uint32_t)(res.end_bit & 7);
+    e->carry = e->carry_bits ? *slot : 0;
+    out->whole = whole;
+    out->have = true;
+    return LFX_OK;
+}
+
+// Start the closed blocks of `pending` (all of it when `final`, which first closes the stream) as a batch; collect the batch
+// before it; with `drain` also the one just started.  The open block's bytes stay pending.
+static int enc_run(lfx_encoder *e, bool final, bool drain = true) {
+    Ctx *c = e->c;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    if (!e->ev_out && (hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&e->ev_small, hipEventDisableTiming) != hipSuccess)) return LFX_E_DEVICE;
+    if (final) e->pl->finish();
+    const uint64_t n = final ? e->pending.size() : e->pl->closed_bytes();
+    Plan plan = final ? std::move(e->pl->plan()) : e->pl->take_closed();
+    int rc;
+    EncCollected prev;
+    if ((rc = enc_collect(e, &prev))) return rc;
+    const bool launched = !plan.blocks.empty();
+    if (launched && (rc = enc_launch(e, std::move(plan), n, final))) return rc;
+    if (prev.have) {
+        // the earlier batch's bytes go to the sink while the GPU works on the batch just started
+        if (hipEventSynchronize(e->ev_out) != hipSuccess) return LFX_E_DEVICE;
+        if ((rc = enc_emit_bytes(e, e->h_out.data(), prev.whole))) return rc;
+    }
+    if (drain && launched) {
+        EncCollected cur;
+        if ((rc = enc_collect(e, &cur))) return rc;
+        if (cur.have) {
+            if (hipEventSynchronize(e->ev_out) != hipSuccess) return LFX_E_DEVICE;
+            if ((rc = enc_emit_bytes(e, e->h_out.data(), cur.whole))) return rc;
+        }
+    }
+    return LFX_OK;
 }
 
 // codes mode: encode every closed block (CompressBuf::flush from the histogram on, encode.rs:416-425)
@@ -1136,6 +1216,7 @@ extern "C" int lfx_encoder_write_codes(lfx_encoder *e, const uint32_t *codes, si
     return LFX_OK;
 } LFX_ABI_CATCH
 
+extern "C" void lfx_encoder_free(lfx_encoder *e);
 extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encode_opts *o, lfx_write_cb w,
                                         lfx_flush_cb f, void *user, int *status) try {
     if (!cc || !w) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
@@ -1151,6 +1232,12 @@ extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encod
     if (d.extra) { e->extra.assign(d.extra, d.extra + d.extra_len); e->o.extra = e->extra.data(); }
     e->po = plan_opts(format, e->o);
     e->pl = new Planner(e->po);
+    // (page-locked and device buffers of an earlier encoder of this context, when there are any)
+    e->pending = e->c->take_pin();
+    e->h_out = e->c->take_pin();
+    e->inflight_buf = e->c->take_pin();
+    e->d_in = e->c->take_dev();
+    e->d_out = e->c->take_dev();
     e->w = w;
     e->f = f;
     e->user = user;
@@ -1158,7 +1245,7 @@ extern "C" lfx_encoder *lfx_encoder_new(lfx_ctx *cc, int format, const lfx_encod
     std::vector<uint8_t> hdr;
     rc = container_header(format, e->o, hdr);
     if (!rc) rc = enc_emit_bytes(e, hdr.data(), hdr.size());
-    if (rc) { if (status) *status = rc; delete e->pl; delete e; return nullptr; }
+    if (rc) { if (status) *status = rc; lfx_encoder_free(e); return nullptr; }
     if (status) *status = LFX_OK;
     return e;
 } LFX_ABI_CATCH_NEW
@@ -1177,7 +1264,7 @@ extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n)
     e->pl->write(n);
     e->total_in += n;
     if (e->pl->closed_bytes() >= enc_batch_bytes(e) || (e->po.no_compression && e->pl->closed_blocks() >= 1024)) {
-        int rc = enc_run(e, false);
+        int rc = enc_run(e, false, /*drain=*/false);     // (the batch is started; the next one — or flush / finish — collects it)
         if (rc) { e->failed = true; return -(int64_t)rc; }
     }
     return (int64_t)n;  // encode.rs:243: always consumes everything
@@ -1231,8 +1318,14 @@ extern "C" const char *lfx_encoder_last_error(const lfx_encoder *e) { return e ?
 extern "C" void lfx_encoder_free(lfx_encoder *e) {
     if (!e) return;
     (void)hipSetDevice(e->c->device);
-    e->d_in.release();
-    e->d_out.release();
+    e->c->give_dev(e->d_in);
+    e->c->give_dev(e->d_out);
+    if (e->inflight) (void)hipStreamSynchronize(e->c->stream);      // (freed without finish: the DMA engine still reads the buffers)
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->ev_small) (void)hipEventDestroy(e->ev_small);
+    e->c->give_pin(std::move(e->pending));
+    e->c->give_pin(std::move(e->h_out));
+    e->c->give_pin(std::move(e->inflight_buf));
     delete e->pl;
     delete e;
 }

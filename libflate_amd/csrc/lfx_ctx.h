@@ -93,6 +93,37 @@ struct Ctx {
     bool force_match_v1 = false;   // sticky: the second-generation match kernel reported a lane-order violation
     uint64_t match_fallbacks = 0;  // encode passes this context ran on the fallback kernel because of it (lfx_ctx_match_fallbacks)
     HostIo hostio;                 // copy streams and page-locked slabs for callers' pageable buffers (lfx_hostio.h), made on first use
+    // Buffers of stream encoders / decoders that were freed, kept for the next handle of this context: page-locking 16 .. 64 MiB
+    // and a hipMalloc per handle cost more than encoding a small stream (an encoder per file is the reference's own usage,
+    // examples/flate.rs:89-110).  Taken and given back under `mu`; at most POOL_MAX of each kind are kept.
+    static constexpr size_t POOL_MAX = 6;
+    std::vector<PinVec> pin_pool;
+    std::vector<DevBuf> dev_pool;
+    PinVec take_pin() {
+        std::lock_guard<std::recursive_mutex> lock(mu);
+        if (pin_pool.empty()) return PinVec();
+        PinVec v = std::move(pin_pool.back());
+        pin_pool.pop_back();
+        v.clear();
+        return v;
+    }
+    void give_pin(PinVec &&v) {
+        std::lock_guard<std::recursive_mutex> lock(mu);
+        if (v.capacity() && pin_pool.size() < POOL_MAX) { v.clear(); pin_pool.push_back(std::move(v)); }
+    }
+    DevBuf take_dev() {
+        std::lock_guard<std::recursive_mutex> lock(mu);
+        if (dev_pool.empty()) return DevBuf();
+        DevBuf b = dev_pool.back();
+        dev_pool.pop_back();
+        return b;
+    }
+    void give_dev(DevBuf &b) {
+        std::lock_guard<std::recursive_mutex> lock(mu);
+        if (b.p && dev_pool.size() < POOL_MAX) dev_pool.push_back(b);
+        else b.release();
+        b = DevBuf();
+    }
     std::vector<uint8_t> shard_hdr;
     int shard_format = 0;
     bool shard_last = false;

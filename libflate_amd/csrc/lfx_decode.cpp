@@ -1769,10 +1769,13 @@ int dec_body(lfx_decoder *d) {
 
 }  // namespace
 
+extern "C" void lfx_decoder_free(lfx_decoder *d);
 extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags, lfx_read_cb r, void *user, int *status) try {
     if (!cc || !r || format < 0 || format > 2) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
     lfx_decoder *d = new lfx_decoder();
     d->c = reinterpret_cast<Ctx *>(cc);
+    d->in = d->c->take_pin();          // (page-locked buffers of an earlier decoder of this context, when there are any)
+    d->out = d->c->take_pin();
     d->format = format;
     d->flags = flags;
     d->r = r;
@@ -1784,7 +1787,7 @@ extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags,
         if (rc) {
             if (status) *status = rc;
             d->c->set_error(d->err);
-            delete d;
+            lfx_decoder_free(d);
             return nullptr;
         }
         d->state = lfx_decoder::ST_BODY;
@@ -1893,4 +1896,9 @@ extern "C" uint64_t lfx_decoder_buffered(const lfx_decoder *d) {
     return d ? (uint64_t)(d->in.size() + d->out.size() + d->hist.size()) : 0;
 }
 extern "C" const char *lfx_decoder_last_error(const lfx_decoder *d) { return d ? d->err.c_str() : "null"; }
-extern "C" void lfx_decoder_free(lfx_decoder *d) { delete d; }
+extern "C" void lfx_decoder_free(lfx_decoder *d) {
+    if (!d) return;
+    d->c->give_pin(std::move(d->in));
+    d->c->give_pin(std::move(d->out));
+    delete d;
+}

@@ -25,5 +25,5 @@ for mb in (0, 4, 16, 32, 64):
         os.environ["LFX_ENC_BATCH_MB"] = str(mb)
     c = libflate_amd.Context(0)
     r = bench.sub_stream_api(c, _ffi, data)
-    print(json.dumps({"enc_batch_mb": mb or 8, "stream_api": {k: r[k] for k in ("value", "encode_GBps", "decode_GBps", "encode_ms", "decode_ms", "round_trip_ok")}}), flush=True)
+    print(json.dumps({"enc_batch_mb": mb or 8, "stream_api": {k: r[k] for k in ("value", "encode_GBps", "decode_GBps", "encode_ms", "decode_ms", "round_trip_ok", "encode_ms_in_batch_calls", "encode_batch_calls", "decode_ms_in_window_calls", "decode_window_calls", "host_memcpy_ms")}}), flush=True)
     c.close()

@@ -30,6 +30,9 @@ def _get():
         vp, sz = C.c_void_p, C.c_size_t
         _lib.lfx_sc_encode.argtypes = [vp, C.c_int, vp, vp, sz, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_double)]
         _lib.lfx_sc_decode.argtypes = [vp, C.c_int, vp, sz, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_double)]
+        _lib.lfx_sc_last_split.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        _lib.lfx_sc_memcpy.restype = C.c_double
+        _lib.lfx_sc_memcpy.argtypes = [vp, vp, sz, sz]
     return _lib
 
 
@@ -46,3 +49,14 @@ def decode(ctx, fmt, in_ptr, n, chunk, out_ptr, cap):
     ln, t = C.c_size_t(0), C.c_double(0)
     rc = _get().lfx_sc_decode(ctx.handle, fmt, in_ptr, n, chunk, out_ptr, cap, C.byref(ln), C.byref(t))
     return rc, ln.value, t.value
+
+
+def last_split():
+    """(seconds in calls that ran GPU work — a batch, a window —, their number) of the last encode / decode"""
+    t, k = C.c_double(0), C.c_long(0)
+    _get().lfx_sc_last_split(C.byref(t), C.byref(k))
+    return t.value, k.value
+
+
+def memcpy_seconds(dst_ptr, src_ptr, n, chunk):
+    return _get().lfx_sc_memcpy(dst_ptr, src_ptr, n, chunk)
