@@ -344,7 +344,11 @@ def sub_stream_api(ctx, _ffi, data, enc_want=None, chunk=8192):
     opts = _ffi.make_opts(mtime=0)
     enc = np.empty(n + n // 4 + 4096, dtype=np.uint8)
     dec = np.empty(n, dtype=np.uint8)
-    stream_copy.encode(ctx, _ffi.GZIP, opts, data.ctypes.data, min(n, 16 << 20), chunk, enc.ctypes.data, enc.size)   # warm-up
+    enc[:] = 0          # (np.empty's pages are not there yet: first touches would be timed as page faults)
+    dec[:] = 0
+    # warm-up of both directions: page-locked buffers of the context's pool, device scratch
+    rc, m0, _ = stream_copy.encode(ctx, _ffi.GZIP, opts, data.ctypes.data, min(n, 48 << 20), chunk, enc.ctypes.data, enc.size)
+    stream_copy.decode(ctx, _ffi.GZIP, enc.ctypes.data, m0, chunk, dec.ctypes.data, n)
     rc, m, te = stream_copy.encode(ctx, _ffi.GZIP, opts, data.ctypes.data, n, chunk, enc.ctypes.data, enc.size)
     if rc:
         raise RuntimeError("stream encode failed: %d" % rc)

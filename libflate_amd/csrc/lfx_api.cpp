@@ -1264,7 +1264,9 @@ extern "C" int64_t lfx_encoder_write(lfx_encoder *e, const uint8_t *p, size_t n)
     e->pl->write(n);
     e->total_in += n;
     if (e->pl->closed_bytes() >= enc_batch_bytes(e) || (e->po.no_compression && e->pl->closed_blocks() >= 1024)) {
-        int rc = enc_run(e, false, /*drain=*/false);     // (the batch is started; the next one — or flush / finish — collects it)
+        // the batch is started; the next one — or flush / finish — collects it.  Stored blocks (a batch is 64 MiB of them,
+        // copied, not compressed) leave as they are closed.
+        int rc = enc_run(e, false, /*drain=*/e->po.no_compression);
         if (rc) { e->failed = true; return -(int64_t)rc; }
     }
     return (int64_t)n;  // encode.rs:243: always consumes everything

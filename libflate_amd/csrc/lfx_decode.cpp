@@ -17,6 +17,7 @@
 #include "lfx_ctx.h"
 #include "lfx_container.h"
 #include "lfx_decode.h"
+#include <thread>
 
 static_assert(offsetof(lfx::DecStream, out_off) == 16 && sizeof(lfx::DecStream) % 8 == 0, "checksum_ranges stride");
 static_assert(offsetof(lfx::InflateResult, out_len) == 8 && sizeof(lfx::InflateResult) % 8 == 0, "checksum_ranges stride");
@@ -1518,6 +1519,19 @@ struct lfx_decoder {
     bool member_final = false;      // the BFINAL block has been decoded: the trailer is next
     bool more_windows = false;      // ST_SERVE: another window follows the bytes being served
     uint64_t out_cap = 0;           // output capacity of one window
+    // ---- the next window decoded AHEAD (round 6): while the caller copies window k out of `out` (io::copy: 8192 bytes a
+    // read), a worker thread runs window k + 1 on the GPU into `next.out`.  The input was pulled by the CALLER's thread before
+    // the worker started (the read callback never runs on another thread); the worker touches `in` (read only), `hist` (read
+    // only), `next` and the context (under its lock) — nothing the serving path reads.
+    struct Window {
+        PinVec out;
+        MemberResult mr;
+        uint32_t crc = 0, adler = 1;
+        uint64_t n = 0;             // bytes of `in` the window was given
+        int rc = LFX_OK;            // a device-level failure of the attempt
+    } next;
+    std::thread worker;
+    bool ahead = false;             // `worker` is running (or has finished) window k + 1
 };
 
 namespace {
@@ -1579,6 +1593,119 @@ int dec_header(lfx_decoder *d) {
 constexpr uint64_t WINDOW_IN = 16ull << 20, WINDOW_OUT = 96ull << 20, WINDOW_IN_MAX = 4ull << 30;
 
 // → LFX_OK when bytes or a verdict are ready (state ST_SERVE), LFX_E_WOULD_BLOCK / LFX_E_IO from the reader, or a device error
+// ---- one window of the member's body in three steps: input (caller's thread) → GPU (caller's thread, or a worker thread
+//      that decodes AHEAD while the caller drains the window before) → state update (dec_body)
+// input up to the window size; a short read or the end of the reader also triggers an attempt.  → LFX_OK: attempt now
+int dec_fill(lfx_decoder *d) {
+    bool attempt = d->reader_eof;
+    while (!attempt) {
+        if (d->in.size() >= d->target) { attempt = true; break; }
+        size_t got;
+        const size_t want = std::min<uint64_t>(d->target - d->in.size(), 4u << 20);
+        const int pr = dec_pull(d, want, &got);
+        if (pr == PULL_ERR) { d->err = "read callback failed"; return LFX_E_IO; }
+        if (pr == PULL_EOF) { attempt = true; break; }
+        if (pr == PULL_BLOCK) {
+            // everything the peer has sent is here: decode it if enough new bytes arrived since an attempt that found
+            // no complete block (an eighth more: the retries of one long block stay linear in its size), else WouldBlock
+            if (d->in.size() > d->tried_at + d->tried_at / 8) { attempt = true; break; }
+            return LFX_E_WOULD_BLOCK;
+        }
+        // a short read hints that the reader has no more right now (pipes, sockets): worth an attempt once the
+        // input has grown by a quarter since the last one (keeps the total work linear)
+        if (got < want && d->in.size() >= d->tried_at + d->tried_at / 4 + 1) { attempt = true; break; }
+    }
+    return LFX_OK;
+}
+
+// one window on the GPU (the context's scratch is shared: one decode at a time per context): in[0, n) from bit bit_off with
+// the history → W.out, W.mr, the window's checksums.  Reads d->in, d->hist, d->bit_off, d->member_out, d->reader_eof,
+// d->out_cap (grows it when the tail of the member does not fit); writes only W and d->out_cap.
+void dec_gpu(lfx_decoder *d, lfx_decoder::Window &W) {
+    Ctx *c = d->c;
+    const uint64_t trailer = d->format == LFX_GZIP ? 8 : d->format == LFX_ZLIB ? 4 : 0;
+    const uint64_t n = d->in.size();
+    W.n = n;
+    W.crc = 0;
+    W.adler = 1;
+    W.rc = LFX_OK;
+    MemberResult &mr = W.mr;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        mr = MemberResult();
+        c->n_ev = 0;
+        c->phase("start");
+        int rc;
+        const uint64_t H = d->hist.size();
+        if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) { W.rc = rc; return; }
+        if ((rc = c->d_io_out.reserve(MAX_WINDOW + d->out_cap))) { W.rc = rc; return; }
+        if ((rc = c->d_res.reserve(256))) { W.rc = rc; return; }
+        uint8_t *d_out = (uint8_t *)c->d_io_out.p + MAX_WINDOW;          // the history lies right in front of it
+        if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) { W.rc = LFX_E_DEVICE; return; }
+        if (H && hipMemcpyAsync(d_out - H, d->hist.data(), H, hipMemcpyHostToDevice, c->stream) != hipSuccess) { W.rc = LFX_E_DEVICE; return; }
+        // (once the reader has ended nothing more can arrive: the exact walk gives the member's verdict)
+        const bool at_limit = !d->reader_eof && n >= WINDOW_IN_MAX;
+        const bool partial = !d->reader_eof && !at_limit;
+        rc = inflate_member(c, (const uint8_t *)c->d_io_in.p, n, 0, d_out, d->out_cap, mr, d->bit_off, ~0ull, partial, d->member_out);
+        if (rc) { W.rc = rc; return; }
+        if (at_limit && mr.status == LFX_E_UNEXPECTED_EOF) {
+            mr.status = LFX_E_UNSUPPORTED;
+            mr.msg = "a DEFLATE block exceeds the stream decoder's window limit (4 GiB of compressed bytes)";
+        }
+        if (mr.status == LFX_E_NOSPACE && !partial) {     // (the tail of the member does not fit one window: grow and retry)
+            d->out_cap *= 2;
+            continue;
+        }
+        const uint64_t keep = mr.out_len;                 // bytes produced (also on failure)
+        if (keep && mr.status == LFX_OK && trailer) {
+            const uint64_t nspans = ck_nspans(keep);
+            if ((rc = c->d_ck.reserve(12 * nspans))) { W.rc = rc; return; }
+            uint32_t *ck = (uint32_t *)c->d_ck.p;
+            if (int e_ = launch_checksum(c->stream, d_out, keep, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,
+                                         d->format == LFX_GZIP ? 1 : 2)) {
+                c->set_error(hipGetErrorString((hipError_t)e_));
+                W.rc = LFX_E_DEVICE;
+                return;
+            }
+            if (hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, c->stream) != hipSuccess) { W.rc = LFX_E_DEVICE; return; }
+        }
+        W.out.resize(keep);
+        if (keep && hipMemcpyAsync(W.out.data(), d_out, keep, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { W.rc = LFX_E_DEVICE; return; }
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { W.rc = LFX_E_DEVICE; return; }
+        if (keep && mr.status == LFX_OK && trailer) {
+            const EncodeResult er = *(EncodeResult *)c->h_res;
+            W.crc = er.crc32;
+            W.adler = er.adler32;
+        }
+        return;
+    }
+}
+
+// ST_SERVE, first read of a window that is worth the thread (a few MiB to copy out) and has a successor: pull the successor's
+// input NOW, on the caller's thread, and let a worker decode it while the caller drains this window.  Not for non-blocking
+// readers (a WouldBlock in the middle of a drain has no call to come back from).
+void dec_start_ahead(lfx_decoder *d) {
+    if (d->ahead || !d->more_windows || d->member_final || d->pending_status != LFX_OK || (d->flags & LFX_DEC_NONBLOCKING) ||
+        !d->body_started || d->serve_limit < (4u << 20)) return;
+    if (dec_fill(d) != LFX_OK) return;                 // (an I/O error is found again, and reported, by the window's own turn)
+    if (d->in.empty()) return;
+    try {
+        d->worker = std::thread([d] {
+            try { dec_gpu(d, d->next); }
+            catch (const std::bad_alloc &) { d->next.rc = LFX_E_OOM; }
+            catch (...) { d->next.rc = LFX_E_DEVICE; }
+        });
+        d->ahead = true;
+    } catch (...) {
+        d->ahead = false;                              // (no thread to be had: the window is decoded when its turn comes)
+    }
+}
+// accessors and the destructor look at state the worker may be writing: let it finish first
+void dec_settle(lfx_decoder *d) {
+    if (d->ahead && d->worker.joinable()) d->worker.join();
+}
+
 int dec_body(lfx_decoder *d) {
     Ctx *c = d->c;
     if (!d->body_started) {
@@ -1632,77 +1759,24 @@ int dec_body(lfx_decoder *d) {
             d->state = lfx_decoder::ST_SERVE;
             return LFX_OK;
         }
-        // ---- input: up to the window size; a short read or the end of the reader also triggers an attempt
-        bool attempt = d->reader_eof;
-        while (!attempt) {
-            if (d->in.size() >= d->target) { attempt = true; break; }
-            size_t got;
-            const size_t want = std::min<uint64_t>(d->target - d->in.size(), 4u << 20);
-            const int pr = dec_pull(d, want, &got);
-            if (pr == PULL_ERR) { d->err = "read callback failed"; return LFX_E_IO; }
-            if (pr == PULL_EOF) { attempt = true; break; }
-            if (pr == PULL_BLOCK) {
-                // everything the peer has sent is here: decode it if enough new bytes arrived since an attempt that found
-                // no complete block (an eighth more: the retries of one long block stay linear in its size), else WouldBlock
-                if (d->in.size() > d->tried_at + d->tried_at / 8) { attempt = true; break; }
-                return LFX_E_WOULD_BLOCK;
-            }
-            // a short read hints that the reader has no more right now (pipes, sockets): worth an attempt once the
-            // input has grown by a quarter since the last one (keeps the total work linear)
-            if (got < want && d->in.size() >= d->tried_at + d->tried_at / 4 + 1) { attempt = true; break; }
+        // ---- input (dec_fill) and one window on the GPU (dec_gpu) — or the window the worker thread decoded ahead while the
+        //      caller was copying the one before out (dec_start_ahead)
+        lfx_decoder::Window &W = d->next;
+        if (d->ahead) {
+            if (d->worker.joinable()) d->worker.join();      // (an accessor may have waited for it already)
+            d->ahead = false;
+        } else {
+            const int fr = dec_fill(d);
+            if (fr != LFX_OK) return fr;
+            dec_gpu(d, W);
         }
-        // ---- one window (the context's scratch is shared: one decode at a time per context)
-        const uint64_t n = d->in.size();
-        MemberResult mr;
-        uint32_t w_crc = 0, w_adler = 1;
-        bool verdict = false;                        // mr is the member's final word (an error, or a decode without `partial`)
-        {
-            std::lock_guard<std::recursive_mutex> lock(c->mu);
-            (void)hipSetDevice(c->device);
-            c->n_ev = 0;
-            c->phase("start");
-            int rc;
-            const uint64_t H = d->hist.size();
-            if ((rc = c->d_io_in.reserve(std::max<uint64_t>(n, 4)))) return rc;
-            if ((rc = c->d_io_out.reserve(MAX_WINDOW + d->out_cap))) return rc;
-            if ((rc = c->d_res.reserve(256))) return rc;
-            uint8_t *d_out = (uint8_t *)c->d_io_out.p + MAX_WINDOW;          // the history lies right in front of it
-            if (n && hipMemcpyAsync(c->d_io_in.p, d->in.data(), n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
-            if (H && hipMemcpyAsync(d_out - H, d->hist.data(), H, hipMemcpyHostToDevice, c->stream) != hipSuccess) return LFX_E_DEVICE;
-            // (once the reader has ended nothing more can arrive: the exact walk gives the member's verdict)
-            const bool at_limit = !d->reader_eof && n >= WINDOW_IN_MAX;
-            const bool partial = !d->reader_eof && !at_limit;
-            rc = inflate_member(c, (const uint8_t *)c->d_io_in.p, n, 0, d_out, d->out_cap, mr, d->bit_off, ~0ull, partial, d->member_out);
-            if (rc) return rc;
-            verdict = mr.status != LFX_OK || !partial;
-            if (at_limit && mr.status == LFX_E_UNEXPECTED_EOF) {
-                mr.status = LFX_E_UNSUPPORTED;
-                mr.msg = "a DEFLATE block exceeds the stream decoder's window limit (4 GiB of compressed bytes)";
-            }
-            if (mr.status == LFX_E_NOSPACE && !partial) {     // (the tail of the member does not fit one window: grow and retry)
-                d->out_cap *= 2;
-                continue;
-            }
-            const uint64_t keep = mr.status == LFX_OK ? mr.out_len : mr.out_len;   // bytes produced (also on failure)
-            if (keep && mr.status == LFX_OK && trailer) {
-                const uint64_t nspans = ck_nspans(keep);
-                if ((rc = c->d_ck.reserve(12 * nspans))) return rc;
-                uint32_t *ck = (uint32_t *)c->d_ck.p;
-                if (int e_ = launch_checksum(c->stream, d_out, keep, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p,
-                                             d->format == LFX_GZIP ? 1 : 2)) {
-                    c->set_error(hipGetErrorString((hipError_t)e_));
-                    return LFX_E_DEVICE;
-                }
-                if (hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(EncodeResult), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return LFX_E_DEVICE;
-            }
-            d->out.resize(keep);
-            if (keep && hipMemcpyAsync(d->out.data(), d_out, keep, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return LFX_E_DEVICE;
-            if (hipStreamSynchronize(c->stream) != hipSuccess) return LFX_E_DEVICE;
-            if (keep && mr.status == LFX_OK && trailer) {
-                const EncodeResult er = *(EncodeResult *)c->h_res;
-                w_crc = er.crc32; w_adler = er.adler32;
-            }
-        }
+        if (W.rc) return W.rc;
+        const uint64_t n = W.n;
+        MemberResult &mr = W.mr;
+        const uint32_t w_crc = W.crc, w_adler = W.adler;
+        d->out.swap(W.out);                          // (the window's bytes; W.out keeps the old buffer's room for the next one)
+        bool verdict = false;
+        (void)verdict;
         if (c->diag.debug)
             fprintf(stderr, "[lfx] window: n=%llu bit_off=%u eof=%d hist=%llu → status=%d out=%llu blk_out=%llu end_bit=%llu final=%d need_cap=%d target=%llu\n",
                     (unsigned long long)n, d->bit_off, (int)d->reader_eof, (unsigned long long)d->member_out, mr.status,
@@ -1805,6 +1879,7 @@ extern "C" int64_t lfx_decoder_read(lfx_decoder *d, uint8_t *out, size_t cap) tr
             case lfx_decoder::ST_FAILED: return 0;   // (the error was reported once, like a latched io::Error)
             case lfx_decoder::ST_SERVE: {
                 if (d->cursor < d->serve_limit) {
+                    if (d->cursor == 0) dec_start_ahead(d);       // (the next window on the GPU while this one is copied out)
                     const uint64_t k = std::min<uint64_t>(cap, d->serve_limit - d->cursor);
                     memcpy(out, d->out.data() + d->cursor, k);
                     d->cursor += k;
@@ -1893,11 +1968,14 @@ extern "C" int lfx_decoder_header(lfx_decoder *d, lfx_header *h) try {
 } LFX_ABI_CATCH
 extern "C" uint64_t lfx_decoder_consumed(const lfx_decoder *d) { return d ? d->consumed_total : 0; }
 extern "C" uint64_t lfx_decoder_buffered(const lfx_decoder *d) {
-    return d ? (uint64_t)(d->in.size() + d->out.size() + d->hist.size()) : 0;
+    if (!d) return 0;
+    dec_settle(const_cast<lfx_decoder *>(d));      // (a window decoded ahead counts, and its buffer is not read while it grows)
+    return (uint64_t)(d->in.size() + d->out.size() + d->hist.size() + d->next.out.size());
 }
 extern "C" const char *lfx_decoder_last_error(const lfx_decoder *d) { return d ? d->err.c_str() : "null"; }
 extern "C" void lfx_decoder_free(lfx_decoder *d) {
     if (!d) return;
+    dec_settle(d);
     d->c->give_pin(std::move(d->in));
     d->c->give_pin(std::move(d->out));
     delete d;

@@ -270,7 +270,7 @@ def test_two_handles_two_threads(env, oracle):
 def test_stream_encoder_batches(env, oracle):
     """The stream encoder hands closed blocks to the sink as they accumulate (8 MiB batches — the reference emits per
     block, encode.rs:277-286; stored blocks every 1024 blocks) instead of holding everything until finish(): what it
-    buffers stays within a batch plus the open block."""
+    buffers stays within two batches (one of them in flight on the GPU) plus the open block."""
     lfx, ctx, ffi, synth = env
     data = synth.text(150 << 20).tobytes()
     sink = io.BytesIO()
@@ -280,10 +280,12 @@ def test_stream_encoder_batches(env, oracle):
         e.write(data[off:off + (1 << 20)])
         seen.append(sink.tell())
     e.finish()
-    assert seen[6] == 10 and seen[8] > (2 << 20) and seen[-1] > (40 << 20)      # only the header until 8 MiB of closed blocks wait
-    # ... and from then on the sink is never more than a batch and the open block behind the writer (C / N ≈ 0.48)
-    for i in range(10, len(seen)):
-        assert seen[i] > ((i + 1 - 10) << 20) * 0.40, (i, seen[i])
+    # only the header until 8 MiB of closed blocks wait; that batch is STARTED by the write that closes it (round 6: one batch
+    # in flight on the GPU while the caller copies the next one in) and reaches the sink when the next batch is started
+    assert seen[6] == 10 and seen[8] == 10 and seen[15] > (2 << 20) and seen[-1] > (40 << 20)
+    # ... and from then on the sink is never more than two batches and the open block behind the writer (C / N ≈ 0.48)
+    for i in range(18, len(seen)):
+        assert seen[i] > ((i + 1 - 18) << 20) * 0.40, (i, seen[i])
     assert pyzlib.decompress(sink.getvalue(), 31) == data
     assert sink.getvalue()[:1 << 20] == oracle.encode(oracle.GZIP, data[:8 << 20], 1 << 20)[:1 << 20]
     raw = synth.text(80 << 20).tobytes()
