@@ -18,6 +18,7 @@
 #include "lfx_container.h"
 #include "lfx_decode.h"
 #include <thread>
+#include <chrono>
 
 static_assert(offsetof(lfx::DecStream, out_off) == 16 && sizeof(lfx::DecStream) % 8 == 0, "checksum_ranges stride");
 static_assert(offsetof(lfx::InflateResult, out_len) == 8 && sizeof(lfx::InflateResult) % 8 == 0, "checksum_ranges stride");
@@ -1647,8 +1648,10 @@ void dec_gpu(lfx_decoder *d, lfx_decoder::Window &W) {
         // (once the reader has ended nothing more can arrive: the exact walk gives the member's verdict)
         const bool at_limit = !d->reader_eof && n >= WINDOW_IN_MAX;
         const bool partial = !d->reader_eof && !at_limit;
+        const auto tw0 = std::chrono::steady_clock::now();
         rc = inflate_member(c, (const uint8_t *)c->d_io_in.p, n, 0, d_out, d->out_cap, mr, d->bit_off, ~0ull, partial, d->member_out);
         if (rc) { W.rc = rc; return; }
+        const auto tw1 = std::chrono::steady_clock::now();
         if (at_limit && mr.status == LFX_E_UNEXPECTED_EOF) {
             mr.status = LFX_E_UNSUPPORTED;
             mr.msg = "a DEFLATE block exceeds the stream decoder's window limit (4 GiB of compressed bytes)";
@@ -1678,6 +1681,10 @@ void dec_gpu(lfx_decoder *d, lfx_decoder::Window &W) {
             W.crc = er.crc32;
             W.adler = er.adler32;
         }
+        if (c->diag.debug)
+            fprintf(stderr, "[lfx] window gpu: in=%llu out=%llu inflate_member %.3f ms, checksum + D2H %.3f ms\n", (unsigned long long)n,
+                    (unsigned long long)keep, std::chrono::duration<double, std::milli>(tw1 - tw0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
         return;
     }
 }

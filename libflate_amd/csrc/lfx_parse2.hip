@@ -127,11 +127,14 @@ __device__ __forceinline__ uint32_t eq_bytes16(const B16 &a, const B16 &b) {
 // stretches of literals — first sights of a word: CPU model on the benchmark text, 23.2 → 19.9 trips per group of 52
 // positions (tools/parse2_model.py has the same rule).  `bits` = 1 otherwise.
 __device__ __forceinline__ uint32_t walk_step(const WalkCtx &w, uint32_t pos, bool act, uint32_t stop, uint32_t &bits) {
-    uint32_t oa = act ? pos + 3 - w.w0 : 0u;                        // (idle lanes read offset 0)
+    // (idle lanes are handed a position of their own group: every address below is inside the staged arrays, so the loads
+    //  need no exec mask — an s_and_saveexec region per load otherwise)
+    uint32_t oa = pos + 3 - w.w0;
     // loads that do not depend on the candidate
-    const uint32_t d = act ? w.cd16[pos - w.c0] : 0u;
-    const uint32_t dnext = act ? w.cd16[pos + 1 - w.c0] : 1u;       // (the entry behind the last position is padding: never used, pos + 1 < stop)
-    const bool two = act && d == 0 && dnext == 0 && pos + 1 < stop;
+    const uint32_t ci = pos - w.c0;
+    const uint32_t d_raw = w.cd16[ci], dn_raw = w.cd16[ci + 1];     // (the entry behind the last position is padding: never used, pos + 1 < stop)
+    const uint32_t d = act ? d_raw : 0u;
+    const bool two = act && (d_raw | dn_raw) == 0 && pos + 1 < stop;
     bits = two ? 3u : 1u;
     B16 a = lds16(w.win32, oa);
     uint32_t lim = w.n - (pos + 3);                                 // default.rs:125 (bounded by the end of the chunk)
