@@ -78,75 +78,111 @@ def dominant_phase(timing, skip=("upload", "start", "done")):
     return max(tot.items(), key=lambda kv: kv[1]) if tot else (None, None)
 
 
-def measure_traffic(kernel, n, schedule):
-    """HBM bytes per launch of `kernel`, measured now: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot
-    share a pass, MI355X_MICROARCH.md §PMC slots) over a one-step child run of this script.  gfx950 correction as the
-    guide's HBM section prescribes: FETCH_SIZE under-counts wide coalesced reads by 2x — calibrated in the same pass on
-    checksum_span_kernel, which reads the n input bytes exactly once.  → dict or None (with the reason in "error")."""
+def _pmc_pass(counters, n, schedule):
+    """one rocprofv3 --pmc child pass of this script's bare timed loop → ({counter: {kernel: [value per dispatch]}}, error)"""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
-        return {"error": "rocprofv3 not found"}
-    out = {}
+        return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="lfx_pmc_", dir="/tmp")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "0", "--bytes", str(n),
-                   "--schedule", schedule]
-            env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=180)
-            if r.returncode != 0:
-                return {"error": "rocprofv3 %s pass failed: %s" % (counter, (r.stderr or r.stdout)[-300:])}
-            acc = {}
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(f, newline="") as fh:
-                    for row in csv.DictReader(fh):
-                        name = (row.get("Kernel_Name") or "").split("(")[0]
-                        if (row.get("Counter_Name") or "") != counter:
-                            continue
-                        key = (name, row.get("Dispatch_Id"))
-                        acc[key] = acc.get(key, 0.0) + float(row.get("Counter_Value") or 0)
-            per = {}
-            for (name, _), v in acc.items():
-                per.setdefault(name, []).append(v)
-            out[counter] = {k: sum(v) / len(v) for k, v in per.items()}     # KiB per dispatch
-            # KiB per encode+decode step: the child's steps = dispatches of a kernel that runs exactly once per step
-            nsteps = max([len(v) for k, v in per.items() if CALIBRATION_KERNEL + "<3>" in k or "lz77_match" in k] or [1])
-            out[counter + ":step"] = {k: sum(v) / nsteps for k, v in per.items()}
+        cmd = [rocprof, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", tmp, "--", sys.executable,
+                                                     os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "0",
+                                                     "--bytes", str(n), "--schedule", schedule]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=180)
+        if r.returncode != 0:
+            return None, "rocprofv3 %s pass failed: %s" % ("+".join(counters), (r.stderr or r.stdout)[-300:])
+        acc = {}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    c = row.get("Counter_Name") or ""
+                    if c not in counters:
+                        continue
+                    name = (row.get("Kernel_Name") or "").split("(")[0]
+                    key = (c, name, row.get("Dispatch_Id"))
+                    acc[key] = acc.get(key, 0.0) + float(row.get("Counter_Value") or 0)
+        out = {c: {} for c in counters}
+        for (c, name, _), v in acc.items():
+            out[c].setdefault(name, []).append(v)
+        return out, None
     except Exception as e:  # noqa: BLE001
-        return {"error": "traffic measurement failed: %r" % (e,)}
+        return None, "pmc pass failed: %r" % (e,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def measure_traffic(kernel, n, schedule):
+    """HBM-side bytes per launch of `kernel` and per encode+decode step of every lfx kernel, measured now: two rocprofv3 --pmc
+    child passes (reads and writes cannot share a pass, MI355X_MICROARCH.md §PMC slots) of this script's timed loop.
+
+    Reads, round 6: the L2's memory-side request counters BY SIZE — TCC_EA0_RDREQ_{32B,64B,128B}_sum: bytes = 32 a + 64 b + 128 c,
+    exact for every access pattern.  (FETCH_SIZE, which the guide's HBM section starts from, tallies this part's 128-byte requests at
+    64 bytes — its expression takes them from a counter that reads 0 here — hence the guide's "double it" for wide coalesced
+    readers; rounds 1-5 applied that factor, calibrated on checksum_span_kernel, to every kernel, which over-counted the
+    scattered readers: parse_emit appeared to move 6.2 TB/s.)  The calibration kernel — it reads the n input bytes exactly once
+    — is kept as a check of the method: `calibration_check` = its measured bytes / n.  Falls back to FETCH_SIZE x factor when
+    the sized counters are not all there.  Writes: WRITE_SIZE (32 / 64-byte requests, tallied as such).  Infinity-Cache hits are
+    counted, not excluded (guide): this is fabric traffic.  → dict or {"error": ...}."""
+    sized = ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")
+    rd, err = _pmc_pass(sized, n, schedule)
+    method = "sized"
+    if rd is None or not rd.get(sized[2]) or not any(sum(v) for v in rd[sized[2]].values()):
+        rd, err2 = _pmc_pass(("FETCH_SIZE",), n, schedule)
+        method = "fetch_size"
+        if rd is None:
+            return {"error": err or err2}
+    wr, err = _pmc_pass(("WRITE_SIZE",), n, schedule)
+    if wr is None:
+        return {"error": err}
 
     def find(table, frag):
         for k, v in table.items():
             if frag in k:
                 return v
         return None
-    cal = find(out["FETCH_SIZE"], CALIBRATION_KERNEL)
-    fetch, write = find(out["FETCH_SIZE"], kernel), find(out["WRITE_SIZE"], kernel)
-    if not cal or fetch is None or write is None:
+    # bytes read per dispatch, per kernel
+    read = {}
+    if method == "sized":
+        names = set().union(*[set(rd[c]) for c in sized])
+        for k in names:
+            per = [rd[c].get(k, []) for c in sized]
+            nd = max(len(p) for p in per)
+            read[k] = [32.0 * (per[0][i] if i < len(per[0]) else 0) + 64.0 * (per[1][i] if i < len(per[1]) else 0) +
+                       128.0 * (per[2][i] if i < len(per[2]) else 0) for i in range(nd)]
+        factor = None
+    else:
+        cal = find(rd["FETCH_SIZE"], CALIBRATION_KERNEL)
+        if not cal:
+            return {"error": "calibration kernel not in the counter output"}
+        factor = n / (sum(cal) / len(cal) * 1024.0)       # ≈ 2 on gfx950
+        read = {k: [x * 1024.0 * factor for x in v] for k, v in rd["FETCH_SIZE"].items()}
+    write = {k: [x * 1024.0 for x in v] for k, v in wr["WRITE_SIZE"].items()}
+    r_k, w_k, cal_r = find(read, kernel), find(write, kernel), find(read, CALIBRATION_KERNEL)
+    if r_k is None or w_k is None or not cal_r:
         return {"error": "kernel %s not in the counter output" % kernel}
-    factor = n / (cal * 1024.0)           # ≈ 2 on gfx950
-    # every lfx kernel of one encode+decode step: HBM bytes (same correction), largest first
+    # one step = the dispatches of a kernel that runs exactly once per step
+    nsteps = max([len(v) for k, v in read.items() if CALIBRATION_KERNEL + "<3>" in k or "lz77_match" in k] or [1])
     per_kernel = {}
-    for name, kib in out["FETCH_SIZE:step"].items():
-        if "lfx::" in name:
-            per_kernel[name.replace("lfx::", "")] = kib * 1024 * factor
-    for name, kib in out["WRITE_SIZE:step"].items():
-        if "lfx::" in name:
-            key = name.replace("lfx::", "")
-            per_kernel[key] = per_kernel.get(key, 0.0) + kib * 1024
-    step_total = int(sum(per_kernel.values()))
-    top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:12]
-    return {"hbm_bytes": int(fetch * 1024 * factor + write * 1024), "fetch_bytes": int(fetch * 1024 * factor),
-            "write_bytes": int(write * 1024), "fetch_size_correction": round(factor, 3),
-            "step_hbm_bytes_all_kernels": step_total,
-            "fetch_calibration": "x%.3f on %s in this run; profiles/r02_fetch_calibration.txt: the same x2 for 16 B/lane and "
-                                 "4 B/lane coalesced reads, x2 with 17 %% real re-fetch for 4 B/lane strided reads" % (factor, CALIBRATION_KERNEL),
-            "step_hbm_bytes_by_kernel": {k: int(v) for k, v in top},
-            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two child passes of this run"}
+    for table in (read, write):
+        for name, v in table.items():
+            if "lfx::" in name:
+                key = name.replace("lfx::", "")
+                per_kernel[key] = per_kernel.get(key, 0.0) + sum(v) / nsteps
+    read_step = {name.replace("lfx::", ""): sum(v) / nsteps for name, v in read.items() if "lfx::" in name}
+    top = sorted(per_kernel.items(), key=lambda kv: -kv[1])[:14]
+    fetch, wbytes = sum(r_k) / len(r_k), sum(w_k) / len(w_k)
+    out = {"hbm_bytes": int(fetch + wbytes), "fetch_bytes": int(fetch), "write_bytes": int(wbytes),
+           "method": ("reads: 32 x TCC_EA0_RDREQ_32B + 64 x _64B + 128 x _128B (exact request sizes); writes: WRITE_SIZE"
+                      if method == "sized" else "reads: FETCH_SIZE x %.3f (calibrated on %s); writes: WRITE_SIZE" % (factor, CALIBRATION_KERNEL)),
+           "calibration_check": round(sum(cal_r) / len(cal_r) / n, 4),
+           "calibration_how": "%s reads the %d input bytes exactly once: measured read bytes / n" % (CALIBRATION_KERNEL, n),
+           "step_hbm_bytes_all_kernels": int(sum(per_kernel.values())),
+           "step_hbm_bytes_by_kernel": {k: int(v) for k, v in top},
+           "step_read_bytes_by_kernel": {k: int(read_step.get(k, 0)) for k, _ in top},
+           "source": "two rocprofv3 --pmc child passes of this run"}
+    if factor is not None:
+        out["fetch_size_correction"] = round(factor, 3)
+    return out
 
 
 _WORKER_BUF = {}

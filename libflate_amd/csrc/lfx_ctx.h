@@ -96,14 +96,17 @@ struct Ctx {
     // Buffers of stream encoders / decoders that were freed, kept for the next handle of this context: page-locking 16 .. 64 MiB
     // and a hipMalloc per handle cost more than encoding a small stream (an encoder per file is the reference's own usage,
     // examples/flate.rs:89-110).  Taken and given back under `mu`; at most POOL_MAX of each kind are kept.
-    static constexpr size_t POOL_MAX = 6;
+    static constexpr size_t POOL_MAX = 8;
     std::vector<PinVec> pin_pool;
     std::vector<DevBuf> dev_pool;
-    PinVec take_pin() {
+    PinVec take_pin() {            // the roomiest one (a handle's first buffer is its largest: pending input, window output)
         std::lock_guard<std::recursive_mutex> lock(mu);
         if (pin_pool.empty()) return PinVec();
-        PinVec v = std::move(pin_pool.back());
-        pin_pool.pop_back();
+        size_t best = 0;
+        for (size_t i = 1; i < pin_pool.size(); i++)
+            if (pin_pool[i].capacity() > pin_pool[best].capacity()) best = i;
+        PinVec v = std::move(pin_pool[best]);
+        pin_pool.erase(pin_pool.begin() + (std::ptrdiff_t)best);
         v.clear();
         return v;
     }

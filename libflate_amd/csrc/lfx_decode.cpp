@@ -1725,7 +1725,10 @@ int dec_body(lfx_decoder *d) {
         d->target = 0; d->tried_at = 0;
         d->out_cap = WINDOW_OUT;
     }
-    if (d->target == 0) d->target = 1 << 16;       // (small members: do not wait for a whole window)
+    // (small members: do not wait for a whole window.  1 MiB since round 6 — a reader that has less hands over a short read or
+    //  its end, either of which triggers an attempt; at 64 KiB a member of 1 MiB blocks made three attempts of 0.45 ms each
+    //  before its first block was complete)
+    if (d->target == 0) d->target = 1 << 20;
     const uint64_t trailer = d->format == LFX_GZIP ? 8 : d->format == LFX_ZLIB ? 4 : 0;
     for (;;) {
         // ---- the member's blocks are done: the trailer (gzip.rs:1030-1042, zlib.rs:387-401)
@@ -1855,8 +1858,9 @@ extern "C" lfx_decoder *lfx_decoder_new(lfx_ctx *cc, int format, uint32_t flags,
     if (!cc || !r || format < 0 || format > 2) { if (status) *status = cc ? LFX_E_ARG : LFX_E_DEVICE; return nullptr; }
     lfx_decoder *d = new lfx_decoder();
     d->c = reinterpret_cast<Ctx *>(cc);
-    d->in = d->c->take_pin();          // (page-locked buffers of an earlier decoder of this context, when there are any)
-    d->out = d->c->take_pin();
+    d->out = d->c->take_pin();         // (page-locked buffers of an earlier decoder of this context, when there are any)
+    d->next.out = d->c->take_pin();
+    d->in = d->c->take_pin();
     d->format = format;
     d->flags = flags;
     d->r = r;
@@ -1985,5 +1989,6 @@ extern "C" void lfx_decoder_free(lfx_decoder *d) {
     dec_settle(d);
     d->c->give_pin(std::move(d->in));
     d->c->give_pin(std::move(d->out));
+    d->c->give_pin(std::move(d->next.out));
     delete d;
 }

@@ -121,21 +121,10 @@ __device__ __forceinline__ uint32_t eq_bytes16(const B16 &a, const B16 &b) {
 // lane with a match of 12 or more, and every lane paid its extra iterations (1400 cycles per step, measured; the LDS
 // round trips of one iteration are the same for 8 and for 16 bytes).  The position's own bytes do not depend on the
 // candidate: they are loaded together with it.
-// Round 6 — TWO LITERALS IN ONE STEP: a position without a candidate is a literal whatever came before (default.rs:102-103),
-// so when pos + 1 has none either (and lies in front of `stop`) the step takes both: `bits` = 3 (positions pos and pos + 1
-// visited), 2 returned.  A wavefront's trip count is that of its slowest lane, and the slowest lanes are the ones in
-// stretches of literals — first sights of a word: CPU model on the benchmark text, 23.2 → 19.9 trips per group of 52
-// positions (tools/parse2_model.py has the same rule).  `bits` = 1 otherwise.
-__device__ __forceinline__ uint32_t walk_step(const WalkCtx &w, uint32_t pos, bool act, uint32_t stop, uint32_t &bits) {
-    // (idle lanes are handed a position of their own group: every address below is inside the staged arrays, so the loads
-    //  need no exec mask — an s_and_saveexec region per load otherwise)
-    uint32_t oa = pos + 3 - w.w0;
+__device__ __forceinline__ uint32_t walk_step(const WalkCtx &w, uint32_t pos, bool act) {
+    uint32_t oa = act ? pos + 3 - w.w0 : 0u;                        // (idle lanes read offset 0)
     // loads that do not depend on the candidate
-    const uint32_t ci = pos - w.c0;
-    const uint32_t d_raw = w.cd16[ci], dn_raw = w.cd16[ci + 1];     // (the entry behind the last position is padding: never used, pos + 1 < stop)
-    const uint32_t d = act ? d_raw : 0u;
-    const bool two = act && (d_raw | dn_raw) == 0 && pos + 1 < stop;
-    bits = two ? 3u : 1u;
+    const uint32_t d = act ? w.cd16[pos - w.c0] : 0u;
     B16 a = lds16(w.win32, oa);
     uint32_t lim = w.n - (pos + 3);                                 // default.rs:125 (bounded by the end of the chunk)
     lim = lim > w.max_len - 3 ? w.max_len - 3 : lim;
@@ -169,7 +158,7 @@ __device__ __forceinline__ uint32_t walk_step(const WalkCtx &w, uint32_t pos, bo
         ob += cmp ? 64u : 0u;
     }
     l = l > lim ? lim : l;
-    return act ? (d ? 3u + l : (two ? 2u : 1u)) : 0u;
+    return act ? (d ? 3u + l : 1u) : 0u;
 }
 
 // The true walk enters this lane's group at `in`.  Re-walk from there until it lands on a position the speculative walk
@@ -188,11 +177,8 @@ __device__ __forceinline__ void resolve(const WalkCtx &w, bool act, uint32_t in,
             else if ((mask >> (pos - a)) & 1) { m = walked | (mask & bits_from(pos - a)); x = exit_spec; run = false; }
         }
         if (!__ballot(run)) break;
-        uint32_t bits;
-        const uint32_t st = walk_step(w, run ? pos : a, run, stop, bits);
-        // (two literals at once: had the second one been a position the speculative walk visited, so is the one behind it —
-        //  a literal's successor — and the merge is found one step later with the same visited set)
-        walked |= run ? (uint64_t)bits << (pos - a) : 0ull;
+        const uint32_t st = walk_step(w, run ? pos : a, run);
+        walked |= run ? 1ull << (pos - a) : 0ull;
         pos += st;
     }
     if (act) { m_out = m; x_out = x; }
@@ -342,9 +328,8 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
     for (uint32_t guard = 0; guard <= U; ++guard) {
         const bool run = have && pos < stop;
         if (!__ballot(run)) break;
-        uint32_t bits;
-        const uint32_t st = walk_step(w, run ? pos : a, run, stop, bits);
-        mask |= run ? (uint64_t)bits << (pos - a) : 0ull;
+        const uint32_t st = walk_step(w, run ? pos : a, run);
+        mask |= run ? 1ull << (pos - a) : 0ull;
         pos += st;
     }
     const uint32_t exit_spec = pos;

@@ -49,15 +49,6 @@ class Chunk:
         return 3 + l
 
 
-def step2(ch, pos, stop):
-    """walk_step of parse_walk_kernel since round 6: two literals in one step when pos + 1 has no candidate either and
-    lies in front of `stop` → (distance to the next position, visited bits relative to pos)"""
-    st = ch.step(pos)
-    if st == 1 and pos + 1 < stop and int(ch.cd[pos + 1]) == 0:
-        return 2, 3
-    return st, 1
-
-
 def resolve(ch, in_, a, stop, mask, exit_spec):
     walked = 0
     pos = in_
@@ -67,9 +58,8 @@ def resolve(ch, in_, a, stop, mask, exit_spec):
         r = pos - a
         if (mask >> r) & 1:
             return walked | (mask & (~0 << r) & ((1 << 64) - 1)), exit_spec
-        st, bits = step2(ch, pos, stop)
-        walked |= bits << r
-        pos += st
+        walked |= 1 << r
+        pos += ch.step(pos)
 
 
 def walk_segment(ch, sidx, stats=None):
@@ -87,9 +77,8 @@ def walk_segment(ch, sidx, stats=None):
     for L in range(64):
         pos = a[L]
         while have[L] and pos < stop[L]:
-            st, bits = step2(ch, pos, stop[L])
-            mask[L] |= bits << (pos - a[L])
-            pos += st
+            mask[L] |= 1 << (pos - a[L])
+            pos += ch.step(pos)
         exit_spec[L] = pos
     used_in = [a[0]] + exit_spec[:63]
     m_fin = list(mask)
