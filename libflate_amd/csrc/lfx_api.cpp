@@ -240,7 +240,6 @@ void Diag::read() {
     if (const char *fs = getenv("LFX_FREE_SHIFT")) free_shift = atoi(fs);
     if (const char *pm = getenv("LFX_POCR_MAX")) pocr_max = atoi(pm);
     if (const char *eb = getenv("LFX_ENC_BATCH_MB")) enc_batch_mb = atoi(eb);
-    scan_fifo = on("LFX_SCAN_FIFO");
 }
 
 void Ctx::phase(const char *name) {

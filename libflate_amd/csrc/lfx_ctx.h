@@ -35,7 +35,6 @@ struct Diag {
     bool no_final_cand = false;  // LFX_NO_FINAL_CAND: the finder reports no BFINAL header at all (the chain walk scans the last block on demand)
     bool window_chain = false;   // LFX_WINDOW_CHAIN
     int free_shift = -1;         // LFX_FREE_SHIFT
-    bool scan_fifo = false;      // LFX_SCAN_FIFO: the block scan of large blocks on the register FIFO (round 5's) instead of LDS rings
     int enc_batch_mb = 0;        // LFX_ENC_BATCH_MB: the stream encoder encodes closed blocks once so many MiB wait (0: the default, 8)
     int pocr_max = 100;          // LFX_POCR_MAX: most candidate ranges the decoder scans in pieces at once
     void read();

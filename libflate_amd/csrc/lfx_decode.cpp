@@ -462,11 +462,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)(nj + EXTRA + 1)))) return rc;
             if ((rc = c->d_dec_tabs.reserve(tab_bytes * (nj + EXTRA + 1)))) return rc;
             HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
-            // (blocks of a megabit and more — a stream's own 1 MiB blocks — on the LDS-ring instance of the scan: one workgroup
-            //  per CU, which 256 blocks on 256 CUs are anyway; LFX_SCAN_FIFO=1 keeps the register FIFO)
-            const bool scan_large = !c->diag.scan_fifo && nj && (n * 8) / nj >= (1ull << 20);
             LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
-                                       (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p, scan_large));
+                                       (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
             std::vector<BlkInfo> bi(nj);
             HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -1684,18 +1681,10 @@ void dec_gpu(lfx_decoder *d, lfx_decoder::Window &W) {
             W.crc = er.crc32;
             W.adler = er.adler32;
         }
-        if (c->diag.debug) {
-            fprintf(stderr, "[lfx] window gpu: in=%llu out=%llu inflate_member %.3f ms, checksum + D2H %.3f ms", (unsigned long long)n,
+        if (c->diag.debug)
+            fprintf(stderr, "[lfx] window gpu: in=%llu out=%llu inflate_member %.3f ms, checksum + D2H %.3f ms\n", (unsigned long long)n,
                     (unsigned long long)keep, std::chrono::duration<double, std::milli>(tw1 - tw0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
-            if (c->timing_on)          // (the kernels' own brackets of this window)
-                for (int i = 0; i + 1 < c->n_ev; i++) {
-                    float ms = 0;
-                    (void)hipEventSynchronize(c->ev[i + 1]);
-                    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) fprintf(stderr, " %s=%.3f", c->ev_name[i + 1], ms);
-                }
-            fprintf(stderr, "\n");
-        }
         return;
     }
 }

@@ -121,8 +121,7 @@ struct SymUnit {
 // tabs: njobs * blk_tabs_bytes() bytes: the decode tables of every scanned block, reused by launch_blk_emit
 size_t blk_tabs_bytes();
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
-                    BlkInfo *infos, BlkLanes *lanes, void *tabs = nullptr,
-                    bool large_blocks = false);      // round 6: the scan instance on LDS bit rings (as launch_blk_emit's): blocks of >= 1 Mbit
+                    BlkInfo *infos, BlkLanes *lanes, void *tabs = nullptr);
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
                     uint32_t *job_flags = nullptr,   // job_flags[j] = 1: block j reads bytes in front of itself

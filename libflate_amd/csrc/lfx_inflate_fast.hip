@@ -885,26 +885,12 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
 // K1: speculative scan of one candidate block: validated per-lane starts, code and byte counts
 // (two workgroups per CU: a stream has a few more candidate blocks than the GPU has CUs, and a second
 // round of workgroups would double the kernel's time — 8 waves per SIMD = at most 64 VGPRs)
-// RING (round 6): the lanes' bits come through LDS rings (RingBits) as in blk_emit_kernel<true> — one workgroup per CU, fewer
-// instructions per symbol; for a stream's own large blocks (256 one-MiB blocks are one workgroup per CU anyway).  Else the
-// register FIFO: two workgroups per CU, the batch path's thousands of small blocks.
-template <bool RING>
-__global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+__global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkJob *__restrict__ jobs,
                                                                 BlkInfo *__restrict__ infos,
                                                                 BlkLanes *__restrict__ lanes,
                                                                 FastTabs *__restrict__ tabs) {
     __shared__ FastTabs T;
-    __shared__ uint32_t s_ring[RING ? SCAN_THREADS * RING_STRIDE : 1];      // the lanes' bit rings
-    // one decode of [from, to): counts only
-    auto dec = [&](uint64_t from, uint64_t to, uint32_t &n_codes, uint64_t &n_out, uint64_t &at) -> int {
-        int64_t dummy = 0;
-        uint32_t cc = 0, co = 0;
-        if constexpr (RING)
-            return lane_decode<false>(T, in, nbytes, from, to, n_codes, n_out, nullptr, dummy, at, cc, co, s_ring + threadIdx.x * RING_STRIDE);
-        else
-            return lane_decode_fifo<false>(T, in, nbytes, from, to, n_codes, n_out, nullptr, dummy, at, cc, co);
-    };
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
@@ -979,6 +965,8 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_scan_kernel(co
     uint32_t rest_nc = 0, rest_flag = 0;
     bool have_cp = false;
     for (;;) {
+        int64_t dummy = 0;
+        uint32_t cc = 0, co = 0;
         const uint64_t st = s_start[tid];
         if (tid < nl && st != ~0ull) {
             if (st != decoded_from) {
@@ -990,25 +978,25 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_scan_kernel(co
                 int r = 0;
                 bool reuse = false;
                 if (have_cp && st < cp_pos) {
-                    r = dec(st, cp_pos, nc, no, at);
+                    r = lane_decode_fifo<false>(T, in, nbytes, st, cp_pos, nc, no, nullptr, dummy, at, cc, co);
                     reuse = r == 0 && at == cp_pos;
                     if (!reuse) have_cp = false;
                 } else {
                     have_cp = false;
                     const uint64_t cpl = st + CP_BITS < lim ? st + CP_BITS : lim;
-                    r = dec(st, cpl, nc, no, at);
+                    r = lane_decode_fifo<false>(T, in, nbytes, st, cpl, nc, no, nullptr, dummy, at, cc, co);
                     if (r == 0 && at < lim) {
                         have_cp = true;
                         cp_pos = at;
                         rest_nc = 0; rest_no = 0;
-                        const int rr = dec(at, lim, rest_nc, rest_no, rest_exit);
+                        const int rr = lane_decode_fifo<false>(T, in, nbytes, at, lim, rest_nc, rest_no, nullptr, dummy, rest_exit, cc, co);
                         rest_flag = rr == 1 ? 1 : rr == 2 ? 2 : 0;
                         reuse = true;
                     }
                 }
                 if (reuse) { nc += rest_nc; no += rest_no; exitpos = rest_exit; flag = rest_flag; }
                 else {
-                    if (r == 0 && at < lim) r = dec(at, lim, nc, no, at);
+                    if (r == 0 && at < lim) r = lane_decode_fifo<false>(T, in, nbytes, at, lim, nc, no, nullptr, dummy, at, cc, co);
                     exitpos = at;
                     flag = r == 1 ? 1 : r == 2 ? 2 : 0;
                 }
@@ -2277,12 +2265,9 @@ __global__ __launch_bounds__(M2_WIDE_THREADS) void blk_materialize2_sym_wide_ker
 
 size_t blk_tabs_bytes() { return sizeof(FastTabs); }
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
-                    BlkInfo *infos, BlkLanes *lanes, void *tabs, bool large_blocks) {
+                    BlkInfo *infos, BlkLanes *lanes, void *tabs) {
     if (!njobs) return 0;
-    if (large_blocks)
-        hipLaunchKernelGGL(blk_scan_kernel<true>, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes, (FastTabs *)tabs);
-    else
-        hipLaunchKernelGGL(blk_scan_kernel<false>, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes, (FastTabs *)tabs);
+    hipLaunchKernelGGL(blk_scan_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes, (FastTabs *)tabs);
     LFX_LAUNCH_CHECK();
     return 0;
 }
