@@ -35,6 +35,7 @@ struct Diag {
     bool no_final_cand = false;  // LFX_NO_FINAL_CAND: the finder reports no BFINAL header at all (the chain walk scans the last block on demand)
     bool window_chain = false;   // LFX_WINDOW_CHAIN
     int free_shift = -1;         // LFX_FREE_SHIFT
+    bool two_pass = false;       // LFX_TWO_PASS: every block through blk_emit_kernel (no storing scan)
     int enc_batch_mb = 0;        // LFX_ENC_BATCH_MB: the stream encoder encodes closed blocks once so many MiB wait (0: the default, 8)
     int pocr_max = 100;          // LFX_POCR_MAX: most candidate ranges the decoder scans in pieces at once
     void read();
@@ -77,11 +78,13 @@ struct Ctx {
     // different plan is copied from the shadow, which outlives the asynchronous copy (no synchronisation either way)
     std::vector<uint8_t> up_shadow[4];
     uint64_t up_dev[4] = {0, 0, 0, 0};      // (buffer address ^ allocation generation << 48)
-    DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks, d_dec_tabs, d_dec_sym, d_dec_win, d_dec_maps;
+    DevBuf d_dec_streams, d_dec_state, d_dec_tmp, d_dec_cand, d_dec_blocks, d_dec_tabs, d_dec_sym, d_dec_win, d_dec_maps,
+        d_dec_temp, d_dec_lanesx;     // round 6: the storing scan's per-lane code regions and BlkLanesX records
     std::vector<DevBuf *> all_bufs() {
         return {&d_chunks, &d_blocks, &d_segs, &d_pwgs, &d_cd, &d_md, &d_codes, &d_ncodes, &d_hist, &d_bc, &d_block_start,
                 &d_tile_bits, &d_tile_start, &d_ck, &d_res, &d_small, &d_hdr, &d_io_in, &d_io_out, &d_vis, &d_segtmp, &d_stage, &d_chunkmap, &d_glnk, &d_ucount,
-                &d_dec_streams, &d_dec_state, &d_dec_tmp, &d_dec_cand, &d_dec_blocks, &d_dec_tabs, &d_dec_sym, &d_dec_win, &d_dec_maps};
+                &d_dec_streams, &d_dec_state, &d_dec_tmp, &d_dec_cand, &d_dec_blocks, &d_dec_tabs, &d_dec_sym, &d_dec_win, &d_dec_maps,
+                &d_dec_temp, &d_dec_lanesx};
     }
     void *h_res = nullptr;  // pinned, 4 KiB
 

@@ -210,6 +210,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             uint32_t nc = (uint32_t)starts.size();
             auto start_at = [&](uint32_t i) { return i < nc ? starts[i] : n * 8; };
             std::vector<BlkEmit> emit;
+            uint32_t n_placed = 0;          // blocks whose codes the scan stored (blk_place_kernel instead of blk_emit_kernel)
             uint64_t pos = first_bit, total = 0, total_codes = 0;
             bool ok_chain = false, chain_final = false;
             bool front_bad = false;      // the window's FIRST block does not scan: damaged rather than incomplete
@@ -461,13 +462,42 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * (nj + EXTRA + 1)))) return rc;
             if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)(nj + EXTRA + 1)))) return rc;
             if ((rc = c->d_dec_tabs.reserve(tab_bytes * (nj + EXTRA + 1)))) return rc;
+            // ---- ONE Huffman pass for a stream's own large blocks (round 6): the scan stores every lane's code words in a
+            //      region of its own (cap = half a code per bit of the slice + a head's worth + slack: a slice whose codes
+            //      average less than two bits overflows, is flagged, and takes the emit kernel as before), blk_place_kernel
+            //      moves them.  Only the first batch of jobs stores; rescans and on-demand scans are the classic ones.
+            //      Not for thousands of small blocks (the regions' fixed part would dominate) or when the regions would
+            //      not fit 16 GiB; LFX_TWO_PASS=1 keeps the emit kernel for everything.
+            std::vector<uint8_t> stored(nj + EXTRA + 1, 0);
+            bool store_mode = !c->diag.two_pass && nj && (n * 8) / nj >= (1ull << 20);
+            if (store_mode) {
+                uint64_t off = 0;
+                for (uint32_t j = 0; j < nj; j++) {
+                    const uint64_t bits = bj[j].end_bit > bj[j].start_bit ? bj[j].end_bit - bj[j].start_bit : 0;
+                    const uint64_t slice = std::max<uint64_t>((bits + 1023) / 1024, 128);
+                    const uint64_t cap = (slice / 2 + 448 + 64 + 3) & ~3ull;          // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
+                    bj[j].temp_off = off;
+                    bj[j].cap = (uint32_t)cap;
+                    off += 1024 * cap;
+                }
+                if (off * 4 > (16ull << 30) || c->d_dec_temp.reserve(off * 4) || c->d_dec_lanesx.reserve(sizeof(BlkLanesX) * (size_t)(nj + 1))) {
+                    store_mode = false;
+                    for (uint32_t j = 0; j < nj; j++) { bj[j].temp_off = 0; bj[j].cap = 0; }
+                }
+            }
             HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
-            LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
-                                       (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
+            if (store_mode)
+                LAUNCH_TRY(launch_blk_scan_store(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
+                                                 (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p, (uint32_t *)c->d_dec_temp.p,
+                                                 (BlkLanesX *)c->d_dec_lanesx.p));
+            else
+                LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
+                                           (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
             std::vector<BlkInfo> bi(nj);
             HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             for (BlkInfo &b : bi) if (b.status == BLK_OK && b.end_bit > n * 8) b.status = BLK_NO_EOB;   // (cut by the input's end)
+            if (store_mode) for (uint32_t j = 0; j < nj; j++) stored[j] = bi[j].status == BLK_OK && bi[j].btype != 0 && bi[j]._pad == 0;
             c->phase("blk_scan");
             // slot[i]: where candidate i's scan result and lanes live (its own slot or the wider job's)
             std::vector<uint32_t> slot(nc);
@@ -497,6 +527,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), sizeof(BlkJob) * redo.size(), hipMemcpyHostToDevice, st));
                 for (size_t q = 0; q < redo.size(); q++) {
                     slot[redo[q]] = redo[q];
+                    stored[redo[q]] = 0;            // (a classic scan takes the slot over: what its lanes stored before is stale)
                     LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_rj + q, 1, (BlkInfo *)c->d_dec_state.p + redo[q],
                                                (BlkLanes *)c->d_dec_blocks.p + redo[q],
                                                (uint8_t *)c->d_dec_tabs.p + tab_bytes * redo[q]));
@@ -538,6 +569,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 e.start_bit = pos; e.data_bit = r.data_bit; e.code_off = total_codes; e.out_off = total;
                 e.n_out = r.n_out; e.n_codes = r.n_codes; e.nlanes = r.nlanes; e.btype = r.btype; e.cand = k;
                 e.hist = hist + total;      // (hist = 0: a member starts with an empty window)
+                if (k < nj && stored[k]) { e.placed = 1; e.temp_off = bj[k].temp_off; e.cap = bj[k].cap; n_placed++; }
                 emit.push_back(e);
                 total += r.n_out;
                 total_codes += r.n_codes;
@@ -586,9 +618,15 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
                 if (pieces_mode && units_per_piece) free_shift = 20;
                 if (c->diag.free_shift >= 0) free_shift = (uint32_t)c->diag.free_shift;
-                LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
-                                           (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
-                                           c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne));
+                // (blocks whose codes the scan stored are moved into place; the others are decoded a second time)
+                if (n_placed)
+                    LAUNCH_TRY(launch_blk_place(st, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (const BlkLanesX *)c->d_dec_lanesx.p,
+                                                (const uint32_t *)c->d_dec_temp.p, (uint32_t *)c->d_codes.p, d_flags,
+                                                (BlkUnits *)c->d_hist.p, unit_target, nullptr, free_shift));
+                if (n_placed < ne)
+                    LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
+                                               (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
+                                               c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne));
                 c->phase("blk_emit");
                 // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
                 // the marker path, which may cut anywhere
@@ -1591,7 +1629,10 @@ int dec_header(lfx_decoder *d) {
 // WINDOW_IN_MAX bounds the doubling (a damaged stream whose block never reaches an EndOfBlock, on a reader that
 // never ends, must not pull the rest of the input into memory): at the limit the window is decoded WITHOUT `partial` — the
 // exact walk gives a verdict for a damaged stream; a valid block larger than the limit is refused.
-constexpr uint64_t WINDOW_IN = 16ull << 20, WINDOW_OUT = 96ull << 20, WINDOW_IN_MAX = 4ull << 30;
+// Round 6: a window's kernels are bound by per-block latency, not by its size — 33 one-MiB blocks (16 MiB of text stream) take
+// 2.0 ms of kernels where the whole 256-block stream takes 2.6 (LFX_DEBUG window lines) — so after a first window of WINDOW_IN
+// bytes (first bytes early) the later ones take WINDOW_IN_LATER: half as many windows for 16 MiB more of page-locked memory.
+constexpr uint64_t WINDOW_IN = 16ull << 20, WINDOW_IN_LATER = 32ull << 20, WINDOW_OUT = 96ull << 20, WINDOW_IN_MAX = 4ull << 30;
 
 // → LFX_OK when bytes or a verdict are ready (state ST_SERVE), LFX_E_WOULD_BLOCK / LFX_E_IO from the reader, or a device error
 // ---- one window of the member's body in three steps: input (caller's thread) → GPU (caller's thread, or a worker thread
@@ -1681,10 +1722,18 @@ void dec_gpu(lfx_decoder *d, lfx_decoder::Window &W) {
             W.crc = er.crc32;
             W.adler = er.adler32;
         }
-        if (c->diag.debug)
-            fprintf(stderr, "[lfx] window gpu: in=%llu out=%llu inflate_member %.3f ms, checksum + D2H %.3f ms\n", (unsigned long long)n,
+        if (c->diag.debug) {
+            fprintf(stderr, "[lfx] window gpu: in=%llu out=%llu inflate_member %.3f ms, checksum + D2H %.3f ms", (unsigned long long)n,
                     (unsigned long long)keep, std::chrono::duration<double, std::milli>(tw1 - tw0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
+            if (c->timing_on)          // (the kernels' own brackets of this window; the first one holds the H2D copy too)
+                for (int i = 0; i + 1 < c->n_ev; i++) {
+                    float ms = 0;
+                    (void)hipEventSynchronize(c->ev[i + 1]);
+                    if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) fprintf(stderr, " %s=%.3f", c->ev_name[i + 1], ms);
+                }
+            fprintf(stderr, "\n");
+        }
         return;
     }
 }
@@ -1844,7 +1893,7 @@ int dec_body(lfx_decoder *d) {
         d->bit_off = (uint32_t)(mr.end_bit & 7);
         d->member_final = mr.final_seen;
         d->more_windows = true;                        // (the trailer check, at least, follows)
-        d->target = std::max<uint64_t>(WINDOW_IN, d->target > (1 << 16) ? d->target : 0);
+        d->target = std::max<uint64_t>(d->member_out > mr.out_len ? WINDOW_IN_LATER : WINDOW_IN, d->target > (1 << 20) ? d->target : 0);
         d->tried_at = 0;
         d->state = lfx_decoder::ST_SERVE;
         return LFX_OK;

@@ -76,6 +76,10 @@ struct BlkJob {
     // Piece 0 starts behind the header like any job (warm_bit = 0).
     uint64_t lo_bit, warm_bit;
     uint32_t piece, _pad;
+    // the storing scan (round 6, launch_blk_scan_store): this job's lanes write their code words to temp + temp_off +
+    // lane * cap (dwords); 0 = none
+    uint64_t temp_off;
+    uint32_t cap, _pad2;
 };
 struct BlkInfo {
     uint64_t end_bit;    // bit after EndOfBlock (stored: after the data)
@@ -91,6 +95,15 @@ struct BlkLanes {
     uint64_t out_off[1024];   // bytes of the block produced before the slice
     uint32_t code_off[1024];  // codes of the block before the slice
 };
+// what a storing scan leaves per lane for blk_place_kernel (indexed like BlkLanes)
+struct BlkLanesX {
+    uint32_t n_head[1024];    // the slice's codes: n_head of them from 0 of the lane's region ...
+    uint32_t n_rest[1024];    // ... and n_rest from rest_at on
+    uint32_t rest_at[1024];
+    int32_t reach[1024];      // smallest (bytes of the slice produced before a match - its distance); INT32_MAX: no match
+    uint32_t cut_code[1024];  // earliest cut of the slice no later code of the slice reads across: code index and byte offset,
+    uint32_t cut_out[1024];   //   relative to the slice (cut_code 0xFFFFFFFF: none)
+};
 struct BlkEmit {
     uint64_t start_bit, data_bit;
     uint64_t code_off;   // first code slot of the block
@@ -100,7 +113,9 @@ struct BlkEmit {
     uint64_t hist;       // output bytes of the same member in front of the block (bounds its back-references)
     uint64_t end_limit;  // 0: the last lane decodes up to EndOfBlock; else (an open piece) up to this bit
     uint32_t preload;    // materialise: those bytes are already final in `out` — load up to 32 KiB of them as history
-    uint32_t _pad;
+    uint32_t placed;     // round 6: 1 = the scan stored this block's codes (blk_place_kernel moves them; blk_emit_kernel skips the block)
+    uint64_t temp_off;   // ... at temp + temp_off + lane * cap
+    uint32_t cap, _pad;
 };
 constexpr uint32_t MAX_FREE_UNITS = 64;   // marker units per block (a schedule-S1 stream is ONE block)
 struct BlkUnits {
@@ -122,6 +137,11 @@ struct SymUnit {
 size_t blk_tabs_bytes();
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
                     BlkInfo *infos, BlkLanes *lanes, void *tabs = nullptr);
+int launch_blk_scan_store(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
+                          BlkInfo *infos, BlkLanes *lanes, void *tabs, uint32_t *temp, BlkLanesX *lanesx);
+int launch_blk_place(hipStream_t st, const BlkEmit *jobs, uint32_t njobs, const BlkLanes *lanes, const BlkLanesX *lanesx,
+                     const uint32_t *temp, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
+                     uint32_t *job_flags, uint32_t free_shift);
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
                     uint32_t *job_flags = nullptr,   // job_flags[j] = 1: block j reads bytes in front of itself

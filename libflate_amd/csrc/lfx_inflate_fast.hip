@@ -472,10 +472,12 @@ template <bool EMIT>
 __device__ __forceinline__ int lane_decode_fifo(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
                                            uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
                                            int64_t &reach, uint64_t &endpos, uint32_t &cut_code, uint32_t &cut_out,
-                                           uint32_t *stage = nullptr) {
+                                           uint32_t *stage = nullptr, uint32_t store_cap = 0xFFFFFFFFu, uint32_t *ovf = nullptr) {
     // EMIT: code words are staged in this lane's LDS row (EMIT_STAGE entries) and written out as runs of
     // 16-byte stores whenever the wavefront pauses to refill its bit FIFOs — a lane's 4-byte stores, each
     // to a cache line of its own, cost ~6x their size in HBM traffic (partial-line evictions).
+    // store_cap (the storing scan, round 6): `codes` has room for so many code words; what does not fit is counted, not
+    // stored, and *ovf is raised (the block then takes the two-pass path).
     FastBits b;
     uint32_t staged = 0;
     b.init(in, nbytes, start);
@@ -537,9 +539,11 @@ __device__ __forceinline__ int lane_decode_fifo(const FastTabs &T, const uint8_t
         if (refill) b.take();
         if (EMIT) {
             uint32_t *dst = codes + (ncodes - staged);
+            const bool fits = ncodes <= store_cap;
+            if (!fits && ovf) *ovf = 1u;
             for (uint32_t j = 0; j < EMIT_STAGE; j += 4) {
                 if (__ballot(j < staged) == 0) break;
-                if (j < staged) {
+                if (j < staged && fits) {
                     const uint32_t c0 = stage[j], c1 = stage[j + 1], c2 = stage[j + 2], c3 = stage[j + 3];
                     if (j + 4 <= staged) {
                         U32x4 q;
@@ -885,11 +889,22 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
 // K1: speculative scan of one candidate block: validated per-lane starts, code and byte counts
 // (two workgroups per CU: a stream has a few more candidate blocks than the GPU has CUs, and a second
 // round of workgroups would double the kernel's time — 8 waves per SIMD = at most 64 VGPRs)
-__global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+// STORE (round 6, the single-pass decode of a stream's own large blocks): the scan KEEPS what it decodes — every lane writes
+// its slice's code words into a region of its own in `temp` (BlkJob::temp_off, `cap` code words per lane) and tracks what
+// blk_emit_kernel tracks (how far back its matches reach, its earliest legal cut), so that the second Huffman pass of the
+// block is replaced by blk_place_kernel: a copy of the code words to their final places.  A slice is decoded in two
+// segments — the head [start, checkpoint), which a corrected start decodes again, and the rest, which is reused — so the
+// lane's region holds the head's codes from 0 on and the rest's from SCAN_HEADCAP on (or right behind the head's when the
+// rest was decoded behind a head that missed the checkpoint); BlkLanesX says which.
+constexpr uint32_t SCAN_HEADCAP = 448;        // code words a head may take: (768 + 48) bits at two bits a code, rounded up to a multiple of 4
+template <bool STORE>
+__global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkJob *__restrict__ jobs,
                                                                 BlkInfo *__restrict__ infos,
                                                                 BlkLanes *__restrict__ lanes,
-                                                                FastTabs *__restrict__ tabs) {
+                                                                FastTabs *__restrict__ tabs,
+                                                                uint32_t *__restrict__ temp, BlkLanesX *__restrict__ lanesx) {
+    extern __shared__ uint32_t scan_stage[];   // STORE: SCAN_THREADS rows of EMIT_STRIDE dwords
     __shared__ FastTabs T;
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
@@ -951,7 +966,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
     const uint32_t nl = (uint32_t)((e - d0 + slice - 1) / slice);  // lanes in use (<= SCAN_THREADS)
     const uint64_t my_bound = d0 + (uint64_t)(tid + 1) * slice;     // end of my slice
     s_start[tid] = tid == 0 ? d0 : (tid < nl ? d0 + (uint64_t)tid * slice : ~0ull);
-    if (tid == 0) s_start[SCAN_THREADS] = ~0ull;
+    if (tid == 0) { s_start[SCAN_THREADS] = ~0ull; hdr[7] = 0; }      // (hdr[7]: STORE's "a lane's codes did not fit" flag)
     __syncthreads();
     uint32_t rounds = 0;
     // Round 1 decodes every slice from its guessed start: a short head [start, checkpoint) and the rest
@@ -961,45 +976,70 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
     constexpr uint64_t CP_BITS = LFX_SCAN_CP_BITS;
     uint32_t nc = 0, flag = 4;
     uint64_t no = 0, exitpos = ~0ull;
-    uint64_t decoded_from = ~0ull, cp_pos = 0, rest_no = 0, rest_exit = 0;
-    uint32_t rest_nc = 0, rest_flag = 0;
+    uint64_t decoded_from = ~0ull, cp_pos = 0, rest_exit = 0;
+    uint32_t rest_flag = 0;
     bool have_cp = false;
+    // STORE: the lane's region of `temp`, and per segment (A = head, B = rest) what the emit kernel's decode tracks: the
+    // smallest (bytes of the segment produced so far - distance) over its matches and its earliest legal cut, both relative
+    // to the segment's own start
+    uint32_t *my_temp = nullptr;
+    uint32_t lane_cap = 0, ovf = 0;
+    if constexpr (STORE) {
+        lane_cap = job.cap;
+        my_temp = temp + job.temp_off + (uint64_t)tid * lane_cap;
+    }
+    struct Seg { uint32_t n; uint64_t no; int64_t reach; uint32_t cc, co; };
+    Seg A{0, 0, INT64_MAX, 0, 0}, B{0, 0, INT64_MAX, 0, 0};
+    bool b_split = false;                      // B's codes lie at SCAN_HEADCAP (else right behind A's)
+    // one segment [from, to): counts (and, STORE, codes at dst with room for `room` of them + tracking) → decoder's return
+    auto seg = [&](uint64_t from, uint64_t to, Seg &g, uint64_t &at, uint32_t *dst, uint32_t room) -> int {
+        g = Seg{0, 0, INT64_MAX, 0, 0};
+        if constexpr (STORE)
+            return lane_decode_fifo<true>(T, in, nbytes, from, to, g.n, g.no, dst, g.reach, at, g.cc, g.co,
+                                          scan_stage + tid * EMIT_STRIDE, room, &ovf);
+        else {
+            int64_t dummy = 0;
+            return lane_decode_fifo<false>(T, in, nbytes, from, to, g.n, g.no, nullptr, dummy, at, g.cc, g.co);
+        }
+    };
     for (;;) {
-        int64_t dummy = 0;
-        uint32_t cc = 0, co = 0;
         const uint64_t st = s_start[tid];
         if (tid < nl && st != ~0ull) {
             if (st != decoded_from) {
                 // the last lane keeps going to the end of the stream range (the block may end exactly at e)
                 // (a piece's last lane stops at the first symbol boundary >= e: the next piece starts exactly there)
                 const uint64_t lim = tid + 1 == nl ? (piece ? e : e + 64) : my_bound;
-                nc = 0; no = 0;
                 uint64_t at = st;
                 int r = 0;
                 bool reuse = false;
                 if (have_cp && st < cp_pos) {
-                    r = lane_decode_fifo<false>(T, in, nbytes, st, cp_pos, nc, no, nullptr, dummy, at, cc, co);
+                    // (a cached rest lies at SCAN_HEADCAP: the head must stay in front of it)
+                    r = seg(st, cp_pos, A, at, my_temp, lane_cap < SCAN_HEADCAP ? lane_cap : SCAN_HEADCAP);
                     reuse = r == 0 && at == cp_pos;
                     if (!reuse) have_cp = false;
                 } else {
                     have_cp = false;
                     const uint64_t cpl = st + CP_BITS < lim ? st + CP_BITS : lim;
-                    r = lane_decode_fifo<false>(T, in, nbytes, st, cpl, nc, no, nullptr, dummy, at, cc, co);
+                    r = seg(st, cpl, A, at, my_temp, lane_cap < SCAN_HEADCAP ? lane_cap : SCAN_HEADCAP);
                     if (r == 0 && at < lim) {
                         have_cp = true;
                         cp_pos = at;
-                        rest_nc = 0; rest_no = 0;
-                        const int rr = lane_decode_fifo<false>(T, in, nbytes, at, lim, rest_nc, rest_no, nullptr, dummy, rest_exit, cc, co);
+                        const int rr = seg(at, lim, B, rest_exit, my_temp + SCAN_HEADCAP, lane_cap > SCAN_HEADCAP ? lane_cap - SCAN_HEADCAP : 0u);
+                        b_split = true;
                         rest_flag = rr == 1 ? 1 : rr == 2 ? 2 : 0;
                         reuse = true;
                     }
                 }
-                if (reuse) { nc += rest_nc; no += rest_no; exitpos = rest_exit; flag = rest_flag; }
+                if (reuse) { exitpos = rest_exit; flag = rest_flag; }
                 else {
-                    if (r == 0 && at < lim) r = lane_decode_fifo<false>(T, in, nbytes, at, lim, nc, no, nullptr, dummy, at, cc, co);
+                    B = Seg{0, 0, INT64_MAX, 0, 0};
+                    b_split = false;
+                    if (r == 0 && at < lim) r = seg(at, lim, B, at, my_temp + A.n, lane_cap > A.n ? lane_cap - A.n : 0u);
                     exitpos = at;
                     flag = r == 1 ? 1 : r == 2 ? 2 : 0;
                 }
+                nc = A.n + B.n;
+                no = A.no + B.no;
                 decoded_from = st;
             }
         } else flag = 4;
@@ -1051,6 +1091,24 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
     L->start[tid] = tid <= eobl ? s_start[tid] : ~0ull;
     L->code_off[tid] = px + x - mync;
     L->out_off[tid] = py + y - myno;
+    if constexpr (STORE) {
+        // the slice as ONE record: where its codes lie, how far back it reads, its earliest legal cut (slice-relative).
+        // A's cut candidate stands if nothing in B reads in front of it; otherwise B's own (B's codes all come later).
+        BlkLanesX *X = &lanesx[blockIdx.x];
+        const bool live = tid <= eobl;
+        const int64_t rb = B.reach == INT64_MAX ? INT64_MAX : (int64_t)A.no + B.reach;
+        const int64_t reach = A.reach < rb ? A.reach : rb;
+        const bool a_stands = rb >= (int64_t)A.co;
+        uint32_t cc = a_stands ? A.cc : A.n + B.cc, co = a_stands ? A.co : (uint32_t)A.no + B.co;
+        if (cc >= A.n + B.n) cc = 0xFFFFFFFFu;          // (a cut behind the last code belongs to the next lane)
+        X->n_head[tid] = live ? A.n : 0u;
+        X->n_rest[tid] = live ? B.n : 0u;
+        X->rest_at[tid] = b_split ? SCAN_HEADCAP : A.n;
+        X->reach[tid] = live && reach != INT64_MAX ? (reach < INT32_MIN ? INT32_MIN : (int32_t)reach) : INT32_MAX;
+        X->cut_code[tid] = live ? cc : 0xFFFFFFFFu;
+        X->cut_out[tid] = co;
+        if (live && ovf) atomicOr(&hdr[7], 1u);
+    }
     if (tid == SCAN_THREADS - 1) {
         bi.n_codes = px + x;
         bi.n_out = py + y;
@@ -1061,6 +1119,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
     if (tid == SCAN_THREADS - 1) { s_tot = px + x; s_tot64 = py + y; }
     __syncthreads();
     if (tid == 0) {
+        if constexpr (STORE) bi._pad = hdr[7] & 1u;      // 1: some lane's codes did not fit its region (the block takes the two-pass path)
         bi.n_codes = s_tot; bi.n_out = s_tot64; bi.end_bit = s_exit[eobl]; bi.nlanes = eobl + 1; bi.rounds = rounds;
         bi.cyc_hdr = (uint32_t)(t_hdr - t_begin); bi.cyc_total = (uint32_t)(clock64() - t_begin);
         infos[blockIdx.x] = bi;
@@ -1073,68 +1132,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 8) void blk_scan_kernel(const uint8_t
 // default.rs:73) so that K3 can materialise them concurrently.
 constexpr uint32_t MAX_UNITS = 8;
 
-// RING: the lanes' bits come through LDS rings (RingBits: one workgroup per CU — the single-stream path, whose blocks are
-// large); else through the register FIFO (FastBits: two workgroups per CU — the batch path's thousands of small blocks)
-template <bool RING>
-__global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
-                                                                const BlkEmit *__restrict__ jobs,
-                                                                const BlkLanes *__restrict__ lanes,
-                                                                uint32_t *__restrict__ codes,
-                                                                uint32_t *__restrict__ flags,
-                                                                BlkUnits *__restrict__ units, uint32_t unit_target, uint32_t free_shift,
-                                                                uint32_t *__restrict__ job_flags,
-                                                                const FastTabs *__restrict__ tabs) {
-    __shared__ FastTabs T;
-    __shared__ __attribute__((aligned(4))) uint8_t lens[640];
-    __shared__ uint32_t hdr[8];
-    __shared__ uint64_t hdr64[2];
-    extern __shared__ uint32_t emit_stage[];   // SCAN_THREADS rows of EMIT_STRIDE dwords
-    __shared__ uint32_t s_ring[RING ? SCAN_THREADS * RING_STRIDE : 1];      // the lanes' bit rings (lane_decode)
-    const uint32_t tid = threadIdx.x;
-    const BlkEmit job = jobs[blockIdx.x];
-    BlkUnits *U = &units[blockIdx.x];
-    if (job.btype == 0) {
-        if (tid == 0) {
-            U->n = 1; U->code0[0] = 0; U->code0[1] = 0; U->out0[0] = 0; U->out0[1] = job.n_out;
-            U->fn = 1; U->fcode0[0] = 0; U->fcode0[1] = 0; U->fout0[0] = 0; U->fout0[1] = job.n_out;
-        }
-        return;
-    }
-    const uint64_t t_begin = clock64();
-    if (tabs) {   // the tables the scan kernel built for this block
-        const uint32_t *srcw = (const uint32_t *)&tabs[job.cand];
-        uint32_t *dst = (uint32_t *)&T;
-        constexpr uint32_t TW = sizeof(FastTabs) / 4, TPER = (TW + SCAN_THREADS - 1) / SCAN_THREADS;
-        uint32_t tv[TPER];                      // (all of a lane's loads in flight, then the LDS stores)
-#pragma unroll
-        for (uint32_t k = 0; k < TPER; ++k) tv[k] = srcw[min(tid + k * SCAN_THREADS, TW - 1)];
-#pragma unroll
-        for (uint32_t k = 0; k < TPER; ++k) if (tid + k * SCAN_THREADS < TW) dst[tid + k * SCAN_THREADS] = tv[k];
-        __syncthreads();
-    } else parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
-    const uint64_t t_hdr = clock64();
-    const BlkLanes *L = &lanes[job.cand];
-    int64_t reach = INT64_MAX;
-    uint32_t cut_code = 0xFFFFFFFFu;
-    uint64_t cut_pos = 0;
-    if (tid < job.nlanes) {
-        const uint64_t st = L->start[tid];
-        const uint64_t lim = tid + 1 < job.nlanes ? L->start[tid + 1] : (job.end_limit ? job.end_limit : ~0ull >> 1);
-        uint32_t nc = 0, cc = 0, co = 0;
-        const uint64_t out0 = L->out_off[tid];   // bytes of this block produced before my slice
-        uint64_t no = out0, endpos;
-        if (RING)
-            lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
-                              s_ring + tid * RING_STRIDE, emit_stage + tid * EMIT_STRIDE);
-        else
-            lane_decode_fifo<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
-                                   emit_stage + tid * EMIT_STRIDE);
-        if (reach < -(int64_t)job.hist) {         // a back-reference reaches in front of the member's first byte
-            atomicOr(&flags[0], 1u);              // ... summary, and per job (batch decode)
-            if (job_flags) job_flags[blockIdx.x] = 1u;
-        } else if (reach < 0) atomicOr(&flags[0], 2u);   // ... in front of the block: it needs the earlier output
-        if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
-    }
+// The part of K2 behind the decode, shared by blk_emit_kernel and blk_place_kernel: from every lane's `reach` (smallest byte of the
+// block a match of its slice reads: absolute, may be negative) and cut candidate → the block's units.
+__device__ __forceinline__ void blk_units_tail(const uint32_t tid, const BlkEmit &job, const BlkLanes *L, const int64_t reach,
+                                               uint32_t cut_code, const uint64_t cut_pos, BlkUnits *U, const uint32_t unit_target,
+                                               const uint32_t free_shift, const uint64_t t_begin, const uint64_t t_hdr) {
     const uint64_t t_dec = clock64();
     // suffix minimum of `reach` over LATER lanes: within the wavefront by shuffles, then across wavefronts
     __shared__ int64_t s_wmin[SCAN_THREADS / 64];
@@ -1225,7 +1227,139 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(co
     }
 }
 
+// RING: the lanes' bits come through LDS rings (RingBits: one workgroup per CU — the single-stream path, whose blocks are
+// large); else through the register FIFO (FastBits: two workgroups per CU — the batch path's thousands of small blocks)
+template <bool RING>
+__global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+                                                                const BlkEmit *__restrict__ jobs,
+                                                                const BlkLanes *__restrict__ lanes,
+                                                                uint32_t *__restrict__ codes,
+                                                                uint32_t *__restrict__ flags,
+                                                                BlkUnits *__restrict__ units, uint32_t unit_target, uint32_t free_shift,
+                                                                uint32_t *__restrict__ job_flags,
+                                                                const FastTabs *__restrict__ tabs) {
+    __shared__ FastTabs T;
+    __shared__ __attribute__((aligned(4))) uint8_t lens[640];
+    __shared__ uint32_t hdr[8];
+    __shared__ uint64_t hdr64[2];
+    extern __shared__ uint32_t emit_stage[];   // SCAN_THREADS rows of EMIT_STRIDE dwords
+    __shared__ uint32_t s_ring[RING ? SCAN_THREADS * RING_STRIDE : 1];      // the lanes' bit rings (lane_decode)
+    const uint32_t tid = threadIdx.x;
+    const BlkEmit job = jobs[blockIdx.x];
+    BlkUnits *U = &units[blockIdx.x];
+    if (job.placed) return;                  // (its codes were stored by the scan: blk_place_kernel's block)
+    if (job.btype == 0) {
+        if (tid == 0) {
+            U->n = 1; U->code0[0] = 0; U->code0[1] = 0; U->out0[0] = 0; U->out0[1] = job.n_out;
+            U->fn = 1; U->fcode0[0] = 0; U->fcode0[1] = 0; U->fout0[0] = 0; U->fout0[1] = job.n_out;
+        }
+        return;
+    }
+    const uint64_t t_begin = clock64();
+    if (tabs) {   // the tables the scan kernel built for this block
+        const uint32_t *srcw = (const uint32_t *)&tabs[job.cand];
+        uint32_t *dst = (uint32_t *)&T;
+        constexpr uint32_t TW = sizeof(FastTabs) / 4, TPER = (TW + SCAN_THREADS - 1) / SCAN_THREADS;
+        uint32_t tv[TPER];                      // (all of a lane's loads in flight, then the LDS stores)
+#pragma unroll
+        for (uint32_t k = 0; k < TPER; ++k) tv[k] = srcw[min(tid + k * SCAN_THREADS, TW - 1)];
+#pragma unroll
+        for (uint32_t k = 0; k < TPER; ++k) if (tid + k * SCAN_THREADS < TW) dst[tid + k * SCAN_THREADS] = tv[k];
+        __syncthreads();
+    } else parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
+    const uint64_t t_hdr = clock64();
+    const BlkLanes *L = &lanes[job.cand];
+    int64_t reach = INT64_MAX;
+    uint32_t cut_code = 0xFFFFFFFFu;
+    uint64_t cut_pos = 0;
+    if (tid < job.nlanes) {
+        const uint64_t st = L->start[tid];
+        const uint64_t lim = tid + 1 < job.nlanes ? L->start[tid + 1] : (job.end_limit ? job.end_limit : ~0ull >> 1);
+        uint32_t nc = 0, cc = 0, co = 0;
+        const uint64_t out0 = L->out_off[tid];   // bytes of this block produced before my slice
+        uint64_t no = out0, endpos;
+        if (RING)
+            lane_decode<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
+                              s_ring + tid * RING_STRIDE, emit_stage + tid * EMIT_STRIDE);
+        else
+            lane_decode_fifo<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
+                                   emit_stage + tid * EMIT_STRIDE);
+        if (reach < -(int64_t)job.hist) {         // a back-reference reaches in front of the member's first byte
+            atomicOr(&flags[0], 1u);              // ... summary, and per job (batch decode)
+            if (job_flags) job_flags[blockIdx.x] = 1u;
+        } else if (reach < 0) atomicOr(&flags[0], 2u);   // ... in front of the block: it needs the earlier output
+        if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
+    }
+    blk_units_tail(tid, job, L, reach, cut_code, cut_pos, U, unit_target, free_shift, t_begin, t_hdr);
+}
 
+
+
+// ------------------------------------------------------------------------------------------------
+// K2' (round 6): the block's codes were STORED by the scan (blk_scan_kernel<true>), one region per lane; this kernel moves
+// them to their final places — code_off of the block + code_off of the lane, known since the scan's prefix sums — and does
+// what blk_emit_kernel does behind its decode (flags of back-references that leave the block, the block's units).  A copy
+// at memory speed in place of a second Huffman pass over the block.
+// A wavefront moves the slices of its own 64 lanes one after the other, all 64 lanes on one slice (coalesced both ways); a
+// slice's loads are all issued before its first store (one memory round trip per slice, not per 64 codes).
+__global__ __launch_bounds__(SCAN_THREADS) void blk_place_kernel(const BlkEmit *__restrict__ jobs, const BlkLanes *__restrict__ lanes,
+                                                                  const BlkLanesX *__restrict__ lanesx, const uint32_t *__restrict__ temp,
+                                                                  uint32_t *__restrict__ codes, uint32_t *__restrict__ flags,
+                                                                  BlkUnits *__restrict__ units, uint32_t unit_target, uint32_t free_shift,
+                                                                  uint32_t *__restrict__ job_flags) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const BlkEmit job = jobs[blockIdx.x];
+    if (!job.placed) return;
+    const uint64_t t_begin = clock64();
+    BlkUnits *U = &units[blockIdx.x];
+    const BlkLanes *L = &lanes[job.cand];
+    const BlkLanesX *X = &lanesx[job.cand];
+    const bool live = tid < job.nlanes;
+    const uint32_t my_head = live ? X->n_head[tid] : 0u, my_rest = live ? X->n_rest[tid] : 0u, my_at = X->rest_at[tid];
+    const uint32_t my_off = L->code_off[tid];
+    const uint32_t *src0 = temp + job.temp_off + (uint64_t)(tid & ~63u) * job.cap;      // region of the wavefront's first lane
+    uint32_t *dst0 = codes + job.code_off;
+    constexpr uint32_t DEEP = 8;                       // 512 codes per trip (a 1 MiB block's slice holds about 270)
+    for (uint32_t j = 0; j < 64; ++j) {
+        const uint32_t nh = (uint32_t)__shfl((int)my_head, (int)j), nr = (uint32_t)__shfl((int)my_rest, (int)j);
+        const uint32_t at = (uint32_t)__shfl((int)my_at, (int)j), off = (uint32_t)__shfl((int)my_off, (int)j);
+        const uint32_t n = nh + nr;
+        if (n == 0) continue;                          // (uniform)
+        const uint32_t *src = src0 + (uint64_t)j * job.cap;
+        uint32_t *dst = dst0 + off;
+        for (uint32_t base = 0; base < n; base += 64 * DEEP) {
+            uint32_t v[DEEP];
+#pragma unroll
+            for (uint32_t k = 0; k < DEEP; ++k) {
+                const uint32_t i = base + k * 64 + lane;               // index among the slice's codes
+                const uint32_t si = i < nh ? i : at + (i - nh);        // ... and in the lane's region
+                v[k] = i < n ? src[si] : 0u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < DEEP; ++k) {
+                const uint32_t i = base + k * 64 + lane;
+                if (i < n) dst[i] = v[k];
+            }
+        }
+    }
+    const uint64_t t_hdr = clock64();
+    // ---- what the emit kernel derives from its decode
+    int64_t reach = INT64_MAX;
+    uint32_t cut_code = 0xFFFFFFFFu;
+    uint64_t cut_pos = 0;
+    if (live) {
+        const uint64_t out0 = L->out_off[tid];
+        const int32_t rr = X->reach[tid];
+        if (rr != INT32_MAX) reach = (int64_t)out0 + (int64_t)rr;
+        if (reach < -(int64_t)job.hist) {         // a back-reference reaches in front of the member's first byte
+            atomicOr(&flags[0], 1u);
+            if (job_flags) job_flags[blockIdx.x] = 1u;
+        } else if (reach < 0) atomicOr(&flags[0], 2u);   // ... in front of the block: it needs the earlier output
+        const uint32_t cc = X->cut_code[tid];
+        if (cc != 0xFFFFFFFFu) { cut_code = my_off + cc; cut_pos = out0 + X->cut_out[tid]; }
+    }
+    blk_units_tail(tid, job, L, reach, cut_code, cut_pos, U, unit_target, free_shift, t_begin, t_hdr);
+}
 
 // ------------------------------------------------------------------------------------------------
 // K3: a 256-lane workgroup per unit, the copy itself data-parallel over BYTES.
@@ -2267,7 +2401,36 @@ size_t blk_tabs_bytes() { return sizeof(FastTabs); }
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
                     BlkInfo *infos, BlkLanes *lanes, void *tabs) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_scan_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes, (FastTabs *)tabs);
+    hipLaunchKernelGGL(blk_scan_kernel<false>, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes, (FastTabs *)tabs,
+                       (uint32_t *)nullptr, (BlkLanesX *)nullptr);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+// the storing scan (round 6): every job's lanes write their code words to temp (BlkJob::temp_off, ::cap) and leave a
+// BlkLanesX record; BlkInfo::_pad = 1 when a lane's codes did not fit (the block then needs launch_blk_emit)
+int launch_blk_scan_store(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
+                          BlkInfo *infos, BlkLanes *lanes, void *tabs, uint32_t *temp, BlkLanesX *lanesx) {
+    if (!njobs) return 0;
+    constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
+    static bool attr_set[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    if (!attr_set[dev_ & 63]) {
+        (void)hipFuncSetAttribute((const void *)blk_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        attr_set[dev_ & 63] = true;
+    }
+    hipLaunchKernelGGL(blk_scan_kernel<true>, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, infos, lanes,
+                       (FastTabs *)tabs, temp, lanesx);
+    LFX_LAUNCH_CHECK();
+    return 0;
+}
+// ... and the move of the stored codes to their places, for the jobs with BlkEmit::placed = 1 (launch_blk_emit skips those)
+int launch_blk_place(hipStream_t st, const BlkEmit *jobs, uint32_t njobs, const BlkLanes *lanes, const BlkLanesX *lanesx,
+                     const uint32_t *temp, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target, uint32_t *job_flags,
+                     uint32_t free_shift) {
+    if (!njobs) return 0;
+    hipLaunchKernelGGL(blk_place_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, jobs, lanes, lanesx, temp, codes, flags, units,
+                       unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags);
     LFX_LAUNCH_CHECK();
     return 0;
 }
