@@ -475,7 +475,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 for (uint32_t j = 0; j < nj; j++) {
                     const uint64_t bits = bj[j].end_bit > bj[j].start_bit ? bj[j].end_bit - bj[j].start_bit : 0;
                     const uint64_t slice = std::max<uint64_t>((bits + 1023) / 1024, 128);
-                    const uint64_t cap = (slice / 2 + 448 + 64 + 3) & ~3ull;          // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
+                    const uint64_t cap = (slice / (c->diag.store_tight ? 16 : 2) + 448 + 64 + 3) & ~3ull;   // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
                     bj[j].temp_off = off;
                     bj[j].cap = (uint32_t)cap;
                     off += 1024 * cap;

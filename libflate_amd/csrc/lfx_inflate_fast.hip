@@ -574,7 +574,8 @@ template <bool EMIT>
 __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
                                            uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
                                            int64_t &reach, uint64_t &endpos, uint32_t &cut_code, uint32_t &cut_out,
-                                           uint32_t *ring, uint32_t *stage = nullptr) {
+                                           uint32_t *ring, uint32_t *stage = nullptr, uint32_t store_cap = 0xFFFFFFFFu,
+                                           uint32_t *ovf = nullptr) {
     // EMIT: code words are staged in this lane's LDS row (EMIT_STAGE entries) and written out as runs of
     // 16-byte stores whenever the wavefront pauses to refill its bit rings — a lane's 4-byte stores, each
     // to a cache line of its own, cost ~6x their size in HBM traffic (partial-line evictions).
@@ -638,9 +639,11 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
         if (refill) b.take();
         if (EMIT) {
             uint32_t *dst = codes + (ncodes - staged);
+            const bool fits = ncodes <= store_cap;       // (the storing scan: what does not fit its region is counted, not stored)
+            if (!fits && ovf) *ovf = 1u;
             for (uint32_t j = 0; j < EMIT_STAGE; j += 4) {
                 if (__ballot(j < staged) == 0) break;
-                if (j < staged) {
+                if (j < staged && fits) {
                     const uint32_t c0 = stage[j], c1 = stage[j + 1], c2 = stage[j + 2], c3 = stage[j + 3];
                     if (j + 4 <= staged) {
                         U32x4 q;
@@ -906,12 +909,16 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
                                                                 uint32_t *__restrict__ temp, BlkLanesX *__restrict__ lanesx) {
     extern __shared__ uint32_t scan_stage[];   // STORE: SCAN_THREADS rows of EMIT_STRIDE dwords
     __shared__ FastTabs T;
+    // STORE: the lanes' bits through LDS rings, as in blk_emit_kernel<true> — a wavefront that stores its codes AND loads its
+    // bits through the register FIFO waits for its own stores at every refill (loads and stores share vmcnt): measured,
+    // 0.945 ms for the storing scan on the FIFO against 0.57 for the counting one
+    __shared__ uint32_t s_ring[STORE ? SCAN_THREADS * RING_STRIDE : 1];
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
     __shared__ uint64_t s_start[SCAN_THREADS + 1];
-    __shared__ uint32_t s_nc[SCAN_THREADS], s_flag[SCAN_THREADS];
-    __shared__ uint64_t s_no[SCAN_THREADS], s_exit[SCAN_THREADS];
+    __shared__ uint32_t s_flag[SCAN_THREADS];
+    __shared__ uint64_t s_exit[SCAN_THREADS];
     __shared__ uint32_t s_scan[SCAN_THREADS / 64];
     __shared__ uint64_t s_scan64[SCAN_THREADS / 64];
     const uint32_t tid = threadIdx.x;
@@ -995,8 +1002,8 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
     auto seg = [&](uint64_t from, uint64_t to, Seg &g, uint64_t &at, uint32_t *dst, uint32_t room) -> int {
         g = Seg{0, 0, INT64_MAX, 0, 0};
         if constexpr (STORE)
-            return lane_decode_fifo<true>(T, in, nbytes, from, to, g.n, g.no, dst, g.reach, at, g.cc, g.co,
-                                          scan_stage + tid * EMIT_STRIDE, room, &ovf);
+            return lane_decode<true>(T, in, nbytes, from, to, g.n, g.no, dst, g.reach, at, g.cc, g.co, s_ring + tid * RING_STRIDE,
+                                     scan_stage + tid * EMIT_STRIDE, room, &ovf);
         else {
             int64_t dummy = 0;
             return lane_decode_fifo<false>(T, in, nbytes, from, to, g.n, g.no, nullptr, dummy, at, g.cc, g.co);
@@ -1043,7 +1050,7 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
                 decoded_from = st;
             }
         } else flag = 4;
-        s_nc[tid] = nc; s_no[tid] = no; s_flag[tid] = flag; s_exit[tid] = exitpos;
+        s_flag[tid] = flag; s_exit[tid] = exitpos;      // (the counts stay in registers: only their owner reads them)
         __syncthreads();
         // lane k+1 must start where lane k stopped (only while no EOB / failure)
         bool changed = false;
@@ -1072,8 +1079,8 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
         eobl = nl - 1;
     } else if (s_flag[eobl] != 1) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
     // exclusive scans of code / byte counts over lanes <= eobl
-    const uint32_t mync = tid <= eobl ? s_nc[tid] : 0;
-    const uint64_t myno = tid <= eobl ? s_no[tid] : 0;
+    const uint32_t mync = tid <= eobl ? nc : 0;
+    const uint64_t myno = tid <= eobl ? no : 0;
     const uint32_t lane = tid & 63, wave = tid >> 6;
     uint32_t x = mync;
     uint64_t y = myno;

@@ -133,3 +133,42 @@ def test_gzip_no_compression_then_header_keeps_the_headers_level(ctx, lfx):
         b = sink.getvalue()
         assert b[:4] == b"\x1f\x8b\x08\x00" and b[4:8] == (5).to_bytes(4, "little") and b[8] == xfl
         assert pygzip.decompress(b) == b"Hello World!"
+
+
+def test_single_pass_decode_of_large_blocks(ffi, lfx, oracle, synth, monkeypatch):
+    """Round 6: for a stream's own large blocks the scan stores its code words per lane and blk_place_kernel moves them
+    (one Huffman pass); blocks whose lanes overflow their regions — forced here by LFX_STORE_TIGHT — and everything under
+    LFX_TWO_PASS take blk_emit_kernel as before.  All three give the input back, with libflate's error behaviour on damage
+    (decode.rs:112-164: the bytes of the blocks in front of the damaged one, then InvalidData)."""
+    n = 24 << 20
+    data = synth.text(n, seed=synth.SEED_BASE + 11).tobytes()
+    low = synth.lowent(8 << 20).tobytes()
+    streams = {
+        "text, 1 MiB blocks": oracle.encode(oracle.GZIP, data, write_size=8192, mtime=0),
+        "text, 4 MiB blocks": oracle.encode(oracle.ZLIB, data, write_size=65536, block_size=4 << 20),
+        "text, 300 KiB blocks": oracle.encode(oracle.DEFLATE, data[:8 << 20], write_size=1000, block_size=300 << 10),
+        "low entropy (258-byte matches)": oracle.encode(oracle.ZLIB, low, write_size=8192),
+        "fixed Huffman blocks": oracle.encode(oracle.GZIP, data[:6 << 20], write_size=8192, mtime=0, dynamic_huffman=0),
+    }
+    fmt = {"text, 1 MiB blocks": ffi.GZIP, "text, 4 MiB blocks": ffi.ZLIB, "text, 300 KiB blocks": ffi.DEFLATE,
+           "low entropy (258-byte matches)": ffi.ZLIB, "fixed Huffman blocks": ffi.GZIP}
+    want = {"text, 1 MiB blocks": data, "text, 4 MiB blocks": data, "text, 300 KiB blocks": data[:8 << 20],
+            "low entropy (258-byte matches)": low, "fixed Huffman blocks": data[:6 << 20]}
+    for env in ({}, {"LFX_STORE_TIGHT": "1"}, {"LFX_TWO_PASS": "1"}):
+        for k in ("LFX_STORE_TIGHT", "LFX_TWO_PASS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = lfx.Context(0)
+        try:
+            for name, z in streams.items():
+                rc, out, used, msg = c2.decode_host(fmt[name], z)
+                assert (rc, used) == (0, len(z)) and out == want[name], (env, name, rc, msg)
+            # damage in the middle of the sixth block: same status, same bytes delivered as the oracle
+            z = bytearray(streams["text, 1 MiB blocks"])
+            z[len(z) * 6 // 24 + 1000] ^= 0x55
+            rc, out, used, msg = c2.decode_host(ffi.GZIP, bytes(z))
+            orc, oout, _oused, omsg = oracle.decode(oracle.GZIP, bytes(z))
+            assert rc == orc and rc != 0 and out == oout, (env, rc, orc, len(out), len(oout), msg, omsg)
+        finally:
+            c2.close()
