@@ -1016,35 +1016,47 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
                 // the last lane keeps going to the end of the stream range (the block may end exactly at e)
                 // (a piece's last lane stops at the first symbol boundary >= e: the next piece starts exactly there)
                 const uint64_t lim = tid + 1 == nl ? (piece ? e : e + 64) : my_bound;
-                uint64_t at = st;
+                // Two segments at most — the head A, then the rest B — through ONE call site of the symbol loop (three
+                // inlined copies of it were 4 400 instructions of kernel): pass 0 decodes A; what it finds decides whether
+                // pass 1 decodes a B, and which kind.
+                const bool retry = have_cp && st < cp_pos;           // a corrected start in front of a cached rest
+                uint64_t at = st, from = st, to = retry ? cp_pos : (st + CP_BITS < lim ? st + CP_BITS : lim);
+                uint32_t *dst = my_temp;
+                uint32_t room = lane_cap < SCAN_HEADCAP ? lane_cap : SCAN_HEADCAP;    // (a cached rest lies at SCAN_HEADCAP)
                 int r = 0;
-                bool reuse = false;
-                if (have_cp && st < cp_pos) {
-                    // (a cached rest lies at SCAN_HEADCAP: the head must stay in front of it)
-                    r = seg(st, cp_pos, A, at, my_temp, lane_cap < SCAN_HEADCAP ? lane_cap : SCAN_HEADCAP);
-                    reuse = r == 0 && at == cp_pos;
-                    if (!reuse) have_cp = false;
-                } else {
-                    have_cp = false;
-                    const uint64_t cpl = st + CP_BITS < lim ? st + CP_BITS : lim;
-                    r = seg(st, cpl, A, at, my_temp, lane_cap < SCAN_HEADCAP ? lane_cap : SCAN_HEADCAP);
-                    if (r == 0 && at < lim) {
-                        have_cp = true;
-                        cp_pos = at;
-                        const int rr = seg(at, lim, B, rest_exit, my_temp + SCAN_HEADCAP, lane_cap > SCAN_HEADCAP ? lane_cap - SCAN_HEADCAP : 0u);
-                        b_split = true;
-                        rest_flag = rr == 1 ? 1 : rr == 2 ? 2 : 0;
-                        reuse = true;
+                bool reuse = false, cache_b = false;
+                if (!retry) have_cp = false;
+                for (int pass = 0; pass < 2; ++pass) {
+                    Seg G;
+                    uint64_t ex = from;
+                    const int rr = seg(from, to, G, ex, dst, room);
+                    if (pass == 0) {
+                        A = G; r = rr; at = ex;
+                        if (retry) {
+                            reuse = r == 0 && at == cp_pos;             // the cached rest stands
+                            if (reuse) break;
+                            have_cp = false;
+                        }
+                        B = Seg{0, 0, INT64_MAX, 0, 0};
+                        b_split = false;
+                        if (!(r == 0 && at < lim)) break;               // the head was all of the slice (or ended it)
+                        // a B behind a fresh head is cached at SCAN_HEADCAP (a later corrected start reuses it when it
+                        // lands on the checkpoint); behind a head that missed the checkpoint it follows A's codes
+                        cache_b = !retry;
+                        from = at; to = lim;
+                        dst = my_temp + (cache_b ? SCAN_HEADCAP : A.n);
+                        room = cache_b ? (lane_cap > SCAN_HEADCAP ? lane_cap - SCAN_HEADCAP : 0u) : (lane_cap > A.n ? lane_cap - A.n : 0u);
+                    } else {
+                        B = G;
+                        if (cache_b) {
+                            have_cp = true; cp_pos = at; b_split = true; reuse = true;
+                            rest_exit = ex;
+                            rest_flag = rr == 1 ? 1 : rr == 2 ? 2 : 0;
+                        } else { r = rr; at = ex; }
                     }
                 }
                 if (reuse) { exitpos = rest_exit; flag = rest_flag; }
-                else {
-                    B = Seg{0, 0, INT64_MAX, 0, 0};
-                    b_split = false;
-                    if (r == 0 && at < lim) r = seg(at, lim, B, at, my_temp + A.n, lane_cap > A.n ? lane_cap - A.n : 0u);
-                    exitpos = at;
-                    flag = r == 1 ? 1 : r == 2 ? 2 : 0;
-                }
+                else { exitpos = at; flag = r == 1 ? 1 : r == 2 ? 2 : 0; }
                 nc = A.n + B.n;
                 no = A.no + B.no;
                 decoded_from = st;
@@ -1327,7 +1339,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_place_kernel(const BlkEmit *
     const uint32_t *src0 = temp + job.temp_off + (uint64_t)(tid & ~63u) * job.cap;      // region of the wavefront's first lane
     uint32_t *dst0 = codes + job.code_off;
     constexpr uint32_t DEEP = 8;                       // 512 codes per trip (a 1 MiB block's slice holds about 270)
-    for (uint32_t j = 0; j < 64; ++j) {
+    // (two workgroups per block — blockIdx.y — each moves half of every wavefront's 64 slices: a wavefront's slices are a
+    //  chain of dependent round trips, and 256 blocks alone leave the copy latency-bound; the units are workgroup 0's)
+    const uint32_t j0 = blockIdx.y * 32u;
+    for (uint32_t j = j0; j < j0 + 32u; ++j) {
         const uint32_t nh = (uint32_t)__shfl((int)my_head, (int)j), nr = (uint32_t)__shfl((int)my_rest, (int)j);
         const uint32_t at = (uint32_t)__shfl((int)my_at, (int)j), off = (uint32_t)__shfl((int)my_off, (int)j);
         const uint32_t n = nh + nr;
@@ -1349,6 +1364,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_place_kernel(const BlkEmit *
             }
         }
     }
+    if (blockIdx.y != 0) return;
     const uint64_t t_hdr = clock64();
     // ---- what the emit kernel derives from its decode
     int64_t reach = INT64_MAX;
@@ -2436,7 +2452,7 @@ int launch_blk_place(hipStream_t st, const BlkEmit *jobs, uint32_t njobs, const 
                      const uint32_t *temp, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target, uint32_t *job_flags,
                      uint32_t free_shift) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_place_kernel, dim3(njobs), dim3(SCAN_THREADS), 0, st, jobs, lanes, lanesx, temp, codes, flags, units,
+    hipLaunchKernelGGL(blk_place_kernel, dim3(njobs, 2), dim3(SCAN_THREADS), 0, st, jobs, lanes, lanesx, temp, codes, flags, units,
                        unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags);
     LFX_LAUNCH_CHECK();
     return 0;
