@@ -90,6 +90,10 @@ constexpr int AHEAD = 4;                       // register sets of the loading w
 #define LFX_M7_BARRIER 1
 #endif
 constexpr uint32_t NP = 7, NC = 7;             // loading / storing helper wavefronts
+// timing experiments only (WRONG answers): bit 0 — no link-record stores, bit 1 — no cd stores (tools/exp/r6_m7_stores.sh)
+#ifndef LFX_M7_EXP
+#define LFX_M7_EXP 0
+#endif
 // RUNS (zero-filled and constant regions, BASELINE cfg5's LOWENT: every position repeats the prefix of the one in front of it).
 // The lanes of an exchange that hit the same dword are served one after the other — a run is sixty-four of them, on both
 // tables (cfg5's match stage took 8.3 ms per GiB against 2.6 for a text).  But a position that repeats its predecessor's prefix
@@ -393,8 +397,8 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
                     const uint32_t ans = d1 > window ? 0u : a1;
                     if (interior) {
                         dmin = min(dmin, min((int32_t)d1, (int32_t)d2));
-                        *(uint32_t *)(glnk_b + 2 * boff + g * 256) = lnk | (rq[g] << 16);   // (the request's low 16 bits: the tag and six bits of the bucket — inside a bucket as good as the tag)
-                        *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
+                        if (!(LFX_M7_EXP & 1)) *(uint32_t *)(glnk_b + 2 * boff + g * 256) = lnk | (rq[g] << 16);   // (the request's low 16 bits: the tag and six bits of the bucket — inside a bucket as good as the tag)
+                        if (!(LFX_M7_EXP & 2)) *(uint16_t *)(cd_b + boff + g * 128) = (uint16_t)ans;
                         um[g] = __ballot(ans > UNRES);
                     } else {
                         const uint32_t p = t0 + hidx + g * 64;
