@@ -382,8 +382,9 @@ def sub_stream_api(ctx, _ffi, data, enc_want=None, chunk=8192):
     dec = np.empty(n, dtype=np.uint8)
     enc[:] = 0          # (np.empty's pages are not there yet: first touches would be timed as page faults)
     dec[:] = 0
-    # warm-up of both directions: page-locked buffers of the context's pool, device scratch
-    rc, m0, _ = stream_copy.encode(ctx, _ffi.GZIP, opts, data.ctypes.data, min(n, 48 << 20), chunk, enc.ctypes.data, enc.size)
+    # warm-up of both directions with the whole buffer: the page-locked buffers of the context's pool grow to what the later
+    # 32 MiB windows need (page-locking ~170 MiB costs more than the run), device scratch
+    rc, m0, _ = stream_copy.encode(ctx, _ffi.GZIP, opts, data.ctypes.data, n, chunk, enc.ctypes.data, enc.size)
     stream_copy.decode(ctx, _ffi.GZIP, enc.ctypes.data, m0, chunk, dec.ctypes.data, n)
     rc, m, te = stream_copy.encode(ctx, _ffi.GZIP, opts, data.ctypes.data, n, chunk, enc.ctypes.data, enc.size)
     if rc:
@@ -740,6 +741,19 @@ def main():
                 self.finish_s.append(t3 - t2)
             return (t1 - t0) + (t3 - t2), t2 - t1, m.value
 
+        def gather_alone(self):
+            """sharded path, outside the timed region: begin → finish with NOTHING in between — what the concatenation costs
+            when it cannot hide behind anything; `overlap_ms` (finish's wait behind the decode, in the timed steps) is read
+            against it"""
+            torch.cuda.synchronize()
+            gh, _part = sharded.encode_begin(ctx, rank, world, _ffi.GZIP, self.opts, self.sched, self.d_in, self.n, self.d_out, self.bound,
+                                             self.d_member, self.bound * world if rank == 0 else 0, self.staging,
+                                             dist if world > 1 else None)
+            t0 = time.perf_counter()
+            sharded.encode_finish(gh)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
         def timed(self, steps, warmup, record=True):
             _, _, m = self.step()
             if not torch.equal(self.d_dec, self.d_in):
@@ -747,6 +761,13 @@ def main():
             self.step_s = []
             for _ in range(warmup):
                 self.step()
+            self.gather_alone_s = None
+            if sharded_path and record:
+                ga = min(self.gather_alone() for _ in range(2))
+                tt = torch.tensor([ga], dtype=torch.float64, device="cpu" if one_gpu_test else dev)
+                if dist and world > 1:
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                self.gather_alone_s = float(tt.cpu()[0])
             if dist:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -964,6 +985,11 @@ def main():
         fin = getattr(run, "finish_max_s", None)
         line["overlap_ms"] = round(fin * 1e3, 3) if fin is not None else None
         line["overlap_frac_of_step"] = round(fin / (elapsed / args.steps), 4) if fin is not None else None
+        # the same wait with nothing between begin and finish (outside the timed steps): the transfers' full duration.  The
+        # difference is what the decode hid.  (Over gloo on one box — LFX_BENCH_ONE_GPU — the shards hop through host memory
+        # and loopback TCP and take several decodes' time: most of the wait remains; over xGMI 7 x 130 MB are ≈ 1.3 ms.)
+        ga = getattr(run, "gather_alone_s", None)
+        line["gather_alone_ms"] = round(ga * 1e3, 3) if ga is not None else None
     # The JSON line is the LAST thing on stdout: RCCL prints its version banner through C stdio, whose buffer (when stdout is
     # a pipe or a file) would otherwise be flushed at process exit, behind this line.
     try:

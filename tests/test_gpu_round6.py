@@ -172,3 +172,117 @@ def test_single_pass_decode_of_large_blocks(ffi, lfx, oracle, synth, monkeypatch
             assert rc == orc and rc != 0 and out == oout, (env, rc, orc, len(out), len(oout), msg, omsg)
         finally:
             c2.close()
+
+
+def test_stream_encoder_batch_in_flight_edge_cases(ctx, lfx, ffi, oracle, synth):
+    """One batch in flight on the GPU (round 6): handles that share a context and take turns, a flush and a sync flush while a
+    batch is in flight, a sink that fails when a batch is collected, an encoder dropped with a batch in flight."""
+    import io
+    data = synth.text(24 << 20, seed=synth.SEED_BASE + 12).tobytes()
+    W = 1 << 20
+    # (1) two encoders on ONE context, writes interleaved: each gets the oracle's bytes for its own schedule
+    sa, sb = io.BytesIO(), io.BytesIO()
+    ea = lfx.gzip.Encoder.new(sa, context=ctx)
+    eb = lfx.zlib.Encoder.new(sb, context=ctx)
+    for off in range(0, len(data), W):
+        ea.write(data[off:off + W])
+        eb.write(data[len(data) - off - W:len(data) - off])
+    ea.finish()
+    eb.finish()
+    rev = b"".join(data[len(data) - off - W:len(data) - off] for off in range(0, len(data), W))
+    assert sa.getvalue() == oracle.encode(oracle.GZIP, data, write_size=W, mtime=0)
+    assert sb.getvalue() == oracle.encode(oracle.ZLIB, rev, write_size=W)
+    # (2) flush() after 17 writes of 1 MiB (a batch is in flight, another block is open), then more writes — both zlib flush modes
+    for sync in (0, 1):
+        sink = io.BytesIO()
+        opts = lfx.zlib.EncodeOptions()
+        if sync:
+            opts.flush_mode(lfx.zlib.FlushMode.SYNC)               # zlib.rs:504-507
+        e = lfx.zlib.Encoder.with_options(sink, opts, context=ctx)
+        o = oracle.Encoder(oracle.ZLIB, zlib_sync_flush=sync)
+        for k, off in enumerate(range(0, len(data), W)):
+            e.write(data[off:off + W]); o.write(data[off:off + W])
+            if k == 16:
+                e.flush(); o.flush()
+                assert len(sink.getvalue()) > (6 << 20)            # everything written so far has reached the sink
+        e.finish()
+        assert sink.getvalue() == o.finish(), sync
+    # (3) a sink that fails while a batch is being handed over: the collecting call reports it, later calls stay failed
+    class Failing(io.BytesIO):
+        def write(self, b):
+            if self.tell() + len(b) > (3 << 20):
+                raise OSError("disk full")
+            return super().write(b)
+    e = lfx.gzip.Encoder.new(Failing(), context=ctx)
+    failed_at = None
+    for k, off in enumerate(range(0, len(data), W)):
+        try:
+            e.write(data[off:off + W])
+        except lfx.deflate.StreamError as err:
+            failed_at = k
+            assert err.status == ffi.E_IO
+            break
+    assert failed_at is not None and failed_at >= 15              # (the first batch's bytes arrive when the second is started)
+    with pytest.raises(lfx.deflate.StreamError):
+        e.write(b"more")
+    e.into_inner()
+    # (4) an encoder dropped with a batch in flight; the context encodes on
+    e = lfx.gzip.Encoder.new(io.BytesIO(), context=ctx)
+    for off in range(0, 9 << 20, W):
+        e.write(data[off:off + W])
+    e.into_inner()
+    assert enc(ctx, ffi, ffi.GZIP, data[:3 << 20], 8192, mtime=0) == oracle.encode(oracle.GZIP, data[:3 << 20], write_size=8192, mtime=0)
+
+
+def test_stream_decoder_decoding_ahead_edge_cases(ctx, lfx, ffi, oracle, synth):
+    """The next window decoded by a worker thread while the caller drains the current one (round 6): members that span several
+    windows in a MultiDecoder, damage and truncation inside a later window (libflate's error kind; the bytes of the blocks in
+    front of it delivered first, decode.rs:136-164), a decoder freed while a window is in flight."""
+    import io
+    a = synth.text(40 << 20, seed=synth.SEED_BASE + 13).tobytes()
+    b = synth.lowent(24 << 20).tobytes()
+    za = oracle.encode(oracle.GZIP, a, write_size=8192, mtime=0)
+    zb = oracle.encode(oracle.GZIP, b, write_size=8192, mtime=1)
+    # (1) two members, read in 1 MiB pieces; trailing bytes behind the second are not a member
+    d = lfx.gzip.MultiDecoder.new(io.BytesIO(za + zb), context=ctx)
+    got = bytearray()
+    while True:
+        piece = d.read(1 << 20)
+        if not piece:
+            break
+        got += piece
+    assert bytes(got) == a + b
+    # (2) a flipped byte 70 % into the member (a later window) / the member cut there: same status and bytes as the oracle
+    for kind in ("flip", "cut"):
+        z = bytearray(za)
+        at = len(z) * 7 // 10
+        if kind == "flip":
+            z[at] ^= 0x10
+        else:
+            del z[at:]
+        orc, oout, _used, _msg = oracle.decode(oracle.GZIP, bytes(z))
+        assert orc != 0
+        dd = lfx.gzip.Decoder.new(io.BytesIO(bytes(z)), context=ctx)
+        out = bytearray()
+        status = 0
+        try:
+            while True:
+                piece = dd.read(4 << 20)
+                if not piece:
+                    break
+                out += piece
+        except lfx.deflate.StreamError as err:
+            status = err.status
+            out += getattr(err, "partial", b"")
+        assert status == orc, (kind, status, orc)
+        assert bytes(out) == oout[:len(out)] and len(out) <= len(oout), kind
+        assert len(oout) - len(out) <= (2 << 20), (kind, len(out), len(oout))      # at most the damaged block's own bytes are withheld
+    # (3) freed in the middle of a window, with the next one in flight; the context decodes on
+    dd = lfx.gzip.Decoder.new(io.BytesIO(za), context=ctx)
+    first = dd.read(100)
+    assert first == a[:100]
+    more = dd.read(5 << 20)            # (into the 16 MiB window: its successor is being decoded)
+    assert more == a[100:100 + len(more)]
+    del dd
+    rc, out, used, _ = ctx.decode_host(ffi.GZIP, zb)
+    assert rc == 0 and out == b and used == len(zb)
