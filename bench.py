@@ -45,7 +45,7 @@ PHASE_KERNEL = {"enc:lz77_match": "lz77_match7_kernel", "dec:lz77_copy": "blk_ma
                 "dec:find1": "find_blocks_stage1", "dec:find2": "find_blocks_stage2", "enc:pack": "pack_kernel",
                 "dec:batch_copy": "blk_materialize2_kernel", "dec:fast": "blk_scan_kernel"}
 # resident wavefronts per SIMD of those kernels (workgroup size x workgroups per CU / 4), for measure_bound
-PHASE_WAVES_PER_SIMD = {"enc:lz77_match": 4, "dec:lz77_copy": 4, "dec:blk_scan": 4, "dec:blk_emit": 4, "enc:lz77_parse": 2}
+PHASE_WAVES_PER_SIMD = {"enc:lz77_match": 4, "dec:lz77_copy": 4, "dec:blk_scan": 4, "dec:blk_emit": 4, "enc:lz77_parse": 3}
 CALIBRATION_KERNEL = "checksum_span_kernel"   # reads its input exactly once with wide coalesced loads
 
 

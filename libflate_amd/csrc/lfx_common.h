@@ -60,7 +60,14 @@ constexpr uint32_t PACK_TILE = 2048;  // codes per pack tile
 // reading at the same offset inside their groups hit 32 different LDS banks (lfx_parse2.hip).
 constexpr uint32_t PARSE_GROUP = 52;
 constexpr uint32_t PARSE_SEG = 64 * PARSE_GROUP;   // 3328 positions
-constexpr uint32_t PARSE_WG_SEGS = 4;              // segments (wavefronts) per workgroup of the walk kernel (8: 1.14 ms against 1.10)
+// Segments (wavefronts) per workgroup of the walk kernel.  Rounds 3-5: 4 (72 KB of LDS, two workgroups per CU = two
+// wavefronts per SIMD; 8 — one workgroup per CU, the same occupancy — measured 1.14 ms against 1.10).  Round 6: 12 — the 32 KiB
+// look-back is paid once for twelve segments, 153 KB of LDS, ONE workgroup per CU but THREE wavefronts per SIMD: the walk is
+// VALU-bound with its wavefronts parked 39 % of the time, a third one fills the gaps (parse 0.954 → 0.896 ms; 10: 0.974).
+#ifndef LFX_PARSE_WG_SEGS
+#define LFX_PARSE_WG_SEGS 12
+#endif
+constexpr uint32_t PARSE_WG_SEGS = LFX_PARSE_WG_SEGS;
 
 #ifdef __HIPCC__
 // pointers that are known to address global memory (HBM): keeps loads on the global_load path —

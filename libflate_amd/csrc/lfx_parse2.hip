@@ -15,9 +15,9 @@
 //     the common case on text) and repaired serially where it does not hold (long matches that jump over whole
 //     groups).  Segments are chained the same way by the three small kernels behind the walk (parse_fixseg / parse_fix
 //     / parse_emit): they re-walk from a segment's true entry to the merge point, through global memory.
-// A workgroup is PARSE_WG_SEGS (4) wavefronts = 13312 consecutive positions of one chunk; it stages the bytes
-// [first position - 32 KiB, last position + 258 + slack) and the cd[] values of its positions in LDS (72 KB: two
-// workgroups per CU), so that a walk step — cd[p] together with 16 bytes at p+3, then 16 bytes at p+3-d per compare step — is two LDS
+// A workgroup is PARSE_WG_SEGS (12 since round 6; 4 before) wavefronts = 39936 consecutive positions of one chunk; it stages the bytes
+// [first position - 32 KiB, last position + 258 + slack) and the cd[] values of its positions in LDS (153 KB: one
+// workgroup per CU, three wavefronts per SIMD), so that a walk step — cd[p] together with 16 bytes at p+3, then 16 bytes at p+3-d per compare step — is two LDS
 // round trips and no HBM access.
 //
 // A code word is derivable from the visited set alone: the step at p is the distance to the next visited position, and
@@ -45,7 +45,7 @@ constexpr uint32_t OFF_CD = (WIN_BYTES + 15) & ~15u;
 constexpr uint32_t CD_BYTES = 2 * WG_POS + 8;       // (+ one entry of alignment shift, + pad)
 constexpr uint32_t LDS_BYTES = OFF_CD + CD_BYTES;
 static_assert(U <= 64 && (U / 4) * 4 == U && ((U / 4) & 1) == 1, "a group is an odd number of dwords: bank-conflict-free lane stride");
-static_assert(2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU");
+static_assert(PARSE_WG_SEGS > 4 ? LDS_BYTES <= 160 * 1024 : 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU (one, of more wavefronts, in the experiments)");
 
 struct ByteSrcG {
     gptr_u32 w;
