@@ -58,7 +58,10 @@ constexpr uint32_t PACK_TILE = 2048;  // codes per pack tile
 // Speculative parse segments: one wavefront per segment, 64 lanes ("groups") of PARSE_GROUP positions each; a group's
 // visited mask is one 64-bit word of vis[].  52 positions = 13 dwords per lane: an odd dword stride, so that 32 lanes
 // reading at the same offset inside their groups hit 32 different LDS banks (lfx_parse2.hip).
-constexpr uint32_t PARSE_GROUP = 52;
+#ifndef LFX_PARSE_GROUP
+#define LFX_PARSE_GROUP 52
+#endif
+constexpr uint32_t PARSE_GROUP = LFX_PARSE_GROUP;
 constexpr uint32_t PARSE_SEG = 64 * PARSE_GROUP;   // 3328 positions
 // Segments (wavefronts) per workgroup of the walk kernel.  Rounds 3-5: 4 (72 KB of LDS, two workgroups per CU = two
 // wavefronts per SIMD; 8 — one workgroup per CU, the same occupancy — measured 1.14 ms against 1.10).  Round 6: 12 — the 32 KiB

@@ -1342,26 +1342,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_place_kernel(const BlkEmit *
     // (two workgroups per block — blockIdx.y — each moves half of every wavefront's 64 slices: a wavefront's slices are a
     //  chain of dependent round trips, and 256 blocks alone leave the copy latency-bound; the units are workgroup 0's)
     const uint32_t j0 = blockIdx.y * 32u;
-    for (uint32_t j = j0; j < j0 + 32u; ++j) {
-        const uint32_t nh = (uint32_t)__shfl((int)my_head, (int)j), nr = (uint32_t)__shfl((int)my_rest, (int)j);
-        const uint32_t at = (uint32_t)__shfl((int)my_at, (int)j), off = (uint32_t)__shfl((int)my_off, (int)j);
-        const uint32_t n = nh + nr;
-        if (n == 0) continue;                          // (uniform)
-        const uint32_t *src = src0 + (uint64_t)j * job.cap;
-        uint32_t *dst = dst0 + off;
-        for (uint32_t base = 0; base < n; base += 64 * DEEP) {
-            uint32_t v[DEEP];
+    // two slices per trip: the loads of both are in flight before the first store (a trip is one memory round trip)
+    for (uint32_t j = j0; j < j0 + 32u; j += 2) {
+        uint32_t nh[2], n[2], at[2];
+        const uint32_t *src[2];
+        uint32_t *dst[2];
 #pragma unroll
-            for (uint32_t k = 0; k < DEEP; ++k) {
-                const uint32_t i = base + k * 64 + lane;               // index among the slice's codes
-                const uint32_t si = i < nh ? i : at + (i - nh);        // ... and in the lane's region
-                v[k] = i < n ? src[si] : 0u;
-            }
+        for (uint32_t q = 0; q < 2; ++q) {
+            nh[q] = (uint32_t)__shfl((int)my_head, (int)(j + q));
+            n[q] = nh[q] + (uint32_t)__shfl((int)my_rest, (int)(j + q));
+            at[q] = (uint32_t)__shfl((int)my_at, (int)(j + q));
+            src[q] = src0 + (uint64_t)(j + q) * job.cap;
+            dst[q] = dst0 + (uint32_t)__shfl((int)my_off, (int)(j + q));
+        }
+        const uint32_t nmax = n[0] > n[1] ? n[0] : n[1];
+        for (uint32_t base = 0; base < nmax; base += 64 * DEEP) {      // (uniform; one trip for slices of up to 512 codes)
+            uint32_t v[2][DEEP];
 #pragma unroll
-            for (uint32_t k = 0; k < DEEP; ++k) {
-                const uint32_t i = base + k * 64 + lane;
-                if (i < n) dst[i] = v[k];
-            }
+            for (uint32_t q = 0; q < 2; ++q)
+#pragma unroll
+                for (uint32_t k = 0; k < DEEP; ++k) {
+                    const uint32_t i = base + k * 64 + lane;               // index among the slice's codes
+                    const uint32_t si = i < nh[q] ? i : at[q] + (i - nh[q]);   // ... and in the lane's region
+                    v[q][k] = i < n[q] ? src[q][si] : 0u;
+                }
+#pragma unroll
+            for (uint32_t q = 0; q < 2; ++q)
+#pragma unroll
+                for (uint32_t k = 0; k < DEEP; ++k) {
+                    const uint32_t i = base + k * 64 + lane;
+                    if (i < n[q]) dst[q][i] = v[q][k];
+                }
         }
     }
     if (blockIdx.y != 0) return;
