@@ -6,15 +6,17 @@ examples/flate.rs does → 1024 LZ77 chunks, 256 one-MiB dynamic blocks + the em
 decode it back, with input and output resident in HBM.  value = whole-job uncompressed bytes per
 second through the round trip: (ranks x 256 MiB) / (encode time + decode time).
 
-N > 1 (one rank per GPU, RCCL): the ranks' buffers form ONE gzip member.  Collectives on the path: the 32-byte-per-rank
-all-gather of (bits, bytes, crc, adler) and the point-to-point transfer of every shard to the writer rank, which
-concatenates them (boundary bytes OR-ed) — both over RCCL / xGMI, both inside the timed encode.  Decode at N > 1 is a
-SHARD decode: every rank inflates its own shard from the bit offsets the encoder exchanged (a plain gzip consumer has
-no such side channel; a one-member N-GPU decode needs the block finder per byte range).  Scaling is weak.
+N > 1 (one rank per GPU, RCCL): the ranks' buffers form ONE gzip member (lfx_sharded_encode_begin / _finish).  Collectives on
+the path: the 32-byte-per-rank all-gather of (bits, bytes, crc, adler) and the point-to-point transfer of every shard to the
+writer rank, which concatenates them (boundary bytes OR-ed) — posted AND started inside begin (lfx_comm.start), so that they are in
+flight while the ranks decode; `overlap_ms` = what finish still waited, `gather_alone_ms` = the same wait with nothing in between.
+Decode at N > 1 is the N-GPU decode of that ONE member by byte ranges (lfx_sharded_decode: block finder + scan per range, one
+all-gather of candidate tuples, the same chain walk on every rank; no bit offset from the encoder).  Scaling is weak by default.
 
 The line also carries (N = 1): `roofline` of the dominant kernel with HBM traffic measured IN THIS RUN (two rocprofv3
---pmc child passes of this script), `whole_path` (2(N+C)/t_step against the HBM peak), the second write schedule of
-SURVEY cfg2 (`schedule_S1`), and `cpu_baseline` — the oracle on one host core over the SAME 256 MiB (its output must
+--pmc child passes of this script: the L2's memory-side read requests by size, WRITE_SIZE), `whole_path` (2(N+C)/t_step against
+the HBM peak), the second write schedule of SURVEY cfg2 (`schedule_S1`), `other_configs` (cfg3, cfg5), `pcie_inclusive`,
+`stream_api` (the reference's io::copy protocol through the stream ABI, from C), `raw_deflate`, `match_fallbacks`, and `cpu_baseline` — the oracle on one host core over the SAME 256 MiB (its output must
 equal the GPU's byte for byte) plus the "N streams on N cores" figure with the host's core count.
 """
 import argparse

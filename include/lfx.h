@@ -217,7 +217,7 @@ int lfx_shard_place_device(lfx_ctx *c, void *d_member, uint64_t cap, const void 
 /* ---- the N-GPU drivers (round 5): the sequencing of the steps above, with the caller's collectives -----------------------
  * One rank per GPU, one lfx_ctx per rank.  The reference has ONE encoder with ONE running checksum (gzip::Encoder::finish,
  * src/gzip.rs:858-868; src/checksum.rs:22-33); here the ranks' block ranges, bit offsets and partial checksums are exchanged
- * through an lfx_comm — four callbacks the caller implements over whatever moves bytes between its ranks (torch.distributed
+ * through an lfx_comm — five callbacks the caller implements over whatever moves bytes between its ranks (torch.distributed
  * in libflate_amd/sharded.py, MPI, ...), or lfx_comm_rccl() for RCCL over xGMI.  Every callback returns 0 on success.
  *   allgather: every rank contributes `bytes` HOST bytes; recv (world * bytes, rank order) is complete on return.
  *   isend / irecv: post a transfer of a DEVICE buffer (a binding may only collect them: RCCL groups them, torch batches them);

@@ -5,8 +5,8 @@
 // lfx_crc32_combine / lfx_adler32_combine); what was Python until round 4 (libflate_amd/sharded.py: layout, the concatenation
 // of the shards on the writer rank, the member decode by byte ranges with its retries, the window hand-over, the checksum
 // fold, "a failure on one rank is raised on every rank") is sequenced HERE, so that a Rust / C / C++ caller gets the sharded
-// path from the library and not from a re-implementation.  The collectives are the caller's: an lfx_comm of four callbacks
-// (all-gather of host bytes, point-to-point transfers of device buffers, wait) — torch.distributed in the Python mirror and
+// path from the library and not from a re-implementation.  The collectives are the caller's: an lfx_comm of five callbacks
+// (all-gather of host bytes, point-to-point transfers of device buffers, start, wait) — torch.distributed in the Python mirror and
 // the tests, RCCL through lfx_comm_rccl() (librccl is loaded at run time: the library does not link it).
 //
 // The reference side of this seam: ONE trailer from ONE checksum over the whole input (gzip::Encoder::finish,

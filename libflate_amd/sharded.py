@@ -3,7 +3,7 @@
 Until round 4 this module WAS the driver (layout, concatenation, the member decode with its retries and its window hand-over);
 since round 5 that sequencing lives in the C ABI (include/lfx.h: lfx_sharded_encode_begin / _finish, lfx_sharded_decode and
 their exchange steps lfx_sharded_layout / _gather_tuples / _fold; libflate_amd/csrc/lfx_sharded.cpp), so that a Rust or C
-caller has the same path.  What is left here: an `lfx_comm` whose four callbacks run over torch.distributed (RCCL on GPUs,
+caller has the same path.  What is left here: an `lfx_comm` whose five callbacks run over torch.distributed (RCCL on GPUs,
 gloo in CPU rigs), and the functions the tests and bench.py call, now forwarding to the library.
 
 The data path has no collective: every rank encodes its own blocks; the ranks exchange 32 bytes each (`lfx_shard_info`, one
