@@ -241,6 +241,7 @@ void Diag::read() {
     if (const char *pm = getenv("LFX_POCR_MAX")) pocr_max = atoi(pm);
     if (const char *eb = getenv("LFX_ENC_BATCH_MB")) enc_batch_mb = atoi(eb);
     two_pass = on("LFX_TWO_PASS");
+    no_small_scan = on("LFX_NO_SMALL_SCAN");
     store_tight = on("LFX_STORE_TIGHT");
 }
 

@@ -35,6 +35,7 @@ struct Diag {
     bool no_final_cand = false;  // LFX_NO_FINAL_CAND: the finder reports no BFINAL header at all (the chain walk scans the last block on demand)
     bool window_chain = false;   // LFX_WINDOW_CHAIN
     int free_shift = -1;         // LFX_FREE_SHIFT
+    bool no_small_scan = false;  // LFX_NO_SMALL_SCAN: 1024 slices a block also for small blocks (round 5's geometry)
     bool two_pass = false;       // LFX_TWO_PASS: every block through blk_emit_kernel (no storing scan)
     bool store_tight = false;    // LFX_STORE_TIGHT: the storing scan's regions sized for 16 bits a code (tests: lanes overflow, blocks fall back)
     int enc_batch_mb = 0;        // LFX_ENC_BATCH_MB: the stream encoder encodes closed blocks once so many MiB wait (0: the default, 8)

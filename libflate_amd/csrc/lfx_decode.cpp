@@ -211,6 +211,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             auto start_at = [&](uint32_t i) { return i < nc ? starts[i] : n * 8; };
             std::vector<BlkEmit> emit;
             uint32_t n_placed = 0;          // blocks whose codes the scan stored (blk_place_kernel instead of blk_emit_kernel)
+            bool scan_small = false;        // the 256-lane instances of scan and emit (small blocks)
             uint64_t pos = first_bit, total = 0, total_codes = 0;
             bool ok_chain = false, chain_final = false;
             bool front_bad = false;      // the window's FIRST block does not scan: damaged rather than incomplete
@@ -470,6 +471,9 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             //      not fit 16 GiB; LFX_TWO_PASS=1 keeps the emit kernel for everything.
             std::vector<uint8_t> stored(nj + EXTRA + 1, 0);
             bool store_mode = !c->diag.two_pass && nj && (n * 8) / nj >= (1ull << 20);
+            // another encoder's blocks of a few tens of KB: the 256-lane instances of the scan and the emit kernel — for EVERY scan
+            // of this call (rescans and on-demand scans too: the emit launch takes all blocks in one geometry)
+            scan_small = !c->diag.no_small_scan && nj && (n * 8) / nj < (512ull << 10);
             if (store_mode) {
                 uint64_t off = 0;
                 for (uint32_t j = 0; j < nj; j++) {
@@ -492,7 +496,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                                                  (BlkLanesX *)c->d_dec_lanesx.p));
             else
                 LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
-                                           (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
+                                           (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p, scan_small));
             std::vector<BlkInfo> bi(nj);
             HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -530,7 +534,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     stored[redo[q]] = 0;            // (a classic scan takes the slot over: what its lanes stored before is stale)
                     LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_rj + q, 1, (BlkInfo *)c->d_dec_state.p + redo[q],
                                                (BlkLanes *)c->d_dec_blocks.p + redo[q],
-                                               (uint8_t *)c->d_dec_tabs.p + tab_bytes * redo[q]));
+                                               (uint8_t *)c->d_dec_tabs.p + tab_bytes * redo[q], scan_small));
                 }
                 for (size_t q = 0; q < redo.size(); q++)
                     HIP_TRY(hipMemcpyAsync(&bi[redo[q]], (BlkInfo *)c->d_dec_state.p + redo[q], sizeof(BlkInfo), hipMemcpyDeviceToHost, st));
@@ -554,7 +558,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     BlkJob *d_one = (BlkJob *)c->d_dec_streams.p + nj;
                     HIP_TRY(hipMemcpyAsync(d_one, &one, sizeof one, hipMemcpyHostToDevice, st));
                     LAUNCH_TRY(launch_blk_scan(st, d_in, n, d_one, 1, (BlkInfo *)c->d_dec_state.p + k,
-                                               (BlkLanes *)c->d_dec_blocks.p + k, (uint8_t *)c->d_dec_tabs.p + tab_bytes * k));
+                                               (BlkLanes *)c->d_dec_blocks.p + k, (uint8_t *)c->d_dec_tabs.p + tab_bytes * k, scan_small));
                     HIP_TRY(hipMemcpyAsync(&r, (BlkInfo *)c->d_dec_state.p + k, sizeof r, hipMemcpyDeviceToHost, st));
                     HIP_TRY(hipStreamSynchronize(st));
                     if (r.status == BLK_OK && r.btype != 0) n_extra++;   // the slot stays in use
@@ -626,7 +630,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 if (n_placed < ne)
                     LAUNCH_TRY(launch_blk_emit(st, d_in, n, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p,
                                                (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p, unit_target, nullptr,
-                                               c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne));
+                                               c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne, scan_small && !pieces_mode));
                 c->phase("blk_emit");
                 // a huge block (a schedule-S1 stream is ONE block) rarely has enough legal cuts: it goes straight to
                 // the marker path, which may cut anywhere
@@ -1343,8 +1347,13 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
         if ((rc = c->d_dec_cand.reserve(sizeof(BlkLanes) * (size_t)nj))) return rc;
         if ((rc = c->d_dec_tabs.reserve(blk_tabs_bytes() * nj))) return rc;
         HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
+        // (streams of a few tens of KB: the 256-lane instances of the scan and the emit kernel — a 32 KB block in 1024 slices is
+        //  17 symbols a lane; LFX_NO_SMALL_SCAN=1 keeps 1024)
+        uint64_t range_bits = 0;
+        for (uint32_t k = 0; k < nj; k++) range_bits += bj[k].end_bit - bj[k].start_bit;
+        const bool small = !c->diag.no_small_scan && range_bits / nj < (512ull << 10);
         LAUNCH_TRY(launch_blk_scan(st, d_in, n_in, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
-                                   (BlkLanes *)c->d_dec_cand.p, c->d_dec_tabs.p));
+                                   (BlkLanes *)c->d_dec_cand.p, c->d_dec_tabs.p, small));
         // (phase brackets of the first rounds only: the timer holds sixteen, and "fast" / "inflate" / "verify" close the call)
         const bool stamp = c->n_ev + 6 < 17;
         if (stamp) c->phase("blk_scan");
@@ -1385,7 +1394,7 @@ static int batch_fast(Ctx *c, const uint8_t *d_in, uint64_t n_in, uint8_t *d_out
             const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
             const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
             LAUNCH_TRY(launch_blk_emit(st, d_in, n_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p, (uint32_t *)c->d_codes.p,
-                                       d_flags, (BlkUnits *)c->d_hist.p, unit_target, d_jf, c->d_dec_tabs.p));
+                                       d_flags, (BlkUnits *)c->d_hist.p, unit_target, d_jf, c->d_dec_tabs.p, 17, false, small));
             if (stamp) c->phase("blk_emit");
             LAUNCH_TRY(launch_blk_materialize(st, d_in, d_emit, ne, (const BlkLanes *)c->d_dec_cand.p,
                                               (const BlkUnits *)c->d_hist.p, (const uint32_t *)c->d_codes.p, d_out, nullptr));

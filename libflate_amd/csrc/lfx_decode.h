@@ -136,7 +136,8 @@ struct SymUnit {
 // tabs: njobs * blk_tabs_bytes() bytes: the decode tables of every scanned block, reused by launch_blk_emit
 size_t blk_tabs_bytes();
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
-                    BlkInfo *infos, BlkLanes *lanes, void *tabs = nullptr);
+                    BlkInfo *infos, BlkLanes *lanes, void *tabs = nullptr,
+                    bool small_blocks = false);      // round 6: 256 slices (and threads) a block instead of 1024: blocks of a few tens of KB
 int launch_blk_scan_store(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
                           BlkInfo *infos, BlkLanes *lanes, void *tabs, uint32_t *temp, BlkLanesX *lanesx);
 int launch_blk_place(hipStream_t st, const BlkEmit *jobs, uint32_t njobs, const BlkLanes *lanes, const BlkLanesX *lanesx,
@@ -147,8 +148,9 @@ int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const Bl
                     uint32_t *job_flags = nullptr,   // job_flags[j] = 1: block j reads bytes in front of itself
                     const void *tabs = nullptr,      // tables from launch_blk_scan, indexed by BlkEmit::cand
                     uint32_t free_shift = 17,        // marker units: 2^free_shift output bytes each (>= 15)
-                    bool large_blocks = false);      // the kernel instance whose lanes read their bits through LDS rings (round 5): one
+                    bool large_blocks = false,       // the kernel instance whose lanes read their bits through LDS rings (round 5): one
                                                      // workgroup per CU, faster per symbol — for blocks of tens of thousands of codes
+                    bool small_blocks = false);      // the 256-lane instance: exactly the blocks that launch_blk_scan(small_blocks) scanned
 int launch_blk_materialize(hipStream_t st, const uint8_t *in, const BlkEmit *jobs, uint32_t njobs,
                            const BlkLanes *lanes, const BlkUnits *units, const uint32_t *codes, uint8_t *out,
                            uint64_t *dbg);

@@ -746,10 +746,11 @@ constexpr int SCAN_THREADS = 1024;   // lanes per block: 16 wavefronts, 4 per SI
 // The code-length sequence itself is a serial Huffman stream (one lane), everything around it is spread
 // over the workgroup: a 128-entry lookup table for the code-length code, pre-zeroed widths (zero runs
 // only advance the cursor) and the table build.
+template <int NT = SCAN_THREADS>      // NT: threads of the workgroup (1024; 256 in the kernels' instances for small blocks)
 __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_bit, FastTabs &T,
                              uint8_t *lens, uint32_t *hdr, uint64_t *hdr64, uint32_t tid) {
     __shared__ uint8_t cl_tab[128];   // symbol | width << 5 ; 0xFF = no code
-    for (uint32_t i = tid; i < 640 / 4; i += SCAN_THREADS) ((uint32_t *)lens)[i] = 0;
+    for (uint32_t i = tid; i < 640 / 4; i += NT) ((uint32_t *)lens)[i] = 0;
     if (tid == 0) {
         HdrBits hb;
         hb.init(in, nbytes, start_bit);
@@ -773,7 +774,7 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
     const uint32_t btype = hdr[0];
     if (hdr[2] || btype == 0) return;
     if (btype == 1) {
-        for (uint32_t s = tid; s < 288 + 30; s += SCAN_THREADS)
+        for (uint32_t s = tid; s < 288 + 30; s += NT)
             lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
         if (tid == 0) { hdr[3] = 288; hdr[4] = 30; }
     } else {
@@ -882,7 +883,7 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
     __syncthreads();
     if (hdr[2]) return;
     const uint32_t nl = hdr[3], nd = hdr[4];
-    if (!build_fast(T, lens, nl, lens + nl, nd, tid, SCAN_THREADS)) {
+    if (!build_fast(T, lens, nl, lens + nl, nd, tid, NT)) {
         if (tid == 0) hdr[2] = 1;
     }
     __syncthreads();
@@ -900,34 +901,38 @@ __device__ void parse_header(const uint8_t *in, uint64_t nbytes, uint64_t start_
 // lane's region holds the head's codes from 0 on and the rest's from SCAN_HEADCAP on (or right behind the head's when the
 // rest was decoded behind a head that missed the checkpoint); BlkLanesX says which.
 constexpr uint32_t SCAN_HEADCAP = 448;        // code words a head may take: (768 + 48) bits at two bits a code, rounded up to a multiple of 4
-template <bool STORE>
-__global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+// NT (round 6): threads of the workgroup = slices of the block.  1024 for a stream's own blocks; 256 for SMALL blocks (the batch
+// path's 64 KiB streams, another encoder's 30 KB blocks): a 32 KB block cut into 1024 slices is 17 symbols a lane — a speculative
+// start is not in step before its slice ends, and five rounds of head decodes follow — and two workgroups of sixteen wavefronts
+// per CU spend most of their time in the header's serial parts; with 256 slices a lane has 68 symbols and five blocks share a CU.
+template <bool STORE, int NT = SCAN_THREADS>
+__global__ __launch_bounds__(NT, STORE ? 4 : 8) void blk_scan_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkJob *__restrict__ jobs,
                                                                 BlkInfo *__restrict__ infos,
                                                                 BlkLanes *__restrict__ lanes,
                                                                 FastTabs *__restrict__ tabs,
                                                                 uint32_t *__restrict__ temp, BlkLanesX *__restrict__ lanesx) {
-    extern __shared__ uint32_t scan_stage[];   // STORE: SCAN_THREADS rows of EMIT_STRIDE dwords
+    extern __shared__ uint32_t scan_stage[];   // STORE: NT rows of EMIT_STRIDE dwords
     __shared__ FastTabs T;
     // STORE: the lanes' bits through LDS rings, as in blk_emit_kernel<true> — a wavefront that stores its codes AND loads its
     // bits through the register FIFO waits for its own stores at every refill (loads and stores share vmcnt): measured,
     // 0.945 ms for the storing scan on the FIFO against 0.57 for the counting one
-    __shared__ uint32_t s_ring[STORE ? SCAN_THREADS * RING_STRIDE : 1];
+    __shared__ uint32_t s_ring[STORE ? NT * RING_STRIDE : 1];
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
-    __shared__ uint64_t s_start[SCAN_THREADS + 1];
-    __shared__ uint32_t s_flag[SCAN_THREADS];
-    __shared__ uint64_t s_exit[SCAN_THREADS];
-    __shared__ uint32_t s_scan[SCAN_THREADS / 64];
-    __shared__ uint64_t s_scan64[SCAN_THREADS / 64];
+    __shared__ uint64_t s_start[NT + 1];
+    __shared__ uint32_t s_flag[NT];
+    __shared__ uint64_t s_exit[NT];
+    __shared__ uint32_t s_scan[NT / 64];
+    __shared__ uint64_t s_scan64[NT / 64];
     const uint32_t tid = threadIdx.x;
     const BlkJob job = jobs[blockIdx.x];
     BlkInfo bi;
     bi.status = BLK_OK; bi.btype = 0; bi.bfinal = 0; bi.nlanes = 0; bi.end_bit = 0; bi.n_codes = 0; bi.n_out = 0;
     bi.data_bit = 0; bi.rounds = 0; bi._pad = 0; bi.cyc_hdr = 0; bi.cyc_total = 0;
     const uint64_t t_begin = clock64();
-    parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
+    parse_header<NT>(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
     const uint64_t t_hdr = clock64();
     bi.btype = hdr[0]; bi.bfinal = hdr[1]; bi.data_bit = hdr64[0];
     if (hdr[2]) { bi.status = BLK_BAD; if (tid == 0) infos[blockIdx.x] = bi; return; }
@@ -946,7 +951,7 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
     if (tabs) {   // the emit kernel takes the block's tables from here instead of parsing the header again
         uint32_t *dst = (uint32_t *)&tabs[blockIdx.x];
         const uint32_t *srcw = (const uint32_t *)&T;
-        for (uint32_t i = tid; i < sizeof(FastTabs) / 4; i += SCAN_THREADS) dst[i] = srcw[i];
+        for (uint32_t i = tid; i < sizeof(FastTabs) / 4; i += NT) dst[i] = srcw[i];
     }
     const bool piece = job.piece != 0;
     if (piece && job.warm_bit) {
@@ -968,12 +973,12 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
     if (e > nbytes * 8) e = nbytes * 8;
     if (e < d0 + 1) e = d0 + 1;
     // slices of >= 128 bits so that one symbol (<= 48 bits) never skips a whole slice
-    uint64_t slice = (e - d0 + SCAN_THREADS - 1) / SCAN_THREADS;
+    uint64_t slice = (e - d0 + NT - 1) / NT;
     if (slice < 128) slice = 128;
-    const uint32_t nl = (uint32_t)((e - d0 + slice - 1) / slice);  // lanes in use (<= SCAN_THREADS)
+    const uint32_t nl = (uint32_t)((e - d0 + slice - 1) / slice);  // lanes in use (<= NT)
     const uint64_t my_bound = d0 + (uint64_t)(tid + 1) * slice;     // end of my slice
     s_start[tid] = tid == 0 ? d0 : (tid < nl ? d0 + (uint64_t)tid * slice : ~0ull);
-    if (tid == 0) { s_start[SCAN_THREADS] = ~0ull; hdr[7] = 0; }      // (hdr[7]: STORE's "a lane's codes did not fit" flag)
+    if (tid == 0) { s_start[NT] = ~0ull; hdr[7] = 0; }      // (hdr[7]: STORE's "a lane's codes did not fit" flag)
     __syncthreads();
     uint32_t rounds = 0;
     // Round 1 decodes every slice from its guessed start: a short head [start, checkpoint) and the rest
@@ -1128,14 +1133,14 @@ __global__ __launch_bounds__(SCAN_THREADS, STORE ? 4 : 8) void blk_scan_kernel(c
         X->cut_out[tid] = co;
         if (live && ovf) atomicOr(&hdr[7], 1u);
     }
-    if (tid == SCAN_THREADS - 1) {
+    if (tid == NT - 1) {
         bi.n_codes = px + x;
         bi.n_out = py + y;
     }
     // broadcast totals through LDS
     __shared__ uint32_t s_tot;
     __shared__ uint64_t s_tot64;
-    if (tid == SCAN_THREADS - 1) { s_tot = px + x; s_tot64 = py + y; }
+    if (tid == NT - 1) { s_tot = px + x; s_tot64 = py + y; }
     __syncthreads();
     if (tid == 0) {
         if constexpr (STORE) bi._pad = hdr[7] & 1u;      // 1: some lane's codes did not fit its region (the block takes the two-pass path)
@@ -1153,12 +1158,13 @@ constexpr uint32_t MAX_UNITS = 8;
 
 // The part of K2 behind the decode, shared by blk_emit_kernel and blk_place_kernel: from every lane's `reach` (smallest byte of the
 // block a match of its slice reads: absolute, may be negative) and cut candidate → the block's units.
+template <int NT = SCAN_THREADS>
 __device__ __forceinline__ void blk_units_tail(const uint32_t tid, const BlkEmit &job, const BlkLanes *L, const int64_t reach,
                                                uint32_t cut_code, const uint64_t cut_pos, BlkUnits *U, const uint32_t unit_target,
                                                const uint32_t free_shift, const uint64_t t_begin, const uint64_t t_hdr) {
     const uint64_t t_dec = clock64();
     // suffix minimum of `reach` over LATER lanes: within the wavefront by shuffles, then across wavefronts
-    __shared__ int64_t s_wmin[SCAN_THREADS / 64];
+    __shared__ int64_t s_wmin[NT / 64];
     const uint32_t lane = tid & 63, wave = tid >> 6;
     int64_t sfx = reach;   // inclusive suffix min
     for (int o = 1; o < 64; o <<= 1) {
@@ -1169,15 +1175,15 @@ __device__ __forceinline__ void blk_units_tail(const uint32_t tid, const BlkEmit
     __syncthreads();
     int64_t later = __shfl_down(sfx, 1);            // min over the later lanes of my wavefront
     if (lane == 63) later = INT64_MAX;
-    for (uint32_t w = wave + 1; w < SCAN_THREADS / 64; ++w) { const int64_t y = s_wmin[w]; if (y < later) later = y; }
+    for (uint32_t w = wave + 1; w < NT / 64; ++w) { const int64_t y = s_wmin[w]; if (y < later) later = y; }
     // the lane's cut is legal iff no later lane reads a byte in front of it either (a later candidate of
     // this lane lies even further right, so it cannot be legal when this one is not)
     if (cut_code != 0xFFFFFFFFu && later < (int64_t)cut_pos) cut_code = 0xFFFFFFFFu;
-    __shared__ uint32_t s_cut_code[SCAN_THREADS];
-    __shared__ uint64_t s_cut_pos[SCAN_THREADS];
+    __shared__ uint32_t s_cut_code[NT];
+    __shared__ uint64_t s_cut_pos[NT];
     s_cut_code[tid] = cut_code;
     s_cut_pos[tid] = cut_pos;
-    __shared__ uint64_t s_legal[SCAN_THREADS / 64];
+    __shared__ uint64_t s_legal[NT / 64];
     const uint64_t legal = __ballot(cut_code != 0xFFFFFFFFu);
     if (lane == 0) s_legal[wave] = legal;
     __syncthreads();
@@ -1196,10 +1202,10 @@ __device__ __forceinline__ void blk_units_tail(const uint32_t tid, const BlkEmit
         for (uint32_t b = 1; b < want_units; ++b) {
             const uint32_t ideal = (uint32_t)((uint64_t)job.n_codes * b / want_units);
             uint32_t l0 = (uint32_t)((uint64_t)job.nlanes * b / want_units);
-            if (l0 >= SCAN_THREADS) l0 = SCAN_THREADS - 1;
+            if (l0 >= NT) l0 = NT - 1;
             // nearest legal lane at or above l0, and below l0
             int up = -1, dn = -1;
-            for (uint32_t w = l0 >> 6; w < SCAN_THREADS / 64 && up < 0; ++w) {
+            for (uint32_t w = l0 >> 6; w < NT / 64 && up < 0; ++w) {
                 uint64_t m = s_legal[w];
                 if (w == (l0 >> 6)) m &= ~0ull << (l0 & 63);
                 if (m) up = (int)(w * 64 + (uint32_t)__builtin_ctzll(m));
@@ -1248,8 +1254,8 @@ __device__ __forceinline__ void blk_units_tail(const uint32_t tid, const BlkEmit
 
 // RING: the lanes' bits come through LDS rings (RingBits: one workgroup per CU — the single-stream path, whose blocks are
 // large); else through the register FIFO (FastBits: two workgroups per CU — the batch path's thousands of small blocks)
-template <bool RING>
-__global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
+template <bool RING, int NT = SCAN_THREADS>
+__global__ __launch_bounds__(NT, RING ? 4 : 8) void blk_emit_kernel(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                                 const BlkEmit *__restrict__ jobs,
                                                                 const BlkLanes *__restrict__ lanes,
                                                                 uint32_t *__restrict__ codes,
@@ -1261,8 +1267,8 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(co
     __shared__ __attribute__((aligned(4))) uint8_t lens[640];
     __shared__ uint32_t hdr[8];
     __shared__ uint64_t hdr64[2];
-    extern __shared__ uint32_t emit_stage[];   // SCAN_THREADS rows of EMIT_STRIDE dwords
-    __shared__ uint32_t s_ring[RING ? SCAN_THREADS * RING_STRIDE : 1];      // the lanes' bit rings (lane_decode)
+    extern __shared__ uint32_t emit_stage[];   // NT rows of EMIT_STRIDE dwords
+    __shared__ uint32_t s_ring[RING ? NT * RING_STRIDE : 1];      // the lanes' bit rings (lane_decode)
     const uint32_t tid = threadIdx.x;
     const BlkEmit job = jobs[blockIdx.x];
     BlkUnits *U = &units[blockIdx.x];
@@ -1278,14 +1284,14 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(co
     if (tabs) {   // the tables the scan kernel built for this block
         const uint32_t *srcw = (const uint32_t *)&tabs[job.cand];
         uint32_t *dst = (uint32_t *)&T;
-        constexpr uint32_t TW = sizeof(FastTabs) / 4, TPER = (TW + SCAN_THREADS - 1) / SCAN_THREADS;
+        constexpr uint32_t TW = sizeof(FastTabs) / 4, TPER = (TW + NT - 1) / NT;
         uint32_t tv[TPER];                      // (all of a lane's loads in flight, then the LDS stores)
 #pragma unroll
-        for (uint32_t k = 0; k < TPER; ++k) tv[k] = srcw[min(tid + k * SCAN_THREADS, TW - 1)];
+        for (uint32_t k = 0; k < TPER; ++k) tv[k] = srcw[min(tid + k * NT, TW - 1)];
 #pragma unroll
-        for (uint32_t k = 0; k < TPER; ++k) if (tid + k * SCAN_THREADS < TW) dst[tid + k * SCAN_THREADS] = tv[k];
+        for (uint32_t k = 0; k < TPER; ++k) if (tid + k * NT < TW) dst[tid + k * NT] = tv[k];
         __syncthreads();
-    } else parse_header(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
+    } else parse_header<NT>(in, nbytes, job.start_bit, T, lens, hdr, hdr64, tid);
     const uint64_t t_hdr = clock64();
     const BlkLanes *L = &lanes[job.cand];
     int64_t reach = INT64_MAX;
@@ -1309,7 +1315,7 @@ __global__ __launch_bounds__(SCAN_THREADS, RING ? 4 : 8) void blk_emit_kernel(co
         } else if (reach < 0) atomicOr(&flags[0], 2u);   // ... in front of the block: it needs the earlier output
         if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
     }
-    blk_units_tail(tid, job, L, reach, cut_code, cut_pos, U, unit_target, free_shift, t_begin, t_hdr);
+    blk_units_tail<NT>(tid, job, L, reach, cut_code, cut_pos, U, unit_target, free_shift, t_begin, t_hdr);
 }
 
 
@@ -2432,11 +2438,16 @@ __global__ __launch_bounds__(M2_WIDE_THREADS) void blk_materialize2_sym_wide_ker
     } while (0)
 
 size_t blk_tabs_bytes() { return sizeof(FastTabs); }
+constexpr int SCAN_SMALL = 256;      // threads of the kernels' instances for small blocks
 int launch_blk_scan(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkJob *jobs, uint32_t njobs,
-                    BlkInfo *infos, BlkLanes *lanes, void *tabs) {
+                    BlkInfo *infos, BlkLanes *lanes, void *tabs, bool small_blocks) {
     if (!njobs) return 0;
-    hipLaunchKernelGGL(blk_scan_kernel<false>, dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes, (FastTabs *)tabs,
-                       (uint32_t *)nullptr, (BlkLanesX *)nullptr);
+    if (small_blocks)
+        hipLaunchKernelGGL((blk_scan_kernel<false, SCAN_SMALL>), dim3(njobs), dim3(SCAN_SMALL), 0, st, in, nbytes, jobs, infos, lanes,
+                           (FastTabs *)tabs, (uint32_t *)nullptr, (BlkLanesX *)nullptr);
+    else
+        hipLaunchKernelGGL((blk_scan_kernel<false, SCAN_THREADS>), dim3(njobs), dim3(SCAN_THREADS), 0, st, in, nbytes, jobs, infos, lanes,
+                           (FastTabs *)tabs, (uint32_t *)nullptr, (BlkLanesX *)nullptr);
     LFX_LAUNCH_CHECK();
     return 0;
 }
@@ -2450,10 +2461,10 @@ int launch_blk_scan_store(hipStream_t st, const uint8_t *in, uint64_t nbytes, co
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     if (!attr_set[dev_ & 63]) {
-        (void)hipFuncSetAttribute((const void *)blk_scan_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        (void)hipFuncSetAttribute((const void *)blk_scan_kernel<true, SCAN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
         attr_set[dev_ & 63] = true;
     }
-    hipLaunchKernelGGL(blk_scan_kernel<true>, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, infos, lanes,
+    hipLaunchKernelGGL((blk_scan_kernel<true, SCAN_THREADS>), dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, infos, lanes,
                        (FastTabs *)tabs, temp, lanesx);
     LFX_LAUNCH_CHECK();
     return 0;
@@ -2470,28 +2481,31 @@ int launch_blk_place(hipStream_t st, const BlkEmit *jobs, uint32_t njobs, const 
 }
 int launch_blk_emit(hipStream_t st, const uint8_t *in, uint64_t nbytes, const BlkEmit *jobs, uint32_t njobs,
                     const BlkLanes *lanes, uint32_t *codes, uint32_t *flags, BlkUnits *units, uint32_t unit_target,
-                    uint32_t *job_flags, const void *tabs, uint32_t free_shift, bool large_blocks) {
+                    uint32_t *job_flags, const void *tabs, uint32_t free_shift, bool large_blocks, bool small_blocks) {
     if (!njobs) return 0;
-    constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4;
+    constexpr size_t stage_bytes = (size_t)SCAN_THREADS * EMIT_STRIDE * 4, stage_small = (size_t)SCAN_SMALL * EMIT_STRIDE * 4;
     // (a function attribute is per device: one flag per device ordinal)
     static bool attr_set[64] = {};
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     if (!attr_set[dev_ & 63]) {
-        (void)hipFuncSetAttribute((const void *)blk_emit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
-        (void)hipFuncSetAttribute((const void *)blk_emit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        (void)hipFuncSetAttribute((const void *)blk_emit_kernel<false, SCAN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
+        (void)hipFuncSetAttribute((const void *)blk_emit_kernel<true, SCAN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage_bytes);
         attr_set[dev_ & 63] = true;
     }
+    const uint32_t ut = unit_target ? unit_target : 1u, fs = free_shift < 15 ? 15u : free_shift;
     // large blocks (a stream's own 1 MiB blocks, pieces): the LDS-ring bit source, one workgroup per CU; many small blocks
-    // (the batch path, another encoder's 30 KB blocks): the register FIFO, two workgroups per CU
-    if (large_blocks)
-        hipLaunchKernelGGL(blk_emit_kernel<true>, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes,
-                           codes, flags, units, unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags,
-                           (const FastTabs *)tabs);
+    // (the batch path, another encoder's 30 KB blocks): the register FIFO — 256 lanes a block when the scan was (small_blocks:
+    // the two kernels' instances go together, BlkEmit::nlanes <= 256 then), else 1024 and two workgroups per CU
+    if (small_blocks)
+        hipLaunchKernelGGL((blk_emit_kernel<false, SCAN_SMALL>), dim3(njobs), dim3(SCAN_SMALL), stage_small, st, in, nbytes, jobs, lanes, codes,
+                           flags, units, ut, fs, job_flags, (const FastTabs *)tabs);
+    else if (large_blocks)
+        hipLaunchKernelGGL((blk_emit_kernel<true, SCAN_THREADS>), dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes,
+                           codes, flags, units, ut, fs, job_flags, (const FastTabs *)tabs);
     else
-        hipLaunchKernelGGL(blk_emit_kernel<false>, dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes,
-                           flags, units, unit_target ? unit_target : 1u, free_shift < 15 ? 15u : free_shift, job_flags,
-                           (const FastTabs *)tabs);
+        hipLaunchKernelGGL((blk_emit_kernel<false, SCAN_THREADS>), dim3(njobs), dim3(SCAN_THREADS), stage_bytes, st, in, nbytes, jobs, lanes, codes,
+                           flags, units, ut, fs, job_flags, (const FastTabs *)tabs);
     LFX_LAUNCH_CHECK();
     return 0;
 }

@@ -286,3 +286,65 @@ def test_stream_decoder_decoding_ahead_edge_cases(ctx, lfx, ffi, oracle, synth):
     del dd
     rc, out, used, _ = ctx.decode_host(ffi.GZIP, zb)
     assert rc == 0 and out == b and used == len(zb)
+
+
+def test_small_blocks_on_256_lanes(ffi, lfx, oracle, synth, monkeypatch):
+    """Round 6: blocks of a few tens of KB (another encoder's; the batch path's 64 KiB streams) are scanned and emitted by the
+    256-lane instances of the kernels; LFX_NO_SMALL_SCAN keeps 1024 lanes.  Same bytes, same verdicts on damage, single
+    stream and batch."""
+    import zlib
+    text = synth.text(12 << 20, seed=synth.SEED_BASE + 14).tobytes()
+    low = synth.lowent(4 << 20).tobytes()
+    rnd = np.random.default_rng(3).integers(0, 256, 2 << 20, dtype=np.uint8).tobytes()
+    singles = {
+        "zlib level 6": (ffi.ZLIB, zlib.compress(text, 6), text),
+        "zlib level 1": (ffi.ZLIB, zlib.compress(text[:5 << 20] + low, 1), text[:5 << 20] + low),
+        "zlib level 9 + random": (ffi.ZLIB, zlib.compress(text[:3 << 20] + rnd, 9), text[:3 << 20] + rnd),
+        "reference, 64 KiB blocks": (ffi.GZIP, oracle.encode(oracle.GZIP, text[:6 << 20], write_size=4096, block_size=65536, mtime=0), text[:6 << 20]),
+        "reference, 20 KB blocks, fixed codes": (ffi.DEFLATE, oracle.encode(oracle.DEFLATE, text[:2 << 20], write_size=1000, block_size=20000, dynamic_huffman=0), text[:2 << 20]),
+    }
+    count, size = 300, 65536
+    streams = [zlib.compress(text[i * size:(i + 1) * size], 6) if i & 1 else oracle.encode(oracle.ZLIB, text[i * size:(i + 1) * size], write_size=0)
+               for i in range(count)]
+    streams[7] = streams[7][:len(streams[7]) // 2]                       # truncated
+    bad = bytearray(streams[8]); bad[len(bad) // 2] ^= 0x20; streams[8] = bytes(bad)      # damaged
+    L = ffi.lib()
+    results = {}
+    for env in ({}, {"LFX_NO_SMALL_SCAN": "1"}):
+        monkeypatch.delenv("LFX_NO_SMALL_SCAN", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = lfx.Context(0)
+        try:
+            for name, (fmt, z, want) in singles.items():
+                rc, out, used, msg = c2.decode_host(fmt, z)
+                assert (rc, used) == (0, len(z)) and out == want, (env, name, rc, msg)
+                zz = bytearray(z); zz[len(zz) // 3] ^= 0x44
+                rc, out, used, msg = c2.decode_host(fmt, bytes(zz))
+                ofmt = {ffi.ZLIB: oracle.ZLIB, ffi.GZIP: oracle.GZIP, ffi.DEFLATE: oracle.DEFLATE}[fmt]
+                orc, oout, _u, _m = oracle.decode(ofmt, bytes(zz))
+                assert rc == orc and out == oout, (env, name, "damaged", rc, orc, len(out), len(oout))
+            # the batch call
+            import torch
+            blob = b"".join(streams)
+            offs = np.cumsum([0] + [len(x) for x in streams[:-1]]).astype(np.uint64)
+            lens = np.array([len(x) for x in streams], dtype=np.uint64)
+            d_in = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda()
+            d_out = torch.zeros(count * size, dtype=torch.uint8, device="cuda")
+            out_off = (np.arange(count, dtype=np.uint64) * np.uint64(size))
+            out_cap = np.full(count, size, dtype=np.uint64)
+            out_len = np.zeros(count, dtype=np.uint64)
+            status = np.zeros(count, dtype=np.int32)
+            rc = L.lfx_decode_batch_device(c2.handle, ffi.ZLIB, count, d_in.data_ptr(), offs.ctypes.data, lens.ctypes.data, d_out.data_ptr(),
+                                           out_off.ctypes.data, out_cap.ctypes.data, out_len.ctypes.data, status.ctypes.data)
+            host = d_out.cpu().numpy()
+            for i in range(count):
+                if i in (7, 8):
+                    orc, oout, _u, _m = oracle.decode(oracle.ZLIB, streams[i])
+                    assert status[i] == orc and orc != 0, (env, i, status[i], orc)
+                else:
+                    assert status[i] == 0 and out_len[i] == size and host[i * size:(i + 1) * size].tobytes() == text[i * size:(i + 1) * size], (env, i)
+            results[bool(env)] = (status.copy(), out_len.copy())
+        finally:
+            c2.close()
+    assert (results[False][0] == results[True][0]).all() and (results[False][1] == results[True][1]).all()
