@@ -303,7 +303,7 @@ def test_small_blocks_on_256_lanes(ffi, lfx, oracle, synth, monkeypatch):
         "reference, 64 KiB blocks": (ffi.GZIP, oracle.encode(oracle.GZIP, text[:6 << 20], write_size=4096, block_size=65536, mtime=0), text[:6 << 20]),
         "reference, 20 KB blocks, fixed codes": (ffi.DEFLATE, oracle.encode(oracle.DEFLATE, text[:2 << 20], write_size=1000, block_size=20000, dynamic_huffman=0), text[:2 << 20]),
     }
-    count, size = 300, 65536
+    count, size = 180, 65536
     streams = [zlib.compress(text[i * size:(i + 1) * size], 6) if i & 1 else oracle.encode(oracle.ZLIB, text[i * size:(i + 1) * size], write_size=0)
                for i in range(count)]
     streams[7] = streams[7][:len(streams[7]) // 2]                       # truncated
