@@ -63,8 +63,10 @@ struct HostIo {
     void release();
 };
 
-// d_dst[0, n) <- h_src[0, n).  On return every byte has left h_src (the caller may reuse it) and `st` is ordered behind the
-// transfers: work queued on `st` afterwards sees the data.  → LFX status
+// d_dst[0, n) <- h_src[0, n).  On return `st` is ordered behind the transfers: work queued on `st` afterwards sees the data.
+// Pageable memory has left h_src by then (it went through the slabs); PAGE-LOCKED memory is only queued — the DMA engine reads
+// h_src until `st` has passed the copy, so the caller's buffer must stay untouched until then (lfx_encode_host /
+// lfx_decode_host synchronise `st` before they return: their callers never see the difference).  → LFX status
 int host_to_device(Ctx *c, void *d_dst, const void *h_src, uint64_t n, hipStream_t st);
 // h_dst[0, n) <- d_src[0, n), after everything queued on `st` so far.  Complete on return.
 int device_to_host(Ctx *c, void *h_dst, const void *d_src, uint64_t n, hipStream_t st);
