@@ -866,7 +866,8 @@ extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o
     if ((rc = host_to_device(c, c->d_io_in.p, in, n, c->stream))) { c->set_error("host to device copy failed"); return rc; }
     uint64_t len = 0;
     rc = lfx_encode_device(cc, format, o, s, c->d_io_in.p, n, c->d_io_out.p, bound & ~3ull, &len);
-    if (rc) return rc;
+    // (a page-locked `in` was only queued for DMA: no return before the stream has passed the copy, on any path)
+    if (rc) { (void)hipStreamSynchronize(c->stream); return rc; }
     if (len > cap) { c->set_error("output capacity too small"); return LFX_E_NOSPACE; }
     if ((rc = device_to_host(c, out, c->d_io_out.p, len, c->stream))) { c->set_error("device to host copy failed"); return rc; }
     if (out_len) *out_len = len;

@@ -1310,7 +1310,8 @@ extern "C" int lfx_decode_host(lfx_ctx *cc, int format, uint32_t flags, const vo
     if (int hr = host_to_device(c, c->d_io_in.p, in, n, c->stream)) { c->set_error("host to device copy failed"); return hr; }
     uint64_t ol = 0;
     rc = lfx_decode_device(cc, format, flags, c->d_io_in.p, n, c->d_io_out.p, cap, &ol, consumed);
-    if (rc == LFX_E_DEVICE || rc == LFX_E_OOM || rc == LFX_E_ARG) return rc;
+    // (a page-locked `in` was only queued for DMA: no return before the stream has passed the copy, on any path)
+    if (rc == LFX_E_DEVICE || rc == LFX_E_OOM || rc == LFX_E_ARG) { (void)hipStreamSynchronize(c->stream); return rc; }
     if (ol) { if (int hr = device_to_host(c, out, c->d_io_out.p, ol, c->stream)) { c->set_error("device to host copy failed"); return hr; } }
     if (out_len) *out_len = ol;
     return rc;
