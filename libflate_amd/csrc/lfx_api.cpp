@@ -1326,7 +1326,7 @@ extern "C" void lfx_encoder_free(lfx_encoder *e) {
     (void)hipSetDevice(e->c->device);
     e->c->give_dev(e->d_in);
     e->c->give_dev(e->d_out);
-    if (e->inflight) (void)hipStreamSynchronize(e->c->stream);      // (freed without finish: the DMA engine still reads the buffers)
+    (void)hipStreamSynchronize(e->c->stream);      // (freed without finish, or after a failed launch: the DMA engine may still read the buffers)
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->ev_small) (void)hipEventDestroy(e->ev_small);
     e->c->give_pin(std::move(e->pending));
