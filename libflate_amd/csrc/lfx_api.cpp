@@ -241,6 +241,7 @@ void Diag::read() {
     if (const char *pm = getenv("LFX_POCR_MAX")) pocr_max = atoi(pm);
     if (const char *eb = getenv("LFX_ENC_BATCH_MB")) enc_batch_mb = atoi(eb);
     two_pass = on("LFX_TWO_PASS");
+    hist_separate = on("LFX_HIST_SEPARATE");
     no_small_scan = on("LFX_NO_SMALL_SCAN");
     store_tight = on("LFX_STORE_TIGHT");
 }
@@ -484,6 +485,9 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
 
     uint64_t *mdbg = nullptr;
     if (c->diag.debug) mdbg = (uint64_t *)((uint8_t *)c->d_small.p + 32768);   // per-wavefront cycle counters of workgroup 0
+    bool fused_hist = false;      // the parse counted the blocks' symbols (no histogram_kernel)
+    bool forked = false;          // the first half of the checksum's sweep is on the side stream already
+    uint32_t emit_per = 0, emit_parts = 0;
     if (hc) {
         // the caller's own Lz77Encode produced the code words (EncodeOptions::with_lz77(E), encode.rs:59-65): they take the
         // place of the match + parse stages' output — one chunk per block, EndOfBlock included; everything from the
@@ -581,10 +585,40 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             if (stage_no == 1) { fprintf(stderr, "[lfx]  cd:"); for (int q = 0; q < 64; q++) fprintf(stderr, " %u", cdv[q]); fprintf(stderr, "\n"); }
         }
     }
+    // The blocks' symbol counts are taken by the kernel that writes the code words (parse_emit_hist_kernel): a grid of
+    // nchunks x (workgroups of the longest chunk), about eight workgroups per CU in all.  A chunk list of very unequal chunks
+    // (a few huge ones among thousands of small ones) would launch mostly empty workgroups: histogram_kernel counts then.
+    {
+        const uint32_t target = PARSE_EMIT_WG_PER_CU * (uint32_t)std::max(c->n_cu, 1);
+        uint32_t per = (uint32_t)div_up(std::max<uint32_t>(plan.n_segs, 1), target);
+        per = (per + PARSE_EMIT_WAVES - 1) / PARSE_EMIT_WAVES * PARSE_EMIT_WAVES;
+        uint32_t max_segs = 0;
+        uint64_t useful = 0;
+        for (uint32_t ci = 0; ci < nchunks; ci++) {
+            max_segs = std::max(max_segs, plan.chunks[ci].n_seg);
+            useful += div_up(plan.chunks[ci].n_seg, per);
+        }
+        const uint64_t parts = div_up(max_segs, per);
+        fused_hist = !c->diag.hist_separate && parts <= 65535 && (uint64_t)nchunks * parts <= 4 * useful + 4096;
+        emit_per = per;
+        emit_parts = (uint32_t)parts;
+    }
     LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const ParseWg *)c->d_pwgs.p,
                             (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
                             (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map, 0,
-                            mdbg ? mdbg + 256 : nullptr));
+                            mdbg ? mdbg + 256 : nullptr, fused_hist ? (uint32_t *)c->d_hist.p : nullptr, emit_per, emit_parts,
+                            want_checksum ? c->ev_fork : nullptr));
+    if (want_checksum) {
+        // the first half of the container checksum's sweep: on the side stream from behind the walk kernel on, beside the
+        // chaining kernels (one wavefront per segment and a handful of steps each: they leave most of the GPU idle); the
+        // second half beside the Huffman kernel, below.  (Measured, round 6: all of it here ran into parse_emit — both
+        // want the memory system — parse + Huffman 1.13 ms; all of it behind the parse no longer fits under the Huffman
+        // kernel now that the histogram kernel is gone.)
+        uint32_t *ck = (uint32_t *)c->d_ck.p;
+        HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        LAUNCH_TRY(launch_checksum_part(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, ck_mode, 0, 2));
+        forked = true;
+    }
     if (mdbg) {
         uint64_t hv[32];
         (void)hipMemcpy(hv, mdbg + 256, sizeof hv, hipMemcpyDeviceToHost);
@@ -595,20 +629,23 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
     c->phase("lz77_parse");
     }   // !hc
     if (want_checksum) {
-        // the container checksum reads only the input: it runs on the side stream, beside the histogram
-        // and the one-wavefront-per-block Huffman kernel, which leave most of the GPU idle
+        // the container checksum reads only the input: it runs on the side stream, beside the parse's chaining kernels
+        // (one wavefront per segment, a handful of steps each) and the one-workgroup-per-block Huffman kernel, which leave
+        // most of the GPU idle (the fork: behind the walk kernel, launch_parse)
         uint32_t *ck = (uint32_t *)c->d_ck.p;
         HIP_TRY(hipEventRecord(c->ev_fork, st));
         HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-        LAUNCH_TRY(launch_checksum(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, ck_mode));
+        if (forked) LAUNCH_TRY(launch_checksum_part(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, ck_mode, 1, 2));
+        else LAUNCH_TRY(launch_checksum(c->side_stream, d_in, n, ck, ck + nspans, ck + 2 * nspans, (EncodeResult *)c->d_res.p, ck_mode));
         HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
     }
     // enough workgroups to fill the GPU even when there are few chunks (schedule S1: one)
     // (more workgroups per chunk were measured slower at 1024 chunks: 8 per chunk 0.23 ms against 0.20 ms for one —
     //  every workgroup ends with a global atomic per non-zero counter)
     uint32_t split = nchunks && nchunks < 1024 ? std::min<uint32_t>(1024, 2048 / nchunks + 1) : 1;
-    LAUNCH_TRY(launch_histogram(st, (const ChunkDesc *)c->d_chunks.p, nchunks, split, (const uint32_t *)c->d_codes.p,
-                                (const uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_hist.p));
+    if (!fused_hist)       // (a caller's own code words, LFX_HIST_SEPARATE, very unequal chunks)
+        LAUNCH_TRY(launch_histogram(st, (const ChunkDesc *)c->d_chunks.p, nchunks, split, (const uint32_t *)c->d_codes.p,
+                                    (const uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_hist.p));
     c->phase("histogram");
     LAUNCH_TRY(launch_huffman(st, (const BlockDesc *)c->d_blocks.p, nblocks, (const uint32_t *)c->d_hist.p,
                               (BlockCodes *)c->d_bc.p, mdbg ? mdbg + 512 : nullptr));

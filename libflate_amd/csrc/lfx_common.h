@@ -71,6 +71,15 @@ constexpr uint32_t PARSE_SEG = 64 * PARSE_GROUP;   // 3328 positions
 #define LFX_PARSE_WG_SEGS 12
 #endif
 constexpr uint32_t PARSE_WG_SEGS = LFX_PARSE_WG_SEGS;
+// parse_emit_hist_kernel (round 6): wavefronts per workgroup, and workgroups per CU the host aims at when it sizes a
+// workgroup's share of segments (every workgroup ends with a global atomic per non-zero symbol counter)
+#ifndef LFX_EMIT_WAVES
+#define LFX_EMIT_WAVES 4
+#endif
+#ifndef LFX_EMIT_WG_PER_CU
+#define LFX_EMIT_WG_PER_CU 8
+#endif
+constexpr uint32_t PARSE_EMIT_WAVES = LFX_EMIT_WAVES, PARSE_EMIT_WG_PER_CU = LFX_EMIT_WG_PER_CU;
 
 #ifdef __HIPCC__
 // pointers that are known to address global memory (HBM): keeps loads on the global_load path —

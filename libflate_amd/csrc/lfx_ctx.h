@@ -37,6 +37,7 @@ struct Diag {
     int free_shift = -1;         // LFX_FREE_SHIFT
     bool no_small_scan = false;  // LFX_NO_SMALL_SCAN: 1024 slices a block also for small blocks (round 5's geometry)
     bool two_pass = false;       // LFX_TWO_PASS: every block through blk_emit_kernel (no storing scan)
+    bool hist_separate = false;  // LFX_HIST_SEPARATE: the blocks' symbol counts by histogram_kernel (round 5) instead of inside parse_emit
     bool store_tight = false;    // LFX_STORE_TIGHT: the storing scan's regions sized for 16 bits a code (tests: lanes overflow, blocks fall back)
     int enc_batch_mb = 0;        // LFX_ENC_BATCH_MB: the stream encoder encodes closed blocks once so many MiB wait (0: the default, 8)
     int pocr_max = 100;          // LFX_POCR_MAX: most candidate ranges the decoder scans in pieces at once

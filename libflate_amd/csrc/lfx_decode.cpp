@@ -217,6 +217,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             bool front_bad = false;      // the window's FIRST block does not scan: damaged rather than incomplete
             uint64_t last_end = 0;   // end bit of the last block of the chain
             bool pieces_mode = false;
+            uint32_t n_on_demand = 0;       // blocks of the chain the finder did not report (scanned one by one)
             bool pieces_multi = false;   // some block was scanned in more than one piece (its pieces read each other's output)
             bool units_per_piece = false; // (pieces over candidate ranges that fill the GPU: one symbol unit per piece)
             const size_t tab_bytes = blk_tabs_bytes();
@@ -479,7 +480,11 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 for (uint32_t j = 0; j < nj; j++) {
                     const uint64_t bits = bj[j].end_bit > bj[j].start_bit ? bj[j].end_bit - bj[j].start_bit : 0;
                     const uint64_t slice = std::max<uint64_t>((bits + 1023) / 1024, 128);
-                    const uint64_t cap = (slice / (c->diag.store_tight ? 16 : 2) + 448 + 64 + 3) & ~3ull;   // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
+                    uint64_t cap = (slice / (c->diag.store_tight ? 16 : 2) + 448 + 64 + 3) & ~3ull;   // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
+                    static const int cap_exp = getenv("LFX_EXP_CAP") ? atoi(getenv("LFX_EXP_CAP")) : 0;       // EXPERIMENT (round 6): lane stride on the channel grid
+                    if (cap_exp == 1) cap = (((cap + 63) / 64) | 1) * 64;          // an odd number of 256-byte units
+                    if (cap_exp == 2) cap = (((cap + 31) / 32) | 1) * 32;          // an odd number of 128-byte lines
+                    if (cap_exp == 3) cap = (cap + 1023) / 1024 * 1024;            // a multiple of 4 KiB (the bad case, if the grid matters)
                     bj[j].temp_off = off;
                     bj[j].cap = (uint32_t)cap;
                     off += 1024 * cap;
@@ -542,7 +547,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
             c->phase("repair");
             // ---- chain from the known first block
-            uint32_t n_extra = 0, n_on_demand = 0;
+            uint32_t n_extra = 0;
+            n_on_demand = 0;
             for (;;) {
                 if (pos == stop_bit && !emit.empty()) { ok_chain = true; break; }
                 auto it = std::lower_bound(starts.begin(), starts.end(), pos);
@@ -584,7 +590,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             // a window: the blocks in front of the first incomplete one are what this call delivers
             if (partial && !ok_chain && !emit.empty()) ok_chain = true;
             }   // !pieces_mode
-            if (c->diag.debug) fprintf(stderr, "[lfx]  chain ok=%d blocks=%zu pos=%llu total=%llu\n", (int)ok_chain, emit.size(), (unsigned long long)pos, (unsigned long long)total);
+            if (c->diag.debug) fprintf(stderr, "[lfx]  chain ok=%d blocks=%zu pos=%llu total=%llu on_demand=%u\n", (int)ok_chain, emit.size(), (unsigned long long)pos, (unsigned long long)total, n_on_demand);
             if (partial && emit.empty() && !front_bad) {
                 // a window without one complete block (or whose first block does not fit `cap`): nothing to deliver — the
                 // caller widens the window (the exact serial walk of the whole window would only find out the same, slowly).

@@ -66,7 +66,12 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
                  uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage /* 4 bytes per input byte */,
                  const uint32_t *seg_map, int stop_after = 0 /* diagnostics: 1 = behind the walk, 2 = behind fixseg */,
-                 uint64_t *dbg = nullptr /* LFX_DEBUG: cycle stamps of one walk workgroup */);
+                 uint64_t *dbg = nullptr /* LFX_DEBUG: cycle stamps of one walk workgroup */,
+                 uint32_t *hist = nullptr /* 320 zeroed counters per block: the code words are counted as they are emitted
+                                             (launch_histogram is then not needed) */,
+                 uint32_t emit_per = 0 /* with hist: segments per emit workgroup ... */,
+                 uint32_t emit_parts = 0 /* ... and workgroups for the chunk of most segments (grid = nchunks x emit_parts) */,
+                 hipEvent_t ev_walked = nullptr /* recorded behind the walk kernel (in front of the chaining kernels) */);
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
                       uint32_t *tile_map, uint32_t *seg_map);
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
@@ -93,6 +98,9 @@ inline uint64_t ck_nspans(uint64_t n) { return div_up(n ? n : 1, ck_span(n)); } 
 int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
                     uint32_t *a_part, uint32_t *b_part, EncodeResult *res,
                     int mode = 3)   /* bit 0: CRC-32, bit 1: Adler-32 (the other result is then 0) */;
+// the same sweep in `nparts` launches (the caller orders them; the last one folds all spans)
+int launch_checksum_part(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part, uint32_t *a_part, uint32_t *b_part,
+                         EncodeResult *res, int mode, uint32_t part, uint32_t nparts);
 // CRC-32 / Adler-32 of count byte ranges data[off[i*off_stride] .. +len[i*len_stride]) (strides in 8-byte units)
 int launch_checksum_ranges(hipStream_t st, const uint8_t *data, uint32_t count, const uint64_t *off,
                            uint32_t off_stride, const uint64_t *len, uint32_t len_stride, uint32_t *crc, uint32_t *adler);

@@ -1048,12 +1048,12 @@ template <int MODE>
 __global__ __launch_bounds__(256) void checksum_span_kernel(const uint8_t *__restrict__ in,
                                                             uint64_t n, uint32_t span, uint32_t *__restrict__ crc_part,
                                                             uint32_t *__restrict__ a_part,
-                                                            uint32_t *__restrict__ b_part) {
+                                                            uint32_t *__restrict__ b_part, uint64_t region0) {
     __shared__ uint32_t tab[4][256];   // slice-by-4: four independent lookups per input dword
     __shared__ uint32_t advt[4][256];
     ck_tables(tab, advt);
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t region = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t region = region0 + (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (region0: the spans of a later part, launch_checksum_part)
     const uint64_t r0 = region * span;      // (span: 64 KiB, or 8 KiB for small inputs — ck_span(): a wavefront's serial share)
     if (r0 >= n) return;
     const uint32_t rlen = (uint32_t)min((uint64_t)span, n - r0);
@@ -1290,21 +1290,32 @@ int launch_pack(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chun
     }
     return 0;
 }
-int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
-                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res, int mode) {
+// the spans of part `part` of `nparts` (whole groups of four spans); part == nparts - 1 also folds ALL spans (it must be
+// ordered behind the other parts).  launch_checksum = one part.  The encoder runs the first part beside the parse's
+// chaining kernels and the last beside the Huffman kernel (lfx_api.cpp): each leaves most of the GPU idle for about as
+// long as half of the sweep takes.
+int launch_checksum_part(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part, uint32_t *a_part, uint32_t *b_part,
+                         EncodeResult *res, int mode, uint32_t part, uint32_t nparts) {
     const uint32_t span = ck_span(n);
     const uint64_t nspans = div_up(n, span);
-    if (nspans) {
-        const dim3 grid((uint32_t)div_up(nspans, 4));
-        if (mode == 1) hipLaunchKernelGGL(checksum_span_kernel<1>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part);
-        else if (mode == 2) hipLaunchKernelGGL(checksum_span_kernel<2>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part);
-        else hipLaunchKernelGGL(checksum_span_kernel<3>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part);
+    const uint64_t ngroups = div_up(nspans, 4);
+    const uint64_t g0 = ngroups * part / nparts, g1 = ngroups * (part + 1) / nparts;
+    if (g1 > g0) {
+        const dim3 grid((uint32_t)(g1 - g0));
+        if (mode == 1) hipLaunchKernelGGL(checksum_span_kernel<1>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part, 4 * g0);
+        else if (mode == 2) hipLaunchKernelGGL(checksum_span_kernel<2>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part, 4 * g0);
+        else hipLaunchKernelGGL(checksum_span_kernel<3>, grid, dim3(256), 0, st, in, n, span, crc_part, a_part, b_part, 4 * g0);
         LFX_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(checksum_combine_kernel, dim3(1), dim3(1024), 0, st, crc_part, a_part, b_part,
-                       n, span, res);
-    LFX_LAUNCH_CHECK();
+    if (part + 1 == nparts) {
+        hipLaunchKernelGGL(checksum_combine_kernel, dim3(1), dim3(1024), 0, st, crc_part, a_part, b_part, n, span, res);
+        LFX_LAUNCH_CHECK();
+    }
     return 0;
+}
+int launch_checksum(hipStream_t st, const uint8_t *in, uint64_t n, uint32_t *crc_part,
+                    uint32_t *a_part, uint32_t *b_part, EncodeResult *res, int mode) {
+    return launch_checksum_part(st, in, n, crc_part, a_part, b_part, res, mode, 0, 1);
 }
 int launch_checksum_ranges(hipStream_t st, const uint8_t *data, uint32_t count, const uint64_t *off,
                            uint32_t off_stride, const uint64_t *len, uint32_t len_stride, uint32_t *crc, uint32_t *adler) {

@@ -2297,6 +2297,57 @@ __device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ 
     uint32_t di = (bp >> 5) + 2;                       // next dword of hbuf to take
     uint32_t cur = hbuf[(bp >> 5) * 64 + lane], nxt = hbuf[((bp >> 5) + 1) * 64 + lane];
     uint32_t o = bp & 31;
+    // Round 6: the literal / length widths first, in a loop that carries only what they need — nearly every false candidate
+    // walks until those widths are complete (their Kraft sum only shows then) and the wavefront's time is its instruction
+    // count per step: no split of a run at the literal / distance boundary, no distance sums, no bound on the total here.
+    // A lane stops IN FRONT of the step that reaches HLIT + 257 (its state untouched: the general loop below takes that
+    // step, the completeness check and the distance widths).  acc = sum of rep * (weight << 9 | 1): Kraft sum and the
+    // number of codes in one multiply-add; `last` starts as 31, which only a repeat-previous code at the very start can
+    // copy into val.
+#if !defined(LFX_FIND2_NO_LEAN)
+    {
+        uint32_t acc = 0;
+        last = 31u;
+        bool runA = good;
+        while (__ballot(runA)) {
+            ++steps;
+            if (__ballot(runA && di >= FIND2_HB)) {
+                ++restaged;
+                gd += di;
+                di = runA ? 0u : di;
+                gd -= di;
+                stage(runA);
+            }
+            const uint32_t win = __builtin_amdgcn_alignbit(nxt, cur, o);
+            const uint32_t e = cl_tab[(win & 127) * 64 + lane];
+            const uint32_t ahead = hbuf[min(di, FIND2_HB - 1) * 64 + lane];
+            const uint32_t sym = e & 31, used = e >> 5;
+            const uint32_t k4 = (sym > 15 ? sym - 15 : 0) * 4;
+            const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
+            uint32_t rep = basex + __builtin_amdgcn_ubfe(win, used, nbx);
+            const uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
+            const bool take = runA && have + rep < nl;           // (else: the step that completes the widths — the loop below)
+            rep = take ? rep : 0u;
+            const uint32_t adv = take ? used + nbx : 0u;
+            o += adv;
+            const bool pass = o >= 32;
+            cur = pass ? nxt : cur;
+            nxt = pass ? ahead : nxt;
+            di += pass ? 1u : 0u;
+            o &= 31u;
+            const uint32_t w9 = val ? (0x1000000u >> val) | 1u : 0u;
+            acc += __umul24(rep, w9);
+            eob_len = (256u - have) < rep ? val : eob_len;       // (have <= 256 < have + rep, once; unsigned: false behind 256)
+            have += rep;
+            last = take ? val : last;
+            good = good && !(take && (val == 31u || acc > (32768u << 9 | 511u)));   // repeat-previous at the start; over-subscribed
+            runA = good && take;
+        }
+        kl = acc >> 9;
+        nlit = acc & 511u;
+        last = last == 31u ? 0u : last;                          // (nothing walked: the general loop checks sym 16 itself)
+    }
+#endif
     bool run = good && have < total;
     while (__ballot(run)) {
         ++steps;

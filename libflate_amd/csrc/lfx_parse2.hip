@@ -30,6 +30,7 @@
 
 #include "lfx_common.h"
 #include "lfx_device.h"
+#include "lfx_huff.h"
 
 namespace lfx {
 
@@ -424,6 +425,8 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
     }
 }
 
+constexpr uint32_t PARSE_HIST_STRIDE = 320;      // a block's symbol counters: [0,288) literal/length, [288,320) distance (= HIST_STRIDE, lfx_encode_kernels.hip)
+
 // ------------------------------------------------------------------------------------------------
 // Walk steps out of global memory, one at a time, by a whole wavefront (the chaining kernels: a handful of steps per
 // segment).  Lane k compares bytes [4k, 4k+4) behind the prefix: one round settles a whole match.
@@ -531,7 +534,8 @@ __global__ __launch_bounds__(1024) void parse_fix_kernel(const uint8_t *__restri
                                                          uint32_t *__restrict__ seg_count,
                                                          uint32_t *__restrict__ seg_exit2,
                                                          uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
-                                                         uint32_t *__restrict__ ncodes, uint32_t *__restrict__ seg_mpos) {
+                                                         uint32_t *__restrict__ ncodes, uint32_t *__restrict__ seg_mpos,
+                                                         uint32_t *__restrict__ hist) {
     __shared__ uint32_t s_first_bad, s_wsum[16], s_redo[2];
     const ChunkDesc ch = chunks[blockIdx.x];
     const uint32_t tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
@@ -601,34 +605,44 @@ __global__ __launch_bounds__(1024) void parse_fix_kernel(const uint8_t *__restri
         }
         // default.rs:105-107: the rest are literals (at most 3 bytes)
         const uint32_t pos = ch.n_seg ? e_last : 0;
-        for (uint32_t i = pos + tid; i < n; i += T) out[total + (i - pos)] = src.load1(i) << 16;
+        // (hist: the block's symbol counts are taken where the code words are written — parse_emit_hist_kernel — so these few are too)
+        uint32_t *hb = hist ? hist + (uint64_t)ch.block * PARSE_HIST_STRIDE : nullptr;
+        for (uint32_t i = pos + tid; i < n; i += T) {
+            const uint32_t byte = src.load1(i);
+            out[total + (i - pos)] = byte << 16;
+            if (hb) atomicAdd(&hb[byte], 1u);
+        }
         if (n > pos) total += n - pos;
     }
     if (ch.flags & CH_LAST_IN_BLOCK) {
-        if (tid == 0) out[total] = CODE_EOB;  // encode.rs:417
+        if (tid == 0) {
+            out[total] = CODE_EOB;  // encode.rs:417
+            if (hist) atomicAdd(&hist[(uint64_t)ch.block * PARSE_HIST_STRIDE + 256], 1u);
+        }
         total += 1;
     }
     if (tid == 0) ncodes[blockIdx.x] = total;
 }
 
-// P3: every segment emits the codes of its visited positions
-__global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
-                                                        const ChunkDesc *__restrict__ chunks,
-                                                        const uint16_t *__restrict__ cd,
-                                                        const uint64_t *__restrict__ vis,
-                                                        const uint32_t *__restrict__ seg_off,
-                                                        uint32_t *__restrict__ codes,
-                                                        const uint32_t *__restrict__ stage,
-                                                        const uint32_t *__restrict__ seg_count,
-                                                        const uint32_t *__restrict__ seg_exit2,
-                                                        const uint32_t *__restrict__ seg_mpos,
-                                                        const uint32_t *__restrict__ seg_kspec,
-                                                        const uint32_t *__restrict__ seg_map) {
+// P3: every segment emits the codes of its visited positions.
+// HIST (round 6): the segment's code words are counted into `h`, this lane's replica of the workgroup's symbol counters in
+// LDS — the block's histogram (DynamicHuffmanCodec::build, symbol.rs:320-341) is taken where the code words pass through
+// registers anyway instead of by a kernel of its own that reads all of them again.
+__device__ __forceinline__ void hist_count(uint32_t *h, uint32_t code) {
+    const uint32_t dist = code & 0xFFFFu, val = code >> 16;
+    uint32_t eb, ex;
+    const uint32_t s1 = dist ? len_symbol(val, eb, ex) : val;
+    atomicAdd(&h[s1], 1u);
+    if (dist) atomicAdd(&h[288 + dist_symbol(dist, eb, ex)], 1u);
+}
+template <bool HIST>
+__device__ __forceinline__ void emit_segment(const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc &ch, uint32_t seg,
+                                             const uint16_t *__restrict__ cd, const uint64_t *__restrict__ vis,
+                                             const uint32_t *__restrict__ seg_off, uint32_t *__restrict__ codes,
+                                             const uint32_t *__restrict__ stage, const uint32_t *__restrict__ seg_count,
+                                             const uint32_t *__restrict__ seg_exit2, const uint32_t *__restrict__ seg_mpos,
+                                             const uint32_t *__restrict__ seg_kspec, uint32_t lane, uint32_t *h) {
     using p2::U;
-    const uint32_t seg = blockIdx.x;
-    const uint32_t c = seg_map[seg];
-    const ChunkDesc ch = chunks[c];
-    const uint32_t lane = threadIdx.x;
     const uint32_t s = seg - ch.seg_base;
     const uint32_t n = (uint32_t)ch.len;
     const uint32_t s0 = s * PARSE_SEG;
@@ -636,7 +650,11 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
     uint32_t *out = codes + ch.code_off + seg_off[seg];
     if (ch.flags & CH_LITERALS) {
         const uint32_t s1 = min(s0 + PARSE_SEG, n);
-        for (uint32_t i = s0 + lane; i < s1; i += 64) out[i - s0] = src.load1(i) << 16;
+        for (uint32_t i = s0 + lane; i < s1; i += 64) {
+            const uint32_t byte = src.load1(i);
+            out[i - s0] = byte << 16;
+            if (HIST) atomicAdd(&h[byte], 1u);
+        }
         return;
     }
     const uint32_t end = (n > 3 ? n : 3) - 3;
@@ -675,7 +693,9 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
                 const uint64_t above = lane < 63 ? V >> (lane + 1) : 0ull;
                 const uint32_t nxt = above ? i + 1 + (uint32_t)__builtin_ctzll(above) : ng;
                 const uint32_t d = cdc[i];
-                out[nout + __popcll(m & lt)] = d ? ((nxt - i) << 16) | d : src.load1(i) << 16;
+                const uint32_t code = d ? ((nxt - i) << 16) | d : src.load1(i) << 16;
+                out[nout + __popcll(m & lt)] = code;
+                if (HIST) hist_count(h, code);
             }
             nout += __popcll(m);
         }
@@ -689,7 +709,70 @@ __global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restric
 #pragma unroll
         for (uint32_t k = 0; k < 8; ++k) v[k] = st[min(j0 + 64 * k + lane, n2 - 1)];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; ++k) { const uint32_t j = j0 + 64 * k + lane; if (j < n2) out[nout + j] = v[k]; }
+        for (uint32_t k = 0; k < 8; ++k) {
+            const uint32_t j = j0 + 64 * k + lane;
+            if (j < n2) {
+                out[nout + j] = v[k];
+                if (HIST) hist_count(h, v[k]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void parse_emit_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                        const ChunkDesc *__restrict__ chunks,
+                                                        const uint16_t *__restrict__ cd,
+                                                        const uint64_t *__restrict__ vis,
+                                                        const uint32_t *__restrict__ seg_off,
+                                                        uint32_t *__restrict__ codes,
+                                                        const uint32_t *__restrict__ stage,
+                                                        const uint32_t *__restrict__ seg_count,
+                                                        const uint32_t *__restrict__ seg_exit2,
+                                                        const uint32_t *__restrict__ seg_mpos,
+                                                        const uint32_t *__restrict__ seg_kspec,
+                                                        const uint32_t *__restrict__ seg_map) {
+    const uint32_t seg = blockIdx.x;
+    const ChunkDesc ch = chunks[seg_map[seg]];
+    emit_segment<false>(in, in_bytes, ch, seg, cd, vis, seg_off, codes, stage, seg_count, seg_exit2, seg_mpos, seg_kspec, threadIdx.x,
+                        nullptr);
+}
+
+// P3 + histogram: a workgroup of EMIT_WAVES wavefronts takes `segs_per_wg` consecutive segments of ONE chunk (blockIdx.x =
+// the chunk, blockIdx.y = the part of it) — a chunk lies in one block, so the workgroup's counters are one block's — a
+// wavefront every EMIT_WAVES-th of them; the counters (EMIT_HREP replicas, chosen by the lane: the lanes of one LDS atomic
+// that count the same symbol are served one after the other) go to the block's with one global atomic per non-zero counter.
+constexpr uint32_t EMIT_WAVES = PARSE_EMIT_WAVES, EMIT_HREP = 4;
+__global__ __launch_bounds__(64 * EMIT_WAVES) void parse_emit_hist_kernel(const uint8_t *__restrict__ in, uint64_t in_bytes,
+                                                                         const ChunkDesc *__restrict__ chunks,
+                                                                         const uint16_t *__restrict__ cd,
+                                                                         const uint64_t *__restrict__ vis,
+                                                                         const uint32_t *__restrict__ seg_off,
+                                                                         uint32_t *__restrict__ codes,
+                                                                         const uint32_t *__restrict__ stage,
+                                                                         const uint32_t *__restrict__ seg_count,
+                                                                         const uint32_t *__restrict__ seg_exit2,
+                                                                         const uint32_t *__restrict__ seg_mpos,
+                                                                         const uint32_t *__restrict__ seg_kspec,
+                                                                         uint32_t segs_per_wg, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t hh[EMIT_HREP * PARSE_HIST_STRIDE];
+    const ChunkDesc ch = chunks[blockIdx.x];
+    const uint32_t sA = blockIdx.y * segs_per_wg;
+    if (sA >= ch.n_seg) return;                                   // (uniform)
+    const uint32_t sB = min(ch.n_seg, sA + segs_per_wg);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < EMIT_HREP * PARSE_HIST_STRIDE; i += 64 * EMIT_WAVES) hh[i] = 0;
+    __syncthreads();
+    uint32_t *h = hh + (lane & (EMIT_HREP - 1)) * PARSE_HIST_STRIDE;
+    for (uint32_t s = sA + wave; s < sB; s += EMIT_WAVES)
+        emit_segment<true>(in, in_bytes, ch, ch.seg_base + s, cd, vis, seg_off, codes, stage, seg_count, seg_exit2, seg_mpos, seg_kspec,
+                           lane, h);
+    __syncthreads();
+    uint32_t *g = hist + (uint64_t)ch.block * PARSE_HIST_STRIDE;
+    for (uint32_t i = tid; i < PARSE_HIST_STRIDE; i += 64 * EMIT_WAVES) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < EMIT_HREP; ++r) v += hh[r * PARSE_HIST_STRIDE + i];
+        if (v) atomicAdd(&g[i], v);
     }
 }
 
@@ -715,7 +798,7 @@ int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
                  uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map, int stop_after,
-                 uint64_t *dbg) {
+                 uint64_t *dbg, uint32_t *hist, uint32_t emit_per, uint32_t emit_parts, hipEvent_t ev_walked) {
     if (nchunks == 0) return 0;
     // seg_tmp: six arrays of nsegs words
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
@@ -730,6 +813,9 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                                vis, seg_exit, seg_count, stage, dbg);
         LFX_LAUNCH_CHECK();
     }
+    // (the caller's side stream — the container checksum — starts here: beside the chaining kernels, which leave the GPU
+    //  mostly idle, instead of behind all of the parse)
+    if (ev_walked && hipEventRecord(ev_walked, st) != hipSuccess) return (int)hipGetLastError();
     if (stop_after == 1) return 0;      // (LFX_DEBUG dumps)
     if (nsegs) {
         hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, cd, max_len, vis, seg_exit,
@@ -740,9 +826,14 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     // (workgroup size by the segments per chunk: the fold over a chunk's segments is serial in batches of that size)
     const uint32_t fix_threads = nsegs / nchunks > 128 ? 1024u : 64u;
     hipLaunchKernelGGL(parse_fix_kernel, dim3(nchunks), dim3(fix_threads), 0, st, in, in_bytes, chunks, cd, max_len, vis,
-                       seg_exit, seg_count, seg_exit2, seg_off, codes, ncodes, seg_mpos);
+                       seg_exit, seg_count, seg_exit2, seg_off, codes, ncodes, seg_mpos, hist);
     LFX_LAUNCH_CHECK();
-    if (nsegs) {
+    if (nsegs && hist) {
+        // (the caller sizes the grid: emit_per segments per workgroup, emit_parts = the longest chunk's workgroups)
+        hipLaunchKernelGGL(parse_emit_hist_kernel, dim3(nchunks, emit_parts ? emit_parts : 1), dim3(64 * EMIT_WAVES), 0, st, in, in_bytes,
+                           chunks, cd, vis, seg_off, codes, stage, seg_count, seg_exit2, seg_mpos, seg_kspec, emit_per ? emit_per : 1, hist);
+        LFX_LAUNCH_CHECK();
+    } else if (nsegs) {
         hipLaunchKernelGGL(parse_emit_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, cd, vis, seg_off, codes,
                            stage, seg_count, seg_exit2, seg_mpos, seg_kspec, seg_map);
         LFX_LAUNCH_CHECK();

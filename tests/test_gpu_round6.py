@@ -348,3 +348,93 @@ def test_small_blocks_on_256_lanes(ffi, lfx, oracle, synth, monkeypatch):
         finally:
             c2.close()
     assert (results[False][0] == results[True][0]).all() and (results[False][1] == results[True][1]).all()
+
+
+def test_histogram_inside_the_parse_and_by_its_own_kernel(ffi, lfx, oracle, synth, monkeypatch):
+    """Round 6: the blocks' symbol counts (DynamicHuffmanCodec::build, symbol.rs:320-341) are taken by the kernel that writes
+    the code words (parse_emit_hist_kernel + the chunk tails and EndOfBlock in parse_fix_kernel); LFX_HIST_SEPARATE=1 keeps
+    histogram_kernel.  Both give the oracle's bytes on every chunk shape: 256 KiB chunks, one huge chunk (S1), ragged write
+    lists with flushes, literal-only chunks, a last block of three bytes, many small chunks."""
+    text = synth.text(9 << 20, seed=synth.SEED_BASE + 21).tobytes()
+    low = synth.lowent(3 << 20).tobytes()
+    cases = [
+        (ffi.GZIP, oracle.GZIP, text, dict(write_size=8192), dict(mtime=0)),
+        (ffi.ZLIB, oracle.ZLIB, text[: (3 << 20) + 3], dict(write_size=0), {}),                                   # one chunk
+        (ffi.DEFLATE, oracle.DEFLATE, text[: (1 << 20) + 3], dict(write_size=8192), {}),                            # a 3-byte tail block
+        (ffi.ZLIB, oracle.ZLIB, low, dict(write_size=8192), {}),
+        (ffi.GZIP, oracle.GZIP, text[: 2 << 20], dict(write_size=8192), dict(mtime=0, no_compression=1)),
+        (ffi.DEFLATE, oracle.DEFLATE, text[: 3 << 20], dict(write_size=1000), dict(block_size=300 << 10)),
+        (ffi.ZLIB, oracle.ZLIB, text[: 2 << 20], dict(write_size=8192), dict(lz77_kind=1)),                         # NoCompressionLz77Encoder: literals
+        (ffi.DEFLATE, oracle.DEFLATE, b"", dict(write_size=8192), {}),
+        (ffi.DEFLATE, oracle.DEFLATE, b"abc", dict(write_size=8192), {}),
+    ]
+    want = []
+    for _f, of, d, sk, ok in cases:
+        try:
+            want.append(oracle.encode(of, d, **sk, **ok))
+        except TypeError:
+            want.append(None)
+    for env in ({}, {"LFX_HIST_SEPARATE": "1"}):
+        monkeypatch.delenv("LFX_HIST_SEPARATE", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = lfx.Context(0)
+        try:
+            for (f, _of, d, sk, ok), w in zip(cases, want):
+                if w is None:
+                    continue
+                got = c2.encode_host(f, d, ffi.make_opts(**ok), ffi.make_schedule(sk["write_size"]))
+                assert got == w, (env, f, len(d), sk, ok)
+            # a ragged list of writes with flushes: chunks of every size, blocks that end inside what a segment group covers
+            rng = np.random.default_rng(5)
+            writes, left = [], len(text)
+            while left:
+                w = int(min(left, rng.choice([1, 100, 8192, 70000, 300000, 1 << 20])))
+                writes.append(w)
+                left -= w
+                if rng.random() < 0.2:
+                    writes.append(None)
+            got = c2.encode_host(ffi.ZLIB, text, ffi.make_opts(), ffi.make_schedule(0, writes))
+            rc, out, used, msg = c2.decode_host(ffi.ZLIB, got)
+            assert (rc, used) == (0, len(got)) and out == text, (env, rc, msg)
+        finally:
+            c2.close()
+    first = {}
+    for env in ("0", "1"):      # ... and the two agree with each other on the ragged list
+        monkeypatch.setenv("LFX_HIST_SEPARATE", env)
+        c2 = lfx.Context(0)
+        try:
+            first[env] = c2.encode_host(ffi.ZLIB, text, ffi.make_opts(), ffi.make_schedule(0, writes))
+        finally:
+            c2.close()
+    assert first["0"] == first["1"]
+
+
+def test_finder_reports_every_dynamic_header(ffi, lfx, oracle, synth, monkeypatch, capfd):
+    """The finder's stage 2 walks a candidate's literal / length widths in a lean loop and the rest in the general one
+    (round 6).  A header it failed to report would not fail a decode — the chain walk scans such a block on demand, a launch
+    later — so the count is checked: LFX_DEBUG's `candidates` = the stream's blocks, for 1 MiB blocks (HLIT / HDIST of text)
+    and for small blocks of low-entropy data (short code-length sequences)."""
+    import re
+    text = synth.text(20 << 20, seed=synth.SEED_BASE + 22).tobytes()
+    low = synth.lowent(6 << 20).tobytes()
+    streams = [
+        (ffi.GZIP, oracle.encode(oracle.GZIP, text, write_size=8192, mtime=0), text, 20),
+        (ffi.DEFLATE, oracle.encode(oracle.DEFLATE, text[: 12 << 20], write_size=1000, block_size=300 << 10), text[: 12 << 20], 40),
+        (ffi.ZLIB, oracle.encode(oracle.ZLIB, low, write_size=8192, block_size=256 << 10), low, 24),
+    ]
+    monkeypatch.setenv("LFX_DEBUG", "1")
+    c2 = lfx.Context(0)
+    try:
+        for f, z, want, nblocks in streams:
+            capfd.readouterr()
+            rc, out, used, msg = c2.decode_host(f, z)
+            err = capfd.readouterr().err
+            assert (rc, used) == (0, len(z)) and out == want, (rc, msg)
+            m = re.search(r"finder: stage1=(\d+) candidates=(\d+) scan jobs=(\d+)", err)
+            assert m, err[-2000:]
+            assert nblocks <= int(m.group(2)) <= nblocks + 2, (nblocks, m.group(0))
+            m2 = re.search(r"chain ok=1 blocks=(\d+) .* on_demand=(\d+)", err)
+            assert m2 and int(m2.group(1)) >= nblocks and int(m2.group(2)) <= 1, err[-2000:]     # (at most the final block)
+    finally:
+        c2.close()

@@ -15,5 +15,6 @@ for f in sorted(glob.glob(sys.argv[1] + "/*.log")):
             d = json.loads(l)
             p = d["phases_ms"]
             print(f.split("/")[-1], "value", d["value"], "enc", d["encode_GBps"], "dec", d["decode_GBps"],
-                  {k: p[k] for k in ("dec:blk_scan", "dec:blk_emit", "dec:find1", "dec:find2", "dec:lz77_copy", "enc:lz77_parse", "enc:lz77_match")})
+                  {k: p[k] for k in ("dec:blk_scan", "dec:blk_emit", "dec:find1", "dec:find2", "dec:lz77_copy", "enc:lz77_parse", "enc:lz77_match",
+                                     "enc:histogram", "enc:huffman", "enc:pack", "enc:checksum") if k in p})
 PY

@@ -17,7 +17,7 @@ for f in sorted(glob.glob(sys.argv[1] + "/*.log")):
         if l.startswith('{"metric"'):
             d = json.loads(l); p = d["phases_ms"]; ok = True
             print(f.split("/")[-1], "value", d["value"], "enc", d["encode_GBps"], "dec", d["decode_GBps"],
-                  {k: p[k] for k in ("enc:lz77_parse", "enc:lz77_match", "dec:blk_scan", "dec:blk_emit", "dec:lz77_copy")})
+                  {k: p[k] for k in ("enc:lz77_parse", "enc:lz77_match", "enc:histogram", "enc:huffman", "enc:checksum", "dec:find1", "dec:find2", "dec:blk_scan", "dec:blk_emit", "dec:lz77_copy")})
     if not ok:
         print(f.split("/")[-1], "NO LINE:", open(f).read()[-300:].replace("\n", " | "))
 PY
