@@ -77,7 +77,7 @@ constexpr uint32_t PARSE_WG_SEGS = LFX_PARSE_WG_SEGS;
 #define LFX_EMIT_WAVES 4
 #endif
 #ifndef LFX_EMIT_WG_PER_CU
-#define LFX_EMIT_WG_PER_CU 8
+#define LFX_EMIT_WG_PER_CU 16
 #endif
 constexpr uint32_t PARSE_EMIT_WAVES = LFX_EMIT_WAVES, PARSE_EMIT_WG_PER_CU = LFX_EMIT_WG_PER_CU;
 

@@ -480,11 +480,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 for (uint32_t j = 0; j < nj; j++) {
                     const uint64_t bits = bj[j].end_bit > bj[j].start_bit ? bj[j].end_bit - bj[j].start_bit : 0;
                     const uint64_t slice = std::max<uint64_t>((bits + 1023) / 1024, 128);
-                    uint64_t cap = (slice / (c->diag.store_tight ? 16 : 2) + 448 + 64 + 3) & ~3ull;   // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
-                    static const int cap_exp = getenv("LFX_EXP_CAP") ? atoi(getenv("LFX_EXP_CAP")) : 0;       // EXPERIMENT (round 6): lane stride on the channel grid
-                    if (cap_exp == 1) cap = (((cap + 63) / 64) | 1) * 64;          // an odd number of 256-byte units
-                    if (cap_exp == 2) cap = (((cap + 31) / 32) | 1) * 32;          // an odd number of 128-byte lines
-                    if (cap_exp == 3) cap = (cap + 1023) / 1024 * 1024;            // a multiple of 4 KiB (the bad case, if the grid matters)
+                    const uint64_t cap = (slice / (c->diag.store_tight ? 16 : 2) + 448 + 64 + 3) & ~3ull;   // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
                     bj[j].temp_off = off;
                     bj[j].cap = (uint32_t)cap;
                     off += 1024 * cap;
