@@ -242,6 +242,7 @@ void Diag::read() {
     if (const char *eb = getenv("LFX_ENC_BATCH_MB")) enc_batch_mb = atoi(eb);
     two_pass = on("LFX_TWO_PASS");
     hist_separate = on("LFX_HIST_SEPARATE");
+    find2_exp = getenv("LFX_FIND2_EXP") ? atoi(getenv("LFX_FIND2_EXP")) : 0;
     no_small_scan = on("LFX_NO_SMALL_SCAN");
     store_tight = on("LFX_STORE_TIGHT");
 }

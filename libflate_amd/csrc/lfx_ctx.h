@@ -37,6 +37,7 @@ struct Diag {
     int free_shift = -1;         // LFX_FREE_SHIFT
     bool no_small_scan = false;  // LFX_NO_SMALL_SCAN: 1024 slices a block also for small blocks (round 5's geometry)
     bool two_pass = false;       // LFX_TWO_PASS: every block through blk_emit_kernel (no storing scan)
+    int find2_exp = 0;           // LFX_FIND2_EXP=1..4: a cut-down finder stage 2 runs in front of the real one (phase "find2x"): timing only
     bool hist_separate = false;  // LFX_HIST_SEPARATE: the blocks' symbol counts by histogram_kernel (round 5) instead of inside parse_emit
     bool store_tight = false;    // LFX_STORE_TIGHT: the storing scan's regions sized for 16 bits a code (tests: lanes overflow, blocks fall back)
     int enc_batch_mb = 0;        // LFX_ENC_BATCH_MB: the stream encoder encodes closed blocks once so many MiB wait (0: the default, 8)

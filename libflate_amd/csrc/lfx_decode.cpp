@@ -147,26 +147,34 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
         uint32_t n1 = 0;
         std::vector<uint64_t> starts;
         auto find_candidates = [&]() -> int {
-            const uint32_t shard_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 17, comp / 1000), 1u << 26);
+            const uint32_t shard_cap = find_shard_cap(comp);
             const uint32_t final_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 16, comp / 4096), 1u << 24);
             int rc;
-            if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 512))) return rc;
-            uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // FIND_SHARDS + 1 words, then final count
-            uint32_t *d_final_count = d_count + 64;
-            uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 512);
+            if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 4 * FIND_HDR_WORDS))) return rc;
+            uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // the header (lfx_decode.h), then the lists
+            uint32_t *d_final_count = d_count + FIND_HDR_FINAL;
+            uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 4 * FIND_HDR_WORDS);
             uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
-            HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
+            HIP_TRY(hipMemsetAsync(d_count, 0, 4 * FIND_HDR_WORDS, st));
             // (the member's last block is looked for in the final eighth of the input, at least 8 MiB of it: one that starts
             //  earlier — a last block of more than that — is scanned on demand by the chain walk below)
             const uint64_t tail_bytes = std::max<uint64_t>(comp / 8, 8ull << 20);
             const uint64_t final_from = c->diag.no_final_cand ? ~0ull >> 1 : comp > tail_bytes ? (n - tail_bytes) * 8 : 0;
-            LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap, final_from));
+            LAUNCH_TRY(launch_find_stage1(st, d_in, n, off0, d_count, d_cand, shard_cap, final_from, (uint32_t)std::max(c->n_cu, 1)));
             c->phase("find1");
             // stage 2 takes the survivor counts from the device (persistent grid): no host round trip between the stages; the
             // counts, the overflow marker, the number of results and the first results come back in ONE round trip
-            LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
-                                          (uint32_t)std::max(c->n_cu, 1), c->diag.debug ? (uint64_t *)(d_count + 104) : nullptr));
-            uint32_t hc[128];
+            const int find2_exp = c->diag.find2_exp >= 1 && c->diag.find2_exp <= 4 ? c->diag.find2_exp : 0;
+            if (find2_exp) {       // timing experiment: a cut-down stage 2 first (phase "find2x"), then the real one
+                LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + FIND_HDR_WORK, d_final_count, d_final, final_cap,
+                                              (uint32_t)std::max(c->n_cu, 1), nullptr, find2_exp));
+                HIP_TRY(hipMemsetAsync(d_count + FIND_HDR_FINAL, 0, 4, st));
+                HIP_TRY(hipMemsetAsync(d_count + FIND_HDR_WORK, 0, 4 * (FIND_HDR_WORDS - FIND_HDR_WORK), st));
+                c->phase("find2x");
+            }
+            LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + FIND_HDR_WORK, d_final_count, d_final, final_cap,
+                                          (uint32_t)std::max(c->n_cu, 1), c->diag.debug ? (uint64_t *)(d_count + FIND_HDR_DBG) : nullptr));
+            uint32_t hc[FIND_HDR_READ];
             constexpr uint32_t HEAD_N = 1024;      // (results that come back with the counts; a stream has a few hundred)
             const uint32_t head_n = std::min<uint32_t>(HEAD_N, final_cap);
             std::vector<uint64_t> cand(head_n);
@@ -178,7 +186,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (hc[k] > shard_cap) overflow = true; n1 += hc[k]; }
             if (c->diag.debug) {
                 uint64_t d[7];
-                memcpy(d, hc + 104, sizeof d);
+                memcpy(d, hc + FIND_HDR_DBG, sizeof d);
                 fprintf(stderr, "[lfx] finder stage 2: batches=%llu cycles per batch: stage+fields=%llu table=%llu walk=%llu; steps per batch=%.1f "
                         "restagings=%llu; wavefront lives (sum)=%llu\n", (unsigned long long)d[5], (unsigned long long)(d[0] / (d[5] ? d[5] : 1)),
                         (unsigned long long)(d[1] / (d[5] ? d[5] : 1)), (unsigned long long)(d[2] / (d[5] ? d[5] : 1)),
@@ -187,7 +195,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             starts.clear();
             starts.push_back(first_bit);  // the first block's start is known
             if (overflow) return LFX_OK;
-            uint32_t nf = hc[64];
+            uint32_t nf = hc[FIND_HDR_FINAL];
             if (nf > final_cap) nf = final_cap;
             cand.resize(nf);
             if (nf > head_n) HIP_TRY(hipMemcpy(cand.data() + head_n, d_final + head_n, 8ull * (nf - head_n), hipMemcpyDeviceToHost));
@@ -1007,15 +1015,15 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
     const uint64_t n = n_part, range_bits = (hi_byte - lo_byte) * 8, base_bit = lo_byte * 8;
     // ---- block-start candidates in the local bytes (the tail behind hi_byte is searched too: a false candidate there
     //      still ends the range guess of the last real block early, exactly as on one GPU)
-    const uint32_t shard_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 17, n / 1000), 1u << 26);
+    const uint32_t shard_cap = find_shard_cap(n);
     const uint32_t final_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 16, n / 4096), 1u << 24);
     int rc;
-    if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 512))) return rc;
+    if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 4 * FIND_HDR_WORDS))) return rc;
     uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;
-    uint32_t *d_final_count = d_count + 64;
-    uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 512);
+    uint32_t *d_final_count = d_count + FIND_HDR_FINAL;
+    uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 4 * FIND_HDR_WORDS);
     uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
-    HIP_TRY(hipMemsetAsync(d_count, 0, 512, st));
+    HIP_TRY(hipMemsetAsync(d_count, 0, 4 * FIND_HDR_WORDS, st));
     std::vector<uint64_t> starts;
     if (n >= 16) {
         // headers with BFINAL set are reported from member bit `final_from_bit` on (the finder's tail rule, inflate_member: a
@@ -1024,16 +1032,16 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
         // block that starts in front of that bit breaks the chain: the caller then scans again with final_from_bit = 0.
         const uint64_t base0 = lo_byte * 8;
         const uint64_t final_local = final_from_bit <= base0 ? 0 : std::min<uint64_t>(final_from_bit - base0, ~0ull >> 1);
-        LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap, final_local));
-        LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + 65, d_final_count, d_final, final_cap,
+        LAUNCH_TRY(launch_find_stage1(st, d_in, n, 0, d_count, d_cand, shard_cap, final_local, (uint32_t)std::max(c->n_cu, 1)));
+        LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + FIND_HDR_WORK, d_final_count, d_final, final_cap,
                                       (uint32_t)std::max(c->n_cu, 1)));
-        uint32_t hc[66];
+        uint32_t hc[FIND_HDR_FINAL + 1];
         HIP_TRY(hipMemcpyAsync(hc, d_count, sizeof hc, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         bool overflow = hc[FIND_SHARDS] != 0;
         for (uint32_t k = 0; k < FIND_SHARDS; k++) if (hc[k] > shard_cap) overflow = true;
         if (overflow) { c->set_error("block finder overflow"); return LFX_E_UNSUPPORTED; }
-        uint32_t nf = hc[64];
+        uint32_t nf = hc[FIND_HDR_FINAL];
         if (nf > final_cap) nf = final_cap;
         starts.resize(nf);
         if (nf) HIP_TRY(hipMemcpy(starts.data(), d_final, 8ull * nf, hipMemcpyDeviceToHost));

@@ -182,17 +182,31 @@ int launch_container(hipStream_t st, int format, uint32_t count, const uint8_t *
                      const DecStream *streams, DecHeader *hdrs);
 int launch_inflate(hipStream_t st, const uint8_t *in, uint8_t *out, const InflateJob *jobs,
                    InflateResult *results, uint32_t njobs);
-constexpr uint32_t FIND_SHARDS = 32;
-struct FindPrefix { uint32_t off[FIND_SHARDS + 1]; };   // prefix sums of the per-shard survivor counts
+// The finder's survivor lists: FIND_SHARDS lists of shard_cap entries — since round 6 a list holds ONE class of survivors
+// (lfx_decode_kernels.hip: FIND_CLASSES classes x FIND_SUB lists each; a device-scope counter serialises at ~11 ns per atomic,
+// and a workgroup of stage 1 now adds to about ten of them instead of one).  The buffer starts with FIND_HDR_WORDS 32-bit
+// words: [0, FIND_SHARDS) the lists' counts, [FIND_SHARDS] a workgroup overflowed, FIND_HDR_FINAL the number of headers stage 2
+// found, FIND_HDR_WORK.. its batch counters, FIND_HDR_DBG.. seven 64-bit LFX_DEBUG counters.
+constexpr uint32_t FIND_SHARDS = 256;
+constexpr uint32_t FIND_HDR_WORDS = 1024, FIND_HDR_FINAL = 320, FIND_HDR_DBG = 360, FIND_HDR_READ = 512 /* words the host reads back */;
+// stage 2's batch counters: FIND2_GROUPS of them, 128 bytes apart.  ONE counter for all batches was the kernel's floor: eight
+// thousand device-scope atomics on one address at ~20 ns each are 0.19 ms whatever the batches cost (measured with batches
+// that do nothing, LFX_FIND2_EXP=3) — the wavefronts of group k deal the batches k, k + GROUPS, ... among themselves.
+constexpr uint32_t FIND2_GROUPS = 16, FIND_HDR_WORK = 512, FIND_HDR_WORK_STRIDE = 32;
+inline uint32_t find_shard_cap(uint64_t comp_bytes) {      // survivors are ~0.4 % of the bytes: room for 16 x a list's expected share
+    const uint64_t want = comp_bytes / 4000;
+    return (uint32_t)(want < 4096 ? 4096 : want > (1u << 23) ? (1u << 23) : want);
+}
 // count: FIND_SHARDS + 1 words (the last one marks a workgroup overflow)
 int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint64_t first_byte,
-                       uint32_t *count, uint64_t *cand, uint32_t shard_cap, uint64_t final_from_bit);
+                       uint32_t *count, uint64_t *cand, uint32_t shard_cap, uint64_t final_from_bit, uint32_t n_cu);
 // survivors of the full header check are appended to final[] (final_count = number appended)
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
                        uint32_t shard_cap, const uint32_t *count /* device: stage 1's FIND_SHARDS + 1 words */,
                        uint32_t *work /* device, zero: the batch counter of the persistent grid */,
                        uint32_t *final_count, uint64_t *final_list, uint32_t final_cap, uint32_t n_cu,
-                       uint64_t *dbg = nullptr /* device, zero: seven counters (LFX_DEBUG) */);
+                       uint64_t *dbg = nullptr /* device, zero: seven counters (LFX_DEBUG) */,
+                       int exp = 0 /* timing experiments: a cut-down kernel that finds nothing (LFX_FIND2_EXP) */);
 int launch_verify_trailers(hipStream_t st, int format, uint32_t count, const uint8_t *in,
                            const DecStream *streams, const DecHeader *hdrs, InflateResult *results,
                            const uint32_t *crc, const uint32_t *adler, uint64_t *consumed);

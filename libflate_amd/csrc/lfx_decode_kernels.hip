@@ -500,10 +500,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(const uint8_t *__restrict__
 // entry per lane: HLIT / HDIST ranges, then the Kraft sum of the (at most 19) 3-bit code-length-code widths from a
 // 4096-entry table of 4-field sums.  (Rounds 1-4 ran the test inside the per-lane loop over the mask: the loop's trip count
 // is the wavefront's maximum, so more than half of the lanes idled through a 70-instruction body.)
-// Survivors are collected per workgroup in LDS and appended with ONE atomic per workgroup to one of
-// FIND_SHARDS counters (a single device-scope counter serialises at ~11 ns per atomic).
+// Survivors are collected per workgroup in LDS and appended to the lists of their CLASSES (below), one global atomic per
+// list the workgroup has entries for (a single device-scope counter serialises at ~11 ns per atomic: FIND_SUB lists per class).
 constexpr uint32_t FIND_DWORDS = 1024;   // dwords (4 KiB of stream) per workgroup
-constexpr uint32_t FIND_WL = 512;        // survivors a workgroup can hold (expected: ~30)
+#ifndef LFX_FIND_FLUSH
+#define LFX_FIND_FLUSH 4
+#endif
+constexpr uint32_t FIND_FLUSH = LFX_FIND_FLUSH;   // tiles of a workgroup per append of its survivors (stage 1 is a persistent grid)
+constexpr uint32_t FIND_WL = 64 * FIND_FLUSH < 256 ? 256 : 64 * FIND_FLUSH;   // survivors a workgroup can hold between two appends (expected: ~14 per tile)
 constexpr uint32_t FIND_LIST = 4096;     // offsets of 256 dwords that pass the mask: no two adjacent ones can (bit 1 clear, bit 2 set)
 // Kraft contribution (128 >> l, 0 for l = 0) of four 3-bit fields | number of nonzero fields << 12
 struct FindLut { uint16_t v[4096]; };
@@ -518,6 +522,33 @@ constexpr FindLut make_find_lut() {
 }
 __device__ const FindLut g_find_lut = make_find_lut();
 
+// Round 6: stage 1 SORTS its survivors for stage 2.  A wavefront of stage 2 walks 64 candidates until its longest walk ends
+// (201 steps for a mean of 43, tools/exp/find2_model.py on a real stream); how long a false candidate walks is mostly a matter
+// of how many widths one symbol of ITS code-length code yields — the repeat codes 16 / 17 / 18 (3-6 / 3-10 / 11-138 widths
+// each) and how short their codes are — and their three widths are the first three 3-bit fields of the header.  Class = the
+// expected widths per symbol from those fields alone, E2 = 2 * 128 * E[widths per symbol] with every other symbol counted
+// as one width, cut at the sixteenths of its distribution over a stream's false candidates: class 0 = the longest walks.
+// Candidates of a class go to that class's lists; stage 2 takes its batches from the lists in order (longest first), so a
+// batch holds candidates of one class: 108 steps per batch in the model.
+constexpr uint32_t FIND_CLASSES = 16, FIND_SUB = FIND_SHARDS / FIND_CLASSES;     // lists = classes x sub-lists (atomics spread)
+static_assert(FIND_CLASSES * FIND_SUB == FIND_SHARDS, "lists");
+struct FindCls { uint8_t v[512]; };
+constexpr FindCls make_find_cls() {
+    constexpr uint32_t th[15] = {432, 568, 652, 832, 944, 1076, 1420, 1604, 2008, 2710, 3016, 4978, 5184, 5664, 9820};
+    FindCls t{};
+    for (uint32_t i = 0; i < 512; ++i) {
+        const uint32_t l16 = i & 7, l17 = (i >> 3) & 7, l18 = i >> 6;
+        const uint32_t p16 = l16 ? 128u >> l16 : 0u, p17 = l17 ? 128u >> l17 : 0u, p18 = l18 ? 128u >> l18 : 0u;
+        const uint32_t rest = p16 + p17 + p18 <= 128 ? 128 - p16 - p17 - p18 : 0;          // (an over-subscribed triple never passes the Kraft test)
+        const uint32_t e2 = p18 * 149 + p17 * 13 + p16 * 9 + 2 * rest;
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < 15; ++k) c += e2 >= th[k] ? 1u : 0u;
+        t.v[i] = (uint8_t)c;
+    }
+    return t;
+}
+__device__ const FindCls g_find_cls = make_find_cls();
+
 __device__ __forceinline__ uint32_t find_wave_inclusive_sum(uint32_t x) {        // (row shifts and broadcasts, no LDS traffic)
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
@@ -528,96 +559,132 @@ __device__ __forceinline__ uint32_t find_wave_inclusive_sum(uint32_t x) {       
     return x;
 }
 
+// Round 6: a PERSISTENT grid — a workgroup takes the 4 KiB tiles blockIdx.x, blockIdx.x + gridDim.x, ... and appends its
+// survivors every FIND_FLUSH tiles: the lists are per class now, a workgroup's append is one device-scope atomic per class it
+// holds, and those atomics (about half a nanosecond each in aggregate, whatever their addresses) are what the append costs —
+// one workgroup per tile made 320 K of them where 32 K had been (+0.15 ms).  The next tile's dwords are loaded while the
+// current one is tested.
 __global__ __launch_bounds__(256) void find_blocks_stage1(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                           uint64_t first_byte, uint32_t *__restrict__ count,
                                                           uint64_t *__restrict__ cand, uint32_t shard_cap,
-                                                          uint64_t final_from_bit) {
+                                                          uint64_t final_from_bit, uint32_t ntiles) {
     __shared__ __attribute__((aligned(16))) uint32_t sd[FIND_DWORDS + 4];
     __shared__ __attribute__((aligned(16))) uint16_t lut[4096];
     __shared__ uint16_t list[FIND_LIST];
     __shared__ uint64_t wl[FIND_WL];
-    __shared__ uint32_t wn, wbase, s_wtot[4];
+    __shared__ uint32_t wn, s_wtot[4], ccnt[FIND_CLASSES], cbase[FIND_CLASSES];
     if (threadIdx.x == 0) wn = 0;
+    if (threadIdx.x < FIND_CLASSES) ccnt[threadIdx.x] = 0;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t a = (uint64_t)in;
     gptr_u32 w = (gptr_u32)(a & ~3ull);
     const uint64_t shift = a & 3;                      // stream byte b lives at aligned byte b + shift
     const uint64_t wlast = (shift + nbytes + 3) / 4 - 1;
-    const uint64_t wg_byte = first_byte + (uint64_t)blockIdx.x * (4 * FIND_DWORDS);   // first stream byte of this workgroup
-    const uint64_t w0 = (wg_byte + shift) >> 2;
+    const uint64_t stream_bits = nbytes * 8, lo_bit = first_byte * 8;
+    const uint32_t sub = blockIdx.x % FIND_SUB;
     {
-        // the staging loads are issued together (clamped addresses): a loop of dependent load → store pairs made every
-        // workgroup wait five HBM round trips before its first test
-        uint32_t v[5];
         const uint4 *gl = (const uint4 *)g_find_lut.v;
         const uint4 l0 = gl[tid], l1 = gl[tid + 256];
-#pragma unroll
-        for (uint32_t k = 0; k < 5; ++k) { const uint64_t idx = w0 + tid + 256 * k; v[k] = w[idx < wlast ? idx : wlast]; }
-#pragma unroll
-        for (uint32_t k = 0; k < 5; ++k) { const uint32_t i = tid + 256 * k; if (i < FIND_DWORDS + 4) sd[i] = v[k]; }
         ((uint4 *)lut)[tid] = l0;
         ((uint4 *)lut)[tid + 256] = l1;
     }
-    __syncthreads();
-    const uint64_t stream_bits = nbytes * 8, lo_bit = first_byte * 8;
-    for (uint32_t t0 = 0; t0 < FIND_DWORDS; t0 += 256) {
-        // ---- (a) my dword = aligned dword w0 + t; its bit 0 is stream bit (4*(w0+t) - shift) * 8
-        const uint32_t t = t0 + tid;
-        const uint32_t d0 = sd[t], d1 = sd[t + 1];
-        // offsets whose BTYPE field (bits 1..2) reads 2: bit 1 clear, bit 2 set — a quarter of them.  A header with
-        // BFINAL set is wanted only near the end of the stream (final_from_bit, see launch_find_stage1): elsewhere the
-        // offsets with bit 0 set are dropped too, which halves the candidates of both stages.
-        const uint64_t dword_bit0 = (4 * (w0 + t) - shift) * 8;    // "negative" only for the first dword when shift > 0
-        const uint32_t allow_final = dword_bit0 + 32 > final_from_bit ? ~0u : 0u;
-        const uint64_t lo = (uint64_t)d0 | (uint64_t)d1 << 32;
-        uint32_t pm = (uint32_t)(~(lo >> 1) & (lo >> 2)) & (~d0 | allow_final);
-        const uint32_t cnt = (uint32_t)__popc(pm);
-        const uint32_t incl = find_wave_inclusive_sum(cnt);
-        if (lane == 63) s_wtot[wave] = incl;
-        __syncthreads();                                     // (also: the previous trip's list has been read)
-        uint32_t pos = incl - cnt, total = 0;
+    // the staging loads of a tile are issued together (clamped addresses): a loop of dependent load → store pairs made every
+    // workgroup wait five HBM round trips before its first test
+    uint32_t v[5];
+    auto tile_w0 = [&](uint32_t tile) { return (first_byte + (uint64_t)tile * (4 * FIND_DWORDS) + shift) >> 2; };
+    auto fetch = [&](uint32_t tile) {
+        const uint64_t tw0 = tile_w0(tile);
 #pragma unroll
-        for (uint32_t j = 0; j < 4; ++j) { const uint32_t wj = s_wtot[j]; pos += j < wave ? wj : 0u; total += wj; }
-        while (pm) {
-            const uint32_t ph = (uint32_t)__builtin_ctz(pm);
-            pm &= pm - 1;
-            list[pos++] = (uint16_t)(t << 5 | ph);
+        for (uint32_t k = 0; k < 5; ++k) { const uint64_t idx = tw0 + tid + 256 * k; v[k] = w[idx < wlast ? idx : wlast]; }
+    };
+    uint32_t done = 0;                                 // tiles since the last append
+    if (blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t w0 = tile_w0(tile);
+        __syncthreads();                               // (the tile before has been read; the append's counters are settled)
+#pragma unroll
+        for (uint32_t k = 0; k < 5; ++k) { const uint32_t i = tid + 256 * k; if (i < FIND_DWORDS + 4) sd[i] = v[k]; }
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        for (uint32_t t0 = 0; t0 < FIND_DWORDS; t0 += 256) {
+            // ---- (a) my dword = aligned dword w0 + t; its bit 0 is stream bit (4*(w0+t) - shift) * 8
+            const uint32_t t = t0 + tid;
+            const uint32_t d0 = sd[t], d1 = sd[t + 1];
+            // offsets whose BTYPE field (bits 1..2) reads 2: bit 1 clear, bit 2 set — a quarter of them.  A header with
+            // BFINAL set is wanted only near the end of the stream (final_from_bit, see launch_find_stage1): elsewhere the
+            // offsets with bit 0 set are dropped too, which halves the candidates of both stages.
+            const uint64_t dword_bit0 = (4 * (w0 + t) - shift) * 8;    // "negative" only for the first dword when shift > 0
+            const uint32_t allow_final = dword_bit0 + 32 > final_from_bit ? ~0u : 0u;
+            const uint64_t lo = (uint64_t)d0 | (uint64_t)d1 << 32;
+            uint32_t pm = (uint32_t)(~(lo >> 1) & (lo >> 2)) & (~d0 | allow_final);
+            const uint32_t cnt = (uint32_t)__popc(pm);
+            const uint32_t incl = find_wave_inclusive_sum(cnt);
+            if (lane == 63) s_wtot[wave] = incl;
+            __syncthreads();                                     // (also: the previous trip's list has been read)
+            uint32_t pos = incl - cnt, total = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) { const uint32_t wj = s_wtot[j]; pos += j < wave ? wj : 0u; total += wj; }
+            while (pm) {
+                const uint32_t ph = (uint32_t)__builtin_ctz(pm);
+                pm &= pm - 1;
+                list[pos++] = (uint16_t)(t << 5 | ph);
+            }
+            __syncthreads();
+            // ---- (b) one list entry per lane: 96 bits of the stream from the offset on
+            for (uint32_t i = tid; i < total; i += 256) {
+                const uint32_t e = list[i], te = e >> 5, ph = e & 31;
+                const uint32_t e0 = sd[te], e1 = sd[te + 1], e2 = sd[te + 2], e3 = sd[te + 3];
+                const uint32_t x0 = __builtin_amdgcn_alignbit(e1, e0, ph), x1 = __builtin_amdgcn_alignbit(e2, e1, ph),
+                               x2 = __builtin_amdgcn_alignbit(e3, e2, ph);
+                const uint32_t hlit = (x0 >> 3) & 31, hdist = (x0 >> 8) & 31, hclen = (x0 >> 13) & 15;
+                if (hlit > 29 || hdist > 29) continue;
+                // the (hclen + 4) 3-bit fields start at bit 17: 57 bits at most
+                const uint32_t nb = 3 * (hclen + 4);
+                uint32_t f0 = __builtin_amdgcn_alignbit(x1, x0, 17), f1 = __builtin_amdgcn_alignbit(x2, x1, 17);
+                const uint32_t m0 = nb >= 32 ? ~0u : (1u << nb) - 1u, m1 = nb > 32 ? (1u << (nb - 32)) - 1u : 0u;
+                f0 &= m0;
+                f1 &= m1;
+                const uint32_t acc = (uint32_t)lut[f0 & 4095] + lut[(f0 >> 12) & 4095] + lut[__builtin_amdgcn_alignbit(f1, f0, 24) & 4095] +
+                                     lut[(f1 >> 4) & 4095] + lut[(f1 >> 16) & 4095];
+                if ((acc & 0xFFF) != 128 || (acc >> 12) < 2) continue;           // complete code-length code
+                const uint64_t bit = (4 * (w0 + te) - shift) * 8 + ph;
+                if ((int64_t)bit < (int64_t)lo_bit || bit + 96 > stream_bits) continue;
+                const uint32_t slot = atomicAdd(&wn, 1u);
+                if (slot < FIND_WL) wl[slot] = bit | (uint64_t)g_find_cls.v[f0 & 511u] << 56;      // (fields 0..2: the widths of 16, 17, 18)
+            }
+        }
+        // ---- every FIND_FLUSH tiles and behind the last one: the survivors go to the lists of their classes (this workgroup's
+        //      sub-list of each) — ranks inside the workgroup by LDS atomics, one global atomic per class it holds
+        const bool last = tile + gridDim.x >= ntiles;
+        if (++done < FIND_FLUSH && !last) continue;
+        done = 0;
+        __syncthreads();
+        const uint32_t mine = wn;   // > FIND_WL would be a pathological input: counted, reported as overflow
+        if (mine > FIND_WL) {
+            if (threadIdx.x == 0) atomicAdd(&count[FIND_SHARDS], 1u);   // overflow marker
+            return;
+        }
+        uint32_t cls[FIND_WL / 256], rnk[FIND_WL / 256];
+#pragma unroll
+        for (uint32_t q = 0; q < FIND_WL / 256; ++q) {
+            const uint32_t k = threadIdx.x + 256 * q;
+            cls[q] = k < mine ? (uint32_t)(wl[k] >> 56) : 0u;
+            rnk[q] = k < mine ? atomicAdd(&ccnt[cls[q]], 1u) : 0u;
         }
         __syncthreads();
-        // ---- (b) one list entry per lane: 96 bits of the stream from the offset on
-        for (uint32_t i = tid; i < total; i += 256) {
-            const uint32_t e = list[i], te = e >> 5, ph = e & 31;
-            const uint32_t e0 = sd[te], e1 = sd[te + 1], e2 = sd[te + 2], e3 = sd[te + 3];
-            const uint32_t x0 = __builtin_amdgcn_alignbit(e1, e0, ph), x1 = __builtin_amdgcn_alignbit(e2, e1, ph),
-                           x2 = __builtin_amdgcn_alignbit(e3, e2, ph);
-            const uint32_t hlit = (x0 >> 3) & 31, hdist = (x0 >> 8) & 31, hclen = (x0 >> 13) & 15;
-            if (hlit > 29 || hdist > 29) continue;
-            // the (hclen + 4) 3-bit fields start at bit 17: 57 bits at most
-            const uint32_t nb = 3 * (hclen + 4);
-            uint32_t f0 = __builtin_amdgcn_alignbit(x1, x0, 17), f1 = __builtin_amdgcn_alignbit(x2, x1, 17);
-            const uint32_t m0 = nb >= 32 ? ~0u : (1u << nb) - 1u, m1 = nb > 32 ? (1u << (nb - 32)) - 1u : 0u;
-            f0 &= m0;
-            f1 &= m1;
-            const uint32_t acc = (uint32_t)lut[f0 & 4095] + lut[(f0 >> 12) & 4095] + lut[__builtin_amdgcn_alignbit(f1, f0, 24) & 4095] +
-                                 lut[(f1 >> 4) & 4095] + lut[(f1 >> 16) & 4095];
-            if ((acc & 0xFFF) != 128 || (acc >> 12) < 2) continue;           // complete code-length code
-            const uint64_t bit = (4 * (w0 + te) - shift) * 8 + ph;
-            if ((int64_t)bit < (int64_t)lo_bit || bit + 96 > stream_bits) continue;
-            const uint32_t slot = atomicAdd(&wn, 1u);
-            if (slot < FIND_WL) wl[slot] = bit;
+        if (threadIdx.x < FIND_CLASSES && ccnt[threadIdx.x]) cbase[threadIdx.x] = atomicAdd(&count[threadIdx.x * FIND_SUB + sub], ccnt[threadIdx.x]);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < FIND_WL / 256; ++q) {
+            const uint32_t k = threadIdx.x + 256 * q;
+            if (k < mine) {
+                const uint32_t at = cbase[cls[q]] + rnk[q];
+                if (at < shard_cap) cand[(uint64_t)(cls[q] * FIND_SUB + sub) * shard_cap + at] = wl[k] & ((1ull << 56) - 1);
+            }
         }
-    }
-    __syncthreads();
-    const uint32_t shard = blockIdx.x % FIND_SHARDS;
-    const uint32_t mine = wn;   // > FIND_WL would be a pathological input: counted, reported as overflow
-    if (threadIdx.x == 0 && mine) wbase = atomicAdd(&count[shard], mine);
-    __syncthreads();
-    if (mine) {
-        const uint32_t b = wbase;
-        if (mine <= FIND_WL)
-            for (uint32_t k = threadIdx.x; k < mine; k += 256)
-                if (b + k < shard_cap) cand[(uint64_t)shard * shard_cap + b + k] = wl[k];
-        if (mine > FIND_WL && threadIdx.x == 0) atomicAdd(&count[FIND_SHARDS], 1u);   // overflow marker
+        __syncthreads();                               // (wl and the counters are free again)
+        if (threadIdx.x == 0) wn = 0;
+        if (threadIdx.x < FIND_CLASSES) ccnt[threadIdx.x] = 0;
     }
 }
 
@@ -686,11 +753,28 @@ int launch_inflate(hipStream_t st, const uint8_t *in, uint8_t *out, const Inflat
 // walks the chain itself may pass the start of the stream's tail (where a last block of ordinary size begins) instead
 // of 0 and save half of the finder's work; a caller that depends on every start being reported passes 0.
 int launch_find_stage1(hipStream_t st, const uint8_t *in, uint64_t nbytes, uint64_t first_byte,
-                       uint32_t *count, uint64_t *cand, uint32_t shard_cap, uint64_t final_from_bit) {
+                       uint32_t *count, uint64_t *cand, uint32_t shard_cap, uint64_t final_from_bit, uint32_t n_cu) {
     if (nbytes <= first_byte) return 0;
     const uint64_t n = nbytes - first_byte;
-    hipLaunchKernelGGL(find_blocks_stage1, dim3((uint32_t)div_up(n + 4, 4 * FIND_DWORDS)), dim3(256), 0, st, in, nbytes,
-                       first_byte, count, cand, shard_cap, final_from_bit);
+    const uint64_t ntiles = div_up(n + 4, 4 * FIND_DWORDS);
+    if (ntiles > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
+    // persistent: as many workgroups as are resident at once (seven of 22.8 KB with FIND_FLUSH = 4), fewer when the stream has fewer tiles
+    // (the runtime's own count of resident workgroups: a workgroup that has to wait for a slot would do its tiles behind all others)
+    static int per_cu_dev[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    int &per_cu = per_cu_dev[dev_ & 63];
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)find_blocks_stage1, 256, 0) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 4;
+        }
+        per_cu = nb;
+    }
+    const uint64_t resident = (uint64_t)per_cu * (n_cu ? n_cu : 256u);
+    hipLaunchKernelGGL(find_blocks_stage1, dim3((uint32_t)(ntiles < resident ? ntiles : resident)), dim3(256), 0, st, in, nbytes,
+                       first_byte, count, cand, shard_cap, final_from_bit, (uint32_t)ntiles);
     LFX_LAUNCH_CHECK();
     return 0;
 }

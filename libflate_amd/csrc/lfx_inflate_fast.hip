@@ -2134,128 +2134,28 @@ __device__ __forceinline__ void clen_table_build(uint8_t *tab, uint32_t lane, ui
     }
 }
 
-// block finder, stage 2: full header parse of each stage-1 survivor (one lane each): the code-length sequence must
-// decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length code must be
-// complete and the distance code complete, single or empty.
-// One stage-1 survivor per lane (`valid` lanes; the others walk along frozen): true when the header at cand_bit checks out.
-__device__ __forceinline__ bool stage2_check(const uint8_t *__restrict__ in, uint64_t nbytes, uint64_t cand_bit, bool valid,
-                                             uint8_t *cl_tab) {
-    HdrBits hb;
-    hb.init(in, nbytes, cand_bit);
-    auto bits = [&](uint32_t w) -> uint32_t { return hb.get(w); };
-    bits(3);
-    const uint32_t nl = bits(5) + 257, nd = bits(5) + 1, nc = bits(4) + 4;
-    uint64_t clw = 0;
-    for (uint32_t k = 0; k < nc; ++k) clw |= (uint64_t)bits(3) << (3 * clen_order(k));
-    clen_table_build(cl_tab, threadIdx.x, clw);
-    uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
-    const uint32_t total = nl + nd;
-    bool good = valid && !hb.bad;
-    // a header is at most 17 + 19*3 + 320*(7+7) = 4554 bits long: when every candidate of the wavefront lies
-    // further than that from the end of the stream, the walk needs no bounds checks at all
-    const bool lean = __ballot(cand_bit + 6000 > hb.nbits) == 0;
-    if (lean) {
-        // Branch-free walk, one uniform loop for the wavefront: nearly every false candidate runs until its literal /
-        // length widths are complete (their Kraft sum only then shows), so the wavefront's time is its instruction
-        // count per step.  A lane that is done or dead is frozen (zero-length step) instead of masked off.
-        // Bit source: the position behind the fixed header fields is known arithmetically; a 64-bit window topped up
-        // from a one-dword-ahead pointer, no bounds checks (lean).
-        const uint64_t a = (uint64_t)in;
-        const uint64_t abs = cand_bit + 17 + 3ull * nc + (a & 3) * 8;
-        gptr_u32 p = (gptr_u32)(a & ~3ull) + (abs >> 5);
-        const uint32_t off = (uint32_t)abs & 31;
-        uint64_t buf = ((uint64_t)p[1] << 32 | p[0]) >> off;
-        uint32_t nb = 64 - off;
-        uint32_t nxt = p[2];
-        p += 3;
-        bool run = good && have < total;
-        while (__ballot(run)) {
-            if (nb <= 32) {
-                buf |= (uint64_t)nxt << nb;
-                nb += 32;
-                nxt = *p++;
-            }
-            const uint32_t e = cl_tab[((uint32_t)buf & 127) * 64 + threadIdx.x];
-            const uint32_t sym = e & 31, used = e >> 5;
-            // repeat codes 16 / 17 / 18: extra bits 2 / 3 / 7, base count 3 / 3 / 11 (packed nibble tables)
-            const uint32_t k4 = (sym > 15 ? sym - 15 : 0) * 4;
-            const uint32_t nbx = (0x7320u >> k4) & 15, basex = (0xB331u >> k4) & 15;
-            uint32_t rep = basex + (((uint32_t)(buf >> used)) & ((1u << nbx) - 1));
-            uint32_t val = sym < 16 ? sym : (sym == 16 ? last : 0);
-            uint32_t adv = used + nbx;
-            bool bad = run && ((sym == 16 && have == 0) || have + rep > total);
-            rep = run ? rep : 0u;
-            val = run ? val : 0u;
-            adv = run ? adv : 0u;
-            buf >>= adv;
-            nb -= adv;
-            // [have, have+rep) split at the literal / distance boundary
-            const uint32_t nlit_part = have < nl ? min(rep, nl - have) : 0u;
-            const uint32_t ndist_part = rep - nlit_part;
-            const uint32_t wgt = val ? 32768u >> val : 0u;
-            kl += __umul24(nlit_part, wgt);
-            kd += __umul24(ndist_part, wgt);
-            nlit += val ? nlit_part : 0u;
-            ndist += val ? ndist_part : 0u;
-            eob_len = (val && have <= 256 && 256 < have + rep) ? val : eob_len;
-            bad |= kl > 32768u || kd > 32768u;                       // over-subscribed
-            // the literal / length widths are complete once `have` passes HLIT+257
-            bad |= have + rep >= nl && have < nl && !(kl == 32768u || (nlit == 1 && kl == 16384u));
-            have += rep;
-            last = val;
-            good = good && !bad;
-            run = good && have < total;
-        }
-    }
-    while (have < total && good) {     // (candidates near the end of the stream: every step checked)
-        if (hb.b.pos >= hb.nbits) { good = false; break; }
-        hb.b.refill();
-        const uint32_t e = cl_tab[((uint32_t)hb.b.buf & 127) * 64 + threadIdx.x];
-        const uint32_t sym = e & 31, used = e >> 5;
-        if (hb.b.pos + used > hb.nbits) { good = false; break; }
-        hb.b.skip(used);
-        uint32_t rep = 1, val = sym;
-        if (sym == 16) { if (have == 0) { good = false; break; } rep = 3 + bits(2); val = last; }
-        else if (sym == 17) { rep = 3 + bits(3); val = 0; }
-        else if (sym == 18) { rep = 11 + bits(7); val = 0; }
-        if (have + rep > total || hb.bad) { good = false; break; }
-        if (val) {
-            // [have, have+rep) split at the literal / distance boundary
-            const uint32_t nlit_part = have < nl ? (have + rep <= nl ? rep : nl - have) : 0;
-            const uint32_t ndist_part = rep - nlit_part;
-            kl += nlit_part * (32768u >> val); nlit += nlit_part;
-            kd += ndist_part * (32768u >> val); ndist += ndist_part;
-            if (have <= 256 && 256 < have + rep) eob_len = val;
-            if (kl > 32768u || kd > 32768u) { good = false; break; }   // over-subscribed: most false candidates end here
-        }
-        have += rep;
-        last = val;
-        // the literal/length widths are complete once `have` passes HLIT+257: nearly every false candidate
-        // ends here (its code is not Kraft-complete) instead of after the distance widths
-        if (have >= nl && have - rep < nl && !(kl == 32768u || (nlit == 1 && kl == 16384u))) { good = false; break; }
-    }
-    if (hb.bad) good = false;
-    if (good) {
-        if (eob_len == 0) good = false;
-        if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
-        if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
-    }
-    return good;
-}
-
-// The same check for a wavefront whose candidates all lie at least 6000 bits in front of the stream's end (a header is at
-// most 17 + 19*3 + 320*(7+7) = 4554 bits long: no bounds checks), round 5: the lanes' bits come from LDS.  Every lane
-// stages FIND2_HB dwords of the stream from its candidate on with all loads in flight (hbuf: dword k of lane l at k * 64 + l),
-// takes the header's fixed fields from them by funnel shifts, and walks on them; a lane that uses its dwords up makes
-// every lane still walking stage again from where it stands (a few times per batch).  Rounds 3-4 topped the window up from global memory inside the walk: one dependent, uncoalesced load and
-// its wait per step of the wavefront — the stage's time was that latency, about 200 times per batch, and the generic bit
-// reader's in front of it.
+// block finder, stage 2: full header parse of each stage-1 survivor, one lane each (`valid` lanes; the others walk along
+// frozen): the code-length sequence must decode to exactly HLIT+257+HDIST+1 lengths, EOB must have a code, the literal/length
+// code must be complete and the distance code complete, single or empty, and the header must end inside the stream.
+// Round 5: the lanes' bits come from LDS.  Every lane stages FIND2_HB dwords of the stream from its candidate on with all loads
+// in flight (hbuf: dword k of lane l at k * 64 + l), takes the header's fixed fields from them by funnel shifts, and walks on
+// them; a lane that uses its dwords up makes every lane still walking stage again from where it stands (a few times per
+// batch).  Rounds 3-4 topped the window up from global memory inside the walk: one dependent, uncoalesced load and its wait
+// per step of the wavefront — the stage's time was that latency, about 200 times per batch, and the generic bit reader's in
+// front of it.
+// Round 6: EVERY candidate takes this path — the loads are clamped to the stream's last dword and a header that ends behind
+// the stream's last bit fails at the end (the bits a walk reads behind the end are the last dword's, over and over: whatever
+// it makes of them is discarded).  Until then a wavefront that held a candidate within 6000 bits of the stream's end took a
+// second, byte-wise walk with every step bounds-checked: three or four wavefronts per stream, ~100 us each — two thirds of
+// the kernel's time whenever one of them started late (found with batches that do nothing, LFX_FIND2_EXP=4: 102 us).
 #ifndef LFX_FIND2_HB
 #define LFX_FIND2_HB 16
 #endif
 constexpr uint32_t FIND2_HB = LFX_FIND2_HB;   // dwords of the stream a lane stages at a time (stage2_check_staged)
-__device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ in, uint64_t cand_bit, bool valid,
-                                                    uint8_t *cl_tab, uint32_t *hbuf, uint64_t *dbg) {
+template <int EXP>      // EXP: timing experiments (LFX_FIND2_EXP: a cut-down kernel runs in front of the real one): 1 = no walk (every candidate
+                        // fails), 2 = no table either, 3 = no staging either, 4 = no batch counter either (batches by stride)
+__device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ in, uint64_t nbytes, uint64_t cand_bit, bool valid,
+                                                    uint8_t *cl_tab, uint32_t *hbuf, uint64_t *dbg, uint32_t *work, uint32_t &next_raw) {
     const uint32_t lane = threadIdx.x;
     const uint64_t t0 = dbg ? clock64() : 0;
     const uint64_t a = (uint64_t)in;
@@ -2263,15 +2163,16 @@ __device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ 
     gptr_u32 w = (gptr_u32)(a & ~3ull);
     uint64_t gd = abs0 >> 5;                         // dword of the stream that hbuf[0] holds
     const uint32_t off = (uint32_t)abs0 & 31;
+    const uint64_t wlast = ((a & 3) + nbytes + 3) / 4 - 1;       // the stream's last (aligned) dword: loads are clamped to it
     auto stage = [&](bool need) {
         uint32_t v[FIND2_HB];
 #pragma unroll
-        for (uint32_t k = 0; k < FIND2_HB; ++k) v[k] = need ? w[gd + k] : 0u;
+        for (uint32_t k = 0; k < FIND2_HB; ++k) { const uint64_t idx = gd + k; v[k] = need ? w[idx < wlast ? idx : wlast] : 0u; }
 #pragma unroll
         for (uint32_t k = 0; k < FIND2_HB; ++k)
             if (need) hbuf[k * 64 + lane] = v[k];
     };
-    stage(valid);
+    stage(valid && EXP < 3);
     const uint32_t e0 = hbuf[lane], e1 = hbuf[64 + lane], e2 = hbuf[128 + lane], e3 = hbuf[192 + lane];
     const uint32_t x0 = __builtin_amdgcn_alignbit(e1, e0, off), x1 = __builtin_amdgcn_alignbit(e2, e1, off),
                    x2 = __builtin_amdgcn_alignbit(e3, e2, off);
@@ -2284,7 +2185,17 @@ __device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ 
         clw |= (uint64_t)(k < nc ? fw & 7u : 0u) << (3 * f_clen_order_c(k));
     }
     const uint64_t t1 = dbg ? clock64() : 0;
-    clen_table_build(cl_tab, lane, clw);
+    if (EXP < 2) clen_table_build(cl_tab, lane, clw);
+    // the wavefront's next batch is reserved HERE — behind the staging loads and the table, in front of the walk, which only
+    // touches LDS: the counter's answer (a device-scope atomic, thousands on one address) arrives while the wavefront walks.
+    // (In front of the staging loads — rounds 3-5 — the loads' wait was the atomic's wait too: memory operations return in order.)
+    // (the address through an opaque zero: on a uniform address the compiler's atomic optimizer rewrites the call into "one lane
+    //  adds for all, broadcast, every lane derives its value" and waits for the answer on the spot)
+    {
+        uint32_t zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+        if (lane == 0 && EXP < 4) next_raw = atomicAdd(work + zero, 1u);
+    }
     const uint64_t t2 = dbg ? clock64() : 0;
     uint32_t steps = 0, restaged = 0;
     uint32_t have = 0, kl = 0, kd = 0, nlit = 0, ndist = 0, eob_len = 0, last = 0;
@@ -2308,6 +2219,7 @@ __device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ 
     {
         uint32_t acc = 0;
         last = 31u;
+        if (EXP >= 1) good = false;
         bool runA = good;
         uint32_t badv = 0;                 // (the only verdict carried through the loop besides runA: `good` is settled behind it)
         // (the re-staging stands OUTSIDE the step loop: with the branch inside it the compiler merged the two paths with a copy of
@@ -2406,6 +2318,8 @@ __device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ 
         if (eob_len == 0) good = false;
         if (!(kl == 32768u || (nlit == 1 && kl == 16384u))) good = false;
         if (!(kd == 32768u || (ndist == 1 && kd == 16384u) || ndist == 0)) good = false;
+        // the header's last bit lies inside the stream (cur is dword gd + di - 2 of the aligned grid, o the offset in it)
+        if (((gd + di - 2) << 5) + o > nbytes * 8 + (a & 3) * 8) good = false;
     }
     if (dbg && lane == 0) {   // LFX_DEBUG: cycles of staging + fields, table, walk; steps, restagings, batches
         const uint64_t t3 = clock64();
@@ -2423,6 +2337,7 @@ __device__ __forceinline__ bool stage2_check_staged(const uint8_t *__restrict__ 
 // workgroups fetch batches of 64 survivors from a device counter until the lists are exhausted — stage 1 and stage 2 run
 // back to back without the host reading the counts in between (it reads them, the overflow marker and the result list
 // in ONE round trip afterwards).
+template <int EXP>
 __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restrict__ in, uint64_t nbytes,
                                                          const uint64_t *__restrict__ cand, uint32_t shard_cap,
                                                          const uint32_t *__restrict__ count, uint32_t *__restrict__ work,
@@ -2434,37 +2349,47 @@ __global__ __launch_bounds__(64) void find_blocks_stage2(const uint8_t *__restri
     const uint64_t tk0 = dbg ? clock64() : 0;
     __shared__ uint32_t s_pre[FIND_SHARDS + 1];
     {
-        // exclusive prefix of the shard counts, a lane per shard
-        const uint32_t cnt = threadIdx.x < FIND_SHARDS ? min(count[threadIdx.x], shard_cap) : 0u;   // (an overflow is the host's to report)
-        const uint32_t incl = wave_inclusive_sum(cnt);
-        if (threadIdx.x < FIND_SHARDS) s_pre[threadIdx.x] = incl - cnt;
-        if (threadIdx.x == FIND_SHARDS) s_pre[FIND_SHARDS] = incl;
+        // exclusive prefix of the lists' counts (FIND_SHARDS / 64 lists per lane)
+        constexpr uint32_t PER = FIND_SHARDS / 64;
+        static_assert(PER * 64 == FIND_SHARDS, "lists per lane");
+        uint32_t cnt[PER], sum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) { cnt[q] = min(count[threadIdx.x * PER + q], shard_cap); sum += cnt[q]; }   // (an overflow is the host's to report)
+        const uint32_t incl = wave_inclusive_sum(sum);
+        uint32_t at = incl - sum;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; ++q) { s_pre[threadIdx.x * PER + q] = at; at += cnt[q]; }
+        if (threadIdx.x == 63) s_pre[FIND_SHARDS] = incl;
     }
     __syncthreads();
     const uint32_t n1 = s_pre[FIND_SHARDS];
-    // Batches of 64 survivors: a wavefront's first one by its index, the later ones from a device counter — asked for a batch
-    // ahead.  (Rounds 3-4 fetched every batch, the first included, from the counter and waited for it: the grid's first atomics,
+    // Batches of 64 survivors: a wavefront's first one by its index, the later ones from a device counter — asked for while
+    // the wavefront walks.  (Rounds 3-4 fetched every batch, the first included, from the counter and waited for it: the grid's first atomics,
     // thousands on one address at about 11 ns each, arrived together — LFX_DEBUG: the wavefronts' lives summed to 1.6 times their
     // batches' cycles.  A fixed deal by stride alone loses a third to rounding: 2.4 batches per wavefront are three rounds.)
-    __shared__ uint32_t s_base;
-    uint32_t base = blockIdx.x * 64u;
+    // Round 6: FIND2_GROUPS counters.  Wavefront w belongs to group k = w mod GROUPS and is its r-th member; the group's batches
+    // are k, k + GROUPS, k + 2 GROUPS, ... (the lists are sorted by class, longest walks first: every group gets the same mix),
+    // its first members' by rank, the later ones from the group's counter.
+    const uint32_t grp = blockIdx.x % FIND2_GROUPS, members = (gridDim.x - grp + FIND2_GROUPS - 1) / FIND2_GROUPS;
+    uint32_t *my_work = work + grp * FIND_HDR_WORK_STRIDE;
+    uint32_t base = (grp + FIND2_GROUPS * (blockIdx.x / FIND2_GROUPS)) * 64u;      // (= blockIdx.x * 64)
     while (base < n1) {
-        if (threadIdx.x == 0) s_base = gridDim.x * 64u + atomicAdd(work, 64u);      // the batch behind this one
+        uint32_t next_raw = 0;                            // lane 0: the work counter's answer (the batch behind this one)
         const uint32_t gi = base + threadIdx.x;
         const bool valid = gi < n1;
-        uint32_t shard = 0;
-        for (uint32_t k = 1; k < FIND_SHARDS; ++k) shard += gi >= s_pre[k];
+        uint32_t shard = 0;                               // the last list whose first index is <= gi (empty lists share theirs)
+#pragma unroll
+        for (uint32_t step = FIND_SHARDS / 2; step; step >>= 1) shard += s_pre[shard + step] <= gi ? step : 0u;
         const uint64_t i = (uint64_t)shard * shard_cap + (gi - s_pre[shard]);
         const uint64_t cand_bit = valid ? cand[i] : 0;
-        const bool lean = __ballot(cand_bit + 6000 > nbytes * 8) == 0;   // (uniform; see stage2_check_staged)
-        const bool good = lean ? stage2_check_staged(in, cand_bit, valid, cl_tab, hbuf, dbg) : stage2_check(in, nbytes, cand_bit, valid, cl_tab);
+        const bool good = stage2_check_staged<EXP>(in, nbytes, cand_bit, valid, cl_tab, hbuf, dbg, my_work, next_raw);
         if (good) {
             const uint32_t slot = atomicAdd(final_count, 1u);   // a few hundred per stream
             if (slot < final_cap) final_list[slot] = cand_bit;
         }
         __syncthreads();      // (the per-lane tables are reused)
-        base = s_base;
-        __syncthreads();
+        if (EXP == 4) base += gridDim.x * 64u;                    // (timing: a fixed deal by stride, no counter)
+        else base = (grp + FIND2_GROUPS * (members + (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw))) * 64u;
     }
     if (dbg && threadIdx.x == 0) atomicAdd((unsigned long long *)&dbg[6], (unsigned long long)(clock64() - tk0));   // a wavefront's life
 }
@@ -2690,11 +2615,29 @@ int launch_sym_substitute(hipStream_t st, const uint16_t *sym, const SymUnit *un
 }
 int launch_find_stage2(hipStream_t st, const uint8_t *in, uint64_t nbytes, const uint64_t *cand,
                        uint32_t shard_cap, const uint32_t *count, uint32_t *work, uint32_t *final_count, uint64_t *final_list,
-                       uint32_t final_cap, uint32_t n_cu, uint64_t *dbg) {
-    // (one-wavefront workgroups, 8 KB + 256 bytes per staged dword of LDS each: as many as fit a CU's 160 KB)
-    constexpr uint32_t per_cu = (160u * 1024u) / (8192u + 256u * FIND2_HB + 256u);
-    hipLaunchKernelGGL(find_blocks_stage2, dim3(per_cu * (n_cu ? n_cu : 256u)), dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work,
-                       final_count, final_list, final_cap, dbg);
+                       uint32_t final_cap, uint32_t n_cu, uint64_t *dbg, int exp) {
+    // One-wavefront workgroups, 8 KB + 256 bytes per staged dword + the lists' prefix of LDS each: EXACTLY as many as are
+    // resident at once, by the runtime's own count.  (Rounds 3-5 divided 160 KB by the arrays' bytes: 13 — but the allocation
+    // is rounded up and twelve fit; the thirteenth workgroup of every CU started when the first ones LEFT, at the end, and the
+    // batch it owns by its index ran behind everything else: one batch's time on top of the kernel's.)
+    static int per_cu_dev[64] = {};
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    int &per_cu = per_cu_dev[dev_ & 63];
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)find_blocks_stage2<0>, 64, 0) != hipSuccess || nb < 1) {
+            (void)hipGetLastError();
+            nb = 8;
+        }
+        per_cu = nb;
+    }
+    const dim3 grid((uint32_t)per_cu * (n_cu ? n_cu : 256u));
+    if (exp == 1) hipLaunchKernelGGL(find_blocks_stage2<1>, grid, dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work, final_count, final_list, final_cap, dbg);
+    else if (exp == 2) hipLaunchKernelGGL(find_blocks_stage2<2>, grid, dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work, final_count, final_list, final_cap, dbg);
+    else if (exp == 3) hipLaunchKernelGGL(find_blocks_stage2<3>, grid, dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work, final_count, final_list, final_cap, dbg);
+    else if (exp == 4) hipLaunchKernelGGL(find_blocks_stage2<4>, grid, dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work, final_count, final_list, final_cap, dbg);
+    else hipLaunchKernelGGL(find_blocks_stage2<0>, grid, dim3(64), 0, st, in, nbytes, cand, shard_cap, count, work, final_count, final_list, final_cap, dbg);
     LFX_LAUNCH_CHECK();
     return 0;
 }
