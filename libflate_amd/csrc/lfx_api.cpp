@@ -295,7 +295,7 @@ extern "C" lfx_ctx *lfx_ctx_new(int device, int *status) try {
         if (status) *status = LFX_E_DEVICE;
         return nullptr;
     }
-    if (hipHostMalloc((void **)&c->h_res, 4096, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&c->h_res, 4096 + Ctx::PIN_ARENA, hipHostMallocDefault) != hipSuccess) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         if (status) *status = LFX_E_OOM;

@@ -132,6 +132,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
     const uint64_t first_bit = start_bit0 == ~0ull ? off0 * 8 : start_bit0;
     mr.end_bit = first_bit;
     hipStream_t st = c->stream;
+    c->pin_reset();        // (the page-locked slots of the small transfers, lfx_ctx.h: nothing of an earlier member is in flight)
     std::vector<InflateJob> jobs;
     std::vector<InflateResult> res;
     bool parallel_done = false;
@@ -151,10 +152,10 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             const uint32_t final_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 16, comp / 4096), 1u << 24);
             int rc;
             if ((rc = c->d_dec_cand.reserve(8ull * shard_cap * FIND_SHARDS + 8ull * final_cap + 4 * FIND_HDR_WORDS))) return rc;
-            uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // the header (lfx_decode.h), then the lists
+            uint32_t *d_count = (uint32_t *)c->d_dec_cand.p;                       // the header (lfx_decode.h), the results, the lists
             uint32_t *d_final_count = d_count + FIND_HDR_FINAL;
-            uint64_t *d_cand = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 4 * FIND_HDR_WORDS);
-            uint64_t *d_final = d_cand + (uint64_t)shard_cap * FIND_SHARDS;
+            uint64_t *d_final = (uint64_t *)((uint8_t *)c->d_dec_cand.p + 4 * FIND_HDR_WORDS);   // (behind the header: both come back in ONE transfer)
+            uint64_t *d_cand = d_final + final_cap;
             HIP_TRY(hipMemsetAsync(d_count, 0, 4 * FIND_HDR_WORDS, st));
             // (the member's last block is looked for in the final eighth of the input, at least 8 MiB of it: one that starts
             //  earlier — a last block of more than that — is scanned on demand by the chain walk below)
@@ -174,13 +175,13 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
             }
             LAUNCH_TRY(launch_find_stage2(st, d_in, n, d_cand, shard_cap, d_count, d_count + FIND_HDR_WORK, d_final_count, d_final, final_cap,
                                           (uint32_t)std::max(c->n_cu, 1), c->diag.debug ? (uint64_t *)(d_count + FIND_HDR_DBG) : nullptr));
-            uint32_t hc[FIND_HDR_READ];
             constexpr uint32_t HEAD_N = 1024;      // (results that come back with the counts; a stream has a few hundred)
             const uint32_t head_n = std::min<uint32_t>(HEAD_N, final_cap);
-            std::vector<uint64_t> cand(head_n);
-            HIP_TRY(hipMemcpyAsync(hc, d_count, sizeof hc, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(cand.data(), d_final, 8ull * head_n, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<uint64_t> back(FIND_HDR_WORDS / 2 + head_n);      // header words, then the first results
+            HIP_TRY(c->small_down(back.data(), d_count, 8ull * back.size(), st));
+            HIP_TRY(c->small_sync(st));
+            const uint32_t *hc = (const uint32_t *)back.data();
+            std::vector<uint64_t> cand(back.begin() + FIND_HDR_WORDS / 2, back.end());
             overflow = hc[FIND_SHARDS] != 0;
             n1 = 0;
             for (uint32_t k = 0; k < FIND_SHARDS; k++) { if (hc[k] > shard_cap) overflow = true; n1 += hc[k]; }
@@ -498,7 +499,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     for (uint32_t j = 0; j < nj; j++) { bj[j].temp_off = 0; bj[j].cap = 0; }
                 }
             }
-            HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, hipMemcpyHostToDevice, st));
+            HIP_TRY(c->small_up(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nj, st));
             if (store_mode)
                 LAUNCH_TRY(launch_blk_scan_store(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
                                                  (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p, (uint32_t *)c->d_dec_temp.p,
@@ -507,8 +508,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nj, (BlkInfo *)c->d_dec_state.p,
                                            (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p, scan_small));
             std::vector<BlkInfo> bi(nj);
-            HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(c->small_down(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nj, st));
+            HIP_TRY(c->small_sync(st));
             for (BlkInfo &b : bi) if (b.status == BLK_OK && b.end_bit > n * 8) b.status = BLK_NO_EOB;   // (cut by the input's end)
             if (store_mode) for (uint32_t j = 0; j < nj; j++) stored[j] = bi[j].status == BLK_OK && bi[j].btype != 0 && bi[j]._pad == 0;
             c->phase("blk_scan");
@@ -620,7 +621,7 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     HIP_TRY(hipMemsetAsync(dbgbuf, 0, 64ull * 8 * ne, st));
                 }
                 HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
-                HIP_TRY(hipMemcpyAsync(d_emit, emit.data(), sizeof(BlkEmit) * ne, hipMemcpyHostToDevice, st));
+                HIP_TRY(c->small_up(d_emit, emit.data(), sizeof(BlkEmit) * ne, st));
                 // K3 keeps four units resident per CU (LDS): size the units so that all of them are resident at once
                 const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
                 const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
@@ -652,8 +653,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                 const bool probe = !giant && total / ne < (256u << 10);
                 uint32_t fl = 0;
                 if (probe) {
-                    HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
+                    HIP_TRY(c->small_down(&fl, d_flags, 4, st));
+                    HIP_TRY(c->small_sync(st));
                 }
                 bool ck_spec = false;
                 if (!giant && !(probe && fl == 2 && !c->diag.no_markers)) {
@@ -673,8 +674,8 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                         ck_spec = true;
                     }
                 }
-                HIP_TRY(hipMemcpyAsync(&fl, d_flags, 4, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(c->small_down(&fl, d_flags, 4, st));
+                HIP_TRY(c->small_sync(st));
                 if (ck_spec && fl == 0) {
                     const EncodeResult er = *(EncodeResult *)c->h_res;
                     mr.ck_done = true; mr.crc32 = er.crc32; mr.adler32 = er.adler32;
