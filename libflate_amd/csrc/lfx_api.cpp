@@ -166,7 +166,10 @@ static void apply_schedule(Planner &pl, const lfx_schedule *s, uint64_t n) {
         pl.write(n);  // write_all of one slice == one write() (encode.rs:243 consumes everything)
     } else if (s->kind == LFX_SCHED_FIXED) {
         uint64_t w = s->fixed_write ? s->fixed_write : n;
-        for (uint64_t off = 0; off < n; off += w) pl.write(std::min(w, n - off));
+        if (w) {
+            pl.write_repeat(w, n / w);
+            if (n % w) pl.write(n % w);
+        }
     } else {
         uint64_t used = 0;
         for (size_t i = 0; i < s->n_writes; i++) {

@@ -56,6 +56,35 @@ class Planner {
         if (o_.lz77_kind == 0 && lz_len_ >= (uint64_t)o_.window_size * 8) lz_flush();  // default.rs:65
         while (original_size_ >= block_size_) block_flush(false);
     }
+    // `count` consecutive write() calls of n bytes each — the reference's io::copy protocol is 32768 writes of 8 KiB per
+    // 256 MiB, 157 us of this loop per encode call when each goes through write().  Between two events (an LZ77 flush at
+    // window * 8 buffered bytes, a block at block_size) a write only moves counters: those writes are taken in one step, the
+    // write that triggers an event goes through write() itself.
+    void write_repeat(uint64_t n, uint64_t count) {
+        if (n == 0) return;  // (a write of nothing moves no counter: the thresholds were settled by the write before)
+        while (count) {
+            // writes that can pass without reaching a threshold: the state after k of them is (x + k n) for every counter
+            uint64_t quiet;
+            if (raw_) quiet = raw_len_ < block_size_ ? (block_size_ - raw_len_ - 1) / n : 0;      // raw_len_ + k n < block_size_
+            else {
+                quiet = original_size_ < block_size_ ? (block_size_ - original_size_ - 1) / n : 0;
+                if (o_.lz77_kind == 0) {
+                    const uint64_t w8 = (uint64_t)o_.window_size * 8;
+                    const uint64_t q2 = lz_len_ < w8 ? (w8 - lz_len_ - 1) / n : 0;
+                    quiet = quiet < q2 ? quiet : q2;
+                }
+            }
+            if (quiet > count) quiet = count;
+            if (quiet) {
+                const uint64_t bytes = quiet * n;
+                cursor_ += bytes;
+                if (raw_) raw_len_ += bytes;
+                else { original_size_ += bytes; lz_len_ += bytes; }
+                count -= quiet;
+            }
+            if (count) { write(n); --count; }
+        }
+    }
     // Write::flush
     void flush() {
         if (raw_) raw_block(false); else block_flush(false);
