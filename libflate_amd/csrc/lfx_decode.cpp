@@ -620,8 +620,13 @@ int inflate_member(Ctx *c, const uint8_t *d_in, uint64_t n, uint64_t off0, uint8
                     dbgbuf = (uint64_t *)c->d_ck.p;
                     HIP_TRY(hipMemsetAsync(dbgbuf, 0, 64ull * 8 * ne, st));
                 }
-                HIP_TRY(hipMemsetAsync(d_flags, 0, 64, st));
-                HIP_TRY(c->small_up(d_emit, emit.data(), sizeof(BlkEmit) * ne, st));
+                {
+                    // the flags (64 zero bytes) and the emit jobs behind them in ONE transfer (a fill and a copy of their own were
+                    // two launches with ten microseconds of idle GPU in front of each, between the scan and the place kernel)
+                    std::vector<uint8_t> upl(64 + sizeof(BlkEmit) * (size_t)ne, 0);
+                    memcpy(upl.data() + 64, emit.data(), sizeof(BlkEmit) * (size_t)ne);
+                    HIP_TRY(c->small_up(d_flags, upl.data(), upl.size(), st));
+                }
                 // K3 keeps four units resident per CU (LDS): size the units so that all of them are resident at once
                 const uint64_t slots = 4ull * (uint64_t)std::max(c->n_cu, 1);
                 const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
@@ -875,11 +880,12 @@ int decode_stream(Ctx *c, int format, uint32_t flags, const uint8_t *d_in, uint6
         if (format != LFX_DEFLATE) {
             DecStream ds{base, n - base, 0, 0};
             DecHeader dh{};
-            HIP_TRY(hipMemcpyAsync(c->d_small.p, &ds, sizeof ds, hipMemcpyHostToDevice, st));
+            c->pin_reset();       // (page-locked slots for the two small transfers, lfx_ctx.h)
+            HIP_TRY(c->small_up(c->d_small.p, &ds, sizeof ds, st));
             LAUNCH_TRY(launch_container(st, format, 1, d_in, (const DecStream *)c->d_small.p,
                                         (DecHeader *)((uint8_t *)c->d_small.p + 256)));
-            HIP_TRY(hipMemcpyAsync(&dh, (uint8_t *)c->d_small.p + 256, sizeof dh, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(c->small_down(&dh, (uint8_t *)c->d_small.p + 256, sizeof dh, st));
+            HIP_TRY(c->small_sync(st));
             if (dh.status != 0) {
                 if (!first && dh.status == 2) {  // MultiDecoder: UnexpectedEof on the next header = clean end
                     oc.consumed = n;             // (gzip.rs:1150-1156; the partial header bytes were read)
