@@ -122,7 +122,7 @@ def measure_traffic(kernel, n, schedule):
     64 bytes — its expression takes them from a counter that reads 0 here — hence the guide's "double it" for wide coalesced
     readers; rounds 1-5 applied that factor, calibrated on checksum_span_kernel, to every kernel, which over-counted the
     scattered readers: parse_emit appeared to move 6.2 TB/s.)  The calibration kernel — it reads the n input bytes exactly once
-    — is kept as a check of the method: `calibration_check` = its measured bytes / n.  Falls back to FETCH_SIZE x factor when
+    per direction — is kept as a check of the method: `calibration_check` = its measured bytes per step / 2 n.  Falls back to FETCH_SIZE x factor when
     the sized counters are not all there.  Writes: WRITE_SIZE (32 / 64-byte requests, tallied as such).  Infinity-Cache hits are
     counted, not excluded (guide): this is fabric traffic.  → dict or {"error": ...}."""
     sized = ("TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum")
@@ -156,7 +156,8 @@ def measure_traffic(kernel, n, schedule):
         cal = find(rd["FETCH_SIZE"], CALIBRATION_KERNEL)
         if not cal:
             return {"error": "calibration kernel not in the counter output"}
-        factor = n / (sum(cal) / len(cal) * 1024.0)       # ≈ 2 on gfx950
+        nsteps_f = max([len(v) for k, v in rd["FETCH_SIZE"].items() if "lz77_match" in k] or [1])
+        factor = 2.0 * n * nsteps_f / (sum(cal) * 1024.0)   # ≈ 2 on gfx950 (the kernel reads n bytes per encode, in two launches, and n per decode)
         read = {k: [x * 1024.0 * factor for x in v] for k, v in rd["FETCH_SIZE"].items()}
     write = {k: [x * 1024.0 for x in v] for k, v in wr["WRITE_SIZE"].items()}
     r_k, w_k, cal_r = find(read, kernel), find(write, kernel), find(read, CALIBRATION_KERNEL)
@@ -176,8 +177,9 @@ def measure_traffic(kernel, n, schedule):
     out = {"hbm_bytes": int(fetch + wbytes), "fetch_bytes": int(fetch), "write_bytes": int(wbytes),
            "method": ("reads: 32 x TCC_EA0_RDREQ_32B + 64 x _64B + 128 x _128B (exact request sizes); writes: WRITE_SIZE"
                       if method == "sized" else "reads: FETCH_SIZE x %.3f (calibrated on %s); writes: WRITE_SIZE" % (factor, CALIBRATION_KERNEL)),
-           "calibration_check": round(sum(cal_r) / len(cal_r) / n, 4),
-           "calibration_how": "%s reads the %d input bytes exactly once: measured read bytes / n" % (CALIBRATION_KERNEL, n),
+           "calibration_check": round(sum(cal_r) / (2.0 * nsteps * n), 4),
+           "calibration_how": ("%s reads the %d input bytes once per encode (in two launches) and the %d output bytes once per decode: "
+                               "measured read bytes of a step / 2 n" % (CALIBRATION_KERNEL, n, n)),
            "step_hbm_bytes_all_kernels": int(sum(per_kernel.values())),
            "step_hbm_bytes_by_kernel": {k: int(v) for k, v in top},
            "step_read_bytes_by_kernel": {k: int(read_step.get(k, 0)) for k, _ in top},

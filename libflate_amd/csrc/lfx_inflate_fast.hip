@@ -1252,6 +1252,25 @@ __device__ __forceinline__ void blk_units_tail(const uint32_t tid, const BlkEmit
     }
 }
 
+// A block's verdict on its back-references → the call's flags (bit 0: a reference in front of the member's first byte, bit 1: in
+// front of the block — it needs the earlier output): ONE device-scope atomic per block, and none once the bit stands.  (One per
+// wavefront with a reference that leaves its block — another encoder's stream of thousands of small blocks — was tens of
+// thousands of atomics on one address, ~12 ns each one after the other: tools/exp/atomic_lat.hip.)  Every thread calls it.
+__device__ __forceinline__ void blk_flag_reach(uint32_t tid, int64_t reach, uint64_t hist, uint32_t *__restrict__ flags,
+                                               uint32_t *__restrict__ job_flags) {
+    __shared__ uint32_t s_fl;
+    if (tid == 0) s_fl = 0;
+    __syncthreads();
+    if (reach < -(int64_t)hist) atomicOr(&s_fl, 1u);
+    else if (reach < 0) atomicOr(&s_fl, 2u);
+    __syncthreads();
+    if (tid == 0 && s_fl) {
+        const uint32_t f = s_fl;
+        if ((f & 1u) && job_flags) job_flags[blockIdx.x] = 1u;
+        if ((__atomic_load_n(&flags[0], __ATOMIC_RELAXED) & f) != f) atomicOr(&flags[0], f);
+    }
+}
+
 // RING: the lanes' bits come through LDS rings (RingBits: one workgroup per CU — the single-stream path, whose blocks are
 // large); else through the register FIFO (FastBits: two workgroups per CU — the batch path's thousands of small blocks)
 template <bool RING, int NT = SCAN_THREADS>
@@ -1309,12 +1328,9 @@ __global__ __launch_bounds__(NT, RING ? 4 : 8) void blk_emit_kernel(const uint8_
         else
             lane_decode_fifo<true>(T, in, nbytes, st, lim, nc, no, codes + job.code_off + L->code_off[tid], reach, endpos, cc, co,
                                    emit_stage + tid * EMIT_STRIDE);
-        if (reach < -(int64_t)job.hist) {         // a back-reference reaches in front of the member's first byte
-            atomicOr(&flags[0], 1u);              // ... summary, and per job (batch decode)
-            if (job_flags) job_flags[blockIdx.x] = 1u;
-        } else if (reach < 0) atomicOr(&flags[0], 2u);   // ... in front of the block: it needs the earlier output
         if (cc < nc) { cut_code = L->code_off[tid] + cc; cut_pos = out0 + co; }   // a cut behind the last code belongs to the next lane
     }
+    blk_flag_reach(tid, reach, job.hist, flags, job_flags);
     blk_units_tail<NT>(tid, job, L, reach, cut_code, cut_pos, U, unit_target, free_shift, t_begin, t_hdr);
 }
 
@@ -1391,13 +1407,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void blk_place_kernel(const BlkEmit *
         const uint64_t out0 = L->out_off[tid];
         const int32_t rr = X->reach[tid];
         if (rr != INT32_MAX) reach = (int64_t)out0 + (int64_t)rr;
-        if (reach < -(int64_t)job.hist) {         // a back-reference reaches in front of the member's first byte
-            atomicOr(&flags[0], 1u);
-            if (job_flags) job_flags[blockIdx.x] = 1u;
-        } else if (reach < 0) atomicOr(&flags[0], 2u);   // ... in front of the block: it needs the earlier output
         const uint32_t cc = X->cut_code[tid];
         if (cc != 0xFFFFFFFFu) { cut_code = my_off + cc; cut_pos = out0 + X->cut_out[tid]; }
     }
+    blk_flag_reach(tid, reach, job.hist, flags, job_flags);
     blk_units_tail(tid, job, L, reach, cut_code, cut_pos, U, unit_target, free_shift, t_begin, t_hdr);
 }
 
