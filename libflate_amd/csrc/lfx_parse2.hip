@@ -464,11 +464,16 @@ __device__ __forceinline__ SegFix parse_rewalk(const GWalk &gw, uint64_t *__rest
     using p2::U;
     uint32_t pos = e, walked = 0, spec_below = 0, merge_pos = s1;
     bool merged = false;
+    // (the 64 groups' masks in ONE load, lane g holds group g's: a load per trip of the loop was 64 dependent memory round trips
+    //  per segment on data whose walk jumps over whole groups — BASELINE cfg5: parse_fixseg 1.3 ms per GiB.  A group's mask is read
+    //  before the loop rewrites it.)
+    const uint64_t Vmine = vw[lane];
     for (uint32_t g = 0; g < 64 && !merged; ++g) {
         const uint32_t base = s0 + g * U;
         if (base >= s1) break;
         const uint32_t stop = min(base + U, s1);
-        const uint64_t V = vw[g];
+        const uint64_t V = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)Vmine, (int)g) |
+                           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(Vmine >> 32), (int)g) << 32;
         if (pos >= stop) {               // wholly before the true entry: nothing visited here
             spec_below += __popcll(V);
             if (lane == 0 && V) vw[g] = 0;
@@ -678,15 +683,24 @@ __device__ __forceinline__ void emit_segment(const uint8_t *__restrict__ in, uin
         if (lane == 63) nxt_g = 0xFFFFFFFFu;
         nxt_g = min(nxt_g, seg_exit2[seg]);
         const uint64_t lt = p2::lanemask_lt();
-        for (uint32_t g = 0; g < 64; ++g) {
+        // (only the groups that hold a visited position in front of the merge point: on data whose matches jump over whole groups
+        //  most of the 64 trips found nothing — cfg5)
+        uint64_t todo;
+        {
+            const uint32_t mybase = s0 + lane * U;
+            uint64_t mine = mybase < mpos ? W : 0ull;
+            if (mybase < mpos && mpos - mybase < 64) mine &= (1ull << (mpos - mybase)) - 1;
+            todo = __ballot(mine != 0);
+        }
+        while (todo) {
+            const uint32_t g = (uint32_t)__builtin_ctzll(todo);
+            todo &= todo - 1;
             const uint32_t base = s0 + g * U;
-            if (base >= mpos) break;
             // (readlane returns int: through uint32_t, or a mask whose bit 31 is set is sign-extended into all of bits 32-63)
             const uint64_t V = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)W, (int)g) |
                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(W >> 32), (int)g) << 32;
             uint64_t m = V;
             if (mpos - base < 64) m &= (1ull << (mpos - base)) - 1;
-            if (m == 0) continue;
             const uint32_t ng = __builtin_amdgcn_readlane(nxt_g, g);
             if ((m >> lane) & 1) {
                 const uint32_t i = base + lane;
