@@ -246,6 +246,7 @@ void Diag::read() {
     two_pass = on("LFX_TWO_PASS");
     hist_separate = on("LFX_HIST_SEPARATE");
     find2_exp = getenv("LFX_FIND2_EXP") ? atoi(getenv("LFX_FIND2_EXP")) : 0;
+    no_pin_slots = on("LFX_NO_PIN_SLOTS");
     no_small_scan = on("LFX_NO_SMALL_SCAN");
     store_tight = on("LFX_STORE_TIGHT");
 }

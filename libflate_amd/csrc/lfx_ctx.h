@@ -39,6 +39,7 @@ struct Diag {
     int free_shift = -1;         // LFX_FREE_SHIFT
     bool no_small_scan = false;  // LFX_NO_SMALL_SCAN: 1024 slices a block also for small blocks (round 5's geometry)
     bool two_pass = false;       // LFX_TWO_PASS: every block through blk_emit_kernel (no storing scan)
+    bool no_pin_slots = false;   // LFX_NO_PIN_SLOTS: the decode's small transfers as plain pageable copies (the path of a full arena)
     int find2_exp = 0;           // LFX_FIND2_EXP=1..4: a cut-down finder stage 2 runs in front of the real one (phase "find2x"): timing only
     bool hist_separate = false;  // LFX_HIST_SEPARATE: the blocks' symbol counts by histogram_kernel (round 5) instead of inside parse_emit
     bool store_tight = false;    // LFX_STORE_TIGHT: the storing scan's regions sized for 16 bits a code (tests: lanes overflow, blocks fall back)
@@ -104,7 +105,7 @@ struct Ctx {
     void pin_reset() { pin_used = 0; pin_pending.clear(); }
     void *pin_take(size_t n) {
         const size_t at = (pin_used + 63) & ~(size_t)63;
-        if (!h_res || at + n > PIN_ARENA) return nullptr;
+        if (!h_res || diag.no_pin_slots || at + n > PIN_ARENA) return nullptr;
         pin_used = at + n;
         return (uint8_t *)h_res + 4096 + at;
     }

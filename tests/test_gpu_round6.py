@@ -439,3 +439,34 @@ def test_finder_reports_every_dynamic_header(ffi, lfx, oracle, synth, monkeypatc
             assert m2 and int(m2.group(1)) >= nblocks and int(m2.group(2)) <= 1, err[-2000:]     # (at most the final block)
     finally:
         c2.close()
+
+
+def test_decode_paths_of_the_second_half_of_round_6(ffi, lfx, oracle, synth, monkeypatch):
+    """The decode's small transfers through page-locked slots (Ctx::small_up / small_down) and as the plain pageable copies a full
+    arena falls back to (LFX_NO_PIN_SLOTS=1); a cut-down finder stage 2 in front of the real one (LFX_FIND2_EXP, timing only) must
+    not change an answer; candidates at the very end of a stream (the empty final block of the reference; a stream cut inside its
+    last header) take the staged walk with clamped loads: same bytes, same verdicts as the oracle."""
+    text = synth.text(12 << 20, seed=synth.SEED_BASE + 31).tobytes()
+    z_ref = oracle.encode(oracle.GZIP, text, write_size=8192, mtime=0)
+    z_small_blocks = oracle.encode(oracle.DEFLATE, text[: 6 << 20], write_size=1000, block_size=100 << 10)
+    import zlib as pyzlib
+    z_py = pyzlib.compress(text, 6)
+    cases = [(ffi.GZIP, oracle.GZIP, z_ref, text), (ffi.DEFLATE, oracle.DEFLATE, z_small_blocks, text[: 6 << 20]), (ffi.ZLIB, oracle.ZLIB, z_py, text)]
+    for env in ({}, {"LFX_NO_PIN_SLOTS": "1"}, {"LFX_FIND2_EXP": "1"}, {"LFX_FIND2_EXP": "4"}):
+        for k in ("LFX_NO_PIN_SLOTS", "LFX_FIND2_EXP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c2 = lfx.Context(0)
+        try:
+            for f, of, z, want in cases:
+                rc, out, used, msg = c2.decode_host(f, z)
+                assert (rc, used) == (0, len(z)) and out == want, (env, f, rc, msg)
+            # cut inside the last blocks' headers and right behind them: the oracle's verdict and bytes
+            for cut in (len(z_small_blocks) - 1, len(z_small_blocks) - 3, len(z_small_blocks) - 40, len(z_small_blocks) - 700):
+                zc = z_small_blocks[:cut]
+                rc, out, used, msg = c2.decode_host(ffi.DEFLATE, zc)
+                orc, oout, _ou, omsg = oracle.decode(oracle.DEFLATE, zc)
+                assert rc == orc and out == oout, (env, cut, rc, orc, len(out), len(oout), msg, omsg)
+        finally:
+            c2.close()

@@ -10,6 +10,6 @@ LFX_FUZZ=800 timeout 600 python -m pytest tests/test_gpu_fuzz.py -q -m gpu 2>&1 
 timeout 600 python tools/exp/m5_stress.py 1500 2>&1 | tail -1
 for i in 1 2; do timeout 600 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "cfg2_256mib" 2>&1 | tail -1; done
 # round 6: the decode paths side by side (single pass / tight regions = fallback / two passes) on the randomized suite, and the host-memory tests
-for v in LFX_TWO_PASS LFX_STORE_TIGHT; do env $v=1 LFX_FUZZ=300 timeout 600 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_large.py -q -m gpu 2>&1 | tail -1; done
+for v in LFX_TWO_PASS LFX_STORE_TIGHT LFX_HIST_SEPARATE LFX_NO_PIN_SLOTS; do env $v=1 LFX_FUZZ=300 timeout 600 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_large.py -q -m gpu 2>&1 | tail -1; done
 for i in 1 2 3; do timeout 600 python -m pytest tests/test_gpu_round6.py -m gpu -q 2>&1 | tail -1; done
 } | grep -v amdgpu | tee $O/r06_soak.txt
