@@ -408,7 +408,9 @@ typedef struct lfx_timing {
  *  was seen violated — 0 on every part measured so far; a non-zero value explains a 3x slower match stage */
 uint64_t lfx_ctx_match_fallbacks(const lfx_ctx *c);
 int lfx_ctx_last_timing(lfx_ctx *c, lfx_timing *t);
-void lfx_ctx_enable_timing(lfx_ctx *c, int on);
+void lfx_ctx_enable_timing(lfx_ctx *c, int on);   /* 0: off; 1: a HIP event behind every phase of a call (lfx_ctx_last_timing);
+                                                      2: only the two events around an encode's parse phase — an event record between
+                                                      two kernels costs ~6 us of idle GPU */
 uint32_t lfx_version(void);
 
 #ifdef __cplusplus

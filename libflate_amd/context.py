@@ -34,7 +34,8 @@ class Context:
         _ffi.lib().lfx_ctx_set_stream(self._h, hip_stream_ptr)
 
     def enable_timing(self, on=True):
-        _ffi.lib().lfx_ctx_enable_timing(self._h, 1 if on else 0)
+        """True / 1: an event behind every phase; 2: only the events around an encode's parse phase; False / 0: none."""
+        _ffi.lib().lfx_ctx_enable_timing(self._h, 2 if on == 2 and on is not True else (1 if on else 0))
 
     def last_timing(self):
         t = _ffi.Timing()

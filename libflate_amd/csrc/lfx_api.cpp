@@ -253,6 +253,7 @@ void Diag::read() {
 
 void Ctx::phase(const char *name) {
     if (!timing_on) return;
+    if (timing_on == 2 && strcmp(name, "lz77_match") != 0 && strcmp(name, "lz77_parse") != 0) return;
     if (n_ev >= 17) return;
     if (!ev[n_ev]) (void)hipEventCreate(&ev[n_ev]);
     (void)hipEventRecord(ev[n_ev], stream);
@@ -339,7 +340,7 @@ extern "C" void lfx_ctx_set_stream(lfx_ctx *cc, void *s) {
 extern "C" uint64_t lfx_ctx_match_fallbacks(const lfx_ctx *cc) {
     return cc ? reinterpret_cast<const Ctx *>(cc)->match_fallbacks : 0;
 }
-extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on != 0; }
+extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on == 2 ? 2 : on != 0; }
 extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) try {
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);

@@ -178,7 +178,8 @@ struct Ctx {
     bool shard_last = false;
 
     // phase timers
-    bool timing_on = false;
+    int timing_on = 0;      // 0: no events; 1: an event behind every phase; 2: only the events around the parse phase (the bench's timed steps:
+                            // an event record between two kernels is ~6 us of idle GPU, two dozen of them 3 % of a 256 MiB round trip)
     hipEvent_t ev[17] = {};
     char ev_name[17][24] = {};
     int n_ev = 0;
