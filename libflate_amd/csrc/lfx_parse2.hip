@@ -27,6 +27,9 @@
 // front of the merge point from the visit bits.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <algorithm>
 
 #include "lfx_common.h"
 #include "lfx_device.h"
@@ -41,10 +44,14 @@ constexpr uint32_t WAVES = PARSE_WG_SEGS;           // segments per workgroup
 constexpr uint32_t THREADS = 64 * WAVES;
 constexpr uint32_t WG_POS = WAVES * PARSE_SEG;      // 13312 positions per workgroup
 constexpr uint32_t TAIL = 288;                      // bytes staged behind the last position: 3 + 240 + 16 + 4 (dword reads) + alignment
-constexpr uint32_t WIN_BYTES = MAX_WINDOW + WG_POS + TAIL + 8;   // (+ the byte phase of the window start on the dword grid)
+constexpr uint32_t WIN_BYTES = MAX_WINDOW + WG_POS + TAIL + 16;  // (+ the byte phase of the window start on the 16-byte grid)
 constexpr uint32_t OFF_CD = (WIN_BYTES + 15) & ~15u;
-constexpr uint32_t CD_BYTES = 2 * WG_POS + 8;       // (+ one entry of alignment shift, + pad)
+constexpr uint32_t CD_BYTES = (2 * WG_POS + 16 + 15) & ~15u;    // (+ up to seven entries of alignment shift)
 constexpr uint32_t LDS_BYTES = OFF_CD + CD_BYTES;
+constexpr uint32_t WQ = (OFF_CD / 16 + THREADS - 1) / THREADS;   // 16-byte units of the window a lane copies (6)
+constexpr uint32_t CQ = (CD_BYTES / 16 + THREADS - 1) / THREADS; // ... of the candidates (7)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4 *gptr_x4;
 static_assert(U <= 64 && (U / 4) * 4 == U && ((U / 4) & 1) == 1, "a group is an odd number of dwords: bank-conflict-free lane stride");
 static_assert(PARSE_WG_SEGS > 4 ? LDS_BYTES <= 160 * 1024 : 2 * LDS_BYTES <= 160 * 1024, "two workgroups per CU (one, of more wavefronts, in the experiments)");
 
@@ -229,77 +236,63 @@ __device__ __forceinline__ void resolve_one(const WalkCtx &w, uint32_t lane, uin
 
 }  // namespace p2
 
-// workgroup → (chunk, first segment of the chunk it walks)
+// What a workgroup's slot of the launch order asks for (uniform).
+struct WalkSlot {
+    uint32_t kind;            // 0: empty slot / nothing to do, 1: behind the chunk's last walked position (pass through), 2: walk
+    ParseWg wg;
+    ChunkDesc ch;
+    uint32_t n, end, g0, w0, sh, csh;
+    p2::gptr_x4 gw, gc;       // first 16-byte unit of the bytes / of the candidates
+    uint32_t lastw, lastc;    // last unit that may be read
+};
+__device__ __forceinline__ WalkSlot walk_slot(uint32_t slot, uint32_t nwgs, const uint8_t *in, uint64_t in_bytes,
+                                              const ChunkDesc *chunks, const ParseWg *wgs, const uint16_t *cd) {
+    using namespace p2;
+    WalkSlot q;
+    q.kind = 0;
+    if (slot >= nwgs) return q;
+    q.wg = wgs[slot];
+    if (q.wg.chunk == 0xFFFFFFFFu) return q;          // an empty slot of the XCD-aware order (lfx_api.cpp)
+    q.ch = chunks[q.wg.chunk];
+    if (q.ch.flags & CH_LITERALS) return q;           // no walk: every byte is a literal
+    q.n = (uint32_t)q.ch.len;
+    q.end = (q.n > 3 ? q.n : 3) - 3;                  // default.rs:75
+    q.g0 = q.wg.seg0 * PARSE_SEG;                     // first position of the workgroup
+    if (q.g0 >= q.end) { q.kind = 1; return q; }
+    q.kind = 2;
+    // The bytes [w0, hi) and the candidates of [g0, g0 + WG_POS) are copied on their own 16-byte grid (position p sits at LDS
+    // byte p - w0 + sh, its candidate at entry p - g0 + csh): aligned 16-byte loads and LDS stores.
+    q.w0 = q.g0 > MAX_WINDOW ? q.g0 - MAX_WINDOW : 0u;
+    const uint64_t abs0 = (uint64_t)(in + q.ch.in_off) + q.w0;
+    q.sh = (uint32_t)abs0 & 15;
+    const uint64_t e0 = q.ch.in_off + q.g0;           // cd[] index of position g0
+    q.csh = (uint32_t)e0 & 7;
+    q.gw = (gptr_x4)(abs0 & ~15ull);
+    const uint64_t left = (uint64_t)in + in_bytes - (abs0 & ~15ull);                     // bytes up to the end of the input
+    const uint32_t hi = min(q.g0 + WG_POS + TAIL, q.n);                                  // (the compare never reads past the chunk)
+    const uint64_t want = ((uint64_t)(hi - q.w0) + q.sh + 15) >> 4, have = (left + 15) >> 4;
+    q.lastw = (uint32_t)(want < have ? want : have) - 1;                                 // (>= 1 unit here)
+    q.gc = (gptr_x4)(cd + (e0 - q.csh));
+    q.lastc = ((min(WG_POS, q.end - q.g0) + q.csh + 7) >> 3) - 1;
+    return q;
+}
+
 // K1: speculative walk, in-wavefront chaining, staging.  seg_exit / seg_count / vis / stage describe the segment as
 // walked from its FIRST position.
+// Round 6 (second half): the kernel is PERSISTENT — one workgroup per CU takes every gridDim.x-th slot of the launch order
+// (gridDim.x a multiple of 8: a slot stays on the XCD the order gave it to) — and the 16-byte loads of the NEXT slot's bytes
+// and candidates are in flight while the wavefronts walk the current one (52 registers per lane); they reach LDS behind the
+// barrier that ends the walk.  Before, a workgroup's first 9 K of its 39 K cycles were the fill, with nothing else on the CU.
 template <bool DBG>
-__global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
-    const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
-    const ParseWg *__restrict__ wgs, const uint16_t *__restrict__ cd, uint32_t max_len,
-    uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit, uint32_t *__restrict__ seg_count,
-    uint32_t *__restrict__ stage, uint64_t *__restrict__ dbg) {
+__device__ __forceinline__ void walk_segment(const WalkSlot &q, uint32_t max_len, uint64_t *__restrict__ vis,
+                                             uint32_t *__restrict__ seg_exit, uint32_t *__restrict__ seg_count,
+                                             uint32_t *__restrict__ stage, const uint32_t *win32, const uint32_t *cd32,
+                                             uint32_t lane, uint32_t wave, uint64_t *stamps) {
     using namespace p2;
-    const uint64_t t0 = DBG ? clock64() : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    uint32_t *win32 = (uint32_t *)smem;
-    uint32_t *cd32 = (uint32_t *)(smem + OFF_CD);
-
-    const ParseWg wg = wgs[blockIdx.x];
-    if (wg.chunk == 0xFFFFFFFFu) return;              // an empty slot of the XCD-aware order (lfx_api.cpp)
-    const ChunkDesc ch = chunks[wg.chunk];
-    if (ch.flags & CH_LITERALS) return;               // no walk: every byte is a literal
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t n = (uint32_t)ch.len;
-    const uint32_t end = (n > 3 ? n : 3) - 3;         // default.rs:75
-    const uint32_t g0 = wg.seg0 * PARSE_SEG;          // first position of the workgroup
-    if (g0 >= end) {
-        // nothing to walk (the chunk's last three bytes, or an empty chunk): the segments pass the walk through
-        const uint32_t sidx = wg.seg0 + wave;
-        if (sidx < ch.n_seg) {
-            vis[ch.vis_base + (uint64_t)sidx * 64 + lane] = 0;
-            if (lane == 0) { seg_exit[ch.seg_base + sidx] = sidx * PARSE_SEG; seg_count[ch.seg_base + sidx] = 0; }
-        }
-        return;
-    }
-    // ---- stage the bytes [w0, w0 + WIN_BYTES) and the candidates of [g0, g0 + WG_POS).  Both are copied on their own
-    //      dword grid (position p sits at LDS byte p - w0 + sh, its candidate at entry p - g0 + csh): plain aligned
-    //      dword loads, all of a batch in flight before the first LDS store — a loop of load / store pairs waits one
-    //      memory round trip per iteration (46 of them: 85 K cycles per workgroup, measured).
-    const uint32_t w0 = g0 > MAX_WINDOW ? g0 - MAX_WINDOW : 0u;
-    const uint64_t abs0 = (uint64_t)(in + ch.in_off) + w0;
-    const uint32_t sh = (uint32_t)abs0 & 3;
-    const uint64_t e0 = ch.in_off + g0;               // cd[] index of position g0
-    const uint32_t csh = (uint32_t)e0 & 1;
-    {
-        const gptr_u32 gw = (gptr_u32)(abs0 & ~3ull);
-        const uint64_t left = (uint64_t)in + in_bytes - (abs0 & ~3ull);                   // bytes up to the end of the input
-        const uint32_t hi = min(g0 + WG_POS + TAIL, n);                                    // (the compare never reads past the chunk)
-        const uint64_t want_dw = ((uint64_t)(hi - w0) + sh + 3) >> 2, have_dw = (left + 3) >> 2;
-        const uint32_t ndw = (uint32_t)(want_dw < have_dw ? want_dw : have_dw);
-        const gptr_u32 gc = (gptr_u32)(cd + (e0 - csh));
-        const uint32_t ncd = (min(WG_POS, end - g0) + csh + 1) >> 1;                       // dwords of candidates
-        constexpr uint32_t CB = (CD_BYTES / 4 + THREADS - 1) / THREADS;                    // 26 + 1
-        constexpr uint32_t WB = ((WIN_BYTES / 4 + THREADS - 1) / THREADS + 1) / 2;         // two batches of window dwords
-        // (branch-free: indices past the end are clamped to the last dword — a few redundant loads and stores of the same
-        //  value instead of 73 exec-mask round trips)
-        const uint32_t lastw = ndw - 1, lastc = ncd - 1;                                   // (ndw, ncd >= 1 here)
-        uint32_t cv[CB], wv[WB];
-#pragma unroll
-        for (uint32_t q = 0; q < CB; ++q) cv[q] = gc[min(q * THREADS + tid, lastc)];
-#pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) wv[q] = gw[min(q * THREADS + tid, lastw)];
-#pragma unroll
-        for (uint32_t q = 0; q < CB; ++q) cd32[min(q * THREADS + tid, lastc)] = cv[q];
-#pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) win32[min(q * THREADS + tid, lastw)] = wv[q];
-#pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) wv[q] = gw[min((WB + q) * THREADS + tid, lastw)];
-#pragma unroll
-        for (uint32_t q = 0; q < WB; ++q) win32[min((WB + q) * THREADS + tid, lastw)] = wv[q];
-    }
-    __syncthreads();
+    const ParseWg &wg = q.wg;
+    const ChunkDesc &ch = q.ch;
+    const uint32_t n = q.n, end = q.end, g0 = q.g0, w0 = q.w0, sh = q.sh, csh = q.csh;
     const uint64_t t1 = DBG ? clock64() : 0;
-
     const uint32_t sidx = wg.seg0 + wave;
     if (sidx >= ch.n_seg) return;
     const uint32_t s0 = sidx * PARSE_SEG;
@@ -419,9 +412,67 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
         }
         k += nc4;
     }
-    if (DBG && dbg && blockIdx.x == 1000 && lane == 0) {      // (a workgroup in the middle of the launch)
-        uint64_t *d = dbg + wave * 8;
-        d[0] = t1 - t0; d[1] = t2 - t1; d[2] = t3 - t2; d[3] = clock64() - t3;
+    if (DBG && stamps && lane == 0) { stamps[1] = t2 - t1; stamps[2] = t3 - t2; stamps[3] = clock64() - t3; }
+}
+
+template <bool DBG>
+__global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
+    const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
+    const ParseWg *__restrict__ wgs, uint32_t nwgs, const uint16_t *__restrict__ cd, uint32_t max_len,
+    uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit, uint32_t *__restrict__ seg_count,
+    uint32_t *__restrict__ stage, uint64_t *__restrict__ dbg) {
+    using namespace p2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    uint32_t *win32 = (uint32_t *)smem;
+    uint32_t *cd32 = (uint32_t *)(smem + OFF_CD);
+    u32x4 *winx = (u32x4 *)smem, *cdx = (u32x4 *)(smem + OFF_CD);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t dbg_slot = nwgs > 1000 ? 1000u : 0u;          // (a workgroup in the middle of the launch)
+
+    uint32_t slot = blockIdx.x;
+    WalkSlot q = walk_slot(slot, nwgs, in, in_bytes, chunks, wgs, cd);
+    u32x4 wv[WQ], cv[CQ];
+    // (branch-free: indices past the end are clamped to the last unit — a few redundant loads and stores of the same value)
+    if (q.kind == 2) {
+#pragma unroll
+        for (uint32_t k = 0; k < CQ; ++k) cv[k] = q.gc[min(k * THREADS + tid, q.lastc)];
+#pragma unroll
+        for (uint32_t k = 0; k < WQ; ++k) wv[k] = q.gw[min(k * THREADS + tid, q.lastw)];
+    }
+    while (slot < nwgs) {
+        const uint64_t t0 = DBG ? clock64() : 0;
+        // (the next slot's descriptors — two dependent scalar loads — are fetched beside the LDS stores)
+        const uint32_t nslot = slot + gridDim.x;
+        const WalkSlot qn = walk_slot(nslot, nwgs, in, in_bytes, chunks, wgs, cd);
+        if (q.kind == 2) {
+#pragma unroll
+            for (uint32_t k = 0; k < CQ; ++k) cdx[min(k * THREADS + tid, q.lastc)] = cv[k];
+#pragma unroll
+            for (uint32_t k = 0; k < WQ; ++k) winx[min(k * THREADS + tid, q.lastw)] = wv[k];
+        }
+        __syncthreads();
+        // the next slot's loads: in flight while this one is walked
+        if (qn.kind == 2) {
+#pragma unroll
+            for (uint32_t k = 0; k < CQ; ++k) cv[k] = qn.gc[min(k * THREADS + tid, qn.lastc)];
+#pragma unroll
+            for (uint32_t k = 0; k < WQ; ++k) wv[k] = qn.gw[min(k * THREADS + tid, qn.lastw)];
+        }
+        uint64_t *stamps = (DBG && dbg && slot == dbg_slot) ? dbg + wave * 8 : nullptr;
+        if (DBG && stamps && lane == 0) stamps[0] = clock64() - t0;
+        if (q.kind == 1) {
+            // nothing to walk (the chunk's last three bytes, or an empty chunk): the segments pass the walk through
+            const uint32_t sidx = q.wg.seg0 + wave;
+            if (sidx < q.ch.n_seg) {
+                vis[q.ch.vis_base + (uint64_t)sidx * 64 + lane] = 0;
+                if (lane == 0) { seg_exit[q.ch.seg_base + sidx] = sidx * PARSE_SEG; seg_count[q.ch.seg_base + sidx] = 0; }
+            }
+        } else if (q.kind == 2) {
+            walk_segment<DBG>(q, max_len, vis, seg_exit, seg_count, stage, win32, cd32, lane, wave, stamps);
+        }
+        __syncthreads();          // every wavefront is done with this slot's LDS
+        q = qn;
+        slot = nslot;
     }
 }
 
@@ -809,6 +860,20 @@ int launch_md_to_cd(hipStream_t st, const uint32_t *md, uint64_t n, uint16_t *cd
     return 0;
 }
 
+// workgroups of the persistent walk kernel: one per CU of the current device (read once)
+static uint32_t walk_grid() {
+    static uint32_t g = 0;
+    if (!g) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        const char *e = getenv("LFX_WALK_GRID");     // (experiments)
+        if (e && atoi(e) > 0) cus = atoi(e);
+        g = ((uint32_t)cus + 7) & ~7u;
+    }
+    return g;
+}
+
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
                  uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map, int stop_after,
@@ -819,11 +884,13 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs, *seg_mpos = seg_tmp + 4 * (size_t)nsegs;
     uint32_t *seg_kspec = seg_tmp + 5 * (size_t)nsegs;
     if (nwgs) {
+        // persistent: one workgroup per CU (153 KB of LDS), every grid-th slot; the grid a multiple of 8 so that a slot keeps its XCD
+        const uint32_t grid = std::min<uint32_t>((nwgs + 7) & ~7u, walk_grid());
         if (dbg)
-            hipLaunchKernelGGL(parse_walk_kernel<true>, dim3(nwgs), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, cd, max_len,
+            hipLaunchKernelGGL(parse_walk_kernel<true>, dim3(grid), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, nwgs, cd, max_len,
                                vis, seg_exit, seg_count, stage, dbg);
         else
-            hipLaunchKernelGGL(parse_walk_kernel<false>, dim3(nwgs), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, cd, max_len,
+            hipLaunchKernelGGL(parse_walk_kernel<false>, dim3(grid), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, nwgs, cd, max_len,
                                vis, seg_exit, seg_count, stage, dbg);
         LFX_LAUNCH_CHECK();
     }
