@@ -613,7 +613,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                             (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
                             (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map, 0,
                             mdbg ? mdbg + 256 : nullptr, fused_hist ? (uint32_t *)c->d_hist.p : nullptr, emit_per, emit_parts,
-                            want_checksum ? c->ev_fork : nullptr));
+                            want_checksum ? c->ev_fork : nullptr, d_match_flags));
     if (want_checksum) {
         // the first half of the container checksum's sweep: on the side stream from behind the walk kernel on, beside the
         // chaining kernels (one wavefront per segment and a handful of steps each: they leave most of the GPU idle); the

@@ -23,7 +23,8 @@ struct EncodeResult {
     uint32_t status;     // 0 ok, 1 capacity exceeded
     uint32_t crc32;
     uint32_t adler32;
-    uint32_t match_flags;  // bit 0: the second-generation match kernel saw an LDS lane-order violation (results void)
+    uint32_t match_flags;  // bit 0: the second-generation match kernel saw an LDS lane-order violation (results void);
+                           // bit 1: one of its segments held runs of equal bytes (its sample) — the parse walk takes its instance for such data
 };
 
 // one stream of a batch encode: where its bytes lie, where its output goes, which blocks of the merged plan are its own
@@ -71,7 +72,8 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                                              (launch_histogram is then not needed) */,
                  uint32_t emit_per = 0 /* with hist: segments per emit workgroup ... */,
                  uint32_t emit_parts = 0 /* ... and workgroups for the chunk of most segments (grid = nchunks x emit_parts) */,
-                 hipEvent_t ev_walked = nullptr /* recorded behind the walk kernel (in front of the chaining kernels) */);
+                 hipEvent_t ev_walked = nullptr /* recorded behind the walk kernel (in front of the chaining kernels) */,
+                 const uint32_t *mflags = nullptr /* EncodeResult::match_flags of this call (bit 1 picks the walk's instance) */);
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
                       uint32_t *tile_map, uint32_t *seg_map);
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,

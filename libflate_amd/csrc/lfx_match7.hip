@@ -253,6 +253,7 @@ __global__ __launch_bounds__(m7::THREADS) void lz77_match7_kernel(
         runs_mode = *cnt >= THREADS / 16;
         lds_barrier();
         if (tid == 0) *cnt = 0;
+        if (tid == 0 && runs_mode) atomicOr(flags, 2u);      // (tells the parse walk which of its instances this call's data wants)
     }
     lds_barrier();
 

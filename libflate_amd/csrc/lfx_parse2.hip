@@ -169,36 +169,11 @@ __device__ __forceinline__ uint32_t walk_step(const WalkCtx &w, uint32_t pos, bo
     return act ? (d ? 3u + l : 1u) : 0u;
 }
 
-// The true walk enters this lane's group at `in`.  Re-walk from there until it lands on a position the speculative walk
-// visited (mask, exit) — from there on both coincide — or leaves the group.  → the visited mask and the exit for THAT
-// entry.  `act` lanes take part (wave-uniform loops inside).
-__device__ __forceinline__ void resolve(const WalkCtx &w, bool act, uint32_t in, uint32_t a, uint32_t stop, uint64_t mask,
-                                        uint32_t exit_spec, uint64_t &m_out, uint32_t &x_out) {
-    uint64_t walked = 0;
-    uint32_t pos = in;
-    bool run = act;
-    uint64_t m = 0;
-    uint32_t x = in;                                   // (passed over: nothing visited, the walk goes on where it was)
-    for (uint32_t guard = 0; guard <= U + 1; ++guard) {               // (a group holds U positions: U + 1 rounds settle it)
-        if (run) {
-            if (pos >= stop) { m = walked; x = pos; run = false; }
-            else if ((mask >> (pos - a)) & 1) { m = walked | (mask & bits_from(pos - a)); x = exit_spec; run = false; }
-        }
-        if (!__ballot(run)) break;
-        const uint32_t st = walk_step(w, run ? pos : a, run);
-        walked |= run ? 1ull << (pos - a) : 0ull;
-        pos += st;
-    }
-    if (act) { m_out = m; x_out = x; }
-}
-
-
 // One walk step at a UNIFORM position by the whole wavefront: lane k compares bytes [4k, 4k + 4) behind the prefix, so one
 // LDS round trip settles a match of any length (the repair of the entry chain walks ONE group at a time: with a single
 // lane at work a 258-byte match cost six dependent round trips — that chain is what made the walk of low-entropy data,
 // BASELINE cfg5, three times as slow as a text's).
-__device__ __forceinline__ uint32_t walk_step_coop(const WalkCtx &w, uint32_t pos, uint32_t lane) {
-    const uint32_t d = w.cd16[pos - w.c0];                         // (one address: a broadcast read)
+__device__ __forceinline__ uint32_t walk_step_coop_d(const WalkCtx &w, uint32_t pos, uint32_t d, uint32_t lane) {
     if (d == 0) return 1;
     uint32_t lim = w.n - (pos + 3);                                 // default.rs:125
     lim = lim > w.max_len - 3 ? w.max_len - 3 : lim;
@@ -219,11 +194,50 @@ __device__ __forceinline__ uint32_t walk_step_coop(const WalkCtx &w, uint32_t po
     }
     return 3 + l;
 }
+__device__ __forceinline__ uint32_t walk_step_coop(const WalkCtx &w, uint32_t pos, uint32_t lane) {
+    return walk_step_coop_d(w, pos, w.cd16[pos - w.c0], lane);    // (one address: a broadcast read)
+}
+// Few lanes left at work (round 6): a wavefront's loop over walk steps costs its ~100 instructions per trip whatever the number of lanes
+// that still walk — on data with long literal stretches among long matches (BASELINE cfg5: a record seen for the first time is 64
+// literals, everything around it 258-byte matches) one lane took 52 trips and 63 lanes one or two.  When at most COOP_K lanes are left,
+// the wavefront finishes their groups one after the other, all lanes on ONE group: a stretch of literals is one ballot over the
+// group's candidates, a match one LDS round trip.
+// This way of finishing is a serial chain of LDS round trips — slower than the common loop for lanes that have a few steps left (a
+// text: any COOP_K made the walk slower, 8 by 20 %) — so it is taken only when a lane left has FAR to go (COOP_FAR positions, or
+// COOP_CODES code words in the emit loop), and the test is made every fourth trip (measured: cfg5 parse 6.23 -> 4.7 ms per GiB).
+#ifndef LFX_WALK_COOP_K
+#define LFX_WALK_COOP_K 16
+#endif
+#ifndef LFX_WALK_COOP_FAR
+#define LFX_WALK_COOP_FAR 16
+#endif
+constexpr uint32_t COOP_K = LFX_WALK_COOP_K, COOP_FAR = LFX_WALK_COOP_FAR, COOP_CODES = 12;
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t j) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)j) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)j) << 32;
+}
+// the speculative walk of ONE group [ja, jstop) from position p on (everything uniform) → the positions visited, the exit
+__device__ __forceinline__ void spec_one(const WalkCtx &w, uint32_t lane, uint32_t p, uint32_t ja, uint32_t jstop, uint64_t &m_out,
+                                         uint32_t &x_out) {
+    const uint32_t width = jstop - ja;                                       // <= U < 64
+    const uint32_t D = lane < width ? w.cd16[ja + lane - w.c0] : 0u;         // the group's candidates, a lane each
+    const uint64_t nzall = __ballot(D != 0);
+    uint64_t mj = 0;
+    for (uint32_t guard = 0; guard <= U && p < jstop; ++guard) {
+        const uint32_t r = p - ja;
+        const uint64_t nz = nzall & bits_from(r);
+        if (!nz) { mj |= bits_from(r) & ((1ull << width) - 1); p = jstop; break; }     // literals up to the group's end
+        const uint32_t f = (uint32_t)__builtin_ctzll(nz);
+        mj |= bits_from(r) & ((2ull << f) - 1);                               // literals [r, f) and the match at f
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)D, (int)f);
+        p = ja + f + walk_step_coop_d(w, ja + f, d, lane);
+    }
+    m_out = mj; x_out = p;
+}
 // resolve() for ONE group with everything uniform (the group's first position a, its end, its speculative mask and exit):
 // the true walk enters at `in` → the visited mask and the exit for that entry
 __device__ __forceinline__ void resolve_one(const WalkCtx &w, uint32_t lane, uint32_t in, uint32_t a, uint32_t stop, uint64_t mask,
-                                            uint32_t exit_spec, uint64_t &m_out, uint32_t &x_out) {
-    uint64_t walked = 0;
+                                            uint32_t exit_spec, uint64_t &m_out, uint32_t &x_out, uint64_t walked = 0) {
     uint32_t pos = in;
     for (uint32_t guard = 0; guard <= U + 1; ++guard) {
         if (pos >= stop) { m_out = walked; x_out = pos; return; }
@@ -233,6 +247,45 @@ __device__ __forceinline__ void resolve_one(const WalkCtx &w, uint32_t lane, uin
     }
     m_out = walked; x_out = pos;
 }
+
+// The true walk enters this lane's group at `in`.  Re-walk from there until it lands on a position the speculative walk
+// visited (mask, exit) — from there on both coincide — or leaves the group.  → the visited mask and the exit for THAT
+// entry.  `act` lanes take part (wave-uniform loops inside).
+template <bool COOP>
+__device__ __forceinline__ void resolve(const WalkCtx &w, bool act, uint32_t in, uint32_t a, uint32_t stop, uint64_t mask,
+                                        uint32_t exit_spec, uint64_t &m_out, uint32_t &x_out) {
+    uint64_t walked = 0;
+    uint32_t pos = in;
+    bool run = act;
+    uint64_t m = 0;
+    uint32_t x = in;                                   // (passed over: nothing visited, the walk goes on where it was)
+    for (uint32_t guard = 0; guard <= U + 1; ++guard) {               // (a group holds U positions: U + 1 rounds settle it)
+        if (run) {
+            if (pos >= stop) { m = walked; x = pos; run = false; }
+            else if ((mask >> (pos - a)) & 1) { m = walked | (mask & bits_from(pos - a)); x = exit_spec; run = false; }
+        }
+        const uint64_t left = __ballot(run);
+        if (!left) break;
+        if (COOP && (guard & 3) == 3 && (uint32_t)__popcll(left) <= COOP_K && __ballot(run && stop - pos >= COOP_FAR)) {
+            for (uint64_t todo = left; todo; todo &= todo - 1) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                uint64_t mj = 0;
+                uint32_t xj = 0;
+                resolve_one(w, __lane_id(), (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)j), (uint32_t)__builtin_amdgcn_readlane((int)a, (int)j),
+                            (uint32_t)__builtin_amdgcn_readlane((int)stop, (int)j), readlane64(mask, j),
+                            (uint32_t)__builtin_amdgcn_readlane((int)exit_spec, (int)j), mj, xj, readlane64(walked, j));
+                if (__lane_id() == j) { m = mj; x = xj; }
+            }
+            break;
+        }
+        const uint32_t st = walk_step(w, run ? pos : a, run);
+        walked |= run ? 1ull << (pos - a) : 0ull;
+        pos += st;
+    }
+    if (act) { m_out = m; x_out = x; }
+}
+
+
 
 }  // namespace p2
 
@@ -283,7 +336,7 @@ __device__ __forceinline__ WalkSlot walk_slot(uint32_t slot, uint32_t nwgs, cons
 // (gridDim.x a multiple of 8: a slot stays on the XCD the order gave it to) — and the 16-byte loads of the NEXT slot's bytes
 // and candidates are in flight while the wavefronts walk the current one (52 registers per lane); they reach LDS behind the
 // barrier that ends the walk.  Before, a workgroup's first 9 K of its 39 K cycles were the fill, with nothing else on the CU.
-template <bool DBG>
+template <bool DBG, bool COOP>
 __device__ __forceinline__ void walk_segment(const WalkSlot &q, uint32_t max_len, uint64_t *__restrict__ vis,
                                              uint32_t *__restrict__ seg_exit, uint32_t *__restrict__ seg_count,
                                              uint32_t *__restrict__ stage, const uint32_t *win32, const uint32_t *cd32,
@@ -321,7 +374,19 @@ __device__ __forceinline__ void walk_segment(const WalkSlot &q, uint32_t max_len
     uint32_t pos = a;
     for (uint32_t guard = 0; guard <= U; ++guard) {
         const bool run = have && pos < stop;
-        if (!__ballot(run)) break;
+        const uint64_t left = __ballot(run);
+        if (!left) break;
+        if (COOP && (guard & 3) == 3 && (uint32_t)__popcll(left) <= COOP_K && __ballot(run && stop - pos >= COOP_FAR)) {
+            for (uint64_t todo = left; todo; todo &= todo - 1) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t ja = s0 + j * U;
+                uint64_t mj = 0;
+                uint32_t xj = 0;
+                spec_one(w, lane, (uint32_t)__builtin_amdgcn_readlane((int)pos, (int)j), ja, min(ja + U, s1), mj, xj);
+                if (lane == j) { mask |= mj; pos = xj; }
+            }
+            break;
+        }
         const uint32_t st = walk_step(w, run ? pos : a, run);
         mask |= run ? 1ull << (pos - a) : 0ull;
         pos += st;
@@ -334,7 +399,7 @@ __device__ __forceinline__ void walk_segment(const WalkSlot &q, uint32_t max_len
     if (lane == 0) used_in = a;
     uint64_t m_fin = mask;
     uint32_t x_fin = exit_spec;
-    resolve(w, have && lane != 0, used_in, a, stop, mask, exit_spec, m_fin, x_fin);
+    resolve<COOP>(w, have && lane != 0, used_in, a, stop, mask, exit_spec, m_fin, x_fin);
     // ---- ... and verify the chain: lane 0's entry is the segment's first position by definition, so every lane in front
     //      of the first one whose assumed entry is not its predecessor's exit is exact.  Repair that lane with its true
     //      entry and look again (strictly increasing: at most nact rounds; none on text, one per jumped-over group on
@@ -380,7 +445,27 @@ __device__ __forceinline__ void walk_segment(const WalkSlot &q, uint32_t max_len
     // width, so a quarter of the store instructions is a quarter of the line transactions.
     uint64_t m = m_fin;
     uint32_t k = 0;
-    for (uint32_t guard = 0; guard < 16 && __ballot(m != 0); ++guard) {
+    for (uint32_t guard = 0; guard < 16; ++guard) {
+        const uint64_t left = __ballot(m != 0);
+        if (!left) break;
+        if (COOP && (guard & 1) && (uint32_t)__popcll(left) <= COOP_K && __ballot((uint32_t)__popcll(m) >= COOP_CODES)) {
+            // few lanes left with code words: their groups one after the other, a lane per POSITION
+            for (uint64_t todo = left; todo; todo &= todo - 1) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(todo);
+                const uint64_t mj = readlane64(m, j);
+                const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)(incl - cnt + k), (int)j);
+                const uint32_t xj = (uint32_t)__builtin_amdgcn_readlane((int)x_fin, (int)j);
+                if ((mj >> lane) & 1) {
+                    const uint32_t i = s0 + j * U + lane;
+                    const uint64_t above = lane < 63 ? mj >> (lane + 1) : 0ull;
+                    const uint32_t nxt = above ? i + 1 + (uint32_t)__builtin_ctzll(above) : xj;
+                    const uint32_t d = w.cd16[i - w.c0];
+                    const uint32_t code = d ? ((nxt - i) << 16) | d : (uint32_t)win8[i - w.w0] << 16;
+                    stage[ch.in_off + s0 + kj + __popcll(mj & lanemask_lt())] = code;
+                }
+            }
+            break;
+        }
         // the (up to) four positions and their successors come from the mask alone; all eight LDS loads are issued before
         // the first use (one round trip per four code words: issued one by one they cost 2000-3500 cycles per round)
         uint32_t pp[4], nx[4], dd[4], bb[4];
@@ -420,9 +505,11 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
     const uint8_t *__restrict__ in, uint64_t in_bytes, const ChunkDesc *__restrict__ chunks,
     const ParseWg *__restrict__ wgs, uint32_t nwgs, const uint16_t *__restrict__ cd, uint32_t max_len,
     uint64_t *__restrict__ vis, uint32_t *__restrict__ seg_exit, uint32_t *__restrict__ seg_count,
-    uint32_t *__restrict__ stage, uint64_t *__restrict__ dbg) {
+    uint32_t *__restrict__ stage, const uint32_t *__restrict__ mflags, uint64_t *__restrict__ dbg) {
     using namespace p2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+    // (bit 1 of the match stage's flags: a segment of this call held runs of equal bytes — lfx_match7.hip's sample)
+    const bool coop = mflags && (*mflags & 2u);
     uint32_t *win32 = (uint32_t *)smem;
     uint32_t *cd32 = (uint32_t *)(smem + OFF_CD);
     u32x4 *winx = (u32x4 *)smem, *cdx = (u32x4 *)(smem + OFF_CD);
@@ -468,7 +555,9 @@ __global__ __launch_bounds__(p2::THREADS) void parse_walk_kernel(
                 if (lane == 0) { seg_exit[q.ch.seg_base + sidx] = sidx * PARSE_SEG; seg_count[q.ch.seg_base + sidx] = 0; }
             }
         } else if (q.kind == 2) {
-            walk_segment<DBG>(q, max_len, vis, seg_exit, seg_count, stage, win32, cd32, lane, wave, stamps);
+            // two instances: the tests of the cooperative finish cost a text's loops 2 to 10 % and never fire there
+            if (coop) walk_segment<DBG, true>(q, max_len, vis, seg_exit, seg_count, stage, win32, cd32, lane, wave, stamps);
+            else walk_segment<DBG, false>(q, max_len, vis, seg_exit, seg_count, stage, win32, cd32, lane, wave, stamps);
         }
         __syncthreads();          // every wavefront is done with this slot's LDS
         q = qn;
@@ -877,7 +966,7 @@ static uint32_t walk_grid() {
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
                  uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map, int stop_after,
-                 uint64_t *dbg, uint32_t *hist, uint32_t emit_per, uint32_t emit_parts, hipEvent_t ev_walked) {
+                 uint64_t *dbg, uint32_t *hist, uint32_t emit_per, uint32_t emit_parts, hipEvent_t ev_walked, const uint32_t *mflags) {
     if (nchunks == 0) return 0;
     // seg_tmp: six arrays of nsegs words
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
@@ -888,10 +977,10 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
         const uint32_t grid = std::min<uint32_t>((nwgs + 7) & ~7u, walk_grid());
         if (dbg)
             hipLaunchKernelGGL(parse_walk_kernel<true>, dim3(grid), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, nwgs, cd, max_len,
-                               vis, seg_exit, seg_count, stage, dbg);
+                               vis, seg_exit, seg_count, stage, mflags, dbg);
         else
             hipLaunchKernelGGL(parse_walk_kernel<false>, dim3(grid), dim3(p2::THREADS), 0, st, in, in_bytes, chunks, wgs, nwgs, cd, max_len,
-                               vis, seg_exit, seg_count, stage, dbg);
+                               vis, seg_exit, seg_count, stage, mflags, dbg);
         LFX_LAUNCH_CHECK();
     }
     // (the caller's side stream — the container checksum — starts here: beside the chaining kernels, which leave the GPU
