@@ -170,6 +170,36 @@ def test_encode_parity_options(ctx, ffi, oracle, synth):
     assert enc(ctx, ffi, ffi.GZIP, c["test_i"], 8192, **kw) == oracle.encode(oracle.GZIP, c["test_i"], 8192, **kw)
 
 
+def test_encode_parity_literal_stretches_among_long_matches(ctx, ffi, oracle, synth):
+    """The parse walk's instance for data with runs (picked by the match stage's sample; `parse_walk_kernel`'s cooperative finish):
+    a few lanes of a wavefront walk long literal stretches while the others take one 258-byte step.  Literal stretches of every
+    length 1..130 between runs, at every phase of the 52-position groups and across the 3328-position segments, runs that end
+    inside / at / behind a group; text and run regions in one call (one instance for all of it); a run region behind 200 KB of
+    text (the sample that picks the instance sees only part of the input)."""
+    rng = np.random.default_rng(5252)
+    parts = []
+    for k in range(1, 131):
+        parts.append(bytes([k & 0xFF]) * int(rng.integers(40, 700)))
+        parts.append(rng.integers(0, 256, k, dtype=np.uint8).tobytes())            # k literals (random bytes: no matches)
+    stretches = b"".join(parts)
+    phased = b"".join(bytes(300 + ph) + rng.integers(0, 256, 52 + ph % 7, dtype=np.uint8).tobytes() for ph in range(0, 3400, 37))
+    text = synth.text(400000).tobytes()
+    low = synth.lowent(500000, seed=0x5EED00AA).tobytes()
+    cases = {
+        "stretches": stretches,
+        "phased": phased,
+        "text_then_runs": text[:200000] + low[:300000] + text[200000:] + bytes(70000) + stretches,
+        "runs_then_text": low + text,
+        "zeros_literal_zeros": bytes(100000) + rng.integers(0, 256, 64, dtype=np.uint8).tobytes() + bytes(100000),
+    }
+    for name, data in cases.items():
+        for ws in (0, 8192, 3000):
+            got = enc(ctx, ffi, ffi.ZLIB, data, ws)
+            assert got == oracle.encode(ffi.ZLIB, data, write_size=ws), (name, ws, len(data), len(got))
+            rc, out, used, msg = ctx.decode_host(ffi.ZLIB, got)
+            assert rc == 0 and out == data, (name, ws, rc, msg)
+
+
 def test_encode_parity_write_lists(ctx, ffi, oracle, synth, lfx):
     data = synth.text(700000).tobytes()
     rng = np.random.default_rng(8)
