@@ -44,10 +44,17 @@ HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec.  The peak a
 # and compaction kernels are the rest of that bracket)
 PHASE_KERNEL = {"enc:lz77_match": "lz77_match7_kernel", "dec:lz77_copy": "blk_materialize2_kernel",
                 "dec:blk_scan": "blk_scan_kernel", "dec:blk_emit": "blk_emit_kernel", "enc:lz77_parse": "parse_walk_kernel",
+                # (timing level 6, the main record: the encode's match and parse phases split by kernel)
+                "enc:lz77_cand": "lz77_match7_kernel", "enc:lz77_resolve": "lz77_resolve7_kernel", "enc:lz77_walk": "parse_walk_kernel",
+                "enc:lz77_chain": "parse_emit_hist_kernel",
                 "dec:find1": "find_blocks_stage1", "dec:find2": "find_blocks_stage2", "enc:pack": "pack_kernel",
                 "dec:batch_copy": "blk_materialize2_kernel", "dec:fast": "blk_scan_kernel"}
 # resident wavefronts per SIMD of those kernels (workgroup size x workgroups per CU / 4), for measure_bound
-PHASE_WAVES_PER_SIMD = {"enc:lz77_match": 4, "dec:lz77_copy": 4, "dec:blk_scan": 4, "dec:blk_emit": 4, "enc:lz77_parse": 3}
+PHASE_WAVES_PER_SIMD = {"enc:lz77_match": 4, "dec:lz77_copy": 4, "dec:blk_scan": 4, "dec:blk_emit": 4, "enc:lz77_parse": 3,
+                        "enc:lz77_cand": 4, "enc:lz77_walk": 3}
+# lfx_ctx_enable_timing levels that carry only the two events around ONE phase (the timed steps: that of the dominant kernel)
+PHASE_BRACKET_LEVEL = {"enc:lz77_walk": 2, "dec:blk_scan": 3, "enc:lz77_cand": 4, "dec:lz77_copy": 5}
+TIMING_FINE = 6
 CALIBRATION_KERNEL = "checksum_span_kernel"   # reads its input exactly once with wide coalesced loads
 
 
@@ -655,7 +662,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(local)
     ctx = libflate_amd.Context(local)
-    ctx.enable_timing(True)
+    ctx.enable_timing(TIMING_FINE)
     n = args.bytes if args.scaling == "weak" else strong_share(args.bytes, world)
     data = synth.text(n, seed=synth.SEED_BASE + 2 + rank)
     d_in = torch.from_numpy(data).to(dev)
@@ -765,6 +772,17 @@ def main():
             self.step_s = []
             for _ in range(warmup):
                 self.step()
+            # which phase is the longest kernel's?  (one fully instrumented step; its events go nowhere else)
+            self.bracket_level, self.bracket_phase = 2, "enc:lz77_walk"
+            if record:
+                keep, self.phase_acc = self.phase_acc, {}
+                ctx.enable_timing(TIMING_FINE)
+                self.step(record=True)
+                one = {k: v[-1] for k, v in self.phase_acc.items() if k in PHASE_BRACKET_LEVEL}
+                self.phase_acc = keep
+                if one:
+                    self.bracket_phase = max(one, key=one.get)
+                    self.bracket_level = PHASE_BRACKET_LEVEL[self.bracket_phase]
             self.gather_alone_s = None
             if sharded_path and record:
                 ga = min(self.gather_alone() for _ in range(2))
@@ -775,10 +793,10 @@ def main():
             if dist:
                 dist.barrier()
             torch.cuda.synchronize()
-            # The timed steps carry TWO events per step (timing level 2: around the encode's parse phase, the dominant kernel's
-            # bracket) — an event record between two kernels is ~6 us of idle GPU (kernel trace), and the two dozen of a fully
+            # The timed steps carry TWO events per step (timing levels 2..5: around the phase of the longest kernel, picked above)
+            # — an event record between two kernels is ~6 us of idle GPU (kernel trace), and the two dozen of a fully
             # instrumented step were 3 % of it.  Every phase is measured in extra, untimed steps behind the loop.
-            ctx.enable_timing(2 if record else False)
+            ctx.enable_timing(self.bracket_level if record else False)
             t_start = time.perf_counter()
             enc_t = dec_t = 0.0
             for _ in range(steps):
@@ -790,9 +808,9 @@ def main():
             if dist:
                 dist.barrier()
             elapsed = time.perf_counter() - t_start
-            self.phase_timed = self.phase_acc           # {"enc:lz77_parse": [...]} from the timed steps
+            self.phase_timed = {k: v for k, v in self.phase_acc.items() if k == self.bracket_phase}   # from the timed steps
             self.phase_acc = {}
-            ctx.enable_timing(True)
+            ctx.enable_timing(TIMING_FINE)
             if record:
                 keep = self.finish_s
                 for _ in range(max(2, min(5, steps))):
@@ -877,7 +895,7 @@ def main():
                 "avg_launch_ms": round(avg[dom], 4), "algorithmic_bytes": algo_bytes,
                 "avg_launch_how": ("HIP events around this phase in the %d timed steps" % args.steps if dom_from_timed else
                                    "HIP events in extra, fully instrumented steps behind the timed loop (the timed steps only carry "
-                                   "the events of enc:lz77_parse)")}
+                                   "the events of " + str(getattr(run, "bracket_phase", None)) + ")")}
         if under_profiler():
             roof["traffic_error"] = "not measured: this run is itself under a profiler"
         elif world == 1 and not args.no_traffic and dom in PHASE_KERNEL:
@@ -994,7 +1012,11 @@ def main():
         "decode_GBps": round(total_bytes * args.steps / dec_t / 1e9, 4),
         "phases_ms": {k: round(v, 4) for k, v in sorted(avg.items())},
         "phases_ms_how": "HIP events behind every phase in extra steps behind the timed loop (an event record between two kernels costs "
-                         "~6 us of idle GPU: the timed steps carry only the two around enc:lz77_parse, whose figure here is theirs)",
+                         "~6 us of idle GPU: the timed steps carry only the two around the longest kernel's phase — " +
+                         str(getattr(run, "bracket_phase", None)) + ", picked from one instrumented step in front of them — whose figure "
+                         "here is theirs); the encode's match and parse phases are split by kernel (timing level 6): lz77_cand = "
+                         "lz77_match7_kernel, lz77_resolve = compaction + resolver, lz77_walk = parse_walk_kernel, lz77_chain = parse_fixseg + "
+                         "parse_fix + parse_emit_hist",
         "roofline": roof, "whole_path": whole, "schedule_S1" if args.schedule == "S8K" else "schedule_S8K": s1,
         "other_configs": subs,
         "pcie_inclusive": pcie,

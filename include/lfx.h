@@ -409,8 +409,11 @@ typedef struct lfx_timing {
 uint64_t lfx_ctx_match_fallbacks(const lfx_ctx *c);
 int lfx_ctx_last_timing(lfx_ctx *c, lfx_timing *t);
 void lfx_ctx_enable_timing(lfx_ctx *c, int on);   /* 0: off; 1: a HIP event behind every phase of a call (lfx_ctx_last_timing);
-                                                      2: only the two events around an encode's parse phase — an event record between
-                                                      two kernels costs ~6 us of idle GPU */
+                                                      2..5: only the two events around ONE kernel's phase — an event record between
+                                                      two kernels costs ~6 us of idle GPU — 2: lz77_walk (parse_walk_kernel),
+                                                      3: blk_scan, 4: lz77_cand (lz77_match7_kernel), 5: lz77_copy;
+                                                      6: as 1, with the encode's match and parse phases split by kernel
+                                                      (lz77_cand + lz77_resolve, lz77_walk + lz77_chain) */
 uint32_t lfx_version(void);
 
 #ifdef __cplusplus

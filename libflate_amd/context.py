@@ -34,8 +34,9 @@ class Context:
         _ffi.lib().lfx_ctx_set_stream(self._h, hip_stream_ptr)
 
     def enable_timing(self, on=True):
-        """True / 1: an event behind every phase; 2: only the events around an encode's parse phase; False / 0: none."""
-        _ffi.lib().lfx_ctx_enable_timing(self._h, 2 if on == 2 and on is not True else (1 if on else 0))
+        """True / 1: an event behind every phase; 2..5: only the two events around one kernel's phase (2: lz77_walk, 3: blk_scan,
+        4: lz77_cand, 5: lz77_copy); 6: every phase, the encode's match and parse phases split by kernel; False / 0: none."""
+        _ffi.lib().lfx_ctx_enable_timing(self._h, int(on) if on is not True and on is not False and 2 <= int(on) <= 6 else (1 if on else 0))
 
     def last_timing(self):
         t = _ffi.Timing()

@@ -253,7 +253,12 @@ void Diag::read() {
 
 void Ctx::phase(const char *name) {
     if (!timing_on) return;
-    if (timing_on == 2 && strcmp(name, "lz77_match") != 0 && strcmp(name, "lz77_parse") != 0) return;
+    if (timing_on >= 2 && timing_on <= 5) {
+        // only the event in front of ONE kernel's phase and the one behind it
+        static const char *const pair[4][2] = {{"lz77_resolve", "lz77_walk"}, {"find2", "blk_scan"}, {"upload", "lz77_cand"}, {"blk_emit", "lz77_copy"}};
+        const char *const *pr = pair[timing_on - 2];
+        if (strcmp(name, pr[0]) != 0 && strcmp(name, pr[1]) != 0) return;
+    }
     if (n_ev >= 17) return;
     if (!ev[n_ev]) (void)hipEventCreate(&ev[n_ev]);
     (void)hipEventRecord(ev[n_ev], stream);
@@ -340,7 +345,7 @@ extern "C" void lfx_ctx_set_stream(lfx_ctx *cc, void *s) {
 extern "C" uint64_t lfx_ctx_match_fallbacks(const lfx_ctx *cc) {
     return cc ? reinterpret_cast<const Ctx *>(cc)->match_fallbacks : 0;
 }
-extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on == 2 ? 2 : on != 0; }
+extern "C" void lfx_ctx_enable_timing(lfx_ctx *cc, int on) { reinterpret_cast<Ctx *>(cc)->timing_on = on >= 2 && on <= 6 ? on : on != 0; }
 extern "C" int lfx_ctx_last_timing(lfx_ctx *cc, lfx_timing *t) try {
     Ctx *c = reinterpret_cast<Ctx *>(cc);
     std::lock_guard<std::recursive_mutex> lock(c->mu);
@@ -528,6 +533,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                 const uint32_t s0 = (uint32_t)((uint64_t)ns * k / parts), s1 = (uint32_t)((uint64_t)ns * (k + 1) / parts);
                 LAUNCH_TRY(launch_match7(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, dsegs + s0, s1 - s0, po.window_size, d_cd,
                                          d_glnk, d_umask, d_match_flags, k == 0 ? mdbg : nullptr));
+                if (parts == 1 && c->timing_fine()) c->phase("lz77_cand");
                 hipStream_t rs = parts > 1 ? c->side_stream : st;
                 if (parts > 1) {
                     HIP_TRY(hipEventRecord(c->ev_part[k], st));
@@ -570,7 +576,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
                         (unsigned)(hv[w * 8 + 3] >> 32), (unsigned)hv[w * 8 + 4], (unsigned)(hv[w * 8 + 4] >> 32));
         }
     }
-    c->phase("lz77_match");
+    c->phase(c->timing_fine() ? "lz77_resolve" : "lz77_match");
     if (c->diag.debug && getenv("LFX_DUMP_SEG")) {
         // diagnostics: the parse state of one segment behind the walk, behind fixseg and at the end
         const uint32_t sg = (uint32_t)atoi(getenv("LFX_DUMP_SEG"));
@@ -609,11 +615,15 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
         emit_per = per;
         emit_parts = (uint32_t)parts;
     }
-    LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const ParseWg *)c->d_pwgs.p,
-                            (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
-                            (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map, 0,
-                            mdbg ? mdbg + 256 : nullptr, fused_hist ? (uint32_t *)c->d_hist.p : nullptr, emit_per, emit_parts,
-                            want_checksum ? c->ev_fork : nullptr, d_match_flags));
+    // (fine timing: the walk kernel in a bracket of its own — the same launches in two calls)
+    for (int part = c->timing_fine() ? 1 : 0; part <= (c->timing_fine() ? 2 : 0); part++) {
+        LAUNCH_TRY(launch_parse(st, d_in, n, (const ChunkDesc *)c->d_chunks.p, nchunks, plan.n_segs, (const ParseWg *)c->d_pwgs.p,
+                                (uint32_t)pwgs.size(), d_cd, po.max_length, (uint64_t *)c->d_vis.p, (uint32_t *)c->d_segtmp.p,
+                                (uint32_t *)c->d_codes.p, (uint32_t *)c->d_ncodes.p, (uint32_t *)c->d_stage.p, seg_map, part == 1 ? 1 : 0,
+                                mdbg ? mdbg + 256 : nullptr, fused_hist ? (uint32_t *)c->d_hist.p : nullptr, emit_per, emit_parts,
+                                want_checksum ? c->ev_fork : nullptr, d_match_flags, part == 2 ? 1 : 0));
+        if (part == 1) c->phase("lz77_walk");
+    }
     if (want_checksum) {
         // the first half of the container checksum's sweep: on the side stream from behind the walk kernel on, beside the
         // chaining kernels (one wavefront per segment and a handful of steps each: they leave most of the GPU idle); the
@@ -632,7 +642,7 @@ int encode_prepare(Ctx *c, const Plan &plan, const PlanOpts &po, const uint8_t *
             fprintf(stderr, "[lfx] walk wave%d: fill=%llu spec=%llu resolve+chain=%llu emit=%llu cycles\n", w, (unsigned long long)hv[w * 8],
                     (unsigned long long)hv[w * 8 + 1], (unsigned long long)hv[w * 8 + 2], (unsigned long long)hv[w * 8 + 3]);
     }
-    c->phase("lz77_parse");
+    c->phase(c->timing_fine() ? "lz77_chain" : "lz77_parse");
     }   // !hc
     if (want_checksum) {
         // the container checksum reads only the input: it runs on the side stream, beside the parse's chaining kernels

@@ -178,8 +178,11 @@ struct Ctx {
     bool shard_last = false;
 
     // phase timers
-    int timing_on = 0;      // 0: no events; 1: an event behind every phase; 2: only the events around the parse phase (the bench's timed steps:
-                            // an event record between two kernels is ~6 us of idle GPU, two dozen of them 3 % of a 256 MiB round trip)
+    int timing_on = 0;      // 0: no events; 1: an event behind every phase; 2..5: only the two events around ONE kernel's phase (the bench's
+                            // timed steps: an event record between two kernels is ~6 us of idle GPU, two dozen of them 3 % of a 256 MiB
+                            // round trip) — 2: lz77_walk, 3: blk_scan, 4: lz77_cand, 5: lz77_copy; 6: every phase, the encode's match and
+                            // parse phases split by kernel (lz77_cand + lz77_resolve for lz77_match, lz77_walk + lz77_chain for lz77_parse)
+    bool timing_fine() const { return timing_on >= 2; }
     hipEvent_t ev[17] = {};
     char ev_name[17][24] = {};
     int n_ev = 0;

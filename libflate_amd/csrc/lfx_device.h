@@ -73,7 +73,8 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                  uint32_t emit_per = 0 /* with hist: segments per emit workgroup ... */,
                  uint32_t emit_parts = 0 /* ... and workgroups for the chunk of most segments (grid = nchunks x emit_parts) */,
                  hipEvent_t ev_walked = nullptr /* recorded behind the walk kernel (in front of the chaining kernels) */,
-                 const uint32_t *mflags = nullptr /* EncodeResult::match_flags of this call (bit 1 picks the walk's instance) */);
+                 const uint32_t *mflags = nullptr /* EncodeResult::match_flags of this call (bit 1 picks the walk's instance) */,
+                 int start_at = 0 /* 1: the walk kernel has been launched (by a call with stop_after = 1): the chaining kernels only */);
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
                       uint32_t *tile_map, uint32_t *seg_map);
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,

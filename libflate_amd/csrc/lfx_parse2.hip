@@ -966,13 +966,14 @@ static uint32_t walk_grid() {
 int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const ChunkDesc *chunks, uint32_t nchunks,
                  uint32_t nsegs, const ParseWg *wgs, uint32_t nwgs, const uint16_t *cd, uint32_t max_len, uint64_t *vis,
                  uint32_t *seg_tmp, uint32_t *codes, uint32_t *ncodes, uint32_t *stage, const uint32_t *seg_map, int stop_after,
-                 uint64_t *dbg, uint32_t *hist, uint32_t emit_per, uint32_t emit_parts, hipEvent_t ev_walked, const uint32_t *mflags) {
+                 uint64_t *dbg, uint32_t *hist, uint32_t emit_per, uint32_t emit_parts, hipEvent_t ev_walked, const uint32_t *mflags,
+                 int start_at) {
     if (nchunks == 0) return 0;
     // seg_tmp: six arrays of nsegs words
     uint32_t *seg_exit = seg_tmp, *seg_count = seg_tmp + nsegs, *seg_off = seg_tmp + 2 * (size_t)nsegs;
     uint32_t *seg_exit2 = seg_tmp + 3 * (size_t)nsegs, *seg_mpos = seg_tmp + 4 * (size_t)nsegs;
     uint32_t *seg_kspec = seg_tmp + 5 * (size_t)nsegs;
-    if (nwgs) {
+    if (nwgs && start_at < 1) {
         // persistent: one workgroup per CU (153 KB of LDS), every grid-th slot; the grid a multiple of 8 so that a slot keeps its XCD
         const uint32_t grid = std::min<uint32_t>((nwgs + 7) & ~7u, walk_grid());
         if (dbg)
@@ -985,8 +986,8 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     }
     // (the caller's side stream — the container checksum — starts here: beside the chaining kernels, which leave the GPU
     //  mostly idle, instead of behind all of the parse)
-    if (ev_walked && hipEventRecord(ev_walked, st) != hipSuccess) return (int)hipGetLastError();
-    if (stop_after == 1) return 0;      // (LFX_DEBUG dumps)
+    if (start_at < 1 && ev_walked && hipEventRecord(ev_walked, st) != hipSuccess) return (int)hipGetLastError();
+    if (stop_after == 1) return 0;      // (LFX_DEBUG dumps; the walk's own bracket of the fine phase timing)
     if (nsegs) {
         hipLaunchKernelGGL(parse_fixseg_kernel, dim3(nsegs), dim3(64), 0, st, in, in_bytes, chunks, cd, max_len, vis, seg_exit,
                            seg_count, seg_exit2, seg_mpos, seg_kspec, seg_map);
