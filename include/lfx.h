@@ -87,6 +87,9 @@ typedef struct lfx_schedule {
 /* ---- device context (one per GPU; owns a HIP stream + cached scratch in HBM) ------------- */
 typedef struct lfx_ctx lfx_ctx;
 lfx_ctx *lfx_ctx_new(int device, int *status);
+/* Every handle made from a context (lfx_encoder, lfx_decoder, lfx_lz77, a sharded encode in flight) uses it until that handle is
+ * freed — free the handles first.  (The Rust crate's handles hold an Arc<Context>; the Python wrappers count themselves in and out
+ * of their Context, because a garbage collector runs the finalizers of one unreachable group in an undefined order.) */
 void lfx_ctx_free(lfx_ctx *c);
 const char *lfx_ctx_last_error(const lfx_ctx *c);
 /* use the caller's HIP stream (hipStream_t as void*) instead of the context's own */

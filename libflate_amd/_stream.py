@@ -38,6 +38,7 @@ class _EncoderBase:
                                              self._fcb, None, C.byref(st))
         if not self._h:
             raise StreamError(st.value, "encoder construction failed (status %d)" % st.value)
+        self._ctx._retain()
 
     def _on_write(self, _user, p, n):
         try:
@@ -99,8 +100,7 @@ class _EncoderBase:
             self._close_block(2)
         rc = _ffi.lib().lfx_encoder_finish(self._h)
         msg = self._err()
-        _ffi.lib().lfx_encoder_free(self._h)
-        self._h = None
+        self._free()
         if rc:
             raise StreamError(rc, msg)
         return self._inner
@@ -109,18 +109,22 @@ class _EncoderBase:
         return self._inner
 
     def into_inner(self):
-        if self._h:
-            _ffi.lib().lfx_encoder_free(self._h)
-            self._h = None
+        self._free()
         return self._inner
 
     def _err(self):
         return (_ffi.lib().lfx_encoder_last_error(self._h) or b"").decode("utf-8", "replace")
 
-    def __del__(self):
+    def _free(self):
+        """frees the native handle, then lets go of the context (Context._retain / _release: the context outlives its handles
+        whatever the order of the finalizers)"""
         if getattr(self, "_h", None):
             _ffi.lib().lfx_encoder_free(self._h)
             self._h = None
+            self._ctx._release()
+
+    def __del__(self):
+        self._free()
 
 
 class _DecoderBase:
@@ -140,6 +144,7 @@ class _DecoderBase:
                                              C.byref(st))
         if not self._h:
             raise StreamError(st.value, self._ctx.last_error())
+        self._ctx._retain()
 
     def _on_read(self, _user, p, cap):
         try:
@@ -221,3 +226,4 @@ class _DecoderBase:
         if getattr(self, "_h", None):
             _ffi.lib().lfx_decoder_free(self._h)
             self._h = None
+            self._ctx._release()

@@ -11,11 +11,31 @@ class Context:
         if not self._h:
             raise _ffi.DeviceError(st.value, "no usable MI355X device %d (there is no CPU fallback)" % device)
         self.device = device
+        self._users = 0          # native handles (encoders, decoders, LZ77 encoders) made from this context and not yet freed
+        self._closing = False
 
-    def close(self):
+    # A native handle uses its context until it is freed (it takes the context's mutex in lfx_*_free).  A Python reference from
+    # the handle's wrapper to this object is not enough: the garbage collector runs the finalizers of an unreachable group in
+    # an undefined order (PEP 442) — at interpreter exit Context.__del__ ran before a decoder's, whose free then locked a mutex
+    # in freed memory ("std::system_error: Invalid argument" under MALLOC_PERTURB_, a corrupted heap without).  So the wrappers
+    # count themselves in and out, and the native context is freed by whoever comes last.
+    def _retain(self):
+        self._users += 1
+
+    def _release(self):
+        self._users -= 1
+        if self._users <= 0 and self._closing:
+            self._free_now()
+
+    def _free_now(self):
         if self._h:
             _ffi.lib().lfx_ctx_free(self._h)
             self._h = None
+
+    def close(self):
+        self._closing = True
+        if self._users <= 0:
+            self._free_now()
 
     def __del__(self):
         try:

@@ -47,6 +47,7 @@ class DefaultLz77Encoder:
         self._h = _ffi.lib().lfx_lz77_new(self._ctx.handle, self._window, self._max_length, C.byref(st))
         if not self._h:
             raise _ffi.LfxError(st.value, "lfx_lz77_new failed")
+        self._ctx._retain()      # (the context outlives its handles whatever the order of the finalizers: Context._retain)
 
     @classmethod
     def new(cls):
@@ -89,6 +90,7 @@ class DefaultLz77Encoder:
         if getattr(self, "_h", None):
             _ffi.lib().lfx_lz77_free(self._h)
             self._h = None
+            self._ctx._release()
 
 
 class DefaultLz77EncoderBuilder:  # default.rs:202-249

@@ -470,3 +470,34 @@ def test_decode_paths_of_the_second_half_of_round_6(ffi, lfx, oracle, synth, mon
                 assert rc == orc and out == oout, (env, cut, rc, orc, len(out), len(oout), msg, omsg)
         finally:
             c2.close()
+
+
+def test_context_outlives_its_handles_whatever_the_finalizer_order(lfx, oracle, synth):
+    """A native handle uses its context until it is freed (lfx_*_free takes the context's mutex).  The garbage collector runs the
+    finalizers of an unreachable group in an undefined order — at interpreter exit Context.__del__ ran before a decoder's, and
+    the decoder's free then worked on freed memory (an abort under MALLOC_PERTURB_, a corrupted heap without).  The wrappers
+    count themselves in and out of their Context: closing a context that still has handles frees nothing until the last one
+    is gone."""
+    import gc
+    import io
+    data = synth.text(300000).tobytes()
+    stream = oracle.encode(oracle.GZIP, data, 8192)
+    own = lfx.Context(0)
+    d = lfx.gzip.Decoder.new(stream, context=own)
+    sink = io.BytesIO()
+    e = lfx.gzip.Encoder.new(sink, context=own)
+    z = lfx.lz77.DefaultLz77Encoder(context=own)
+    assert own._users == 3
+    own.close()                                  # (what Context.__del__ does)
+    assert own.handle                            # still there: three handles use it
+    assert d.read_to_end() == data               # ... and it works
+    e.write(data[:100000])
+    e.finish()                                   # frees the encoder's handle
+    assert own._users == 2 and own.handle
+    del d
+    gc.collect()
+    assert own._users == 1 and own.handle
+    del z
+    gc.collect()
+    assert own._users == 0 and not own.handle    # the last handle took the context with it
+    assert sink.getvalue() == oracle.encode(oracle.GZIP, data[:100000], 0)
