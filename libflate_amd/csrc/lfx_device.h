@@ -75,8 +75,10 @@ int launch_parse(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
                  hipEvent_t ev_walked = nullptr /* recorded behind the walk kernel (in front of the chaining kernels) */,
                  const uint32_t *mflags = nullptr /* EncodeResult::match_flags of this call (bit 1 picks the walk's instance) */,
                  int start_at = 0 /* 1: the walk kernel has been launched (by a call with stop_after = 1): the chaining kernels only */);
+struct ZeroSpan { uint32_t *p; uint32_t n; };      // n words at p to be cleared (by the kernel that runs first anyway)
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
-                      uint32_t *tile_map, uint32_t *seg_map);
+                      uint32_t *tile_map, uint32_t *seg_map, ZeroSpan z0 = ZeroSpan{nullptr, 0}, ZeroSpan z1 = ZeroSpan{nullptr, 0},
+                      ZeroSpan z2 = ZeroSpan{nullptr, 0});
 int launch_histogram(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint32_t split,
                      const uint32_t *codes, const uint32_t *ncodes, uint32_t *hist);
 int launch_huffman(hipStream_t st, const BlockDesc *blocks, uint32_t nblocks, const uint32_t *hist,

@@ -372,9 +372,18 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz77_match_kernel(
 // tile → chunk and segment → chunk tables (one workgroup per chunk): the tile / segment kernels start with one load
 // instead of a binary search over the chunk list (ten dependent L2 round trips per workgroup, also in the many
 // workgroups of tiles that hold no code)
+// (round 6: the call's first kernel also clears its small accumulators — the blocks' symbol counters, the result record, the
+//  match stage's per-segment counts: three fill operations of 5 to 12 us each in front of the match kernel before)
 __global__ __launch_bounds__(256) void chunk_maps_kernel(const ChunkDesc *__restrict__ chunks, uint32_t nchunks,
                                                          uint64_t ntiles, uint32_t nsegs,
-                                                         uint32_t *__restrict__ tile_map, uint32_t *__restrict__ seg_map) {
+                                                         uint32_t *__restrict__ tile_map, uint32_t *__restrict__ seg_map,
+                                                         ZeroSpan z0, ZeroSpan z1, ZeroSpan z2) {
+    {
+        const uint32_t nthreads = 256u * gridDim.x * gridDim.y, me = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+        for (uint32_t i = me; i < z0.n; i += nthreads) z0.p[i] = 0;
+        for (uint32_t i = me; i < z1.n; i += nthreads) z1.p[i] = 0;
+        for (uint32_t i = me; i < z2.n; i += nthreads) z2.p[i] = 0;
+    }
     const uint32_t c = blockIdx.x;
     const ChunkDesc ch = chunks[c];
     const uint64_t t1 = c + 1 < nchunks ? chunks[c + 1].tile_base : ntiles;
@@ -1240,12 +1249,17 @@ int launch_match(hipStream_t st, const uint8_t *in, uint64_t in_bytes, const Chu
     return 0;
 }
 int launch_chunk_maps(hipStream_t st, const ChunkDesc *chunks, uint32_t nchunks, uint64_t ntiles, uint32_t nsegs,
-                      uint32_t *tile_map, uint32_t *seg_map) {
-    if (nchunks == 0) return 0;
+                      uint32_t *tile_map, uint32_t *seg_map, ZeroSpan z0, ZeroSpan z1, ZeroSpan z2) {
+    if (nchunks == 0) {
+        // (no kernel: plain fills)
+        for (const ZeroSpan &z : {z0, z1, z2})
+            if (z.n && hipMemsetAsync(z.p, 0, 4ull * z.n, st) != hipSuccess) return (int)hipGetLastError();
+        return 0;
+    }
     // (few chunks = long chunks: several workgroups share one)
     uint32_t split = nchunks >= 256 ? 1 : 256 / nchunks + 1;
     if (split > 64) split = 64;
-    hipLaunchKernelGGL(chunk_maps_kernel, dim3(nchunks, split), dim3(256), 0, st, chunks, nchunks, ntiles, nsegs, tile_map, seg_map);
+    hipLaunchKernelGGL(chunk_maps_kernel, dim3(nchunks, split), dim3(256), 0, st, chunks, nchunks, ntiles, nsegs, tile_map, seg_map, z0, z1, z2);
     LFX_LAUNCH_CHECK();
     return 0;
 }
