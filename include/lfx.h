@@ -155,6 +155,10 @@ int lfx_encode_shard_prepare(lfx_ctx *c, int format, const lfx_encode_opts *o,
  * shard the trailer built from the combined checksum / size given here. */
 int lfx_encode_shard_emit(lfx_ctx *c, uint64_t start_bit, uint32_t combined_check,
                           uint64_t total_n, void *d_out, uint64_t cap, uint64_t *out_len);
+/* Optional, in front of lfx_encode_shard_prepare: names the buffer lfx_encode_shard_emit will write, which is then zero-filled on
+ * the context's side stream beside the prepare call's kernels instead of in front of the pack kernels (what lfx_encode_device
+ * does with its own output).  (NULL, 0) waits for a fill in flight and forgets it (no emit call will follow). */
+int lfx_encode_shard_prezero(lfx_ctx *c, void *d_out, uint64_t cap);
 /* inverse of the sharded encode: decodes the blocks of ONE shard of a member.  d_in[0] is the byte
  * that holds bit `start_bit` (0..7) of the shard; a non-last shard ends when a block ends exactly
  * `total_bits` later (it holds no BFINAL block).  Reference-made blocks never reference earlier

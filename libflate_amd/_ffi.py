@@ -22,7 +22,7 @@ DEC_NONBLOCKING = 2
 EXPORTS = [
     "lfx_encode_opts_default", "lfx_ctx_new", "lfx_ctx_free", "lfx_ctx_last_error", "lfx_ctx_set_stream",
     "lfx_device_count", "lfx_encode_bound", "lfx_encode_device", "lfx_encode_batch_device", "lfx_encode_host", "lfx_decode_device",
-    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_decode_shard_device", "lfx_shard_place_device", "lfx_decode_range_scan", "lfx_decode_chain", "lfx_decode_range_emit", "lfx_decode_range_map", "lfx_decode_range_finish",
+    "lfx_decode_host", "lfx_decode_batch_device", "lfx_encode_shard_prepare", "lfx_encode_shard_emit", "lfx_encode_shard_prezero", "lfx_decode_shard_device", "lfx_shard_place_device", "lfx_decode_range_scan", "lfx_decode_chain", "lfx_decode_range_emit", "lfx_decode_range_map", "lfx_decode_range_finish",
     "lfx_crc32_combine", "lfx_adler32_combine", "lfx_container_header_len", "lfx_encoder_new",
     "lfx_encoder_write", "lfx_encoder_write_codes", "lfx_encoder_flush", "lfx_encoder_finish", "lfx_encoder_last_error",
     "lfx_encoder_free", "lfx_decoder_new", "lfx_decoder_read", "lfx_decoder_unread",
@@ -159,6 +159,7 @@ def lib():
     L.lfx_encode_shard_prepare.argtypes = [vp, i32, C.POINTER(EncodeOpts), C.POINTER(Schedule), vp, u64, i32,
                                            i32, C.POINTER(ShardInfo)]
     L.lfx_encode_shard_emit.argtypes = [vp, u64, u32, u64, vp, u64, C.POINTER(u64)]
+    L.lfx_encode_shard_prezero.argtypes = [vp, vp, u64]
     L.lfx_decode_shard_device.argtypes = [vp, vp, u64, u64, u64, i32, vp, u64, C.POINTER(u64)]
     L.lfx_shard_place_device.argtypes = [vp, vp, u64, vp, u64, u64, i32]
     L.lfx_decode_range_scan.argtypes = [vp, vp, u64, u64, u64, u64, u64, u32, C.POINTER(BlkTuple), u32, C.POINTER(u32)]

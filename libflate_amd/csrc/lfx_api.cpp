@@ -932,6 +932,27 @@ extern "C" int lfx_encode_host(lfx_ctx *cc, int format, const lfx_encode_opts *o
 } LFX_ABI_CATCH
 
 // ---- sharded encode -------------------------------------------------------------------------
+// Where lfx_encode_shard_emit will write: zero-filled on the side stream NOW, beside the match kernel of the prepare call, as
+// lfx_encode_device does for its own output (the pack kernels OR into zeros; on the main stream the fill of a 130 MB shard was
+// 0.07 ms in front of them).  (NULL, 0): wait for a fill in flight and forget it — the emit call is not going to come.
+extern "C" int lfx_encode_shard_prezero(lfx_ctx *cc, void *d_out, uint64_t cap) try {
+    if (!cc) return LFX_E_DEVICE;
+    Ctx *c = reinterpret_cast<Ctx *>(cc);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (c->prezero_ptr) (void)hipEventSynchronize(c->ev_zero);
+    c->prezero_ptr = nullptr;
+    if (!d_out || ((uintptr_t)d_out & 3) != 0 || cap < 16) return LFX_OK;
+    (void)hipSetDevice(c->device);
+    const uint64_t bytes = cap / 4 * 4;
+    // (ordered behind whatever the caller's stream still has queued on d_out: forked from c->stream as in lfx_encode_device)
+    if (hipEventRecord(c->ev_fork, c->stream) == hipSuccess && hipStreamWaitEvent(c->side_stream, c->ev_fork, 0) == hipSuccess &&
+        hipMemsetAsync(d_out, 0, bytes, c->side_stream) == hipSuccess && hipEventRecord(c->ev_zero, c->side_stream) == hipSuccess) {
+        c->prezero_ptr = d_out;
+        c->prezero_bytes = bytes;
+    }
+    return LFX_OK;
+} LFX_ABI_CATCH
+
 extern "C" int lfx_encode_shard_prepare(lfx_ctx *cc, int format, const lfx_encode_opts *o, const lfx_schedule *s,
                                         const void *d_in, uint64_t n, int is_first, int is_last,
                                         lfx_shard_info *info) try {

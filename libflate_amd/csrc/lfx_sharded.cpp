@@ -156,6 +156,7 @@ extern "C" int lfx_sharded_encode_begin(lfx_ctx *c, const lfx_comm *cm, int form
     *state = nullptr;
     const uint32_t rank = cm->rank, world = cm->world;
     lfx_shard_info info{};
+    (void)lfx_encode_shard_prezero(c, d_part, part_cap);     // (the shard's output is zero-filled beside the prepare call's kernels)
     int rc = lfx_encode_shard_prepare(c, format, o, s, d_in, n, rank == 0, rank == world - 1, &info);
     // (a failed prepare still takes part in the exchange: the others must not wait for this rank)
     std::unique_ptr<lfx_sharded_enc> st(new lfx_sharded_enc());
@@ -173,6 +174,7 @@ extern "C" int lfx_sharded_encode_begin(lfx_ctx *c, const lfx_comm *cm, int form
             if (st->start_bits[r + 1] - st->start_bits[r] == ~0ull) rc = LFX_E_IO;
     }
     if (!rc) rc = lfx_encode_shard_emit(c, st->start_bits[rank], check, total_n, d_part, part_cap, &part_len);
+    if (rc) (void)lfx_encode_shard_prezero(c, nullptr, 0);   // (no emit, or one that failed before it took the fill: nothing stays in flight)
     // ---- every rank's emitted byte count (and status), then the shards travel to rank 0, all transfers posted at once: on
     //      RCCL they arrive over different xGMI links concurrently (the links are point-to-point).  Rank 0's capacities ride
     //      in the same row: whether the member and the staging area are large enough is then decided by EVERY rank
