@@ -59,6 +59,10 @@ struct RangeState {
 struct Ctx {
     int device = 0;
     RangeState range;
+    // lfx_decode_range_scan → lfx_decode_range_emit: which scan jobs stored their code words (the storing scan), and where
+    std::vector<uint8_t> range_stored;
+    std::vector<uint64_t> range_temp_off;
+    std::vector<uint32_t> range_cap;
     Diag diag;
     int n_cu = 0;   // compute units of the device
     hipStream_t own_stream = nullptr, stream = nullptr;

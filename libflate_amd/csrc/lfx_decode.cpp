@@ -1065,6 +1065,7 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
     while (nc < starts.size() && starts[nc] < range_bits) nc++;
     if (nc > cap) { c->set_error("more candidates than the caller's tuple buffer holds"); return LFX_E_NOSPACE; }
     const size_t tab_bytes = blk_tabs_bytes();
+    c->range_stored.clear();
     if (nc) {
         auto start_at = [&](uint32_t i) { return i < starts.size() ? starts[i] : n * 8; };
         std::vector<BlkJob> bj(nc);
@@ -1073,20 +1074,54 @@ extern "C" int lfx_decode_range_scan(lfx_ctx *cc, const void *d_part_, uint64_t 
         if ((rc = c->d_dec_state.reserve(sizeof(BlkInfo) * (nc + 1)))) return rc;
         if ((rc = c->d_dec_blocks.reserve(sizeof(BlkLanes) * (size_t)(nc + 1)))) return rc;
         if ((rc = c->d_dec_tabs.reserve(tab_bytes * (nc + 1)))) return rc;
+        // ONE Huffman pass for large blocks, as in inflate_member (round 6): the scan stores every lane's code words in a region of
+        // its own, lfx_decode_range_emit moves the owned blocks' codes into place (blk_place_kernel) instead of decoding them again
+        bool store_mode = !c->diag.two_pass && (n * 8) / nc >= (1ull << 20);
+        if (store_mode) {
+            uint64_t off = 0;
+            for (uint32_t j = 0; j < nc; j++) {
+                const uint64_t bits = bj[j].end_bit > bj[j].start_bit ? bj[j].end_bit - bj[j].start_bit : 0;
+                const uint64_t slice = std::max<uint64_t>((bits + 1023) / 1024, 128);
+                const uint64_t lcap = (slice / (c->diag.store_tight ? 16 : 2) + 448 + 64 + 3) & ~3ull;   // (448 = SCAN_HEADCAP, lfx_inflate_fast.hip)
+                bj[j].temp_off = off;
+                bj[j].cap = (uint32_t)lcap;
+                off += 1024 * lcap;
+            }
+            if (off * 4 > (16ull << 30) || c->d_dec_temp.reserve(off * 4) || c->d_dec_lanesx.reserve(sizeof(BlkLanesX) * (size_t)(nc + 1))) {
+                store_mode = false;
+                for (uint32_t j = 0; j < nc; j++) { bj[j].temp_off = 0; bj[j].cap = 0; }
+            }
+        }
         HIP_TRY(hipMemcpyAsync(c->d_dec_streams.p, bj.data(), sizeof(BlkJob) * nc, hipMemcpyHostToDevice, st));
-        LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nc, (BlkInfo *)c->d_dec_state.p,
-                                   (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
+        if (store_mode)
+            LAUNCH_TRY(launch_blk_scan_store(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nc, (BlkInfo *)c->d_dec_state.p,
+                                             (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p, (uint32_t *)c->d_dec_temp.p,
+                                             (BlkLanesX *)c->d_dec_lanesx.p));
+        else
+            LAUNCH_TRY(launch_blk_scan(st, d_in, n, (const BlkJob *)c->d_dec_streams.p, nc, (BlkInfo *)c->d_dec_state.p,
+                                       (BlkLanes *)c->d_dec_blocks.p, c->d_dec_tabs.p));
         std::vector<BlkInfo> bi(nc);
         HIP_TRY(hipMemcpyAsync(bi.data(), c->d_dec_state.p, sizeof(BlkInfo) * nc, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (BlkInfo &b : bi) if (b.status == BLK_OK && b.end_bit > n * 8) b.status = BLK_NO_EOB;
+        c->range_stored.assign(nc, 0);
+        c->range_temp_off.assign(nc, 0);
+        c->range_cap.assign(nc, 0);
+        if (store_mode)
+            for (uint32_t j = 0; j < nc; j++) {
+                // (a compressed block that scanned to its EndOfBlock and whose lanes' codes all fitted their regions; a job that is
+                //  scanned again below loses the mark: the plain scan rewrites its lanes)
+                c->range_stored[j] = bi[j].status == BLK_OK && bi[j].btype != 0 && bi[j]._pad == 0;
+                c->range_temp_off[j] = bj[j].temp_off;
+                c->range_cap[j] = bj[j].cap;
+            }
         // a false candidate inside a block cuts that block's range guess short (no EndOfBlock): rescan with wider ranges
         for (uint32_t widen = 2; widen <= 6; widen++) {
             std::vector<uint32_t> redo;
             for (uint32_t i = 0; i < nc; i++) if (bi[i].status == BLK_NO_EOB && i + widen <= starts.size()) redo.push_back(i);
             if (redo.empty()) break;
             std::vector<BlkJob> rj(redo.size());
-            for (size_t q = 0; q < redo.size(); q++) rj[q] = BlkJob{starts[redo[q]], start_at(redo[q] + widen)};
+            for (size_t q = 0; q < redo.size(); q++) { rj[q] = BlkJob{starts[redo[q]], start_at(redo[q] + widen)}; c->range_stored[redo[q]] = 0; }
             if ((rc = c->d_dec_tmp.reserve(sizeof(BlkJob) * redo.size()))) return rc;
             BlkJob *d_rj = (BlkJob *)c->d_dec_tmp.p;
             HIP_TRY(hipMemcpyAsync(d_rj, rj.data(), sizeof(BlkJob) * redo.size(), hipMemcpyHostToDevice, st));
@@ -1164,6 +1199,7 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
     // the chain blocks this rank owns (consecutive in stream order: ownership goes by start position)
     std::vector<BlkEmit> emit;
     uint64_t before = 0, total = 0, total_codes = 0;
+    uint32_t n_placed = 0;
     bool seen = false;
     for (uint32_t q = 0; q < n_chain; q++) {
         const lfx_blk_tuple &t = all[chain[q]];
@@ -1173,6 +1209,9 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
         e.start_bit = t.start_bit - base_bit; e.data_bit = t.data_bit - base_bit; e.code_off = total_codes; e.out_off = total;
         e.n_out = t.n_out; e.n_codes = t.n_codes; e.nlanes = t.nlanes; e.btype = t.btype; e.cand = t.slot;
         e.hist = before + total;             // bytes of the member in front of the block: bounds its back-references
+        if (t.slot < c->range_stored.size() && c->range_stored[t.slot]) {      // (this rank's scan kept the block's code words)
+            e.placed = 1; e.temp_off = c->range_temp_off[t.slot]; e.cap = c->range_cap[t.slot]; n_placed++;
+        }
         emit.push_back(e);
         total += t.n_out;
         total_codes += t.n_codes;
@@ -1196,8 +1235,13 @@ extern "C" int lfx_decode_range_emit(lfx_ctx *cc, const void *d_part_, uint64_t 
     const uint32_t unit_target = (uint32_t)std::min<uint64_t>((total_codes + slots - 1) / slots + 1, 0x7FFFFFFFu);
     uint32_t free_shift = 15;   // marker units as on one GPU: two resident per CU, as large as that allows
     while (free_shift < 20 && (total >> (free_shift + 1)) >= 2ull * (uint64_t)std::max(c->n_cu, 1)) free_shift++;
-    LAUNCH_TRY(launch_blk_emit(st, d_in, n_part, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (uint32_t *)c->d_codes.p, d_flags,
-                               (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne));
+    if (n_placed)
+        LAUNCH_TRY(launch_blk_place(st, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (const BlkLanesX *)c->d_dec_lanesx.p,
+                                    (const uint32_t *)c->d_dec_temp.p, (uint32_t *)c->d_codes.p, d_flags, (BlkUnits *)c->d_hist.p,
+                                    unit_target, nullptr, free_shift));
+    if (n_placed < ne)
+        LAUNCH_TRY(launch_blk_emit(st, d_in, n_part, d_emit, ne, (const BlkLanes *)c->d_dec_blocks.p, (uint32_t *)c->d_codes.p, d_flags,
+                                   (BlkUnits *)c->d_hist.p, unit_target, nullptr, c->d_dec_tabs.p, free_shift, total_codes >= 32768ull * ne));
     c->phase("blk_emit");
     // small blocks smell of another encoder: look at the flags before materialising (as inflate_member does); the reference's
     // 1 MiB blocks are materialised at once and the flags read afterwards
