@@ -468,6 +468,48 @@ __device__ __forceinline__ void rotate_prio(uint32_t trip) {
     }
 }
 
+// Writes a lane's staged code words (stage[0, staged), LDS) to dst[0, ...) with ALIGNED 16-byte stores only (round 6: the stores cost
+// the storing scan 0.16 of its 0.80 ms, HISTORY.md): the words in front of the first 16-byte boundary leave as dwords, whole groups
+// of four as one aligned store each, and the (up to three) words behind the last boundary STAY staged (moved to the front of the
+// row) until the next pause — at the call's last one (`more` false) they leave as dwords.  A 16-byte store at any dword address
+// touched two 32-byte sectors more often than not.  → the number of words that stay staged.
+__device__ __forceinline__ uint32_t flush_staged(uint32_t *stage, uint32_t staged, uint32_t *dst, bool fits, bool more) {
+    const uint32_t a0 = (uint32_t)((uintptr_t)dst >> 2) & 3u;
+    const uint32_t head = min(staged, (4u - a0) & 3u);              // dwords up to the first boundary (<= 3)
+    const uint32_t body = (staged - head) & ~3u;                    // 0, 4, or 8 (8: head = tail = 0)
+    const uint32_t tail = staged - head - body;                     // <= 3
+    const uint32_t tt = head + body;                                // where the tail starts (<= 8)
+    {
+        const uint32_t s0 = stage[0], s1 = stage[1], s2 = stage[2];
+        const uint32_t g0 = stage[head], g1 = stage[head + 1], g2 = stage[head + 2], g3 = stage[head + 3];   // (head + 3 <= 6)
+        if (fits) {
+            if (head > 0) dst[0] = s0;
+            if (head > 1) dst[1] = s1;
+            if (head > 2) dst[2] = s2;
+            if (body >= 4) *(u32x4 *)(dst + head) = u32x4{g0, g1, g2, g3};
+        }
+    }
+    if (__ballot(body == 8)) {
+        const uint32_t h0 = stage[4], h1 = stage[5], h2 = stage[6], h3 = stage[7];
+        if (fits && body == 8) *(u32x4 *)(dst + 4) = u32x4{h0, h1, h2, h3};
+    }
+    if (__ballot(tail != 0)) {
+        const uint32_t e0 = stage[min(tt, 8u)], e1 = stage[min(tt + 1, 8u)], e2 = stage[min(tt + 2, 8u)];
+        if (!more) {
+            if (fits) {
+                if (tail > 0) dst[tt] = e0;
+                if (tail > 1) dst[tt + 1] = e1;
+                if (tail > 2) dst[tt + 2] = e2;
+            }
+        } else {
+            if (tail > 0) stage[0] = e0;
+            if (tail > 1) stage[1] = e1;
+            if (tail > 2) stage[2] = e2;
+        }
+    }
+    return more ? tail : 0u;
+}
+
 template <bool EMIT>
 __device__ __forceinline__ int lane_decode_fifo(const FastTabs &T, const uint8_t *in, uint64_t nbytes, uint64_t start,
                                            uint64_t limit, uint32_t &ncodes, uint64_t &nout, uint32_t *codes,
@@ -538,25 +580,9 @@ __device__ __forceinline__ int lane_decode_fifo(const FastTabs &T, const uint8_t
         const bool refill = ret == 0 && b.used < lim && b.qn < 2;
         if (refill) b.take();
         if (EMIT) {
-            uint32_t *dst = codes + (ncodes - staged);
             const bool fits = ncodes <= store_cap;
             if (!fits && ovf) *ovf = 1u;
-            for (uint32_t j = 0; j < EMIT_STAGE; j += 4) {
-                if (__ballot(j < staged) == 0) break;
-                if (j < staged && fits) {
-                    const uint32_t c0 = stage[j], c1 = stage[j + 1], c2 = stage[j + 2], c3 = stage[j + 3];
-                    if (j + 4 <= staged) {
-                        U32x4 q;
-                        q.v = u32x4{c0, c1, c2, c3};
-                        *(U32x4 *)(dst + j) = q;
-                    } else {
-                        dst[j] = c0;
-                        if (j + 1 < staged) dst[j + 1] = c1;
-                        if (j + 2 < staged) dst[j + 2] = c2;
-                    }
-                }
-            }
-            staged = 0;
+            staged = flush_staged(stage, staged, codes + (ncodes - staged), fits, ret == 0 && b.used < lim);
         }
         if (refill) b.issue();
     }
@@ -638,25 +664,9 @@ __device__ __forceinline__ int lane_decode(const FastTabs &T, const uint8_t *in,
         const bool refill = ret == 0 && b.rel < rlim && !b.room();
         if (refill) b.take();
         if (EMIT) {
-            uint32_t *dst = codes + (ncodes - staged);
             const bool fits = ncodes <= store_cap;       // (the storing scan: what does not fit its region is counted, not stored)
             if (!fits && ovf) *ovf = 1u;
-            for (uint32_t j = 0; j < EMIT_STAGE; j += 4) {
-                if (__ballot(j < staged) == 0) break;
-                if (j < staged && fits) {
-                    const uint32_t c0 = stage[j], c1 = stage[j + 1], c2 = stage[j + 2], c3 = stage[j + 3];
-                    if (j + 4 <= staged) {
-                        U32x4 q;
-                        q.v = u32x4{c0, c1, c2, c3};
-                        *(U32x4 *)(dst + j) = q;
-                    } else {
-                        dst[j] = c0;
-                        if (j + 1 < staged) dst[j + 1] = c1;
-                        if (j + 2 < staged) dst[j + 2] = c2;
-                    }
-                }
-            }
-            staged = 0;
+            staged = flush_staged(stage, staged, codes + (ncodes - staged), fits, ret == 0 && b.rel < rlim);
         }
         if (refill) b.issue();
     }
