@@ -331,7 +331,7 @@ struct FastBits {
 // sixteen-byte piece by the ONE lane that decodes it, not reloaded around the L2 (blk_emit: 1.8 GB of fabric traffic for a
 // 130 MB stream until round 4).
 #ifndef LFX_RING_DW
-#define LFX_RING_DW 16        // dwords of a lane's ring
+#define LFX_RING_DW 16        // dwords of a lane's ring (16 / 8 is the geometry the suite runs; 12 / 4 compiles and HANGS the storing scan — HISTORY.md, round 6)
 #endif
 #ifndef LFX_RING_FILL
 #define LFX_RING_FILL 8       // dwords per refill (in flight in registers meanwhile)
